@@ -1,0 +1,152 @@
+"""Deterministic synthetic tensors for fixtures, parity tests and the smoke check.
+
+Every tensor is a pure function of (its name, its shape, a kind) through a counter-based generator
+(splitmix64 of a name hash + element index), so fixtures only need to store OUTPUTS: inputs and
+weights are regenerated bit-for-bit wherever the tests run.  No torch, no global RNG state.
+"""
+import hashlib
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+    z = x
+    z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+    z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+    return z ^ (z >> np.uint64(31))
+
+
+def _key(name):
+    return np.uint64(int.from_bytes(hashlib.sha256(name.encode()).digest()[:8], "little"))
+
+
+def uniform01(name, n):
+    """n float64 in (0,1), 24 significant bits, keyed by name."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(n, dtype=np.uint64)
+        bits = _splitmix64(_splitmix64(idx + _key(name)))
+    return ((bits >> np.uint64(40)).astype(np.float64) + 0.5) / float(1 << 24)
+
+
+def uniform(name, shape, lo=-1.0, hi=1.0):
+    n = int(np.prod(shape))
+    return (lo + (hi - lo) * uniform01(name, n)).astype(np.float32).reshape(shape)
+
+
+def normal(name, shape, std=1.0):
+    n = int(np.prod(shape))
+    u1 = uniform01(name + "#u1", n)
+    u2 = uniform01(name + "#u2", n)
+    g = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+    return (std * g).astype(np.float32).reshape(shape)
+
+
+def orthogonal(name, c):
+    """c x c orthogonal matrix with det > 0 (modified Gram-Schmidt of a keyed gaussian matrix);
+    plays the role of the reference's QR init (model/efficient_modules.py:22-26), perturbed a little so
+    that W is well conditioned but NOT orthogonal (logdet != 0, W^-1 != W^T)."""
+    a = normal(name, (c, c)).astype(np.float64)
+    q = np.zeros_like(a)
+    for j in range(c):
+        v = a[:, j].copy()
+        for i in range(j):
+            v = v - (q[:, i] * v).sum() * q[:, i]
+        q[:, j] = v / np.sqrt((v * v).sum())
+    q = q + 0.15 * normal(name + "#pert", (c, c)).astype(np.float64) / np.sqrt(c)
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    return q.astype(np.float32)
+
+
+def flow_channels(cfg, k):
+    c = cfg["n_group"]
+    for j in range(1, k + 1):
+        if j % cfg["n_early_every"] == 0:
+            c -= cfg["n_early_size"]
+    return c
+
+
+def wn_param_specs(prefix, in_ch, aux, C, Cd, Cs, depth, radix):
+    """(name, shape, kind) of one WN in the reference's parameter order (model/waveglow.py:70-96)."""
+    specs = [(prefix + "V.weight_g", (2 * Cd * depth, 1, 1), "g"), (prefix + "V.weight_v", (2 * Cd * depth, aux, 1), "v"),
+             (prefix + "start.weight_g", (C, 1, 1), "g"), (prefix + "start.weight_v", (C, in_ch, 1), "v")]
+    for i in range(depth):
+        rows = Cs if i == depth - 1 else C + Cs
+        specs += [(prefix + "layers.%d.W.weight_g" % i, (2 * Cd, 1, 1), "g"),
+                  (prefix + "layers.%d.W.weight_v" % i, (2 * Cd, C, radix), "v"),
+                  (prefix + "layers.%d.W_o.weight_g" % i, (rows, 1, 1), "g"),
+                  (prefix + "layers.%d.W_o.weight_v" % i, (rows, Cd, 1), "v")]
+    specs.append((prefix + "end.weight", (2 * in_ch, Cs, 1), "end"))
+    return specs
+
+
+def model_param_specs(cfg):
+    """cfg: dict with the reference's WaveGlow ctor keywords (configs/waveglow_LJ_speech.json:6-19)."""
+    up = cfg["hop_size"] // cfg["n_group"]
+    K = 2 * up + 1
+    M = cfg["n_mels"]
+    specs = [("upsampler.bias", (M,), "bias"), ("upsampler.weight_g", (M, 1, 1), "g"), ("upsampler.weight_v", (M, 1, K), "v")]
+    for k in range(cfg["flows"]):
+        c = flow_channels(cfg, k)
+        specs.append(("invconv1x1.%d.weight" % k, (c, c, 1), "orth"))
+    for k in range(cfg["flows"]):
+        c = flow_channels(cfg, k)
+        specs += wn_param_specs("WNs.%d.F." % k, c // 2, M, cfg["residual_channels"], cfg["dilation_channels"],
+                                cfg["skip_channels"], cfg["depth"], cfg["radix"])
+    return specs
+
+
+def fill_params(specs, tag=""):
+    """dict name -> float32 array.  `v` ~ U(+-1/sqrt(fan_in)); `g` = ||v|| * (1 + 0.2 u) (so g != ||v||);
+    `end` ~ N(0, (0.25/sqrt(Cs))^2) (NOT the reference's zero init: log_s, t must be non-trivial)."""
+    out = {}
+    for name, shape, kind in specs:
+        key = tag + name
+        if kind == "v":
+            fan_in = int(np.prod(shape[1:]))
+            b = 1.0 / np.sqrt(fan_in)
+            out[name] = uniform(key, shape, -b, b)
+        elif kind == "bias":
+            out[name] = uniform(key, shape, -0.1, 0.1)
+        elif kind == "end":
+            out[name] = normal(key, shape, 0.25 / np.sqrt(shape[1]))
+        elif kind == "orth":
+            out[name] = orthogonal(key, shape[0]).reshape(shape)
+    for name, shape, kind in specs:
+        if kind == "g":
+            v = out[name[:-1] + "v"].astype(np.float64)
+            nrm = np.sqrt((v.reshape(shape[0], -1) ** 2).sum(1))
+            out[name] = (nrm * (1.0 + 0.2 * uniform(tag + name, (shape[0],)).astype(np.float64))).astype(np.float32).reshape(shape)
+    return out
+
+
+def table(specs, params):
+    """list of arrays in table (= named_parameters) order"""
+    return [params[name] for name, _, _ in specs]
+
+
+# named configurations shared by the fixture generator and the tests ---------------------------------
+CONFIGS = {
+    # tiny model whose FULL gradient set fits in a fixture
+    "micro": dict(flows=4, n_group=8, n_early_every=2, n_early_size=2, hop_size=64, n_mels=20,
+                  dilation_channels=32, residual_channels=32, skip_channels=32, depth=3, radix=3),
+    # BASELINE.json configs[0]: 64ch, 6 flows
+    "c1": dict(flows=6, n_group=8, n_early_every=4, n_early_size=2, hop_size=256, n_mels=80,
+               dilation_channels=64, residual_channels=64, skip_channels=64, depth=8, radix=3),
+    # BASELINE.json configs[1] (waveglow_LJ_speech.json): 256ch, 12 flows
+    "c2": dict(flows=12, n_group=8, n_early_every=4, n_early_size=2, hop_size=256, n_mels=80,
+               dilation_channels=256, residual_channels=256, skip_channels=256, depth=8, radix=3),
+}
+SHAPES = {  # (batch, samples, mel frames)
+    "micro": (2, 512, 8),
+    "c1": (2, 4000, 16),
+    "c2": (1, 16000, 63),
+}
+SIGMA = 0.7   # configs/waveglow_LJ_speech.json:47
+
+
+def inputs(tag, B, N, F, n_mels):
+    return uniform(tag + "/audio", (B, N), -1.0, 1.0), normal(tag + "/mel", (B, n_mels, F))

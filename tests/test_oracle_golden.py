@@ -1,0 +1,141 @@
+"""Pins the CPU oracle (oracle/wg_oracle.c) to the golden vectors the upstream reference produced
+(tests/golden/make_golden.py).  CPU only.  Tolerances: the reference's own fp32 result sits ~1e-6 (z),
+~3e-6 of each tensor's max (grads) and ~1e-7 relative (logdet) from fp64."""
+import os
+
+import numpy as np
+import pytest
+
+import fill
+from oracle import wg_oracle as orc
+from make_golden import COUPLING_CASES
+
+Z_ATOL = 5e-6
+GRAD_RTOL = 2e-5      # relative to each tensor's max-abs
+LOGDET_RTOL = 2e-6   # plus 5e-8 per audio sample: logdet is a sum of ~N terms that partly cancel
+
+
+def _logdet_close(a, b, N):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return bool(np.all(np.abs(a - b) <= LOGDET_RTOL * np.abs(b) + 5e-8 * N))
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _relmax(a, b):
+    return float(np.abs(a - b).max() / max(float(np.abs(b).max()), 1e-30))
+
+
+@pytest.mark.parametrize("name", ["micro", "c1", "c2"])
+@pytest.mark.parametrize("double", [False, True])
+def test_model_step_matches_reference(golden_dir, name, double):
+    if name == "c2" and double:
+        pytest.skip("fp64 C2 step takes ~20 s; the fp32 run already pins it")
+    g = _load(golden_dir, "model_%s.npz" % name)
+    cfg = fill.CONFIGS[name]
+    B, N, F = fill.SHAPES[name]
+    specs = fill.model_param_specs(cfg)
+    P = fill.fill_params(specs, name + "/")
+    tab = fill.table(specs, P)
+    audio, h = fill.inputs(name, B, N, F, cfg["n_mels"])
+    oc = orc.make_config(**cfg)
+    assert orc.param_count(oc) == len(specs)
+    r = orc.train_step(oc, tab, audio, h, fill.SIGMA, need_dh=True, double=double)
+    assert np.abs(r["z"] - g["z"]).max() < Z_ATOL
+    assert _logdet_close(r["logdet"], g["logdet"], N)
+    assert abs(r["loss"] - float(g["loss"])) < 1e-6
+    assert _relmax(r["dh"], g["dh"]) < GRAD_RTOL
+    for i, (n, _, _) in enumerate(specs):
+        gr = r["grads"][i].ravel()
+        scale = max(float(g["grad_max"][i]), 1e-30)
+        nh = min(gr.size, g["grad_head"].shape[1])
+        assert np.abs(gr[:nh] - g["grad_head"][i][:nh]).max() / scale < GRAD_RTOL, n
+        nrm = np.sqrt((gr.astype(np.float64) ** 2).sum())
+        assert abs(nrm - g["grad_norm"][i]) <= 1e-4 * g["grad_norm"][i] + 1e-12, n
+        if "grad::" + n in g:
+            assert _relmax(r["grads"][i], g["grad::" + n]) < GRAD_RTOL, n
+
+
+@pytest.mark.parametrize("name", ["micro", "c1"])
+def test_model_inverse_matches_reference(golden_dir, name):
+    g = _load(golden_dir, "model_%s.npz" % name)
+    cfg = fill.CONFIGS[name]
+    B, N, F = fill.SHAPES[name]
+    specs = fill.model_param_specs(cfg)
+    tab = fill.table(specs, fill.fill_params(specs, name + "/"))
+    audio, h = fill.inputs(name, B, N, F, cfg["n_mels"])
+    oc = orc.make_config(**cfg)
+    x, ld = orc.inverse(oc, tab, g["z"], h)
+    assert np.abs(x - g["x_inv"]).max() < Z_ATOL
+    assert np.abs(x - audio).max() < 1e-5                       # reverse(forward(x)) == x
+    assert _logdet_close(ld, g["logdet_inv"], N)
+    assert _logdet_close(ld, -g["logdet"], N)
+    zlat = fill.normal(name + "/latent", (B, N), fill.SIGMA)
+    xs, _ = orc.inverse(oc, tab, zlat, h)
+    assert np.abs(xs - g["x_from_latent"]).max() < 2e-5 * max(1.0, float(np.abs(g["x_from_latent"]).max()))
+
+
+def test_loss_value():
+    z = fill.normal("loss/z", (3, 64))
+    ld = fill.normal("loss/ld", (3,))
+    want = float(np.mean(0.5 * (z.astype(np.float64) ** 2).sum(1) / 0.49 - ld) / 64)
+    assert abs(orc.loss(z, ld, 0.7) - want) < 1e-6
+
+
+@pytest.mark.parametrize("c", [2, 4, 8])
+@pytest.mark.parametrize("shape", [(1, 64), (3, 200)])
+@pytest.mark.parametrize("rev", [False, True])
+def test_invconv_block(golden_dir, c, shape, rev):
+    g = _load(golden_dir, "block_invconv.npz")
+    B, T = shape
+    tag = "invconv/c%d_b%d_t%d" % (c, B, T)
+    k = tag + ("/rev" if rev else "/fwd")
+    W = fill.orthogonal(tag + "/W", c)
+    x = fill.uniform(tag + "/x", (B, c, T))
+    gz = fill.normal(tag + "/gz", (B, c, T))
+    y, ld = (orc.invconv_reverse if rev else orc.invconv_forward)(W, x)
+    assert np.abs(y - g[k + "/y"]).max() < 2e-6
+    assert abs(float(ld) - float(g[k + "/logdet"])) < 1e-5 * max(1.0, abs(float(g[k + "/logdet"])))
+    xr, dx, dW = orc.invconv_backward(W, y, gz, 0.37, reverse=rev)
+    assert np.abs(xr - x).max() < 2e-6                          # input re-materialised from the output
+    assert _relmax(dx, g[k + "/dx"]) < GRAD_RTOL
+    assert _relmax(dW, g[k + "/dW"]) < GRAD_RTOL
+
+
+def test_invconv_negative_det_gives_nan():
+    W = fill.orthogonal("negdet", 4)
+    W[:, 0] = -W[:, 0]
+    _, ld = orc.invconv_forward(W, fill.uniform("negdet/x", (1, 4, 8)))
+    assert np.isnan(ld)                                          # torch.logdet semantics (efficient_modules.py:38)
+
+
+@pytest.mark.parametrize("cname", list(COUPLING_CASES))
+@pytest.mark.parametrize("rev", [False, True])
+def test_coupling_block(golden_dir, cname, rev):
+    g = _load(golden_dir, "block_coupling.npz")
+    cs = COUPLING_CASES[cname]
+    tag = "coupling/" + cname
+    k = tag + ("/rev" if rev else "/fwd")
+    wn = dict(in_channels=cs["c"] // 2, aux_channels=cs["aux"], residual_channels=cs["wn"], dilation_channels=cs["wn"],
+              skip_channels=cs["wn"], depth=cs["depth"], radix=3)
+    specs = fill.wn_param_specs("F.", cs["c"] // 2, cs["aux"], cs["wn"], cs["wn"], cs["wn"], cs["depth"], 3)
+    tab = fill.table(specs, fill.fill_params(specs, tag + "/"))
+    x = fill.uniform(tag + "/x", (cs["B"], cs["c"], cs["T"]))
+    y = fill.normal(tag + "/y", (cs["B"], cs["aux"], cs["T"]))
+    gz = fill.normal(tag + "/gz", x.shape)
+    gls = fill.normal(tag + "/gls", (cs["B"], cs["c"] // 2, cs["T"]))
+    z, ls = orc.coupling_apply(wn, tab, x, y, reverse=rev)
+    assert np.abs(z - g[k + "/z"]).max() < 1e-5
+    assert np.abs(ls - g[k + "/log_s"]).max() < 1e-5
+    r = orc.coupling_backward(wn, tab, z, y, gz, gls, reverse=rev)
+    assert np.abs(r["x"] - x).max() < 1e-5
+    assert _relmax(r["dx"], g[k + "/dx"]) < GRAD_RTOL
+    assert _relmax(r["dy"], g[k + "/dy"]) < GRAD_RTOL
+    for i, (n, _, _) in enumerate(specs):
+        gr = r["grads"][i]
+        nrm = np.sqrt((gr.astype(np.float64) ** 2).sum())
+        assert abs(nrm - g[k + "/grad_norm"][i]) <= 2e-4 * g[k + "/grad_norm"][i] + 1e-12, n
+        if k + "/grad::" + n in g:
+            assert _relmax(gr, g[k + "/grad::" + n]) < GRAD_RTOL, n
