@@ -1,0 +1,81 @@
+"""ctypes binding of csrc/libwgflow.so (the C ABI declared in include/wgflow.h).
+
+There is NO fallback: if the shared library is missing or a tensor is not on a HIP device the call
+raises.  Build with `python -c "import __graft_entry__ as g; g.build()"` (or `python build.py`).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libwgflow.so")
+_LIB = None
+
+ABI_SYMBOLS = [
+    "wg_strerror", "wg_abi_version", "wg_param_count", "wg_packed_bytes", "wg_workspace_bytes",
+    "wg_wn_param_count", "wg_wn_packed_bytes", "wg_coupling_workspace_bytes", "wg_invconv_workspace_bytes",
+    "wg_workspace_init", "wg_pack_weights", "wg_wn_pack_weights", "wg_forward", "wg_inverse", "wg_backward",
+    "wg_nll_loss", "wg_nll_loss_backward", "wg_invconv_apply", "wg_invconv_backward", "wg_coupling_apply",
+    "wg_coupling_backward", "wg_upsample", "wg_wn_apply",
+]
+
+
+class WgConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n_flows", "n_group", "n_early_every", "n_early_size", "n_mels",
+        "up_stride", "up_kernel", "up_pad", "res_ch", "dil_ch", "skip_ch", "depth", "radix")]
+
+
+class WgWnDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("in_ch", "aux_ch", "res_ch", "dil_ch", "skip_ch", "depth", "radix")]
+
+
+class WgError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise WgError("HIP extension %s is missing -- build it first (python build.py); "
+                      "this package has no CPU or eager fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, sz, i, f = C.c_void_p, C.c_size_t, C.c_int, C.c_float
+    cfgp, wnp = C.POINTER(WgConfig), C.POINTER(WgWnDims)
+    L.wg_strerror.restype = C.c_char_p
+    L.wg_strerror.argtypes = [i]
+    L.wg_abi_version.restype = i
+    L.wg_param_count.argtypes = [cfgp]
+    L.wg_packed_bytes.restype = sz
+    L.wg_packed_bytes.argtypes = [cfgp]
+    L.wg_workspace_bytes.restype = sz
+    L.wg_workspace_bytes.argtypes = [cfgp, i, i, i]
+    L.wg_wn_param_count.argtypes = [wnp]
+    L.wg_wn_packed_bytes.restype = sz
+    L.wg_wn_packed_bytes.argtypes = [wnp]
+    L.wg_coupling_workspace_bytes.restype = sz
+    L.wg_coupling_workspace_bytes.argtypes = [wnp, i, i, i]
+    L.wg_invconv_workspace_bytes.restype = sz
+    L.wg_invconv_workspace_bytes.argtypes = [i, i, i]
+    L.wg_workspace_init.argtypes = [vp, sz, vp]
+    L.wg_pack_weights.argtypes = [cfgp, vp, vp, vp]
+    L.wg_wn_pack_weights.argtypes = [wnp, vp, vp, vp]
+    L.wg_forward.argtypes = [cfgp, vp, vp, vp, i, i, i, vp, vp, vp, sz, vp]
+    L.wg_inverse.argtypes = [cfgp, vp, vp, vp, i, i, i, vp, vp, vp, sz, vp]
+    L.wg_backward.argtypes = [cfgp, vp, vp, vp, vp, vp, vp, i, i, i, vp, vp, vp, vp, vp, sz, vp]
+    L.wg_nll_loss.argtypes = [vp, vp, i, i, f, i, vp, vp]
+    L.wg_nll_loss_backward.argtypes = [vp, i, i, f, i, vp, vp, vp, vp]
+    L.wg_invconv_apply.argtypes = [vp, i, vp, i, i, i, vp, vp, vp, sz, vp]
+    L.wg_invconv_backward.argtypes = [vp, i, vp, vp, vp, i, i, i, vp, vp, vp, vp, sz, vp]
+    L.wg_coupling_apply.argtypes = [wnp, vp, vp, vp, i, i, i, vp, vp, vp, sz, vp]
+    L.wg_coupling_backward.argtypes = [wnp, vp, vp, vp, vp, vp, vp, i, i, i, vp, vp, vp, vp, vp, sz, vp]
+    L.wg_upsample.argtypes = [cfgp, vp, vp, i, i, i, vp, vp]
+    L.wg_wn_apply.argtypes = [wnp, vp, vp, vp, i, i, vp, vp, vp, sz, vp]
+    _LIB = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        raise WgError("%s failed: %s (code %d)" % (what, lib().wg_strerror(rc).decode(), rc))

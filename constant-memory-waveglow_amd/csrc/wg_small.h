@@ -1,0 +1,525 @@
+// wg_small.h -- the HBM-bound / tiny kernels around the two MFMA kernels: squeeze, 1x1 channel mixing,
+// WN.end + affine coupling (+ its backward seed), upsampler, loss, weight packing, gradient finalisation.
+#pragma once
+#include "wg_gemm.h"
+
+#define WG_MAXC 32   // largest invertible-1x1 / end-conv row count handled by the small kernels
+
+// ------------------------------------------------------------------------------------------------
+// squeeze / unsqueeze   (waveglow.py:153,179): X[b][g][t] = audio[b][t*G + g]
+// ------------------------------------------------------------------------------------------------
+__global__ void squeeze_kernel(const float *__restrict__ audio, PRef X, Geo g, int G, int N)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (t >= g.T) return;
+    const float *src = audio + (size_t)b * N + (size_t)t * G;
+    for (int c = 0; c < G; ++c) *paddr(X, g, b, c, t) = src[c];
+}
+__global__ void unsqueeze_kernel(PRef X, float *__restrict__ audio, Geo g, int G, int N)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (t >= g.T) return;
+    float *dst = audio + (size_t)b * N + (size_t)t * G;
+    for (int c = 0; c < G; ++c) dst[c] = *paddr(X, g, b, c, t);
+}
+
+// plain [B][C][T] <-> plane (block-level API and mel planes)
+__global__ void import_kernel(const float *__restrict__ src, PRef X, Geo g, int C)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (t < g.T) *paddr(X, g, b, c, t) = src[((size_t)b * C + c) * g.T + t];
+}
+__global__ void export_kernel(PRef X, float *__restrict__ dst, Geo g, int C, float scale)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (t < g.T) dst[((size_t)b * C + c) * g.T + t] = scale * *paddr(X, g, b, c, t);
+}
+__global__ void fill_rows_kernel(PRef X, Geo g, const float *__restrict__ perb, float cst)
+{   // X[b][c][t] = (perb ? perb[b] : 0) + cst   for t < T
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (t < g.T) *paddr(X, g, b, c, t) = (perb ? perb[b] : 0.f) + cst;
+}
+
+// ------------------------------------------------------------------------------------------------
+// invertible 1x1 conv as an in-place channel mix  (efficient_modules.py:40,53,237,239)
+//   X[ch0+o][t] = sum_i Mx[o][i] * X[ch0+i][t]   (Mx = W, W^-1, W^T ...; `transpose` swaps indices)
+// ------------------------------------------------------------------------------------------------
+template <int C>
+__global__ void mix_kernel(PRef X, const float *__restrict__ Mx, int transpose, Geo g)
+{
+    __shared__ float w[C * C];
+    for (int e = threadIdx.x; e < C * C; e += blockDim.x) {
+        const int o = e / C, i = e % C;
+        w[e] = transpose ? Mx[i * C + o] : Mx[o * C + i];
+    }
+    __syncthreads();
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (t >= g.T) return;
+    float x[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) x[i] = *paddr(X, g, b, i, t);
+#pragma unroll
+    for (int o = 0; o < C; ++o) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < C; ++i) s += w[o * C + i] * x[i];
+        *paddr(X, g, b, o, t) = s;
+    }
+}
+
+// LU (partial pivoting) of each flow's c x c weight: logdet (NaN if det<0, torch.logdet semantics) and inverse.
+// One thread per matrix; c <= WG_MAXC.  out layout per matrix: [W (c*c) | Winv (c*c) | logdet | pad..] stride `ostride`.
+struct LuJob {
+    const float *W;
+    int c;
+};
+#define WG_MAX_FLOWS 64
+struct LuArgs {
+    int n;
+    LuJob job[WG_MAX_FLOWS];
+    float *out;
+    int ostride;
+};
+__global__ void lu_kernel(const LuArgs a)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.n) return;
+    const int c = a.job[k].c;
+    const float *W = a.job[k].W;
+    float *o = a.out + (size_t)k * a.ostride;
+    float *A = o + 2 * WG_MAXC * WG_MAXC + 8;   // scratch copy (LU in place) inside this matrix's slot
+    float *Wi = o + WG_MAXC * WG_MAXC;
+    int perm[WG_MAXC];
+    for (int i = 0; i < c * c; ++i) { o[i] = W[i]; A[i] = W[i]; }
+    for (int i = 0; i < c; ++i) perm[i] = i;
+    int sg = 1;
+    float la = 0.f;
+    for (int q = 0; q < c; ++q) {
+        int p = q;
+        float best = fabsf(A[q * c + q]);
+        for (int r = q + 1; r < c; ++r) {
+            const float v = fabsf(A[r * c + q]);
+            if (v > best) { best = v; p = r; }
+        }
+        if (p != q) {
+            for (int j = 0; j < c; ++j) { const float tmp = A[q * c + j]; A[q * c + j] = A[p * c + j]; A[p * c + j] = tmp; }
+            const int ti = perm[q]; perm[q] = perm[p]; perm[p] = ti;
+            sg = -sg;
+        }
+        const float piv = A[q * c + q];
+        if (piv < 0.f) sg = -sg;
+        la += logf(fabsf(piv));
+        for (int r = q + 1; r < c; ++r) {
+            const float f = A[r * c + q] / piv;
+            A[r * c + q] = f;
+            for (int j = q + 1; j < c; ++j) A[r * c + j] -= f * A[q * c + j];
+        }
+    }
+    float yv[WG_MAXC];
+    for (int col = 0; col < c; ++col) {
+        for (int r = 0; r < c; ++r) {
+            float s = (perm[r] == col) ? 1.f : 0.f;
+            for (int j = 0; j < r; ++j) s -= A[r * c + j] * yv[j];
+            yv[r] = s;
+        }
+        for (int r = c - 1; r >= 0; --r) {
+            float s = yv[r];
+            for (int j = r + 1; j < c; ++j) s -= A[r * c + j] * Wi[j * c + col];
+            Wi[r * c + col] = s / A[r * c + r];
+        }
+    }
+    o[2 * WG_MAXC * WG_MAXC] = sg > 0 ? la : __builtin_nanf("");
+}
+
+// ------------------------------------------------------------------------------------------------
+// WN.end (1x1, skip_ch -> 2*in_ch, waveglow.py:105) fused with the affine coupling
+// (efficient_modules.py:77-96) and, in backward mode, the seed of the WN backward (efficient_modules.py:132-148).
+// One wave computes a [32 rows] x [32 time steps] tile of out = W_end . S straight from global memory
+// (K = skip_ch, rows zero padded to 32); the tile goes through LDS so that log_s[j] and t[j] meet in one thread.
+// ------------------------------------------------------------------------------------------------
+enum { AFF_FWD = 0, AFF_REV = 1, AFF_BWD = 2, AFF_BWD_REV = 3, AFF_RAW = 4 };
+
+struct AffineArgs {
+    const float *endT;      // [Cs][32]  endT[k][m] = W_end[m][k] (m < 2*ic, else 0)
+    PRef S;                 // skip plane
+    int Cs, ic;
+    PRef X;                 // flow state, ch0 = first channel of this flow (xa rows [0,ic), xb rows [ic,2ic))
+    PRef dX;                // gradient plane (BWD modes)
+    PRef Gp;                // G plane (BWD modes): rows [0,ic) = d/dlog_s, [ic,2ic) = d/dt
+    float *log_s_out;       // optional plain [B][ic][T] (block API): +log_s (FWD) or -log_s (REV)
+    float *t_out;           // AFF_RAW only: plain [B][ic][T] t  (WN.forward output, waveglow.py:105)
+    const float *dls_plain; // optional plain [B][ic][T] gradient of the returned log_s (block API, BWD modes)
+    const float *dld;       // optional [B]: gradient of logdet[b] (model level, BWD)
+    float *partial;         // [B][gridDim.x] per-block sums of +-log_s (FWD/REV), nullable
+    Geo g;
+    int mode;
+};
+
+__global__ __launch_bounds__(256) void end_affine_kernel(const AffineArgs a)
+{
+    __shared__ float tile[4][32][33];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, t0 = blockIdx.x * 128 + wave * 32;
+    const Geo g = a.g;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int kh = lane >> 5, r31 = lane & 31;
+    const float *ap = a.endT + kh * 32 + r31;
+    const float *bp = paddr(a.S, g, b, kh, t0 + r31);
+#pragma unroll 8
+    for (int k = 0; k < a.Cs; k += 2) {
+        const float av = ap[(size_t)k * 32];
+        const float bv = bp[(size_t)k * g.P];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile[wave][acc_row(r, lane)][lane & 31] = acc[r];
+    __syncthreads();
+
+    const int ic = a.ic;
+    float lsum = 0.f;
+    for (int e = tid; e < ic * 128; e += 256) {
+        const int j = e >> 7, tl = e & 127, w = tl >> 5, cl = tl & 31;
+        const int t = blockIdx.x * 128 + tl;
+        if (t >= g.T) continue;
+        const float ls = tile[w][j][cl], tt = tile[w][ic + j][cl];
+        if (a.mode == AFF_RAW) {
+            const size_t q = ((size_t)b * ic + j) * g.T + t;
+            a.log_s_out[q] = ls;
+            a.t_out[q] = tt;
+            continue;
+        }
+        float *xbp = paddr(a.X, g, b, ic + j, t);
+        const float xb = *xbp;
+        const size_t pidx = ((size_t)b * ic + j) * g.T + t;
+        if (a.mode == AFF_FWD) {
+            *xbp = xb * expf(ls) + tt;                                   // efficient_modules.py:81 / :110
+            lsum += ls;
+            if (a.log_s_out) a.log_s_out[pidx] = ls;
+        } else if (a.mode == AFF_REV) {
+            *xbp = (xb - tt) / expf(ls);                                 // :94 / :167
+            lsum -= ls;
+            if (a.log_s_out) a.log_s_out[pidx] = -ls;
+        } else if (a.mode == AFF_BWD) {
+            const float sc = expf(ls);
+            const float xr = (xb - tt) / sc;                             // :133-134 rebuild xb from zb
+            *xbp = xr;
+            float *dp = paddr(a.dX, g, b, ic + j, t);
+            const float dzb = *dp;
+            float gl = dzb * xr * sc;                                    // :143-144 grad_outputs
+            if (a.dld) gl += a.dld[b];
+            if (a.dls_plain) gl += a.dls_plain[pidx];
+            *paddr(a.Gp, g, b, j, t) = gl;
+            *paddr(a.Gp, g, b, ic + j, t) = dzb;
+            *dp = dzb * sc;                                              // :147
+        } else {  // AFF_BWD_REV : InvAffineCouplingFunc.backward, X holds the block OUTPUT xo
+            const float sc = expf(ls);
+            const float zb = xb * sc + tt;                               // :194 rebuild zb from xb
+            *xbp = zb;
+            float *dp = paddr(a.dX, g, b, ic + j, t);
+            const float dxb = *dp;
+            float go = dxb * zb / sc;                                    // :202-203
+            if (a.dls_plain) go += a.dls_plain[pidx];
+            *paddr(a.Gp, g, b, j, t) = -go + dxb * tt / sc;
+            *paddr(a.Gp, g, b, ic + j, t) = -dxb / sc;
+            *dp = dxb / sc;                                              // :206
+        }
+    }
+    if (a.partial) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) lsum += __shfl_down(lsum, o, 64);
+        if (lane == 0) red[wave] = lsum;
+        __syncthreads();
+        if (tid == 0) a.partial[(size_t)b * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    }
+}
+
+// logdet[b] = sum_k coef * T * logdetW_k + sum_k sum_tiles partial[k][b][tile]      (waveglow.py:175 / :202)
+__global__ void logdet_finalize_kernel(const float *__restrict__ lu, int ostride, int n_flows, float coef_T,
+                                       const float *__restrict__ partial, int ntile, int B, float *__restrict__ logdet)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float s = 0.f;
+    for (int k = 0; k < n_flows; ++k) {
+        s += coef_T * lu[(size_t)k * ostride + 2 * WG_MAXC * WG_MAXC];
+        const float *p = partial + ((size_t)k * B + b) * ntile;
+        float q = 0.f;
+        for (int i = 0; i < ntile; ++i) q += p[i];
+        s += q;
+    }
+    logdet[b] = s;
+}
+__global__ void scalar_logdet_kernel(const float *lu, float coef_T, float *out) { out[0] = coef_T * lu[2 * WG_MAXC * WG_MAXC]; }
+
+// ------------------------------------------------------------------------------------------------
+// mel upsampler: depthwise ConvTranspose1d (waveglow.py:126-130), cropped to T (waveglow.py:157)
+//   y[c][j] = bias[c] + sum_i h[c][i] * w[c][j + pad - stride*i]
+// ------------------------------------------------------------------------------------------------
+__global__ void upsample_fwd_kernel(const float *__restrict__ h, const float *__restrict__ w, const float *__restrict__ bias,
+                                    PRef Y, float *__restrict__ yplain, Geo g, int C, int F, int K, int S, int Pd)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (j >= g.T) return;
+    float s = bias ? bias[c] : 0.f;
+    int ihi = (j + Pd) / S;
+    if (ihi > F - 1) ihi = F - 1;
+    int ilo = (j + Pd - K + 1 + S - 1);
+    ilo = ilo <= 0 ? 0 : ilo / S;
+    const float *hc = h + ((size_t)b * C + c) * F;
+    for (int i = ilo; i <= ihi; ++i) s += hc[i] * w[c * K + (j + Pd - S * i)];
+    if (Y.p) *paddr(Y, g, b, c, j) = s;
+    if (yplain) yplain[((size_t)b * C + c) * g.T + j] = s;
+}
+
+// one block per mel channel: dbias, dw (then weight-norm backward), optional dh
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float *__restrict__ h, const float *__restrict__ w, PRef dY, Geo g,
+                                                           int C, int F, int K, int S, int Pd,
+                                                           const float *__restrict__ gparam, const float *__restrict__ v,
+                                                           float *__restrict__ dbias, float *__restrict__ dg,
+                                                           float *__restrict__ dv, float *__restrict__ dh)
+{
+    extern __shared__ float sm[];   // [K] dw + [256] scratch
+    float *dw = sm, *red = sm + K;
+    const int c = blockIdx.x, tid = threadIdx.x;
+    // dbias
+    float sb = 0.f;
+    for (int e = tid; e < g.B * g.T; e += 256) sb += *paddr(dY, g, e / g.T, c, e % g.T);
+    red[tid] = sb;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0 && dbias) dbias[c] = red[0];
+    __syncthreads();
+    // dw[kk] = sum_{b,i} h[b,c,i] * dY[b,c,S*i+kk-Pd]
+    for (int kk = tid; kk < K; kk += 256) {
+        float s = 0.f;
+        for (int b = 0; b < g.B; ++b)
+            for (int i = 0; i < F; ++i) {
+                const int j = S * i + kk - Pd;
+                if (j >= 0 && j < g.T) s += h[((size_t)b * C + c) * F + i] * *paddr(dY, g, b, c, j);
+            }
+        dw[kk] = s;
+    }
+    __syncthreads();
+    if (dh)
+        for (int e = tid; e < g.B * F; e += 256) {
+            const int b = e / F, i = e % F;
+            float s = 0.f;
+            for (int kk = 0; kk < K; ++kk) {
+                const int j = S * i + kk - Pd;
+                if (j >= 0 && j < g.T) s += *paddr(dY, g, b, c, j) * w[c * K + kk];
+            }
+            dh[((size_t)b * C + c) * F + i] = s;
+        }
+    // weight-norm backward of row c (utils.py:14-16): serial over K (K ~ 65)
+    if (tid == 0 && dv) {
+        if (gparam) {
+            float ss = 0.f, dot = 0.f;
+            for (int kk = 0; kk < K; ++kk) { const float vv = v[c * K + kk]; ss += vv * vv; dot += dw[kk] * vv; }
+            const float nrm = sqrtf(ss);
+            if (dg) dg[c] = dot / nrm;
+            const float aa = gparam[c] / nrm, bq = dot / ss;
+            for (int kk = 0; kk < K; ++kk) dv[c * K + kk] = aa * (dw[kk] - v[c * K + kk] * bq);
+        } else {
+            for (int kk = 0; kk < K; ++kk) dv[c * K + kk] = dw[kk];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// NLL loss (model/loss.py:10-15)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void nll_loss_kernel(const float *__restrict__ z, const float *__restrict__ logdet, int B, int N,
+                                                        float inv_sigma2, int elementwise_mean, float *__restrict__ loss)
+{
+    __shared__ float red[1024];
+    const int tid = threadIdx.x;
+    float total = 0.f;
+    for (int b = 0; b < B; ++b) {
+        float s = 0.f;
+        for (int n = tid; n < N; n += 1024) { const float v = z[(size_t)b * N + n]; s += v * v; }
+        red[tid] = s;
+        __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+        if (tid == 0) total += 0.5f * red[0] * inv_sigma2 - logdet[b];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        float l = total / (float)B;
+        if (elementwise_mean) l /= (float)N;
+        loss[0] = l;
+    }
+}
+__global__ void nll_loss_bwd_kernel(const float *__restrict__ z, int B, int N, float inv_sigma2, int elementwise_mean,
+                                    const float *__restrict__ dloss, float *__restrict__ dz, float *__restrict__ dlogdet)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float sc = (dloss ? dloss[0] : 1.f) / (float)B;
+    if (elementwise_mean) sc /= (float)N;
+    if (i < (size_t)B * N) dz[i] = z[i] * inv_sigma2 * sc;
+    if (i < (size_t)B) dlogdet[i] = -sc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: effective weights (weight norm, utils.py:14-16) laid out k-major for the MFMA kernels
+// ------------------------------------------------------------------------------------------------
+struct NormJob {
+    const float *g, *v;   // g may be NULL (plain weight): scale = 1
+    float *scale;
+    int rows, cols;
+};
+#define WG_JOBS 40
+struct NormArgs {
+    int n;
+    NormJob job[WG_JOBS];
+};
+// one wave per row
+__global__ void rownorm_kernel(const NormArgs a)
+{
+    const NormJob j = a.job[blockIdx.y];
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= j.rows) return;
+    if (!j.g) { if (lane == 0) j.scale[row] = 1.f; return; }
+    float ss = 0.f;
+    for (int c = lane; c < j.cols; c += 64) { const float x = j.v[(size_t)row * j.cols + c]; ss += x * x; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
+    if (lane == 0) j.scale[row] = j.g[row] / sqrtf(ss);
+}
+
+// dst[k][m] (ld = ldd, Kp x Mp region, zero filled) = scale[o] * src[o*so + i*si + off]
+//   mode 0 ("T"): o = perm(m), i = k      (valid: m < no, k < ni)
+//   mode 1 ("N"): o = k,       i = m      (valid: k < no, m < ni)
+//   perm (gate interleave, only mode 0 with half > 0): 64-blocks [32 tanh rows | 32 sigmoid rows]
+struct PackJob {
+    float *dst;
+    const float *src, *scale;
+    int ldd, Kp, Mp;
+    int mode, no, ni, half;
+    int so, si, off;
+};
+struct PackArgs {
+    int n;
+    PackJob job[WG_JOBS];
+};
+__global__ void pack_kernel(const PackArgs a)
+{
+    const PackJob j = a.job[blockIdx.y];
+    const size_t total = (size_t)j.Kp * j.Mp;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(e / j.Mp), m = (int)(e % j.Mp);
+        float val = 0.f;
+        if (j.mode == 0) {
+            int o = m;
+            if (j.half > 0) {
+                const int q = m >> 6, r = m & 63;
+                o = r < 32 ? q * 32 + r : j.half + q * 32 + (r - 32);
+                if ((q * 32 + (r & 31)) >= j.half) o = -1;
+            }
+            if (o >= 0 && o < j.no && k < j.ni) val = j.scale[o] * j.src[(size_t)o * j.so + (size_t)k * j.si + j.off];
+        } else {
+            if (k < j.no && m < j.ni) val = j.scale[k] * j.src[(size_t)k * j.so + (size_t)m * j.si + j.off];
+        }
+        j.dst[(size_t)k * j.ldd + m] = val;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gradient finalisation: sum the split-K slabs of one weight tensor and apply the weight-norm backward
+//   dw[o][i][r] = sum_s slab[s][o][col0 + r*cr + i*ci]
+//   dg[o] = <dw,v>/||v|| ; dv = g/||v|| (dw - v <dw,v>/||v||^2)      (g == NULL: dv = dw)
+// optionally adds extra[o*I*R + e] * extra_scale  (the W^-T * dlogdet * T term of efficient_modules.py:242)
+// ------------------------------------------------------------------------------------------------
+struct FinJob {
+    const float *slab;
+    int nsplit;
+    size_t sstride;     // Mp*Np
+    int ldn;            // Np
+    int row0;           // first slab row of this tensor
+    int rows, I, R;     // tensor is [rows][I][R]
+    int col0, ci, cr;
+    const float *g, *v;
+    float *dg, *dv;
+    const float *extra; // nullable, [rows][I*R] accessed transposed: extra[e*rows + o]
+    const float *extra_scale_src; // device vector summed over n_extra entries
+    int n_extra;
+    float extra_mul;
+};
+#define WG_FIN_MAXCOLS 8192
+__global__ __launch_bounds__(256) void finalize_kernel(const FinJob j)
+{
+    __shared__ float dw[WG_FIN_MAXCOLS];
+    __shared__ float red[2][256];
+    const int o = blockIdx.x, tid = threadIdx.x;
+    const int cols = j.I * j.R;
+    float esc = 0.f;
+    if (j.extra) {
+        for (int i = 0; i < j.n_extra; ++i) esc += j.extra_scale_src[i];
+        esc *= j.extra_mul;
+    }
+    float dot = 0.f, ss = 0.f;
+    for (int e = tid; e < cols; e += 256) {
+        const int i = e / j.R, r = e % j.R;
+        const size_t off = (size_t)(j.row0 + o) * j.ldn + j.col0 + r * j.cr + i * j.ci;
+        float s = 0.f;
+        for (int sp = 0; sp < j.nsplit; ++sp) s += j.slab[sp * j.sstride + off];
+        if (j.extra) s += j.extra[(size_t)e * j.rows + o] * esc;
+        dw[e] = s;
+        if (j.g) { const float vv = j.v[(size_t)o * cols + e]; dot += s * vv; ss += vv * vv; }
+    }
+    if (!j.g) {
+        for (int e = tid; e < cols; e += 256) j.dv[(size_t)o * cols + e] = dw[e];
+        return;
+    }
+    red[0][tid] = dot; red[1][tid] = ss;
+    __syncthreads();
+    for (int q = 128; q > 0; q >>= 1) {
+        if (tid < q) { red[0][tid] += red[0][tid + q]; red[1][tid] += red[1][tid + q]; }
+        __syncthreads();
+    }
+    dot = red[0][0]; ss = red[1][0];
+    const float nrm = sqrtf(ss);
+    if (tid == 0 && j.dg) j.dg[o] = dot / nrm;
+    const float aa = j.g[o] / nrm, bq = dot / ss;
+    for (int e = tid; e < cols; e += 256) j.dv[(size_t)o * cols + e] = aa * (dw[e] - j.v[(size_t)o * cols + e] * bq);
+}
+
+// InvConv1x1Func.backward tail (efficient_modules.py:276-277): dW = -W^-T dw W^-T - W^-T * dlogdet * T,
+// dw = sum of the split-K slabs.  c <= WG_MAXC, one block.
+struct InvRevFinArgs {
+    const float *slab;
+    int nsplit;
+    size_t sstride;
+    int ldn, c;
+    const float *Winv, *dlogdet;
+    float T;
+    float *dW;
+};
+__global__ __launch_bounds__(256) void invconv_rev_finalize_kernel(const InvRevFinArgs a)
+{
+    __shared__ float dw[WG_MAXC * WG_MAXC], tmp[WG_MAXC * WG_MAXC];
+    const int c = a.c, tid = threadIdx.x;
+    for (int e = tid; e < c * c; e += 256) {
+        const int i = e / c, j = e % c;
+        float s = 0.f;
+        for (int sp = 0; sp < a.nsplit; ++sp) s += a.slab[sp * a.sstride + (size_t)i * a.ldn + j];
+        dw[e] = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < c * c; e += 256) {     // tmp = W^-T dw
+        const int i = e / c, j = e % c;
+        float s = 0.f;
+        for (int k = 0; k < c; ++k) s += a.Winv[k * c + i] * dw[k * c + j];
+        tmp[e] = s;
+    }
+    __syncthreads();
+    const float gl = a.dlogdet[0] * a.T;
+    for (int e = tid; e < c * c; e += 256) {     // -(tmp W^-T) - W^-T gl
+        const int i = e / c, j = e % c;
+        float s = 0.f;
+        for (int k = 0; k < c; ++k) s += tmp[i * c + k] * a.Winv[j * c + k];
+        a.dW[e] = -s - a.Winv[j * c + i] * gl;
+    }
+}

@@ -1,0 +1,1035 @@
+// wgflow.hip -- host side of libwgflow.so: the C ABI of include/wgflow.h on top of the kernels in
+// wg_gemm.h / wg_small.h.  Every function only enqueues kernels on the caller's stream; all device memory
+// comes from the caller (packed-weight buffer + workspace), carved by the deterministic layouts below.
+#include "../../include/wgflow.h"
+#include "wg_small.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+namespace {
+
+inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+inline size_t rupz(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------------
+// launch bookkeeping
+// ------------------------------------------------------------------------------------------------
+struct Ctx {
+    hipStream_t st;
+    int err;
+};
+#define WG_LAUNCH(ctx, kern, grid, block, shmem, ...)                         \
+    do {                                                                      \
+        if ((ctx).err == 0) {                                                 \
+            hipLaunchKernelGGL(kern, grid, block, shmem, (ctx).st, __VA_ARGS__); \
+            if (hipGetLastError() != hipSuccess) (ctx).err = WG_ELAUNCH;      \
+        }                                                                     \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// geometry
+// ------------------------------------------------------------------------------------------------
+struct WnD {
+    int ic, aux, C, Cd, Cs, depth, radix;
+    int auxp() const { return rup(aux, WG_BK); }
+    int wo_rows(int i) const { return i == depth - 1 ? Cs : C + Cs; }
+    int nparams() const { return 4 + 4 * depth + 1; }
+    int maxdil() const { return 1 << (depth - 1); }
+};
+
+Geo make_geo(int B, int T, int halo_need)
+{
+    Geo g;
+    g.B = B;
+    g.T = T;
+    g.Tt = rup(T, WG_TILE);
+    g.H = std::max(16, rup(halo_need, 16));
+    g.P = g.H + g.Tt + g.H;
+    return g;
+}
+
+int wn_check(const WnD &d)
+{
+    if (d.ic < 1 || d.aux < 1 || d.depth < 1 || d.depth > 16) return WG_EINVAL;
+    if (d.radix != 1 && d.radix != 3) return WG_EUNSUPPORTED;            // odd kernels only make sense upstream; 1 and 3 built
+    if (d.C % 32 || d.Cd % 32 || d.Cs % 32) return WG_EUNSUPPORTED;       // MFMA tile granularity
+    if (2 * d.ic > WG_MAXC) return WG_EUNSUPPORTED;                       // end-conv rows handled by one MFMA tile
+    if (d.C * d.radix > WG_FIN_MAXCOLS || d.aux > WG_FIN_MAXCOLS || d.Cd > WG_FIN_MAXCOLS) return WG_EUNSUPPORTED;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// packed weights of one WN (offsets in floats from the WN's base)
+// ------------------------------------------------------------------------------------------------
+struct WnPack {
+    size_t scale_V, scale_start, scale_W[16], scale_Wo[16];
+    size_t startT, startN, endT, endN;
+    size_t Acat[16], WoT[16], WoN[16], WT[16], VN[16];
+    int ld_startT, ld_startN, ld_endN, ld_Acat, ld_WoT[16], ld_WoN, ld_WT, ld_VN;
+    int kp_start, kp_end, kcat;
+    size_t total;
+};
+
+WnPack wn_pack_layout(const WnD &d)
+{
+    WnPack L;
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += rupz(n, 64); return o; };
+    L.scale_V = take((size_t)2 * d.Cd * d.depth);
+    L.scale_start = take(d.C);
+    for (int i = 0; i < d.depth; ++i) { L.scale_W[i] = take(2 * d.Cd); L.scale_Wo[i] = take(d.wo_rows(i)); }
+    L.kp_start = rup(d.ic, WG_BK);
+    L.kp_end = rup(2 * d.ic, WG_BK);
+    L.kcat = d.radix * d.C + d.auxp();
+    L.ld_startT = rup(d.C, WG_TILE);
+    L.ld_startN = rup(d.ic, WG_TILE);
+    L.ld_endN = rup(d.Cs, WG_TILE);
+    L.ld_Acat = rup(2 * d.Cd, WG_TILE);
+    L.ld_WoN = rup(d.Cd, WG_TILE);
+    L.ld_WT = rup(d.C, WG_TILE);
+    L.ld_VN = rup(d.aux, WG_TILE);
+    L.startT = take((size_t)L.kp_start * L.ld_startT);
+    L.startN = take((size_t)d.C * L.ld_startN);
+    L.endT = take((size_t)d.Cs * 32);
+    L.endN = take((size_t)L.kp_end * L.ld_endN);
+    for (int i = 0; i < d.depth; ++i) {
+        L.ld_WoT[i] = rup(d.wo_rows(i), WG_TILE);
+        L.Acat[i] = take((size_t)L.kcat * L.ld_Acat);
+        L.WoT[i] = take((size_t)d.Cd * L.ld_WoT[i]);
+        L.WoN[i] = take((size_t)d.wo_rows(i) * L.ld_WoN);
+        L.WT[i] = take((size_t)d.radix * 2 * d.Cd * L.ld_WT);
+        L.VN[i] = take((size_t)2 * d.Cd * L.ld_VN);
+    }
+    L.total = off;
+    return L;
+}
+
+struct JobBatch {
+    Ctx *ctx;
+    NormArgs na;
+    PackArgs pa;
+    JobBatch(Ctx *c) : ctx(c) { na.n = 0; pa.n = 0; }
+    void norm(const float *g, const float *v, float *scale, int rows, int cols)
+    {
+        if (na.n == WG_JOBS) flush_norm();
+        NormJob &j = na.job[na.n++];
+        j.g = g; j.v = v; j.scale = scale; j.rows = rows; j.cols = cols;
+    }
+    void pack(float *dst, int ldd, int Kp, int Mp, int mode, int no, int ni, int half, const float *src,
+              const float *scale, int so, int si, int off)
+    {
+        if (pa.n == WG_JOBS) flush_pack();
+        PackJob &j = pa.job[pa.n++];
+        j.dst = dst; j.src = src; j.scale = scale; j.ldd = ldd; j.Kp = Kp; j.Mp = Mp; j.mode = mode;
+        j.no = no; j.ni = ni; j.half = half; j.so = so; j.si = si; j.off = off;
+    }
+    void flush_norm()
+    {
+        if (!na.n) return;
+        int maxrows = 0;
+        for (int i = 0; i < na.n; ++i) maxrows = std::max(maxrows, na.job[i].rows);
+        WG_LAUNCH(*ctx, rownorm_kernel, dim3((maxrows + 3) / 4, na.n), dim3(256), 0, na);
+        na.n = 0;
+    }
+    void flush_pack()
+    {
+        if (!pa.n) return;
+        WG_LAUNCH(*ctx, pack_kernel, dim3(64, pa.n), dim3(256), 0, pa);
+        pa.n = 0;
+    }
+};
+
+// params: WN table (nparams entries).  Two passes over the stream: all row norms, then all packs.
+void wn_pack_norms(JobBatch &jb, const WnD &d, const WnPack &L, const float *const *p, float *pk)
+{
+    jb.norm(p[0], p[1], pk + L.scale_V, 2 * d.Cd * d.depth, d.aux);
+    jb.norm(p[2], p[3], pk + L.scale_start, d.C, d.ic);
+    for (int i = 0; i < d.depth; ++i) {
+        jb.norm(p[4 + 4 * i], p[5 + 4 * i], pk + L.scale_W[i], 2 * d.Cd, d.C * d.radix);
+        jb.norm(p[6 + 4 * i], p[7 + 4 * i], pk + L.scale_Wo[i], d.wo_rows(i), d.Cd);
+    }
+}
+void wn_pack_mats(JobBatch &jb, const WnD &d, const WnPack &L, const float *const *p, float *pk, float *ones)
+{
+    const float *vV = p[1], *vS = p[3], *wE = p[4 + 4 * d.depth];
+    // start: src [C][ic]
+    jb.pack(pk + L.startT, L.ld_startT, L.kp_start, L.ld_startT, 0, d.C, d.ic, 0, vS, pk + L.scale_start, d.ic, 1, 0);
+    jb.pack(pk + L.startN, L.ld_startN, d.C, L.ld_startN, 1, d.C, d.ic, 0, vS, pk + L.scale_start, d.ic, 1, 0);
+    // end: src [2ic][Cs], plain weight (scale = ones)
+    jb.pack(pk + L.endT, 32, d.Cs, 32, 0, 2 * d.ic, d.Cs, 0, wE, ones, d.Cs, 1, 0);
+    jb.pack(pk + L.endN, L.ld_endN, L.kp_end, L.ld_endN, 1, 2 * d.ic, d.Cs, 0, wE, ones, d.Cs, 1, 0);
+    for (int i = 0; i < d.depth; ++i) {
+        const float *vW = p[5 + 4 * i], *vWo = p[7 + 4 * i];
+        const int rows = d.wo_rows(i);
+        float *acat = pk + L.Acat[i];
+        for (int kt = 0; kt < d.radix; ++kt)   // rows kt*C.. : A[kt*C + c][perm m] = W[o][c][kt]
+            jb.pack(acat + (size_t)kt * d.C * L.ld_Acat, L.ld_Acat, d.C, L.ld_Acat, 0, 2 * d.Cd, d.C, d.Cd, vW,
+                    pk + L.scale_W[i], d.C * d.radix, d.radix, kt);
+        // conditioning rows: A[radix*C + j][perm m] = V[i*2Cd + o][j]
+        jb.pack(acat + (size_t)d.radix * d.C * L.ld_Acat, L.ld_Acat, d.auxp(), L.ld_Acat, 0, 2 * d.Cd, d.aux, d.Cd,
+                vV + (size_t)i * 2 * d.Cd * d.aux, pk + L.scale_V + (size_t)i * 2 * d.Cd, d.aux, 1, 0);
+        jb.pack(pk + L.WoT[i], L.ld_WoT[i], d.Cd, L.ld_WoT[i], 0, rows, d.Cd, 0, vWo, pk + L.scale_Wo[i], d.Cd, 1, 0);
+        jb.pack(pk + L.WoN[i], L.ld_WoN, rows, L.ld_WoN, 1, rows, d.Cd, 0, vWo, pk + L.scale_Wo[i], d.Cd, 1, 0);
+        for (int kt = 0; kt < d.radix; ++kt)   // A[kt*2Cd + o][c] = W[o][c][kt]
+            jb.pack(pk + L.WT[i] + (size_t)kt * 2 * d.Cd * L.ld_WT, L.ld_WT, 2 * d.Cd, L.ld_WT, 1, 2 * d.Cd, d.C, 0, vW,
+                    pk + L.scale_W[i], d.C * d.radix, d.radix, kt);
+        jb.pack(pk + L.VN[i], L.ld_VN, 2 * d.Cd, L.ld_VN, 1, 2 * d.Cd, d.aux, 0, vV + (size_t)i * 2 * d.Cd * d.aux,
+                pk + L.scale_V + (size_t)i * 2 * d.Cd, d.aux, 1, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// model-level packed layout
+// ------------------------------------------------------------------------------------------------
+#define WG_LU_STRIDE (3 * WG_MAXC * WG_MAXC + 64)
+#define WG_ONES 8192
+
+int flow_channels(const wg_config *cf, int k)
+{
+    int c = cf->n_group;
+    for (int j = 1; j <= k; ++j)
+        if (j % cf->n_early_every == 0) c -= cf->n_early_size;   // waveglow.py:140-142
+    return c;
+}
+WnD flow_wn(const wg_config *cf, int k)
+{
+    WnD d;
+    d.ic = flow_channels(cf, k) / 2;
+    d.aux = cf->n_mels; d.C = cf->res_ch; d.Cd = cf->dil_ch; d.Cs = cf->skip_ch; d.depth = cf->depth; d.radix = cf->radix;
+    return d;
+}
+int wn_table_off(const wg_config *cf, int k) { return 3 + cf->n_flows + k * (4 + 4 * cf->depth + 1); }
+
+struct ModelPack {
+    size_t ones, lu, up_scale, up_w, up_bias, wn[WG_MAX_FLOWS];
+    size_t total;
+};
+ModelPack model_pack_layout(const wg_config *cf)
+{
+    ModelPack L;
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += rupz(n, 64); return o; };
+    L.ones = take(WG_ONES);
+    L.lu = take((size_t)cf->n_flows * WG_LU_STRIDE);
+    L.up_scale = take(cf->n_mels);
+    L.up_w = take((size_t)cf->n_mels * cf->up_kernel);
+    L.up_bias = take(cf->n_mels);
+    for (int k = 0; k < cf->n_flows; ++k) L.wn[k] = take(wn_pack_layout(flow_wn(cf, k)).total);
+    L.total = off;
+    return L;
+}
+
+int cfg_check(const wg_config *cf)
+{
+    if (!cf || cf->n_flows < 1 || cf->n_flows > WG_MAX_FLOWS || cf->n_group < 2 || cf->n_group > WG_MAXC) return WG_EINVAL;
+    if (cf->n_early_every < 1 || cf->n_early_size < 0 || cf->n_mels < 1) return WG_EINVAL;
+    for (int k = 0; k < cf->n_flows; ++k) {
+        const int c = flow_channels(cf, k);
+        if (c < 2 || (c & 1)) return WG_EINVAL;
+        int rc = wn_check(flow_wn(cf, k));
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace
+// ------------------------------------------------------------------------------------------------
+struct WgradPlan {
+    int nts, t_per_split, b_per_split, nsplit;
+};
+WgradPlan plan_wgrad(const Geo &g, int tiles)
+{
+    WgradPlan p;
+    const int target = 1024;
+    p.nts = 1;
+    p.b_per_split = 1;
+    const int blocks = tiles * g.B;
+    if (blocks < target) {
+        p.nts = std::min(std::max(1, g.Tt / 256), (target + blocks - 1) / blocks);
+    } else {
+        while (tiles * ((g.B + p.b_per_split - 1) / p.b_per_split) > 2 * target && p.b_per_split < g.B) p.b_per_split *= 2;
+    }
+    p.t_per_split = rup((g.Tt + p.nts - 1) / p.nts, WG_WBK);
+    p.nts = (g.Tt + p.t_per_split - 1) / p.t_per_split;
+    p.nsplit = ((g.B + p.b_per_split - 1) / p.b_per_split) * p.nts;
+    return p;
+}
+size_t slab_floats(const Geo &g, int Mp, int Np)
+{
+    const WgradPlan p = plan_wgrad(g, (Mp / WG_TILE) * (Np / WG_TILE));
+    return (size_t)p.nsplit * Mp * Np;
+}
+
+struct WnWs {               // plane bases (float offsets) of one WN's activations
+    size_t H[16], tw[16], sf[16], gate[16], skip, G, dS, dH, dxy, slab;
+    int nH;                 // 2 (ping-pong) or depth
+    size_t slab_floats;
+};
+struct Bump {
+    size_t off = 0;
+    size_t take(size_t n) { size_t o = off; off += rupz(n, 64); return o; }
+};
+void wn_ws_layout(Bump &bp, const WnD &d, int ic_max, const Geo &g, int mode, WnWs &w)
+{
+    const size_t pC = (size_t)g.B * d.C * g.P, pD = (size_t)g.B * d.Cd * g.P, pS = (size_t)g.B * d.Cs * g.P;
+    w.nH = mode ? d.depth : 2;
+    for (int i = 0; i < w.nH; ++i) w.H[i] = bp.take(pC);
+    for (int i = 0; i < d.depth; ++i) {
+        w.gate[i] = (mode || i == 0) ? bp.take(pD) : w.gate[0];
+        w.tw[i] = mode ? bp.take(pD) : 0;
+        w.sf[i] = mode ? bp.take(pD) : 0;
+    }
+    w.skip = bp.take(pS);
+    w.slab_floats = 0;
+    if (mode) {
+        w.G = bp.take((size_t)g.B * rup(2 * ic_max, WG_BK) * g.P);
+        w.dS = bp.take(pS);
+        w.dH = bp.take(pC);
+        w.dxy = bp.take(2 * pD);
+        size_t s = 0;
+        const int nW = rup(d.radix * rup(d.C, 32) + rup(d.aux, 32), WG_TILE);
+        s = std::max(s, slab_floats(g, rup(2 * d.Cd, WG_TILE), nW));
+        s = std::max(s, slab_floats(g, rup(d.C + d.Cs, WG_TILE), rup(d.Cd, WG_TILE)));
+        s = std::max(s, slab_floats(g, WG_TILE, rup(d.Cs, WG_TILE)));
+        s = std::max(s, slab_floats(g, rup(d.C, WG_TILE), WG_TILE));
+        s = std::max(s, slab_floats(g, WG_TILE, WG_TILE));
+        w.slab_floats = s;
+        w.slab = bp.take(s);
+    }
+}
+
+struct ModelWs {
+    Geo g;
+    int Gp, auxp, ntile;
+    size_t X, dX, Y, dY, partial, total;
+    WnWs wn;
+};
+ModelWs model_ws_layout(const wg_config *cf, int B, int T, int mode)
+{
+    ModelWs w;
+    const WnD d0 = flow_wn(cf, 0);
+    w.g = make_geo(B, T, d0.maxdil() * (d0.radix - 1) / 2);
+    w.Gp = rup(cf->n_group, WG_BK) + WG_BK;
+    w.auxp = d0.auxp();
+    w.ntile = w.g.Tt / 128;
+    Bump bp;
+    w.X = bp.take((size_t)B * w.Gp * w.g.P);
+    w.Y = bp.take((size_t)B * w.auxp * w.g.P);
+    w.partial = bp.take((size_t)cf->n_flows * B * w.ntile);
+    w.dX = w.dY = 0;
+    if (mode) {
+        w.dX = bp.take((size_t)B * w.Gp * w.g.P);
+        w.dY = bp.take((size_t)B * w.auxp * w.g.P);
+    }
+    wn_ws_layout(bp, d0, cf->n_group / 2, w.g, mode, w.wn);
+    w.total = bp.off + 4096;   // slack
+    return w;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel drivers
+// ------------------------------------------------------------------------------------------------
+PRef pref(float *p, int Cp, int ch0 = 0) { PRef r; r.p = p; r.Cp = Cp; r.ch0 = ch0; return r; }
+PRef pnull() { PRef r; r.p = nullptr; r.Cp = 0; r.ch0 = 0; return r; }
+
+struct SegSpec {
+    const float *src;
+    int Cp, ch0, nch, shift;
+};
+
+void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const SegSpec *segs, int nseg, int epi,
+                  PRef out0, PRef out1, PRef out2, PRef aux0, PRef aux1, int nsplit, int accumulate)
+{
+    ConvGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.A = A; a.lda = lda; a.M = M; a.nseg = nseg;
+    for (int s = 0; s < nseg; ++s) {
+        a.seg[s].src = segs[s].src; a.seg[s].Cp = segs[s].Cp; a.seg[s].ch0 = segs[s].ch0;
+        a.seg[s].nch = segs[s].nch; a.seg[s].shift = segs[s].shift;
+    }
+    a.g = g; a.epi = epi; a.nsplit = nsplit; a.accumulate = accumulate;
+    a.out0 = out0; a.out1 = out1; a.out2 = out2; a.aux0 = aux0; a.aux1 = aux1;
+    const int mrows = epi == EPI_GATE ? M : M;
+    dim3 grid(g.Tt / WG_TILE, rup(mrows, WG_TILE) / WG_TILE, g.B), block(256);
+    switch (epi) {
+    case EPI_STORE: WG_LAUNCH(cx, convgemm_kernel<EPI_STORE>, grid, block, 0, a); break;
+    case EPI_GATE: WG_LAUNCH(cx, convgemm_kernel<EPI_GATE>, grid, block, 0, a); break;
+    case EPI_RESSKIP: WG_LAUNCH(cx, convgemm_kernel<EPI_RESSKIP>, grid, block, 0, a); break;
+    case EPI_DGATE: WG_LAUNCH(cx, convgemm_kernel<EPI_DGATE>, grid, block, 0, a); break;
+    }
+}
+
+struct WSegSpec {
+    const float *src;
+    int Cp, ch0, nch, shift;
+};
+// returns the plan used (finalize needs nsplit / strides)
+struct WgradOut {
+    int nsplit, Mp, Np;
+};
+WgradOut run_wgrad(Ctx &cx, const Geo &g, const WSegSpec *sa, int nsa, const WSegSpec *sb, int nsb, float *slab, size_t slab_cap)
+{
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nseg_a = nsa; a.nseg_b = nsb;
+    int blk = 0;
+    for (int s = 0; s < nsa; ++s) {
+        a.sa[s].src = sa[s].src; a.sa[s].Cp = sa[s].Cp; a.sa[s].ch0 = sa[s].ch0; a.sa[s].nch = sa[s].nch;
+        a.sa[s].shift = 0; a.sa[s].blk0 = blk;
+        blk += rup(sa[s].nch, 32) / 32;
+    }
+    a.Mp = rup(blk * 32, WG_TILE);
+    blk = 0;
+    for (int s = 0; s < nsb; ++s) {
+        a.sb[s].src = sb[s].src; a.sb[s].Cp = sb[s].Cp; a.sb[s].ch0 = sb[s].ch0; a.sb[s].nch = sb[s].nch;
+        a.sb[s].shift = sb[s].shift; a.sb[s].blk0 = blk;
+        blk += rup(sb[s].nch, 32) / 32;
+    }
+    a.Np = rup(blk * 32, WG_TILE);
+    a.g = g;
+    const WgradPlan p = plan_wgrad(g, (a.Mp / WG_TILE) * (a.Np / WG_TILE));
+    a.t_per_split = p.t_per_split; a.nts = p.nts; a.b_per_split = p.b_per_split;
+    a.slab = slab;
+    WgradOut o;
+    o.nsplit = p.nsplit; o.Mp = a.Mp; o.Np = a.Np;
+    if ((size_t)p.nsplit * a.Mp * a.Np > slab_cap) { if (!cx.err) cx.err = WG_EWORKSPACE; return o; }
+    dim3 grid(a.Np / WG_TILE, a.Mp / WG_TILE, p.nsplit), block(256);
+    WG_LAUNCH(cx, wgrad_kernel, grid, block, 0, a);
+    return o;
+}
+
+void run_finalize(Ctx &cx, const float *slab, const WgradOut &wo, int row0, int rows, int I, int R, int col0, int ci, int cr,
+                  const float *gp, const float *vp, float *dg, float *dv,
+                  const float *extra = nullptr, const float *esrc = nullptr, int n_extra = 0, float emul = 0.f)
+{
+    if (!dv) return;
+    FinJob j;
+    j.slab = slab; j.nsplit = wo.nsplit; j.sstride = (size_t)wo.Mp * wo.Np; j.ldn = wo.Np; j.row0 = row0;
+    j.rows = rows; j.I = I; j.R = R; j.col0 = col0; j.ci = ci; j.cr = cr;
+    j.g = gp; j.v = vp; j.dg = dg; j.dv = dv;
+    j.extra = extra; j.extra_scale_src = esrc; j.n_extra = n_extra; j.extra_mul = emul;
+    WG_LAUNCH(cx, finalize_kernel, dim3(rows), dim3(256), 0, j);
+}
+
+void run_mix(Ctx &cx, const Geo &g, PRef X, int c, const float *Mx, int transpose)
+{
+    dim3 grid((g.T + 255) / 256, g.B), block(256);
+    switch (c) {
+#define WG_MIX_CASE(CC) case CC: WG_LAUNCH(cx, mix_kernel<CC>, grid, block, 0, X, Mx, transpose, g); break;
+        WG_MIX_CASE(2) WG_MIX_CASE(4) WG_MIX_CASE(6) WG_MIX_CASE(8) WG_MIX_CASE(10) WG_MIX_CASE(12)
+        WG_MIX_CASE(14) WG_MIX_CASE(16) WG_MIX_CASE(20) WG_MIX_CASE(24) WG_MIX_CASE(28) WG_MIX_CASE(32)
+#undef WG_MIX_CASE
+    default: if (!cx.err) cx.err = WG_EUNSUPPORTED;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// WN on planes
+// ------------------------------------------------------------------------------------------------
+struct WnRun {
+    WnD d;
+    WnPack L;
+    const float *pk;     // packed weights of this WN
+    Geo g;
+    float *ws;           // workspace base
+    WnWs w;
+    PRef X;              // flow state at ch0 = first channel of this flow
+    const float *Y;      // aux plane base (auxp rows per item)
+    int save;            // keep all layers (backward) or ping-pong
+};
+
+void wn_forward(Ctx &cx, const WnRun &r)
+{
+    const WnD &d = r.d;
+    const Geo &g = r.g;
+    float *ws = r.ws;
+    const int mid = (d.radix - 1) / 2;
+    SegSpec s0 = {r.X.p, r.X.Cp, r.X.ch0, r.L.kp_start, 0};
+    run_convgemm(cx, g, r.pk + r.L.startT, r.L.ld_startT, d.C, &s0, 1, EPI_STORE, pref(ws + r.w.H[0], d.C), pnull(), pnull(),
+                 pnull(), pnull(), 0, 0);                                                       // waveglow.py:99
+    for (int i = 0; i < d.depth; ++i) {
+        const int dil = 1 << i;
+        float *Hin = ws + r.w.H[r.save ? i : (i & 1)];
+        float *Hout = ws + r.w.H[r.save ? std::min(i + 1, d.depth - 1) : ((i + 1) & 1)];
+        float *gate = ws + r.w.gate[r.save ? i : 0];
+        SegSpec sg[WG_MAX_SEG];
+        int ns = 0;
+        for (int kt = 0; kt < d.radix; ++kt) sg[ns++] = {Hin, d.C, 0, d.C, (kt - mid) * dil};
+        sg[ns++] = {r.Y, d.auxp(), 0, d.auxp(), 0};
+        run_convgemm(cx, g, r.pk + r.L.Acat[i], r.L.ld_Acat, 2 * d.Cd, sg, ns, EPI_GATE, pref(gate, d.Cd),
+                     r.save ? pref(ws + r.w.tw[i], d.Cd) : pnull(), r.save ? pref(ws + r.w.sf[i], d.Cd) : pnull(),
+                     pnull(), pnull(), 0, 0);                                                   // waveglow.py:42-44
+        SegSpec so = {gate, d.Cd, 0, d.Cd, 0};
+        const int last = i == d.depth - 1;
+        run_convgemm(cx, g, r.pk + r.L.WoT[i], r.L.ld_WoT[i], d.wo_rows(i), &so, 1, EPI_RESSKIP, pref(Hout, d.C),
+                     pref(ws + r.w.skip, d.Cs), pnull(), pref(Hin, d.C), pnull(), last ? 0 : d.C, i > 0);   // :45-46,104
+    }
+}
+
+// fused WN.end + coupling (mode AFF_*)
+void run_end_affine(Ctx &cx, const WnRun &r, int mode, PRef dX, float *log_s_out, const float *dls_plain, const float *dld,
+                    float *partial)
+{
+    AffineArgs a;
+    memset(&a, 0, sizeof(a));
+    a.endT = r.pk + r.L.endT;
+    a.S = pref(r.ws + r.w.skip, r.d.Cs);
+    a.Cs = r.d.Cs; a.ic = r.d.ic;
+    a.X = r.X; a.dX = dX;
+    a.Gp = pref(r.ws + r.w.G, r.L.kp_end);
+    a.log_s_out = log_s_out; a.dls_plain = dls_plain; a.dld = dld; a.partial = partial;
+    a.g = r.g; a.mode = mode;
+    WG_LAUNCH(cx, end_affine_kernel, dim3(r.g.Tt / 128, r.g.B), dim3(256), 0, a);
+}
+
+// backward through WN given the G plane (what autograd.grad at efficient_modules.py:143 evaluates).
+// p/grads: this WN's parameter / gradient tables.  dX: gradient plane at the same ch0 as r.X (dxa accumulates into it).
+void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *grads, PRef dX, float *dY)
+{
+    const WnD &d = r.d;
+    const Geo &g = r.g;
+    float *ws = r.ws;
+    const int mid = (d.radix - 1) / 2, nd = d.depth;
+    float *slab = ws + r.w.slab;
+    const size_t cap = r.w.slab_floats;
+    float *G = ws + r.w.G, *dS = ws + r.w.dS, *dH = ws + r.w.dH, *dxy = ws + r.w.dxy, *skip = ws + r.w.skip;
+    const int Gc = r.L.kp_end;
+    // end: dW_end = sum G (x) S ; dS = W_end^T G
+    {
+        WSegSpec sa = {G, Gc, 0, 2 * d.ic, 0}, sb = {skip, d.Cs, 0, d.Cs, 0};
+        WgradOut wo = run_wgrad(cx, g, &sa, 1, &sb, 1, slab, cap);
+        run_finalize(cx, slab, wo, 0, 2 * d.ic, d.Cs, 1, 0, 1, 0, nullptr, nullptr, nullptr, grads[4 + 4 * nd]);
+        SegSpec s = {G, Gc, 0, Gc, 0};
+        run_convgemm(cx, g, r.pk + r.L.endN, r.L.ld_endN, d.Cs, &s, 1, EPI_STORE, pref(dS, d.Cs), pnull(), pnull(), pnull(), pnull(), 0, 0);
+    }
+    for (int i = nd - 1; i >= 0; --i) {
+        const int dil = 1 << i, rows = d.wo_rows(i), last = i == nd - 1;
+        float *Hi = ws + r.w.H[i], *gate = ws + r.w.gate[i];
+        // dW_o = sum do (x) gate,  do = last ? dS : cat(dh_{i+1}, dS)
+        {
+            WSegSpec sa[2];
+            int nsa = 0;
+            if (!last) sa[nsa++] = {dH, d.C, 0, d.C, 0};
+            sa[nsa++] = {dS, d.Cs, 0, d.Cs, 0};
+            WSegSpec sb = {gate, d.Cd, 0, d.Cd, 0};
+            WgradOut wo = run_wgrad(cx, g, sa, nsa, &sb, 1, slab, cap);
+            run_finalize(cx, slab, wo, 0, rows, d.Cd, 1, 0, 1, 0, p[6 + 4 * i], p[7 + 4 * i], grads[6 + 4 * i], grads[7 + 4 * i]);
+        }
+        // dgate = W_o^T do  ->  dxy (gate backward, waveglow.py:13-15)
+        {
+            SegSpec s[2];
+            int ns = 0;
+            if (!last) s[ns++] = {dH, d.C, 0, d.C, 0};
+            s[ns++] = {dS, d.Cs, 0, d.Cs, 0};
+            run_convgemm(cx, g, r.pk + r.L.WoN[i], r.L.ld_WoN, d.Cd, s, ns, EPI_DGATE, pref(dxy, 2 * d.Cd), pnull(), pnull(),
+                         pref(ws + r.w.tw[i], d.Cd), pref(ws + r.w.sf[i], d.Cd), d.Cd, 0);
+        }
+        // dW (taps) and dV (conditioning) in one wgrad
+        {
+            WSegSpec sa = {dxy, 2 * d.Cd, 0, 2 * d.Cd, 0};
+            WSegSpec sb[WG_MAX_SEG];
+            int nsb = 0;
+            for (int kt = 0; kt < d.radix; ++kt) sb[nsb++] = {Hi, d.C, 0, d.C, (kt - mid) * dil};
+            sb[nsb++] = {r.Y, d.auxp(), 0, d.aux, 0};
+            WgradOut wo = run_wgrad(cx, g, &sa, 1, sb, nsb, slab, cap);
+            const int C32 = rup(d.C, 32);
+            run_finalize(cx, slab, wo, 0, 2 * d.Cd, d.C, d.radix, 0, 1, C32, p[4 + 4 * i], p[5 + 4 * i], grads[4 + 4 * i], grads[5 + 4 * i]);
+            const size_t ro = (size_t)i * 2 * d.Cd;
+            run_finalize(cx, slab, wo, 0, 2 * d.Cd, d.aux, 1, d.radix * C32, 1, 0, p[0] ? p[0] + ro : nullptr, p[1] + ro * d.aux,
+                         grads[0] ? grads[0] + ro : nullptr, grads[1] ? grads[1] + ro * d.aux : nullptr);
+        }
+        // dy += V_i^T dxy
+        if (dY) {
+            SegSpec s = {dxy, 2 * d.Cd, 0, 2 * d.Cd, 0};
+            run_convgemm(cx, g, r.pk + r.L.VN[i], r.L.ld_VN, d.aux, &s, 1, EPI_STORE, pref(dY, d.auxp()), pnull(), pnull(),
+                         pref(dY, d.auxp()), pnull(), 0, 0);
+        }
+        // dh_i = (last ? 0 : dh_{i+1}) + sum_k W[:,:,k]^T dxy[t - (k-mid) d]
+        {
+            SegSpec s[WG_MAX_SEG];
+            int ns = 0;
+            for (int kt = 0; kt < d.radix; ++kt) s[ns++] = {dxy, 2 * d.Cd, 0, 2 * d.Cd, -(kt - mid) * dil};
+            run_convgemm(cx, g, r.pk + r.L.WT[i], r.L.ld_WT, d.C, s, ns, EPI_STORE, pref(dH, d.C), pnull(), pnull(),
+                         last ? pnull() : pref(dH, d.C), pnull(), 0, 0);
+        }
+    }
+    // start: dW_start = sum dh_0 (x) xa ; dxa += W_start^T dh_0
+    {
+        WSegSpec sa = {dH, d.C, 0, d.C, 0}, sb = {r.X.p, r.X.Cp, r.X.ch0, d.ic, 0};
+        WgradOut wo = run_wgrad(cx, g, &sa, 1, &sb, 1, slab, cap);
+        run_finalize(cx, slab, wo, 0, d.C, d.ic, 1, 0, 1, 0, p[2], p[3], grads[2], grads[3]);
+        SegSpec s = {dH, d.C, 0, d.C, 0};
+        run_convgemm(cx, g, r.pk + r.L.startN, r.L.ld_startN, d.ic, &s, 1, EPI_STORE, dX, pnull(), pnull(), dX, pnull(), 0, 0);
+    }
+}
+
+void run_upsample(Ctx &cx, const wg_config *cf, const float *w, const float *bias, const float *h, int F, const Geo &g,
+                  PRef Y, float *yplain)
+{
+    WG_LAUNCH(cx, upsample_fwd_kernel, dim3((g.T + 255) / 256, cf->n_mels, g.B), dim3(256), 0, h, w, bias, Y, yplain, g,
+              cf->n_mels, F, cf->up_kernel, cf->up_stride, cf->up_pad);
+}
+
+int shape_check(const wg_config *cf, int B, int N, int F, int *T)
+{
+    if (B < 1 || N < 1 || F < 1) return WG_EINVAL;
+    if (N % cf->n_group) return WG_ESHAPE;
+    *T = N / cf->n_group;
+    const long L = (long)(F - 1) * cf->up_stride - 2 * cf->up_pad + cf->up_kernel;
+    if (*T > L) return WG_ESHAPE;                      // assert x.size(2) <= y.size(2)   waveglow.py:156,187
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+const char *wg_strerror(int code)
+{
+    switch (code) {
+    case WG_OK: return "ok";
+    case WG_EINVAL: return "invalid argument";
+    case WG_ESHAPE: return "shape mismatch (audio length % n_group != 0, or mel shorter than audio)";
+    case WG_EUNSUPPORTED: return "configuration not supported by the HIP kernels";
+    case WG_ELAUNCH: return "HIP kernel launch failed";
+    case WG_EWORKSPACE: return "workspace too small";
+    }
+    return "unknown error";
+}
+int wg_abi_version(void) { return 1; }
+
+int wg_param_count(const wg_config *cf) { return cf ? 3 + cf->n_flows + cf->n_flows * (4 + 4 * cf->depth + 1) : WG_EINVAL; }
+size_t wg_packed_bytes(const wg_config *cf) { return cfg_check(cf) ? 0 : model_pack_layout(cf).total * sizeof(float); }
+size_t wg_workspace_bytes(const wg_config *cf, int B, int N, int mode)
+{
+    if (cfg_check(cf) || B < 1 || N < 1 || N % cf->n_group) return 0;
+    return model_ws_layout(cf, B, N / cf->n_group, mode).total * sizeof(float);
+}
+int wg_workspace_init(void *ws, size_t bytes, void *stream)
+{
+    return hipMemsetAsync(ws, 0, bytes, (hipStream_t)stream) == hipSuccess ? WG_OK : WG_ELAUNCH;
+}
+
+static WnD wnd_from(const wg_wn_dims *d)
+{
+    WnD w;
+    w.ic = d->in_ch; w.aux = d->aux_ch; w.C = d->res_ch; w.Cd = d->dil_ch; w.Cs = d->skip_ch; w.depth = d->depth; w.radix = d->radix;
+    return w;
+}
+int wg_wn_param_count(const wg_wn_dims *d) { return d ? 4 + 4 * d->depth + 1 : WG_EINVAL; }
+size_t wg_wn_packed_bytes(const wg_wn_dims *d)
+{
+    if (!d || wn_check(wnd_from(d))) return 0;
+    return (rupz(WG_ONES, 64) + wn_pack_layout(wnd_from(d)).total) * sizeof(float);
+}
+
+int wg_wn_pack_weights(const wg_wn_dims *dd, const void *const *params, void *packed, void *stream)
+{
+    if (!dd || !params || !packed) return WG_EINVAL;
+    const WnD d = wnd_from(dd);
+    int rc = wn_check(d);
+    if (rc) return rc;
+    Ctx cx = {(hipStream_t)stream, 0};
+    float *pk = (float *)packed;
+    float *ones = pk;
+    float *wn = pk + rupz(WG_ONES, 64);
+    const WnPack L = wn_pack_layout(d);
+    WG_LAUNCH(cx, fill_rows_kernel, dim3(WG_ONES / 256, 1, 1), dim3(256), 0, pref(ones, 1), Geo{1, WG_ONES, WG_ONES, 0, WG_ONES}, (const float *)nullptr, 1.0f);
+    JobBatch jb(&cx);
+    wn_pack_norms(jb, d, L, (const float *const *)params, wn);
+    jb.flush_norm();
+    wn_pack_mats(jb, d, L, (const float *const *)params, wn, ones);
+    jb.flush_pack();
+    return cx.err;
+}
+
+int wg_pack_weights(const wg_config *cf, const void *const *params, void *packed, void *stream)
+{
+    int rc = cfg_check(cf);
+    if (rc) return rc;
+    if (!params || !packed) return WG_EINVAL;
+    Ctx cx = {(hipStream_t)stream, 0};
+    const float *const *p = (const float *const *)params;
+    float *pk = (float *)packed;
+    const ModelPack M = model_pack_layout(cf);
+    float *ones = pk + M.ones;
+    WG_LAUNCH(cx, fill_rows_kernel, dim3(WG_ONES / 256, 1, 1), dim3(256), 0, pref(ones, 1), Geo{1, WG_ONES, WG_ONES, 0, WG_ONES}, (const float *)nullptr, 1.0f);
+    // 1x1 weights: LU -> logdet, inverse   (efficient_modules.py:221,235)
+    LuArgs lu;
+    lu.n = cf->n_flows; lu.out = pk + M.lu; lu.ostride = WG_LU_STRIDE;
+    for (int k = 0; k < cf->n_flows; ++k) { lu.job[k].W = p[3 + k]; lu.job[k].c = flow_channels(cf, k); }
+    WG_LAUNCH(cx, lu_kernel, dim3((cf->n_flows + 63) / 64), dim3(64), 0, lu);
+    JobBatch jb(&cx);
+    jb.norm(p[1], p[2], pk + M.up_scale, cf->n_mels, cf->up_kernel);
+    for (int k = 0; k < cf->n_flows; ++k) {
+        const WnD d = flow_wn(cf, k);
+        wn_pack_norms(jb, d, wn_pack_layout(d), p + wn_table_off(cf, k), pk + M.wn[k]);
+    }
+    jb.flush_norm();
+    jb.pack(pk + M.up_w, cf->up_kernel, cf->n_mels, cf->up_kernel, 1, cf->n_mels, cf->up_kernel, 0, p[2], pk + M.up_scale, cf->up_kernel, 1, 0);
+    jb.pack(pk + M.up_bias, cf->n_mels, 1, cf->n_mels, 1, 1, cf->n_mels, 0, p[0], ones, cf->n_mels, 1, 0);
+    for (int k = 0; k < cf->n_flows; ++k) {
+        const WnD d = flow_wn(cf, k);
+        wn_pack_mats(jb, d, wn_pack_layout(d), p + wn_table_off(cf, k), pk + M.wn[k], ones);
+    }
+    jb.flush_pack();
+    return cx.err;
+}
+
+// ---- model level -------------------------------------------------------------------------------
+
+static int model_run_fwd_or_inv(const wg_config *cf, const void *packed, const float *in, const float *h,
+                                int B, int N, int F, int inverse, float *out, float *logdet, void *wsv, size_t ws_bytes, void *stream)
+{
+    int rc = cfg_check(cf);
+    if (rc) return rc;
+    int T;
+    rc = shape_check(cf, B, N, F, &T);
+    if (rc) return rc;
+    if (!packed || !in || !h || !out || !logdet || !wsv) return WG_EINVAL;
+    const ModelWs W = model_ws_layout(cf, B, T, 0);
+    if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
+    Ctx cx = {(hipStream_t)stream, 0};
+    const float *pk = (const float *)packed;
+    const ModelPack M = model_pack_layout(cf);
+    float *ws = (float *)wsv;
+    const Geo g = W.g;
+    const int G = cf->n_group;
+    PRef X = pref(ws + W.X, W.Gp);
+    WG_LAUNCH(cx, squeeze_kernel, dim3((T + 255) / 256, B), dim3(256), 0, in, X, g, G, N);           // waveglow.py:153 / :184
+    run_upsample(cx, cf, pk + M.up_w, pk + M.up_bias, h, F, g, pref(ws + W.Y, W.auxp), nullptr);                // :151,157
+    float *partial = ws + W.partial;
+    WnRun r;
+    r.g = g; r.ws = ws; r.w = W.wn; r.Y = ws + W.Y; r.save = 0;
+    if (!inverse) {
+        int base = 0;
+        for (int k = 0; k < cf->n_flows; ++k) {
+            if (k % cf->n_early_every == 0 && k) base += cf->n_early_size;                            // :164-170
+            const int c = flow_channels(cf, k);
+            const float *lu = pk + M.lu + (size_t)k * WG_LU_STRIDE;
+            PRef Xk = pref(ws + W.X, W.Gp, base);
+            run_mix(cx, g, Xk, c, lu, 0);                                                             // :172
+            r.d = flow_wn(cf, k); r.L = wn_pack_layout(r.d); r.pk = pk + M.wn[k]; r.X = Xk;
+            wn_forward(cx, r);
+            run_end_affine(cx, r, AFF_FWD, pnull(), nullptr, nullptr, nullptr, partial + (size_t)k * B * W.ntile);   // :173
+        }
+    } else {
+        int base = G - flow_channels(cf, cf->n_flows - 1);
+        for (int k = cf->n_flows - 1; k >= 0; --k) {
+            const int c = flow_channels(cf, k);
+            const float *lu = pk + M.lu + (size_t)k * WG_LU_STRIDE;
+            PRef Xk = pref(ws + W.X, W.Gp, base);
+            r.d = flow_wn(cf, k); r.L = wn_pack_layout(r.d); r.pk = pk + M.wn[k]; r.X = Xk;
+            wn_forward(cx, r);
+            run_end_affine(cx, r, AFF_REV, pnull(), nullptr, nullptr, nullptr, partial + (size_t)k * B * W.ntile);   // :199
+            run_mix(cx, g, Xk, c, lu + WG_MAXC * WG_MAXC, 0);                                          // :200
+            if (k % cf->n_early_every == 0 && k) base -= cf->n_early_size;                             // :204-205
+        }
+    }
+    WG_LAUNCH(cx, unsqueeze_kernel, dim3((T + 255) / 256, B), dim3(256), 0, X, out, g, G, N);          // :179 / :207
+    WG_LAUNCH(cx, logdet_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, pk + M.lu, WG_LU_STRIDE, cf->n_flows,
+              inverse ? -(float)T : (float)T, partial, W.ntile, B, logdet);                            // :175 / :202
+    return cx.err;
+}
+
+int wg_forward(const wg_config *cf, const void *packed, const float *audio, const float *h, int B, int N, int F,
+               float *z, float *logdet, void *ws, size_t ws_bytes, void *stream)
+{
+    return model_run_fwd_or_inv(cf, packed, audio, h, B, N, F, 0, z, logdet, ws, ws_bytes, stream);
+}
+int wg_inverse(const wg_config *cf, const void *packed, const float *z, const float *h, int B, int N, int F,
+               float *x, float *logdet, void *ws, size_t ws_bytes, void *stream)
+{
+    return model_run_fwd_or_inv(cf, packed, z, h, B, N, F, 1, x, logdet, ws, ws_bytes, stream);
+}
+
+
+int wg_backward(const wg_config *cf, const void *const *params, const void *packed, const float *z, const float *h,
+                const float *dz, const float *dlogdet, int B, int N, int F, void *const *grads, float *dh, float *dx,
+                float *x_rebuilt, void *wsv, size_t ws_bytes, void *stream)
+{
+    int rc = cfg_check(cf);
+    if (rc) return rc;
+    int T;
+    rc = shape_check(cf, B, N, F, &T);
+    if (rc) return rc;
+    if (!params || !packed || !z || !h || !dz || !dlogdet || !grads || !wsv) return WG_EINVAL;
+    const ModelWs W = model_ws_layout(cf, B, T, 1);
+    if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
+    Ctx cx = {(hipStream_t)stream, 0};
+    const float *pk = (const float *)packed;
+    const float *const *p = (const float *const *)params;
+    float *const *gr = (float *const *)grads;
+    const ModelPack M = model_pack_layout(cf);
+    float *ws = (float *)wsv;
+    const Geo g = W.g;
+    const int G = cf->n_group;
+    PRef X = pref(ws + W.X, W.Gp), dX = pref(ws + W.dX, W.Gp);
+    WG_LAUNCH(cx, squeeze_kernel, dim3((T + 255) / 256, B), dim3(256), 0, z, X, g, G, N);
+    WG_LAUNCH(cx, squeeze_kernel, dim3((T + 255) / 256, B), dim3(256), 0, dz, dX, g, G, N);
+    run_upsample(cx, cf, pk + M.up_w, pk + M.up_bias, h, F, g, pref(ws + W.Y, W.auxp), nullptr);
+    if (cx.err == 0 && hipMemsetAsync(ws + W.dY, 0, (size_t)B * W.auxp * g.P * sizeof(float), cx.st) != hipSuccess) cx.err = WG_ELAUNCH;
+    WnRun r;
+    r.g = g; r.ws = ws; r.w = W.wn; r.Y = ws + W.Y; r.save = 1;
+    int base = G - flow_channels(cf, cf->n_flows - 1);
+    for (int k = cf->n_flows - 1; k >= 0; --k) {
+        const int c = flow_channels(cf, k);
+        const float *lu = pk + M.lu + (size_t)k * WG_LU_STRIDE;
+        PRef Xk = pref(ws + W.X, W.Gp, base), dXk = pref(ws + W.dX, W.Gp, base);
+        r.d = flow_wn(cf, k); r.L = wn_pack_layout(r.d); r.pk = pk + M.wn[k]; r.X = Xk;
+        // AffineCouplingFunc.backward (efficient_modules.py:118-154)
+        wn_forward(cx, r);                                                                   // recompute :127-130
+        run_end_affine(cx, r, AFF_BWD, dXk, nullptr, nullptr, dlogdet, nullptr);              // :132-148 (log_s.sum feeds logdet[b], waveglow.py:175)
+        wn_backward(cx, r, p + wn_table_off(cf, k), gr + wn_table_off(cf, k), dXk, ws + W.dY);
+        // Conv1x1Func.backward (efficient_modules.py:230-244)
+        run_mix(cx, g, Xk, c, lu + WG_MAXC * WG_MAXC, 0);                                     // x = W^-1 z   :235-237
+        {
+            WSegSpec sa = {dXk.p, dXk.Cp, dXk.ch0, c, 0}, sb = {Xk.p, Xk.Cp, Xk.ch0, c, 0};
+            WgradOut wo = run_wgrad(cx, g, &sa, 1, &sb, 1, ws + W.wn.slab, W.wn.slab_floats);   // dW = dz x^T     :240
+            run_finalize(cx, ws + W.wn.slab, wo, 0, c, c, 1, 0, 1, 0, nullptr, nullptr, nullptr, gr[3 + k],
+                         lu + WG_MAXC * WG_MAXC, dlogdet, B, (float)T);                         // + W^-T dlogdet T :242
+        }
+        run_mix(cx, g, dXk, c, lu, 1);                                                        // dx = W^T dz  :239
+        if (k % cf->n_early_every == 0 && k) base -= cf->n_early_size;
+    }
+    if (x_rebuilt) WG_LAUNCH(cx, unsqueeze_kernel, dim3((T + 255) / 256, B), dim3(256), 0, X, x_rebuilt, g, G, N);
+    if (dx) WG_LAUNCH(cx, unsqueeze_kernel, dim3((T + 255) / 256, B), dim3(256), 0, dX, dx, g, G, N);
+    // upsampler backward (+ its weight norm)
+    WG_LAUNCH(cx, upsample_bwd_kernel, dim3(cf->n_mels), dim3(256), (size_t)(cf->up_kernel + 256) * sizeof(float), h, pk + M.up_w,
+              pref(ws + W.dY, W.auxp), g, cf->n_mels, F, cf->up_kernel, cf->up_stride, cf->up_pad, p[1], p[2], gr[0], gr[1], gr[2], dh);
+    return cx.err;
+}
+
+int wg_nll_loss(const float *z, const float *logdet, int B, int N, float sigma, int elementwise_mean, float *loss, void *stream)
+{
+    if (!z || !logdet || !loss || B < 1 || N < 1 || !(sigma > 0.f)) return WG_EINVAL;
+    Ctx cx = {(hipStream_t)stream, 0};
+    WG_LAUNCH(cx, nll_loss_kernel, dim3(1), dim3(1024), 0, z, logdet, B, N, 1.0f / (sigma * sigma), elementwise_mean, loss);
+    return cx.err;
+}
+int wg_nll_loss_backward(const float *z, int B, int N, float sigma, int elementwise_mean, const float *dloss, float *dz,
+                         float *dlogdet, void *stream)
+{
+    if (!z || !dz || !dlogdet || B < 1 || N < 1 || !(sigma > 0.f)) return WG_EINVAL;
+    Ctx cx = {(hipStream_t)stream, 0};
+    const size_t n = (size_t)B * N;
+    WG_LAUNCH(cx, nll_loss_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, z, B, N, 1.0f / (sigma * sigma), elementwise_mean,
+              dloss, dz, dlogdet);
+    return cx.err;
+}
+
+int wg_upsample(const wg_config *cf, const void *packed, const float *h, int B, int F, int T, float *y, void *stream)
+{
+    int rc = cfg_check(cf);
+    if (rc) return rc;
+    if (!packed || !h || !y || B < 1 || F < 1 || T < 1) return WG_EINVAL;
+    const long L = (long)(F - 1) * cf->up_stride - 2 * cf->up_pad + cf->up_kernel;
+    if (T > L) return WG_ESHAPE;
+    Ctx cx = {(hipStream_t)stream, 0};
+    const float *pk = (const float *)packed;
+    const ModelPack M = model_pack_layout(cf);
+    const Geo g = make_geo(B, T, 0);
+    run_upsample(cx, cf, pk + M.up_w, pk + M.up_bias, h, F, g, pnull(), y);
+    return cx.err;
+}
+
+// ---- block level: invertible 1x1 -----------------------------------------------------------------
+struct InvWs {
+    Geo g;
+    int Cp;
+    size_t X, dX, lu, slab, slab_floats, total;
+};
+static InvWs inv_ws_layout(int c, int B, int T)
+{
+    InvWs w;
+    w.g = make_geo(B, T, 0);
+    w.Cp = rup(c, WG_BK);
+    Bump bp;
+    w.X = bp.take((size_t)B * w.Cp * w.g.P);
+    w.dX = bp.take((size_t)B * w.Cp * w.g.P);
+    w.lu = bp.take(WG_LU_STRIDE);
+    w.slab_floats = slab_floats(w.g, WG_TILE, WG_TILE);
+    w.slab = bp.take(w.slab_floats);
+    w.total = bp.off + 4096;
+    return w;
+}
+size_t wg_invconv_workspace_bytes(int c, int B, int T)
+{
+    if (c < 1 || c > WG_MAXC || B < 1 || T < 1) return 0;
+    return inv_ws_layout(c, B, T).total * sizeof(float);
+}
+
+int wg_invconv_apply(const float *Wm, int c, const float *x, int B, int T, int reverse, float *z, float *logdet,
+                     void *wsv, size_t ws_bytes, void *stream)
+{
+    if (!Wm || !x || !z || !logdet || !wsv || c < 1 || c > WG_MAXC || B < 1 || T < 1) return WG_EINVAL;
+    const InvWs W = inv_ws_layout(c, B, T);
+    if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
+    Ctx cx = {(hipStream_t)stream, 0};
+    float *ws = (float *)wsv;
+    LuArgs lu;
+    lu.n = 1; lu.out = ws + W.lu; lu.ostride = WG_LU_STRIDE; lu.job[0].W = Wm; lu.job[0].c = c;
+    WG_LAUNCH(cx, lu_kernel, dim3(1), dim3(64), 0, lu);
+    PRef X = pref(ws + W.X, W.Cp);
+    WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, c, B), dim3(256), 0, x, X, W.g, c);
+    run_mix(cx, W.g, X, c, ws + W.lu + (reverse ? WG_MAXC * WG_MAXC : 0), 0);                 // efficient_modules.py:40 / :53
+    WG_LAUNCH(cx, export_kernel, dim3((T + 255) / 256, c, B), dim3(256), 0, X, z, W.g, c, 1.0f);
+    WG_LAUNCH(cx, scalar_logdet_kernel, dim3(1), dim3(1), 0, ws + W.lu, reverse ? -(float)T : (float)T, logdet);   // :39 / :51-52
+    return cx.err;
+}
+
+int wg_invconv_backward(const float *Wm, int c, const float *z, const float *dz, const float *dlogdet, int B, int T, int reverse,
+                        float *x, float *dx, float *dW, void *wsv, size_t ws_bytes, void *stream)
+{
+    if (!Wm || !z || !dz || !dlogdet || !x || !dx || !dW || !wsv || c < 1 || c > WG_MAXC || B < 1 || T < 1) return WG_EINVAL;
+    const InvWs W = inv_ws_layout(c, B, T);
+    if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
+    Ctx cx = {(hipStream_t)stream, 0};
+    float *ws = (float *)wsv;
+    const Geo g = W.g;
+    LuArgs lu;
+    lu.n = 1; lu.out = ws + W.lu; lu.ostride = WG_LU_STRIDE; lu.job[0].W = Wm; lu.job[0].c = c;
+    WG_LAUNCH(cx, lu_kernel, dim3(1), dim3(64), 0, lu);
+    const float *Wd = ws + W.lu, *Wi = ws + W.lu + WG_MAXC * WG_MAXC;
+    PRef X = pref(ws + W.X, W.Cp), dX = pref(ws + W.dX, W.Cp);
+    WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, c, B), dim3(256), 0, z, X, g, c);
+    WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, c, B), dim3(256), 0, dz, dX, g, c);
+    WSegSpec sa = {dX.p, dX.Cp, 0, c, 0}, sb = {X.p, X.Cp, 0, c, 0};
+    if (!reverse) {                      // Conv1x1Func.backward  (efficient_modules.py:230-244)
+        run_mix(cx, g, X, c, Wi, 0);                                                          // x = W^-1 z
+        WgradOut wo = run_wgrad(cx, g, &sa, 1, &sb, 1, ws + W.slab, W.slab_floats);           // dz x^T
+        run_finalize(cx, ws + W.slab, wo, 0, c, c, 1, 0, 1, 0, nullptr, nullptr, nullptr, dW, Wi, dlogdet, 1, (float)T);
+        run_mix(cx, g, dX, c, Wd, 1);                                                         // dx = W^T dz
+    } else {                             // InvConv1x1Func.backward (efficient_modules.py:262-279)
+        run_mix(cx, g, X, c, Wd, 0);                                                          // x = W z       :267
+        WgradOut wo = run_wgrad(cx, g, &sa, 1, &sb, 1, ws + W.slab, W.slab_floats);           // dw = dz x^T   :274-275
+        InvRevFinArgs fa;
+        fa.slab = ws + W.slab; fa.nsplit = wo.nsplit; fa.sstride = (size_t)wo.Mp * wo.Np; fa.ldn = wo.Np;
+        fa.c = c; fa.Winv = Wi; fa.dlogdet = dlogdet; fa.T = (float)T; fa.dW = dW;
+        WG_LAUNCH(cx, invconv_rev_finalize_kernel, dim3(1), dim3(256), 0, fa);                // :276-277
+        run_mix(cx, g, dX, c, Wi, 1);                                                         // dx = W^-T dz  :271-273
+    }
+    WG_LAUNCH(cx, export_kernel, dim3((T + 255) / 256, c, B), dim3(256), 0, X, x, g, c, 1.0f);
+    WG_LAUNCH(cx, export_kernel, dim3((T + 255) / 256, c, B), dim3(256), 0, dX, dx, g, c, 1.0f);
+    return cx.err;
+}
+
+// ---- block level: affine coupling with F = WN ------------------------------------------------------
+struct CplWs {
+    Geo g;
+    int Xp, auxp;
+    size_t X, dX, Y, dY, total;
+    WnWs wn;
+};
+static CplWs cpl_ws_layout(const WnD &d, int B, int T, int mode)
+{
+    CplWs w;
+    w.g = make_geo(B, T, d.maxdil() * (d.radix - 1) / 2);
+    w.Xp = rup(2 * d.ic, WG_BK) + WG_BK;
+    w.auxp = d.auxp();
+    Bump bp;
+    w.X = bp.take((size_t)B * w.Xp * w.g.P);
+    w.Y = bp.take((size_t)B * w.auxp * w.g.P);
+    w.dX = w.dY = 0;
+    if (mode) {
+        w.dX = bp.take((size_t)B * w.Xp * w.g.P);
+        w.dY = bp.take((size_t)B * w.auxp * w.g.P);
+    }
+    wn_ws_layout(bp, d, d.ic, w.g, mode, w.wn);
+    w.total = bp.off + 4096;
+    return w;
+}
+size_t wg_coupling_workspace_bytes(const wg_wn_dims *dd, int B, int T, int mode)
+{
+    if (!dd || wn_check(wnd_from(dd)) || B < 1 || T < 1) return 0;
+    return cpl_ws_layout(wnd_from(dd), B, T, mode).total * sizeof(float);
+}
+
+int wg_coupling_apply(const wg_wn_dims *dd, const void *packed, const float *x, const float *y, int B, int T, int reverse,
+                      float *z, float *log_s, void *wsv, size_t ws_bytes, void *stream)
+{
+    if (!dd || !packed || !x || !y || !z || !log_s || !wsv || B < 1 || T < 1) return WG_EINVAL;
+    const WnD d = wnd_from(dd);
+    int rc = wn_check(d);
+    if (rc) return rc;
+    const CplWs W = cpl_ws_layout(d, B, T, 0);
+    if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
+    Ctx cx = {(hipStream_t)stream, 0};
+    float *ws = (float *)wsv;
+    const Geo g = W.g;
+    PRef X = pref(ws + W.X, W.Xp);
+    WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, 2 * d.ic, B), dim3(256), 0, x, X, g, 2 * d.ic);
+    WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, d.aux, B), dim3(256), 0, y, pref(ws + W.Y, W.auxp), g, d.aux);
+    WnRun r;
+    r.d = d; r.L = wn_pack_layout(d); r.pk = (const float *)packed + rupz(WG_ONES, 64); r.g = g; r.ws = ws; r.w = W.wn;
+    r.X = X; r.Y = ws + W.Y; r.save = 0;
+    wn_forward(cx, r);
+    run_end_affine(cx, r, reverse ? AFF_REV : AFF_FWD, pnull(), log_s, nullptr, nullptr, nullptr);
+    WG_LAUNCH(cx, export_kernel, dim3((T + 255) / 256, 2 * d.ic, B), dim3(256), 0, X, z, g, 2 * d.ic, 1.0f);
+    return cx.err;
+}
+
+int wg_wn_apply(const wg_wn_dims *dd, const void *packed, const float *x, const float *y, int B, int T, float *log_s, float *t,
+                void *wsv, size_t ws_bytes, void *stream)
+{
+    if (!dd || !packed || !x || !y || !log_s || !t || !wsv || B < 1 || T < 1) return WG_EINVAL;
+    const WnD d = wnd_from(dd);
+    int rc = wn_check(d);
+    if (rc) return rc;
+    const CplWs W = cpl_ws_layout(d, B, T, 0);
+    if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
+    Ctx cx = {(hipStream_t)stream, 0};
+    float *ws = (float *)wsv;
+    const Geo g = W.g;
+    PRef X = pref(ws + W.X, W.Xp);
+    WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, d.ic, B), dim3(256), 0, x, X, g, d.ic);
+    WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, d.aux, B), dim3(256), 0, y, pref(ws + W.Y, W.auxp), g, d.aux);
+    WnRun r;
+    r.d = d; r.L = wn_pack_layout(d); r.pk = (const float *)packed + rupz(WG_ONES, 64); r.g = g; r.ws = ws; r.w = W.wn;
+    r.X = X; r.Y = ws + W.Y; r.save = 0;
+    wn_forward(cx, r);
+    AffineArgs a;
+    memset(&a, 0, sizeof(a));
+    a.endT = r.pk + r.L.endT; a.S = pref(ws + W.wn.skip, d.Cs); a.Cs = d.Cs; a.ic = d.ic; a.X = X;
+    a.log_s_out = log_s; a.t_out = t; a.g = g; a.mode = AFF_RAW;
+    WG_LAUNCH(cx, end_affine_kernel, dim3(g.Tt / 128, g.B), dim3(256), 0, a);
+    return cx.err;
+}
+
+int wg_coupling_backward(const wg_wn_dims *dd, const void *const *params, const void *packed, const float *z, const float *y,
+                         const float *dz, const float *dlog_s, int B, int T, int reverse, float *x, float *dx, float *dy,
+                         void *const *grads, void *wsv, size_t ws_bytes, void *stream)
+{
+    if (!dd || !params || !packed || !z || !y || !dz || !dlog_s || !x || !dx || !grads || !wsv || B < 1 || T < 1) return WG_EINVAL;
+    const WnD d = wnd_from(dd);
+    int rc = wn_check(d);
+    if (rc) return rc;
+    const CplWs W = cpl_ws_layout(d, B, T, 1);
+    if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
+    Ctx cx = {(hipStream_t)stream, 0};
+    float *ws = (float *)wsv;
+    const Geo g = W.g;
+    PRef X = pref(ws + W.X, W.Xp), dX = pref(ws + W.dX, W.Xp);
+    WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, 2 * d.ic, B), dim3(256), 0, z, X, g, 2 * d.ic);
+    WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, 2 * d.ic, B), dim3(256), 0, dz, dX, g, 2 * d.ic);
+    WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, d.aux, B), dim3(256), 0, y, pref(ws + W.Y, W.auxp), g, d.aux);
+    if (dy && cx.err == 0 && hipMemsetAsync(ws + W.dY, 0, (size_t)B * W.auxp * g.P * sizeof(float), cx.st) != hipSuccess) cx.err = WG_ELAUNCH;
+    WnRun r;
+    r.d = d; r.L = wn_pack_layout(d); r.pk = (const float *)packed + rupz(WG_ONES, 64); r.g = g; r.ws = ws; r.w = W.wn;
+    r.X = X; r.Y = ws + W.Y; r.save = 1;
+    wn_forward(cx, r);
+    run_end_affine(cx, r, reverse ? AFF_BWD_REV : AFF_BWD, dX, nullptr, dlog_s, nullptr, nullptr);
+    wn_backward(cx, r, (const float *const *)params, (float *const *)grads, dX, dy ? ws + W.dY : nullptr);
+    WG_LAUNCH(cx, export_kernel, dim3((T + 255) / 256, 2 * d.ic, B), dim3(256), 0, X, x, g, 2 * d.ic, 1.0f);
+    WG_LAUNCH(cx, export_kernel, dim3((T + 255) / 256, 2 * d.ic, B), dim3(256), 0, dX, dx, g, 2 * d.ic, 1.0f);
+    if (dy) WG_LAUNCH(cx, export_kernel, dim3((T + 255) / 256, d.aux, B), dim3(256), 0, pref(ws + W.dY, W.auxp), dy, g, d.aux, 1.0f);
+    return cx.err;
+}
+
+}  // extern "C"

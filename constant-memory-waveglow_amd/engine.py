@@ -1,0 +1,265 @@
+"""Thin torch-side plumbing over the C ABI: device buffers, streams, caches.  No arithmetic happens here.
+
+Everything that computes is a HIP kernel behind include/wgflow.h.  PyTorch only owns the device memory
+(tensors as workspaces / packed-weight buffers) and the stream the kernels are enqueued on.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import WgConfig, WgWnDims, WgError, check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise WgError("constant-memory-waveglow_amd runs on an MI355X (HIP) device only: got a %s tensor. "
+                          "There is no CPU fallback." % t.device)
+        if t.dtype != torch.float32:
+            raise WgError("the HIP engine computes in float32 (got %s)" % t.dtype)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _table(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr() if t is not None else None
+    return arr
+
+
+def make_config(flows, n_group, n_early_every, n_early_size, hop_size, n_mels,
+                residual_channels, dilation_channels, skip_channels, depth, radix):
+    up = hop_size // n_group                  # reference model/waveglow.py:125
+    k = up * 2 + 1                            # :126
+    pad = k // 2 - up // 2                    # :128-129
+    return WgConfig(flows, n_group, n_early_every, n_early_size, n_mels, up, k, pad,
+                    residual_channels, dilation_channels, skip_channels, depth, radix)
+
+
+class _Buffers:
+    """Zero-initialised device workspaces keyed by (device, tag, shape...).  The kernels keep the zero halo of
+    every activation plane intact, so a workspace is zeroed once when it is allocated."""
+
+    def __init__(self):
+        self._ws = {}
+
+    def get(self, key, nbytes, device):
+        buf = self._ws.get(key)
+        if buf is None or buf.numel() < nbytes or buf.device != device:
+            if nbytes == 0:
+                raise WgError("configuration/shape rejected by the HIP engine (workspace query returned 0)")
+            buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+            self._ws[key] = buf
+        return buf
+
+    def clear(self):
+        self._ws.clear()
+
+
+class PackedWeights:
+    """Materialised (weight-normed, k-major) weights; re-packed only when a parameter changed."""
+
+    def __init__(self):
+        self.buf = None
+        self.key = None
+
+    def stale(self, params):
+        key = tuple((p.data_ptr(), p._version) if p is not None else None for p in params)
+        if key != self.key or self.buf is None:
+            self.key = key
+            return True
+        return False
+
+
+class ModelEngine:
+    """Whole-model entry points (wg_pack_weights / wg_forward / wg_inverse / wg_backward)."""
+
+    def __init__(self, cfg: WgConfig):
+        self.cfg = cfg
+        self.buffers = _Buffers()
+        self.packed = PackedWeights()
+        self.n_params = None
+
+    def _pack(self, params, device):
+        L = _lib.lib()
+        if self.n_params is None:
+            self.n_params = L.wg_param_count(C.byref(self.cfg))
+        if len(params) != self.n_params:
+            raise WgError("parameter table has %d entries, expected %d" % (len(params), self.n_params))
+        if self.packed.stale(params) or self.packed.buf.device != device:
+            nbytes = L.wg_packed_bytes(C.byref(self.cfg))
+            if nbytes == 0:
+                raise WgError("WaveGlow configuration not supported by the HIP kernels "
+                              "(channels must be multiples of 32, radix 1 or 3, n_group <= 32)")
+            if self.packed.buf is None or self.packed.buf.numel() < nbytes or self.packed.buf.device != device:
+                self.packed.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            check(L.wg_pack_weights(C.byref(self.cfg), _table(params), _p(self.packed.buf), _stream()), "wg_pack_weights")
+        return self.packed.buf
+
+    def _ws(self, B, N, mode, device):
+        nbytes = _lib.lib().wg_workspace_bytes(C.byref(self.cfg), B, N, mode)
+        return self.buffers.get((device, mode, B, N), nbytes, device)
+
+    def run(self, params, x, h, inverse):
+        require_device(x, h, *params)
+        x, h = x.contiguous(), h.contiguous()
+        B, N = x.shape
+        F = h.shape[2]
+        pk = self._pack(params, x.device)
+        ws = self._ws(B, N, 0, x.device)
+        out = torch.empty_like(x)
+        logdet = torch.empty(B, dtype=torch.float32, device=x.device)
+        fn = _lib.lib().wg_inverse if inverse else _lib.lib().wg_forward
+        check(fn(C.byref(self.cfg), _p(pk), _p(x), _p(h), B, N, F, _p(out), _p(logdet), _p(ws), ws.numel(), _stream()),
+              "wg_inverse" if inverse else "wg_forward")
+        return out, logdet
+
+    def backward(self, params, z, h, dz, dlogdet, need, need_dh, need_dx, want_x=False):
+        """need[i]: produce the gradient of params[i].  Returns (grads list, dh, dx, x_rebuilt)."""
+        require_device(z, h, dz, dlogdet)
+        z, h, dz, dlogdet = z.contiguous(), h.contiguous(), dz.contiguous(), dlogdet.contiguous()
+        B, N = z.shape
+        F = h.shape[2]
+        pk = self._pack(params, z.device)
+        ws = self._ws(B, N, 1, z.device)
+        grads = [torch.empty_like(p) if (p is not None and nd) else None for p, nd in zip(params, need)]
+        dh = torch.empty_like(h) if need_dh else None
+        dx = torch.empty_like(z) if need_dx else None
+        xr = torch.empty_like(z) if want_x else None
+        check(_lib.lib().wg_backward(C.byref(self.cfg), _table(params), _p(pk), _p(z), _p(h), _p(dz), _p(dlogdet), B, N, F,
+                                     _table(grads), _p(dh), _p(dx), _p(xr), _p(ws), ws.numel(), _stream()), "wg_backward")
+        return grads, dh, dx, xr
+
+    def upsample(self, params, h, T):
+        require_device(h)
+        h = h.contiguous()
+        B, M, F = h.shape
+        pk = self._pack(params, h.device)
+        y = torch.empty(B, M, T, dtype=torch.float32, device=h.device)
+        check(_lib.lib().wg_upsample(C.byref(self.cfg), _p(pk), _p(h), B, F, T, _p(y), _stream()), "wg_upsample")
+        return y
+
+
+class CouplingEngine:
+    """Block-level entry points for AffineCouplingBlock(WN) / WN."""
+
+    def __init__(self, dims: WgWnDims):
+        self.dims = dims
+        self.buffers = _Buffers()
+        self.packed = PackedWeights()
+
+    def _pack(self, params, device):
+        L = _lib.lib()
+        if self.packed.stale(params) or self.packed.buf.device != device:
+            nbytes = L.wg_wn_packed_bytes(C.byref(self.dims))
+            if nbytes == 0:
+                raise WgError("WN configuration not supported by the HIP kernels "
+                              "(channels must be multiples of 32, radix 1 or 3, in_channels <= 16)")
+            if self.packed.buf is None or self.packed.buf.numel() < nbytes or self.packed.buf.device != device:
+                self.packed.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            check(L.wg_wn_pack_weights(C.byref(self.dims), _table(params), _p(self.packed.buf), _stream()), "wg_wn_pack_weights")
+        return self.packed.buf
+
+    def _ws(self, B, T, mode, device):
+        nbytes = _lib.lib().wg_coupling_workspace_bytes(C.byref(self.dims), B, T, mode)
+        return self.buffers.get((device, mode, B, T), nbytes, device)
+
+    def apply(self, params, x, y, reverse):
+        require_device(x, y, *params)
+        x, y = x.contiguous(), y.contiguous()
+        B, c, T = x.shape
+        if y.shape[2] != T or y.shape[1] != self.dims.aux_ch or c != 2 * self.dims.in_ch:
+            raise WgError("coupling: x %s / y %s do not match the block's dimensions" % (tuple(x.shape), tuple(y.shape)))
+        pk = self._pack(params, x.device)
+        ws = self._ws(B, T, 0, x.device)
+        z = torch.empty_like(x)
+        log_s = torch.empty(B, c // 2, T, dtype=torch.float32, device=x.device)
+        check(_lib.lib().wg_coupling_apply(C.byref(self.dims), _p(pk), _p(x), _p(y), B, T, int(reverse), _p(z), _p(log_s),
+                                           _p(ws), ws.numel(), _stream()), "wg_coupling_apply")
+        return z, log_s
+
+    def wn(self, params, x, y):
+        require_device(x, y, *params)
+        x, y = x.contiguous(), y.contiguous()
+        B, ic, T = x.shape
+        pk = self._pack(params, x.device)
+        ws = self._ws(B, T, 0, x.device)
+        log_s, t = torch.empty_like(x), torch.empty_like(x)
+        check(_lib.lib().wg_wn_apply(C.byref(self.dims), _p(pk), _p(x), _p(y), B, T, _p(log_s), _p(t), _p(ws), ws.numel(),
+                                     _stream()), "wg_wn_apply")
+        return log_s, t
+
+    def backward(self, params, z, y, dz, dlog_s, reverse, need, need_dy, x_out):
+        require_device(z, y, dz, dlog_s)
+        z, y, dz, dlog_s = z.contiguous(), y.contiguous(), dz.contiguous(), dlog_s.contiguous()
+        B, c, T = z.shape
+        pk = self._pack(params, z.device)
+        ws = self._ws(B, T, 1, z.device)
+        grads = [torch.empty_like(p) if (p is not None and nd) else None for p, nd in zip(params, need)]
+        dx = torch.empty_like(z)
+        dy = torch.empty_like(y) if need_dy else None
+        check(_lib.lib().wg_coupling_backward(C.byref(self.dims), _table(params), _p(pk), _p(z), _p(y), _p(dz), _p(dlog_s), B, T,
+                                              int(reverse), _p(x_out), _p(dx), _p(dy), _table(grads), _p(ws), ws.numel(),
+                                              _stream()), "wg_coupling_backward")
+        return dx, dy, grads
+
+
+_INV_BUFFERS = _Buffers()
+
+
+def invconv_apply(W, x, reverse):
+    require_device(W, x)
+    x = x.contiguous()
+    B, c, T = x.shape
+    Wm = W.reshape(c, c).contiguous()
+    nbytes = _lib.lib().wg_invconv_workspace_bytes(c, B, T)
+    ws = _INV_BUFFERS.get((x.device, c, B, T), nbytes, x.device)
+    z = torch.empty_like(x)
+    logdet = torch.empty((), dtype=torch.float32, device=x.device)
+    check(_lib.lib().wg_invconv_apply(_p(Wm), c, _p(x), B, T, int(reverse), _p(z), _p(logdet), _p(ws), ws.numel(), _stream()),
+          "wg_invconv_apply")
+    return z, logdet
+
+
+def invconv_backward(W, z, dz, dlogdet, reverse, x_out):
+    require_device(W, z, dz, dlogdet)
+    z, dz = z.contiguous(), dz.contiguous()
+    B, c, T = z.shape
+    Wm = W.reshape(c, c).contiguous()
+    nbytes = _lib.lib().wg_invconv_workspace_bytes(c, B, T)
+    ws = _INV_BUFFERS.get((z.device, c, B, T), nbytes, z.device)
+    dx = torch.empty_like(z)
+    dW = torch.empty(c, c, dtype=torch.float32, device=z.device)
+    check(_lib.lib().wg_invconv_backward(_p(Wm), c, _p(z), _p(dz), _p(dlogdet.contiguous()), B, T, int(reverse), _p(x_out), _p(dx),
+                                         _p(dW), _p(ws), ws.numel(), _stream()), "wg_invconv_backward")
+    return dx, dW
+
+
+def nll_loss(z, logdet, sigma, elementwise_mean):
+    require_device(z, logdet)
+    z, logdet = z.contiguous(), logdet.contiguous()
+    B, N = z.shape
+    loss = torch.empty((), dtype=torch.float32, device=z.device)
+    check(_lib.lib().wg_nll_loss(_p(z), _p(logdet), B, N, float(sigma), int(elementwise_mean), _p(loss), _stream()), "wg_nll_loss")
+    return loss
+
+
+def nll_loss_backward(z, sigma, elementwise_mean, dloss):
+    require_device(z, dloss)
+    z = z.contiguous()
+    B, N = z.shape
+    dz = torch.empty_like(z)
+    dlogdet = torch.empty(B, dtype=torch.float32, device=z.device)
+    check(_lib.lib().wg_nll_loss_backward(_p(z), B, N, float(sigma), int(elementwise_mean), _p(dloss.contiguous()), _p(dz),
+                                          _p(dlogdet), _stream()), "wg_nll_loss_backward")
+    return dz, dlogdet

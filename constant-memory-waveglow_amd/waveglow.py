@@ -1,0 +1,179 @@
+"""WaveGlow on the HIP flow engine: same constructor, parameter names and forward/reverse/infer contract as the
+reference's model/waveglow.py, but the computation is one call into libwgflow.so per direction.
+
+Module tree (so state dicts interchange with the reference):
+    upsampler                      ConvTranspose1d(n_mels, n_mels, 2u+1, stride u, groups n_mels) + weight norm
+    invconv1x1.{k}                 InvertibleConv1x1(c_k)
+    WNs.{k}.F                      WN(in=c_k/2, aux=n_mels, ...): V, start, layers.{i}.{W, W_o}, end
+"""
+import warnings
+from typing import Tuple
+
+import torch
+from torch import Tensor, nn
+from torch.autograd import Function
+
+from . import engine
+from ._lib import WgError
+from .base import FlowBase
+from .efficient_modules import AffineCouplingBlock, InvertibleConv1x1
+from .utils import add_weight_norms, conv_gv
+
+
+def fused_gate(x1: Tensor, x2: Tensor) -> Tensor:
+    """tanh(x1) * sigmoid(x2) -- the WN gate (waveglow.py:13-15).  Inside the engine this is the epilogue of the
+    dilated-conv kernel; the function is kept for API parity and device tensors only."""
+    engine.require_device(x1, x2)
+    return torch.tanh(x1) * torch.sigmoid(x2)
+
+
+class NonCausalLayer(nn.Module):
+    """Parameter container of one WN layer: W = dilated conv (residual -> 2*dilation channels), W_o = 1x1
+    (dilation -> residual+skip, or skip only on the last layer)  (waveglow.py:18-46).  Its arithmetic runs inside
+    the fused WN kernels, so calling it on its own is not supported."""
+
+    def __init__(self, dilation, dilation_channels, residual_channels, skip_channels, radix, bias, last_layer=False):
+        super().__init__()
+        self.W = nn.Conv1d(residual_channels, 2 * dilation_channels, kernel_size=radix, dilation=dilation,
+                           padding=dilation * (radix - 1) // 2, bias=bias)
+        out_ch = skip_channels if last_layer else residual_channels + skip_channels
+        self.W_o = nn.Conv1d(dilation_channels, out_ch, 1, bias=bias)
+        self.chs_split = [skip_channels] if last_layer else [residual_channels, skip_channels]
+
+    def forward(self, x, y):
+        raise WgError("NonCausalLayer is executed inside the fused HIP WN kernels; call WN / AffineCouplingBlock instead")
+
+
+class WN(nn.Module):
+    """Non-causal WaveNet-like transform net (waveglow.py:49-105): (log_s, t) = WN(x, y)."""
+
+    def __init__(self, in_channels, aux_channels, dilation_channels=256, residual_channels=256, skip_channels=256,
+                 depth=8, radix=3, bias=False, zero_init=True):
+        super().__init__()
+        if bias:
+            raise WgError("WN(bias=True) is not built into the HIP kernels (every reference config uses bias=False)")
+        self.dilations = [2 ** i for i in range(depth)]
+        self.in_chs, self.aux_chs = in_channels, aux_channels
+        self.res_chs, self.dil_chs, self.skp_chs, self.rdx = residual_channels, dilation_channels, skip_channels, radix
+        self.r_field = sum(self.dilations) + 1
+
+        self.V = nn.Conv1d(aux_channels, 2 * dilation_channels * depth, 1, bias=bias)
+        self.V.apply(add_weight_norms)
+        self.start = nn.Conv1d(in_channels, residual_channels, 1, bias=bias)
+        self.start.apply(add_weight_norms)
+        self.layers = nn.ModuleList(
+            NonCausalLayer(d, dilation_channels, residual_channels, skip_channels, radix, bias, last_layer=(i == depth - 1))
+            for i, d in enumerate(self.dilations))
+        self.layers.apply(add_weight_norms)
+        self.end = nn.Conv1d(skip_channels, 2 * in_channels, 1, bias=bias)
+        if zero_init:
+            nn.init.zeros_(self.end.weight)
+        self._engine = None
+
+    def hip_dims(self):
+        return (self.in_chs, self.aux_chs, self.res_chs, self.dil_chs, self.skp_chs, len(self.layers), self.rdx)
+
+    def param_table(self):
+        """C-ABI order: V(g,v) start(g,v) [W(g,v) W_o(g,v)]*depth end  (include/wgflow.h)."""
+        tab = list(conv_gv(self.V)) + list(conv_gv(self.start))
+        for layer in self.layers:
+            tab += list(conv_gv(layer.W)) + list(conv_gv(layer.W_o))
+        tab.append(self.end.weight)
+        return tab
+
+    def forward(self, x, y):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            warnings.warn("WN.forward on its own runs without autograd; gradients flow through AffineCouplingBlock", stacklevel=2)
+        if self._engine is None:
+            from ._lib import WgWnDims
+            self._engine = engine.CouplingEngine(WgWnDims(*self.hip_dims()))
+        return self._engine.wn([None if t is None else t.detach() for t in self.param_table()], x.detach(), y.detach())
+
+
+class _WaveGlowFn(Function):
+    """Whole-model autograd node: forward = wg_forward; backward = wg_backward, which walks the flows last to first
+    and rebuilds every block input from its output (constant activation memory in the number of flows)."""
+
+    @staticmethod
+    def forward(ctx, model, x, h, *params):
+        table = model.param_table()
+        z, logdet = model._engine.run([None if t is None else t.detach() for t in table], x.detach(), h.detach(), False)
+        ctx.model = model
+        ctx.save_for_backward(z, h)
+        return z, logdet
+
+    @staticmethod
+    def backward(ctx, dz, dlogdet):
+        z, h = ctx.saved_tensors
+        model = ctx.model
+        table = model.param_table()
+        need = [t is not None and t.requires_grad for t in table]
+        grads, dh, dx, _ = model._engine.backward([None if t is None else t.detach() for t in table], z, h, dz, dlogdet,
+                                                  need, ctx.needs_input_grad[2], ctx.needs_input_grad[1])
+        by_id = {id(t): g for t, g in zip(table, grads) if t is not None}
+        return (None, dx, dh) + tuple(by_id.get(id(p)) for p in model.parameters())
+
+
+class WaveGlow(FlowBase):
+    def __init__(self, flows, n_group, n_early_every, n_early_size, hop_size, n_mels, memory_efficient,
+                 reverse_mode=False, **kwargs):
+        super().__init__(hop_size, reverse_mode)
+        if reverse_mode:
+            raise WgError("WaveGlow(reverse_mode=True) (the architecture with flows applied in inverse order, "
+                          "SURVEY.md a14) is not built yet; every shipped reference config uses reverse_mode=false")
+        self.n_group, self.n_early_every, self.n_early_size = n_group, n_early_every, n_early_size
+        self.n_mels, self.mem_efficient = n_mels, memory_efficient
+
+        self.upsample_factor = hop_size // n_group
+        k = 2 * self.upsample_factor + 1
+        self.upsampler = nn.ConvTranspose1d(n_mels, n_mels, k, self.upsample_factor,
+                                            padding=k // 2 - self.upsample_factor // 2, groups=n_mels)
+        self.upsampler.apply(add_weight_norms)
+
+        self.invconv1x1 = nn.ModuleList()
+        self.WNs = nn.ModuleList()
+        self.z_split_sizes = []
+        c = n_group
+        for k_flow in range(flows):
+            if k_flow and k_flow % n_early_every == 0:       # early output: n_early_size channels leave the flow
+                c -= n_early_size
+                self.z_split_sizes.append(n_early_size)
+            self.invconv1x1.append(InvertibleConv1x1(c, memory_efficient=memory_efficient, reverse_mode=reverse_mode))
+            self.WNs.append(AffineCouplingBlock(WN, memory_efficient=memory_efficient, reverse_mode=reverse_mode,
+                                                in_channels=c // 2, aux_channels=n_mels, **kwargs))
+        self.z_split_sizes.append(c)
+
+        wn0 = self.WNs[0].F
+        self._engine = engine.ModelEngine(engine.make_config(
+            flows, n_group, n_early_every, n_early_size, hop_size, n_mels,
+            wn0.res_chs, wn0.dil_chs, wn0.skp_chs, len(wn0.layers), wn0.rdx))
+
+    def param_table(self):
+        """C-ABI parameter table (include/wgflow.h): upsampler bias,g,v; 1x1 weights; per flow the WN table."""
+        g, v = conv_gv(self.upsampler)
+        tab = [self.upsampler.bias, g, v] + [m.weight for m in self.invconv1x1]
+        for blk in self.WNs:
+            tab += blk.F.param_table()
+        return tab
+
+    def _check(self, x: Tensor, h: Tensor):
+        if x.dim() != 2 or h.dim() != 3:
+            raise WgError("expected audio [B, N] and conditioning [B, n_mels, frames]")
+        T = x.size(1) // self.n_group
+        up_len = (h.size(2) - 1) * self.upsample_factor - 2 * self.upsampler.padding[0] + self.upsampler.kernel_size[0]
+        assert T <= up_len            # same contract as the reference's assert (waveglow.py:156,187)
+
+    def forward_computation(self, x: Tensor, h: Tensor) -> Tuple[Tensor, Tensor]:
+        self._check(x, h)
+        return _WaveGlowFn.apply(self, x, h, *self.parameters())
+
+    def reverse_computation(self, z: Tensor, h: Tensor) -> Tuple[Tensor, Tensor]:
+        self._check(z, h)
+        if torch.is_grad_enabled() and (z.requires_grad or h.requires_grad):
+            warnings.warn("WaveGlow.reverse runs without autograd in the HIP engine", stacklevel=2)
+        table = [None if t is None else t.detach() for t in self.param_table()]
+        return self._engine.run(table, z.detach(), h.detach(), True)
+
+    def _upsample_h(self, h):
+        T = (h.size(2) - 1) * self.upsample_factor - 2 * self.upsampler.padding[0] + self.upsampler.kernel_size[0]
+        return self._engine.upsample([None if t is None else t.detach() for t in self.param_table()], h.detach(), T)

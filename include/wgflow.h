@@ -1,0 +1,140 @@
+/*
+ * wgflow.h -- C ABI of the MI355X-native WaveGlow flow engine (libwgflow.so).
+ *
+ * This is the drop-in boundary for the hot path of yoyololicon/constant-memory-waveglow:
+ * every entry point replaces a specific piece of the reference's Python/ATen path (cited
+ * below as path:line under the upstream repo).  Plain C types only: device pointers, sizes,
+ * a stream handle.  No allocation, no global state: every call works inside a caller-provided
+ * workspace whose size comes from the matching *_bytes() query, is re-entrant per stream, and
+ * only ENQUEUES work on `stream` (hipStream_t passed as void*; NULL = the default stream).
+ * All tensors are float32, contiguous, device resident unless a parameter says "host".
+ *
+ * Return value: 0 on success, a negative WG_E* code otherwise (wg_strerror() names it).
+ *
+ * Parameter table ("params"): an array of device pointers in the order of the reference
+ * model's named_parameters():
+ *     [0] upsampler.bias [n_mels]   [1] upsampler.weight_g [n_mels,1,1]   [2] upsampler.weight_v [n_mels,1,K]
+ *     [3 .. 3+flows)                invconv1x1.{k}.weight [c_k,c_k,1]
+ *     then per flow k, 4+4*depth+1 entries:
+ *         V.weight_g, V.weight_v, start.weight_g, start.weight_v,
+ *         layers.{i}.W.weight_g, .W.weight_v, .W_o.weight_g, .W_o.weight_v   (i = 0..depth-1),
+ *         end.weight
+ * A NULL weight_g entry means the convolution carries a plain weight in its weight_v slot
+ * (what the module looks like after utils.remove_weight_norms, utils.py:9-11).
+ * The gradient table ("grads") has the same order and shapes; NULL entries are skipped.
+ */
+#ifndef WGFLOW_H
+#define WGFLOW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WG_OK 0
+#define WG_EINVAL (-1)      /* bad argument / unsupported shape */
+#define WG_ESHAPE (-2)      /* audio length not a multiple of n_group, or mel too short (waveglow.py:156 assert) */
+#define WG_EUNSUPPORTED (-3)/* valid for the reference but outside this engine's kernels */
+#define WG_ELAUNCH (-4)     /* a HIP launch failed */
+#define WG_EWORKSPACE (-5)  /* workspace too small */
+
+/* Constructor arguments of model.WaveGlow (model/waveglow.py:109-118) after the arithmetic of
+ * :125-129 (upsampler geometry).  WN arguments are the **kwargs forwarded to WN (waveglow.py:50-59). */
+typedef struct wg_config {
+    int32_t n_flows, n_group, n_early_every, n_early_size, n_mels;
+    int32_t up_stride, up_kernel, up_pad;            /* ConvTranspose1d(n_mels,n_mels,K,stride,pad,groups=n_mels) */
+    int32_t res_ch, dil_ch, skip_ch, depth, radix;   /* WN: residual/dilation/skip channels, layers, kernel size */
+} wg_config;
+
+/* Dimensions of one WN as AffineCouplingBlock builds it (efficient_modules.py:58-65, waveglow.py:50-59). */
+typedef struct wg_wn_dims {
+    int32_t in_ch, aux_ch, res_ch, dil_ch, skip_ch, depth, radix;
+} wg_wn_dims;
+
+const char *wg_strerror(int code);
+int wg_abi_version(void);
+
+/* ---- sizes -------------------------------------------------------------------------------- */
+int    wg_param_count(const wg_config *cfg);                 /* entries of the parameter table */
+size_t wg_packed_bytes(const wg_config *cfg);                /* materialised-weight buffer of the model */
+/* mode 0: forward / inverse (2 activation planes per WN);  mode 1: backward (all layers kept for ONE flow) */
+size_t wg_workspace_bytes(const wg_config *cfg, int B, int N, int mode);
+int    wg_wn_param_count(const wg_wn_dims *d);
+size_t wg_wn_packed_bytes(const wg_wn_dims *d);
+size_t wg_coupling_workspace_bytes(const wg_wn_dims *d, int B, int T, int mode);
+size_t wg_invconv_workspace_bytes(int c, int B, int T);
+
+/* Workspaces keep zero halos between calls; zero a freshly allocated one ONCE with this. */
+int wg_workspace_init(void *ws, size_t bytes, void *stream);
+
+/* ---- weights ------------------------------------------------------------------------------ */
+/* Replaces the weight_norm forward pre-hooks (utils.py:14-16; w = g*v/||v||, recomputed on every module
+ * call upstream) and the per-call logdet/inverse of the 1x1 weights (efficient_modules.py:221,235):
+ * materialises every effective weight ONCE per step in the layouts the kernels read. */
+int wg_pack_weights(const wg_config *cfg, const void *const *params, void *packed, void *stream);
+int wg_wn_pack_weights(const wg_wn_dims *d, const void *const *params, void *packed, void *stream);
+
+/* ---- model level  (model/waveglow.py:150-208, model/base.py:20-55) ------------------------- */
+/* WaveGlow.forward_computation (waveglow.py:150-179): audio[B,N], h[B,n_mels,F] -> z[B,N], logdet[B]. */
+int wg_forward(const wg_config *cfg, const void *packed, const float *audio, const float *h,
+               int B, int N, int F, float *z, float *logdet, void *ws, size_t ws_bytes, void *stream);
+
+/* WaveGlow.reverse_computation (waveglow.py:181-208): z[B,N], h -> x[B,N], logdet[B].  FlowBase.infer
+ * (base.py:42-55) is this call on a latent the caller draws. */
+int wg_inverse(const wg_config *cfg, const void *packed, const float *z, const float *h,
+               int B, int N, int F, float *x, float *logdet, void *ws, size_t ws_bytes, void *stream);
+
+/* Backward of wg_forward with the reference's constant-memory protocol (efficient_modules.py:118-154,
+ * 230-244): starts from the flow OUTPUT z, walks flows last to first, rebuilds each block's input from
+ * its output, recomputes that flow's WN activations into the workspace and produces the gradient of every
+ * parameter.  dz[B,N], dlogdet[B] are the incoming gradients.  grads: table as params (written, not
+ * accumulated).  dh[B,n_mels,F] and dx[B,N] (gradient wrt the audio) may be NULL.  x_rebuilt (nullable)
+ * receives the re-materialised input audio [B,N]. */
+int wg_backward(const wg_config *cfg, const void *const *params, const void *packed,
+                const float *z, const float *h, const float *dz, const float *dlogdet,
+                int B, int N, int F, void *const *grads, float *dh, float *dx, float *x_rebuilt,
+                void *ws, size_t ws_bytes, void *stream);
+
+/* WaveGlowLoss.forward (model/loss.py:10-15): loss = mean_b(0.5*sum z^2/sigma^2 - logdet_b) [/N].
+ * loss is a device scalar.  The backward writes dz[B,N], dlogdet[B] for an upstream gradient dloss (device scalar,
+ * NULL = 1). */
+int wg_nll_loss(const float *z, const float *logdet, int B, int N, float sigma, int elementwise_mean,
+                float *loss, void *stream);
+int wg_nll_loss_backward(const float *z, int B, int N, float sigma, int elementwise_mean,
+                         const float *dloss, float *dz, float *dlogdet, void *stream);
+
+/* ---- block level  (model/efficient_modules.py) ---------------------------------------------- */
+/* InvertibleConv1x1.forward_computation / reverse_computation (efficient_modules.py:31-54): W[c,c] device,
+ * x[B,c,T] -> z[B,c,T]; logdet = device scalar (+-T*logdet W, NaN when det W < 0 as torch.logdet). */
+int wg_invconv_apply(const float *W, int c, const float *x, int B, int T, int reverse,
+                     float *z, float *logdet, void *ws, size_t ws_bytes, void *stream);
+/* Conv1x1Func.backward / InvConv1x1Func.backward (efficient_modules.py:230-244, 262-279): from the block
+ * OUTPUT z and its gradient dz plus dlogdet (device scalar): rebuilt input x, dx, dW[c,c]. */
+int wg_invconv_backward(const float *W, int c, const float *z, const float *dz, const float *dlogdet,
+                        int B, int T, int reverse, float *x, float *dx, float *dW,
+                        void *ws, size_t ws_bytes, void *stream);
+
+/* AffineCouplingBlock.forward_computation / reverse_computation (efficient_modules.py:70-96) with F = WN:
+ * x[B,2*in_ch,T], y[B,aux,T] -> z[B,2*in_ch,T], log_s[B,in_ch,T] (negated when reverse). */
+int wg_coupling_apply(const wg_wn_dims *d, const void *packed, const float *x, const float *y,
+                      int B, int T, int reverse, float *z, float *log_s,
+                      void *ws, size_t ws_bytes, void *stream);
+/* WN.forward (waveglow.py:98-105): x[B,in_ch,T], y[B,aux,T] -> (log_s, t), each [B,in_ch,T]. */
+int wg_wn_apply(const wg_wn_dims *d, const void *packed, const float *x, const float *y, int B, int T,
+                float *log_s, float *t, void *ws, size_t ws_bytes, void *stream);
+/* AffineCouplingFunc.backward / InvAffineCouplingFunc.backward (efficient_modules.py:118-154, 175-212):
+ * from the block OUTPUT z, y, dz, dlog_s: rebuilt input x, dx, dy (nullable), parameter grads. */
+int wg_coupling_backward(const wg_wn_dims *d, const void *const *params, const void *packed,
+                         const float *z, const float *y, const float *dz, const float *dlog_s,
+                         int B, int T, int reverse, float *x, float *dx, float *dy, void *const *grads,
+                         void *ws, size_t ws_bytes, void *stream);
+
+/* mel upsampler alone (waveglow.py:126-130,210-212, cropped to T as :157): h[B,n_mels,F] -> y[B,n_mels,T] */
+int wg_upsample(const wg_config *cfg, const void *packed, const float *h, int B, int F, int T, float *y, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WGFLOW_H */
