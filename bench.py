@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio samples/s of WaveGlow-256ch forward + NLL backward on 16 000-sample segments.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu] [--no-inverse]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
+z, logdet = model(x, h); loss = NLL(z, logdet); backward to all 459 parameter gradients (+ RCCL mean all-reduce
+of the gradients when N > 1).  Data loading, mel computation, optimizer step and logging are outside, as in
+SURVEY.md 8d.  Per-GPU batch is fixed (weak scaling): configs[1] of BASELINE.json at N=1, configs[2] at N=8.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline     : the dominant kernel (dilated conv + conditioning + gate, convgemm_kernel<EPI_GATE>) timed with HIP
+                 events over the timed steps, algorithmic FLOPs / average launch duration vs the fp32 MFMA peak;
+  cpu_baseline : the CPU oracle (a plain-C port of the reference's algorithm) timed on the host cores on one
+                 16 000-sample segment of the same workload (rank 0, N=1 only);
+  inverse_khz  : single-GPU synthesis speed, timed as the reference does (inference.py:50-56).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+C2 = dict(flows=12, n_group=8, n_early_every=4, n_early_size=2, hop_size=256, n_mels=80,
+          dilation_channels=256, residual_channels=256, skip_channels=256, depth=8, radix=3)   # configs/waveglow_LJ_speech.json:6-19
+SEG, FRAMES, SIGMA = 16000, 63, 0.7
+FP32_MFMA_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+FWD_FLOP_PER_SAMPLE = 13_376_372         # SURVEY.md 2.1 (forward = inverse)
+STEP_FLOP_PER_SAMPLE = 40_129_116        # fwd + dgrad + wgrad (algorithmic; the recompute is not credited)
+
+
+def build_model(dev, seed=0):
+    import constant_memory_waveglow_amd as cm
+    torch.manual_seed(seed)
+    model = cm.WaveGlow(memory_efficient=True, bias=False, **C2)
+    with torch.no_grad():                 # the reference zero-inits WN.end (log_s = t = 0); make the flow non-trivial
+        for blk in model.WNs:
+            blk.F.end.weight.normal_(0.0, 0.02)
+    return model.to(dev)
+
+
+def cpu_baseline():
+    """One training step of the C2 network on ONE segment with the CPU oracle (kind = "port")."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import fill
+    from oracle import wg_oracle as orc
+    specs = fill.model_param_specs(C2)
+    tab = fill.table(specs, fill.fill_params(specs, "c2/"))
+    audio, h = fill.inputs("c2", 1, SEG, FRAMES, C2["n_mels"])
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    oc = orc.make_config(**C2)
+    t0 = time.time()
+    orc.train_step(oc, tab, audio, h, SIGMA)
+    dt = time.time() - t0
+    return {"value": SEG / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "1 segment of 16000 samples (B=1), WaveGlow-256ch 12 flows, fwd+NLL+bwd, one run = %.1f s" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=24, help="per-GPU batch (configs[1]: 24)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-inverse", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    from constant_memory_waveglow_amd import _lib
+    from constant_memory_waveglow_amd.parallel import FlowTrainer
+
+    model = build_model(dev)
+    trainer = FlowTrainer(model, SIGMA)
+    B = args.batch
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.rand(B, SEG, device=dev, generator=g) * 2 - 1              # as tests/test_fwd_bwd.py:28 upstream
+    h = torch.randn(B, C2["n_mels"], FRAMES, device=dev, generator=g)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(x, h)
+    L = _lib.lib()
+    per_step_gate = 2 * C2["flows"] * C2["depth"]                        # forward + recompute
+    timer = L.wg_timer_create(_lib.K_CONV_GATE, per_step_gate * args.steps) if rank == 0 else None
+    barrier()
+    if timer:
+        L.wg_timer_attach(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, z, logdet = trainer.step(x, h)
+    barrier()
+    dt = time.perf_counter() - t0
+    if timer:
+        L.wg_timer_attach(None)
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * SEG * args.steps / dt
+
+    out = None
+    if rank == 0:
+        n = L.wg_timer_count(timer)
+        buf = (C.c_float * n)()
+        L.wg_timer_read(timer, buf, n)
+        L.wg_timer_destroy(timer)
+        gate_ms = float(np.mean(np.frombuffer(buf, dtype=np.float32))) if n else float("nan")
+        T = SEG // C2["n_group"]
+        kcat = C2["radix"] * C2["residual_channels"] + C2["n_mels"]
+        gate_flop = 2.0 * kcat * 2 * C2["dilation_channels"] * B * T     # algorithmic FLOPs of one launch
+        achieved = gate_flop / (gate_ms * 1e-3) / 1e12
+        out = {
+            "metric": "audio samples/sec (fwd+bwd) WaveGlow-256ch seg=16000",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "WaveGlow 256ch, 12 flows, seg=16000, batch=%d per GPU (waveglow_LJ_speech.json), "
+                                   "forward + NLL + constant-memory backward%s" % (B, " + RCCL grad all-reduce" if world > 1 else ""),
+                       "global_batch": B * world, "segment": SEG, "parallelism": "dp%d" % world},
+            "roofline": {"bound": "mfma", "kernel": "convgemm_kernel<EPI_GATE> (dilated k=3 conv + mel conditioning + gate)",
+                         "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launch_ms": gate_ms, "launches_timed": n, "flop_per_launch": gate_flop},
+            "step_tflops_algorithmic": value * STEP_FLOP_PER_SAMPLE / 1e12 / world,
+            "step_frac_of_fp32_mfma_peak": value * STEP_FLOP_PER_SAMPLE / 1e12 / world / FP32_MFMA_PEAK_TFLOPS,
+            "loss": float(loss),
+        }
+        if not args.no_inverse:
+            with torch.no_grad():
+                for frames in (63, 862):                                  # 16 128 samples and ~10 s of audio
+                    hc = torch.randn(1, C2["n_mels"], frames, device=dev, generator=g)
+                    model.infer(hc, 0.6)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    xs = model.infer(hc, 0.6)
+                    torch.cuda.synchronize()
+                    cost = time.perf_counter() - t1
+                    out["inverse_khz_%d" % xs.numel()] = xs.numel() / cost / 1000.0
+            out["inverse_khz"] = out["inverse_khz_%d" % (862 * 256)]
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -5,6 +5,7 @@
 #include "wg_small.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 
@@ -27,6 +28,27 @@ struct Ctx {
             if (hipGetLastError() != hipSuccess) (ctx).err = WG_ELAUNCH;      \
         }                                                                     \
     } while (0)
+
+// Diagnostics only: an attached timer brackets every launch of ONE kernel class with HIP events on the launch
+// stream (bench.py's roofline leg).  Detached (the default) it costs one relaxed pointer load per launch.
+struct KernelTimer {
+    int kernel_id, capacity, count;
+    hipEvent_t *start, *stop;
+};
+std::atomic<KernelTimer *> g_timer{nullptr};
+struct TimerScope {
+    KernelTimer *t;
+    hipStream_t st;
+    int slot;
+    TimerScope(int id, hipStream_t s) : t(g_timer.load(std::memory_order_relaxed)), st(s), slot(-1)
+    {
+        if (t && t->kernel_id == id && t->count < t->capacity) {
+            slot = t->count++;
+            (void)hipEventRecord(t->start[slot], st);
+        }
+    }
+    ~TimerScope() { if (slot >= 0) (void)hipEventRecord(t->stop[slot], st); }
+};
 
 // ------------------------------------------------------------------------------------------------
 // geometry
@@ -354,6 +376,7 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
     a.out0 = out0; a.out1 = out1; a.out2 = out2; a.aux0 = aux0; a.aux1 = aux1;
     const int mrows = epi == EPI_GATE ? M : M;
     dim3 grid(g.Tt / WG_TILE, rup(mrows, WG_TILE) / WG_TILE, g.B), block(256);
+    TimerScope ts(WG_K_CONV_STORE + epi, cx.st);
     switch (epi) {
     case EPI_STORE: WG_LAUNCH(cx, convgemm_kernel<EPI_STORE>, grid, block, 0, a); break;
     case EPI_GATE: WG_LAUNCH(cx, convgemm_kernel<EPI_GATE>, grid, block, 0, a); break;
@@ -397,6 +420,7 @@ WgradOut run_wgrad(Ctx &cx, const Geo &g, const WSegSpec *sa, int nsa, const WSe
     o.nsplit = p.nsplit; o.Mp = a.Mp; o.Np = a.Np;
     if ((size_t)p.nsplit * a.Mp * a.Np > slab_cap) { if (!cx.err) cx.err = WG_EWORKSPACE; return o; }
     dim3 grid(a.Np / WG_TILE, a.Mp / WG_TILE, p.nsplit), block(256);
+    TimerScope ts(WG_K_WGRAD, cx.st);
     WG_LAUNCH(cx, wgrad_kernel, grid, block, 0, a);
     return o;
 }
@@ -603,6 +627,37 @@ const char *wg_strerror(int code)
     return "unknown error";
 }
 int wg_abi_version(void) { return 1; }
+
+void *wg_timer_create(int kernel_id, int capacity)
+{
+    if (capacity < 1) return nullptr;
+    KernelTimer *t = new KernelTimer;
+    t->kernel_id = kernel_id; t->capacity = capacity; t->count = 0;
+    t->start = new hipEvent_t[capacity];
+    t->stop = new hipEvent_t[capacity];
+    for (int i = 0; i < capacity; ++i) { (void)hipEventCreate(&t->start[i]); (void)hipEventCreate(&t->stop[i]); }
+    return t;
+}
+void wg_timer_attach(void *timer) { g_timer.store((KernelTimer *)timer); }
+int wg_timer_count(void *timer) { return timer ? ((KernelTimer *)timer)->count : 0; }
+/* call after the stream has been synchronised; writes one duration (ms) per recorded launch */
+int wg_timer_read(void *timer, float *ms, int n)
+{
+    KernelTimer *t = (KernelTimer *)timer;
+    if (!t || !ms) return WG_EINVAL;
+    const int m = std::min(n, t->count);
+    for (int i = 0; i < m; ++i)
+        if (hipEventElapsedTime(&ms[i], t->start[i], t->stop[i]) != hipSuccess) return WG_ELAUNCH;
+    return m;
+}
+void wg_timer_destroy(void *timer)
+{
+    KernelTimer *t = (KernelTimer *)timer;
+    if (!t) return;
+    if (g_timer.load() == t) g_timer.store(nullptr);
+    for (int i = 0; i < t->capacity; ++i) { (void)hipEventDestroy(t->start[i]); (void)hipEventDestroy(t->stop[i]); }
+    delete[] t->start; delete[] t->stop; delete t;
+}
 
 int wg_param_count(const wg_config *cf) { return cf ? 3 + cf->n_flows + cf->n_flows * (4 + 4 * cf->depth + 1) : WG_EINVAL; }
 size_t wg_packed_bytes(const wg_config *cf) { return cfg_check(cf) ? 0 : model_pack_layout(cf).total * sizeof(float); }

@@ -124,15 +124,18 @@ class ModelEngine:
               "wg_inverse" if inverse else "wg_forward")
         return out, logdet
 
-    def backward(self, params, z, h, dz, dlogdet, need, need_dh, need_dx, want_x=False):
-        """need[i]: produce the gradient of params[i].  Returns (grads list, dh, dx, x_rebuilt)."""
+    def backward(self, params, z, h, dz, dlogdet, need, need_dh, need_dx, want_x=False, grads_out=None):
+        """need[i]: produce the gradient of params[i] (into grads_out[i] when given).  Returns (grads, dh, dx, x_rebuilt)."""
         require_device(z, h, dz, dlogdet)
         z, h, dz, dlogdet = z.contiguous(), h.contiguous(), dz.contiguous(), dlogdet.contiguous()
         B, N = z.shape
         F = h.shape[2]
         pk = self._pack(params, z.device)
         ws = self._ws(B, N, 1, z.device)
-        grads = [torch.empty_like(p) if (p is not None and nd) else None for p, nd in zip(params, need)]
+        if grads_out is not None:
+            grads = [g if nd else None for g, nd in zip(grads_out, need)]
+        else:
+            grads = [torch.empty_like(p) if (p is not None and nd) else None for p, nd in zip(params, need)]
         dh = torch.empty_like(h) if need_dh else None
         dx = torch.empty_like(z) if need_dx else None
         xr = torch.empty_like(z) if want_x else None

@@ -1,0 +1,121 @@
+"""Data-parallel training of the flow: one process per GPU, gradients averaged with RCCL all-reduce over xGMI.
+
+Replaces what the reference gets from Lightning's DDPPlugin (train.py:51-53,73-78): per-GPU batch = global // world,
+mean-all-reduce of every parameter gradient each step, replicas start from rank 0's weights.  The path has no
+other exchange step: batch items are independent units.
+
+Gradients of one step live in ONE flat fp32 buffer (FlatGrads) carved in parameter-table order, so the all-reduce
+runs on contiguous slices: one bucket per flow, issued in backward order (last flow first), plus the upsampler /
+1x1 bucket.  xGMI is point to point, so a few large (>=8 MB) buckets are preferred over DDP's 25 MB default mix.
+"""
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+class FlatGrads:
+    """A flat gradient buffer with per-parameter views and per-bucket slices."""
+
+    def __init__(self, params: Sequence[torch.Tensor], bucket_of: Sequence[int]):
+        assert len(params) == len(bucket_of)
+        self.sizes = [p.numel() for p in params]
+        order = sorted(range(len(params)), key=lambda i: (bucket_of[i], i))
+        self.offsets = [0] * len(params)
+        self.bucket_ranges: List[Tuple[int, int]] = []
+        off = 0
+        cur, start = None, 0
+        for i in order:
+            if bucket_of[i] != cur:
+                if cur is not None:
+                    self.bucket_ranges.append((start, off))
+                cur, start = bucket_of[i], off
+            self.offsets[i] = off
+            off += self.sizes[i]
+        if cur is not None:
+            self.bucket_ranges.append((start, off))
+        self.total = off
+        self.flat = torch.zeros(self.total, dtype=params[0].dtype, device=params[0].device)
+        self.views = [self.flat[o:o + n].view_as(p) for o, n, p in zip(self.offsets, self.sizes, params)]
+
+    def bucket(self, b: int) -> torch.Tensor:
+        s, e = self.bucket_ranges[b]
+        return self.flat[s:e]
+
+
+def waveglow_buckets(n_flows: int, depth: int) -> List[int]:
+    """bucket id per parameter-table entry: flow k -> bucket k; upsampler + 1x1 weights -> bucket n_flows."""
+    ids = [n_flows] * (3 + n_flows)
+    for k in range(n_flows):
+        ids += [k] * (4 + 4 * depth + 1)
+    return ids
+
+
+class GradSync:
+    """Mean all-reduce of a FlatGrads over the process group, bucket by bucket in backward order."""
+
+    def __init__(self, process_group=None):
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        backend = dist.get_backend(process_group) if dist.is_initialized() else None
+        self._avg = backend == "nccl"          # RCCL has a native AVG; gloo does not
+
+    def all_reduce(self, fg: FlatGrads, order: Sequence[int] = None):
+        if self.world == 1:
+            return
+        order = list(order) if order is not None else list(range(len(fg.bucket_ranges) - 1, -1, -1))
+        works = []
+        for b in order:
+            t = fg.bucket(b)
+            if t.numel() == 0:
+                continue
+            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+            works.append((dist.all_reduce(t, op=op, group=self.pg, async_op=True), t))
+        for w, t in works:
+            w.wait()
+            if not self._avg:
+                t.div_(self.world)
+
+    def broadcast_params(self, params: Sequence[torch.Tensor], src: int = 0):
+        """replicas start identical (what DDP does when it wraps the module)"""
+        if self.world == 1:
+            return
+        for p in params:
+            dist.broadcast(p.data, src=src, group=self.pg)
+
+
+class FlowTrainer:
+    """The training step of model/lightning.py:52-56 without Lightning:
+        z, logdet = model(x, h); loss = NLL(z, logdet); backward to every parameter gradient; all-reduce(mean).
+    Runs the HIP engine directly (no autograd graph) and leaves the gradients in p.grad (views of one flat buffer)."""
+
+    def __init__(self, model, sigma: float, elementwise_mean: bool = True, process_group=None):
+        from . import engine
+        self._engine_mod = engine
+        self.model = model
+        self.sigma, self.mean = sigma, elementwise_mean
+        self.sync = GradSync(process_group)
+        self.table = [t for t in model.param_table()]
+        wn0 = model.WNs[0].F
+        ids = waveglow_buckets(len(model.WNs), len(wn0.layers))
+        live = [(t, b) for t, b in zip(self.table, ids) if t is not None]
+        self.fg = FlatGrads([t for t, _ in live], [b for _, b in live])
+        it = iter(self.fg.views)
+        self.grad_views = [next(it) if t is not None else None for t in self.table]
+        self.sync.broadcast_params([t for t in self.table if t is not None])
+
+    @torch.no_grad()
+    def step(self, x: torch.Tensor, h: torch.Tensor):
+        eng, E = self.model._engine, self._engine_mod
+        table = [None if t is None else t.detach() for t in self.table]
+        z, logdet = eng.run(table, x, h, False)
+        loss = E.nll_loss(z, logdet, self.sigma, self.mean)
+        one = torch.ones((), dtype=torch.float32, device=z.device)
+        dz, dlogdet = E.nll_loss_backward(z, self.sigma, self.mean, one)
+        need = [t is not None and t.requires_grad for t in self.table]
+        eng.backward(table, z, h, dz, dlogdet, need, False, False, grads_out=self.grad_views)
+        self.sync.all_reduce(self.fg)
+        for t, g in zip(self.table, self.grad_views):
+            if t is not None:
+                t.grad = g
+        return loss, z, logdet

@@ -56,6 +56,21 @@ typedef struct wg_wn_dims {
 const char *wg_strerror(int code);
 int wg_abi_version(void);
 
+/* Diagnostics (no counterpart upstream; the reference times with wall-clock time(), inference.py:39-53): while a
+ * timer is attached, every launch of ONE kernel class is bracketed with HIP events on its launch stream, so a
+ * benchmark can read that kernel's per-launch durations over the very steps it times.  Process-wide: attach from
+ * one thread, detach (attach NULL) before destroying. */
+#define WG_K_CONV_STORE 0    /* convgemm, plain / accumulate epilogue: start, dgrad (W^T), V^T, W_end^T, W_start^T */
+#define WG_K_CONV_GATE 1     /* convgemm, dilated conv + conditioning + tanh*sigmoid gate   (the dominant kernel) */
+#define WG_K_CONV_RESSKIP 2  /* convgemm, W_o + residual/skip epilogue */
+#define WG_K_CONV_DGATE 3    /* convgemm, W_o^T + gate backward */
+#define WG_K_WGRAD 4         /* weight-gradient kernel */
+void *wg_timer_create(int kernel_id, int capacity);
+void  wg_timer_attach(void *timer);
+int   wg_timer_count(void *timer);
+int   wg_timer_read(void *timer, float *ms, int n);   /* after a stream sync; returns the number written */
+void  wg_timer_destroy(void *timer);
+
 /* ---- sizes -------------------------------------------------------------------------------- */
 int    wg_param_count(const wg_config *cfg);                 /* entries of the parameter table */
 size_t wg_packed_bytes(const wg_config *cfg);                /* materialised-weight buffer of the model */

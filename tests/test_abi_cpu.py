@@ -1,0 +1,112 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol include/wgflow.h declares,
+size queries behave, the torch modules mirror the reference's constructor / state-dict contract, and the product
+path refuses to run without a HIP device (no CPU fallback).  No kernels are launched here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+import constant_memory_waveglow_amd as cm
+from constant_memory_waveglow_amd import _lib, engine
+import fill
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "wgflow.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(wg_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    declared = _header_symbols()
+    assert len(declared) >= 25
+    for s in declared:
+        assert hasattr(L, s), "libwgflow.so lacks %s" % s
+    assert sorted(_lib.ABI_SYMBOLS) == declared
+    assert L.wg_abi_version() == 1
+    assert L.wg_strerror(0) == b"ok"
+
+
+def test_size_queries_and_config_validation():
+    L = _lib.lib()
+    cfg = engine.make_config(12, 8, 4, 2, 256, 80, 256, 256, 256, 8, 3)
+    assert L.wg_param_count(C.byref(cfg)) == 459                       # 459 state-dict entries
+    assert (cfg.up_stride, cfg.up_kernel, cfg.up_pad) == (32, 65, 16)   # waveglow.py:125-129
+    pk = L.wg_packed_bytes(C.byref(cfg))
+    assert pk > 53_658_304 * 4                                          # every weight in >= 1 layout
+    w0 = L.wg_workspace_bytes(C.byref(cfg), 24, 16000, 0)
+    w1 = L.wg_workspace_bytes(C.byref(cfg), 24, 16000, 1)
+    assert 0 < w0 < w1 < 8 << 30                                        # O(1) in flow depth: a few GB for ONE flow's activations
+    cfg6 = engine.make_config(6, 8, 4, 2, 256, 80, 256, 256, 256, 8, 3)
+    assert L.wg_workspace_bytes(C.byref(cfg6), 24, 16000, 1) <= w1     # does not grow with the number of flows
+    assert L.wg_workspace_bytes(C.byref(cfg), 24, 16001, 1) == 0        # N % n_group != 0
+    bad = engine.make_config(12, 8, 4, 2, 256, 80, 250, 256, 256, 8, 3)
+    assert L.wg_packed_bytes(C.byref(bad)) == 0                         # channels must be multiples of 32
+
+
+def test_state_dict_layout_matches_reference_names():
+    cfg = fill.CONFIGS["c1"]
+    m = cm.WaveGlow(memory_efficient=True, bias=False, **cfg)
+    names = [n for n, _ in m.named_parameters()]
+    specs = fill.model_param_specs(cfg)
+    assert names == [n for n, _, _ in specs]
+    sd = m.state_dict()
+    for n, shape, _ in specs:
+        assert tuple(sd[n].shape) == tuple(shape), n
+    assert m.z_split_sizes == [2, 6]
+    assert len(m.param_table()) == len(specs)
+    # remove_weight_norm folds g,v into `weight` (inference.py:17 upstream)
+    m.apply(cm.remove_weight_norms)
+    assert "WNs.0.F.V.weight" in m.state_dict() and "WNs.0.F.V.weight_g" not in m.state_dict()
+    tab = m.param_table()
+    assert tab[1] is None and tab[2] is m.upsampler.weight
+
+
+def test_invconv_init_is_orthogonal_with_positive_det():
+    blk = cm.InvertibleConv1x1(8)
+    W = blk.weight.detach()[:, :, 0]
+    assert torch.allclose(W @ W.t(), torch.eye(8), atol=1e-5)
+    assert torch.det(W) > 0
+
+
+def test_wn_zero_init_and_ctor_errors():
+    wn = cm.WN(4, 80, 64, 64, 64, depth=3)
+    assert float(wn.end.weight.abs().max()) == 0.0
+    assert wn.r_field == 1 + 2 + 4 + 1
+    with pytest.raises(cm.WgError):
+        cm.WN(4, 80, bias=True)
+    with pytest.raises(cm.WgError):
+        cm.WaveGlow(reverse_mode=True, memory_efficient=True, **fill.CONFIGS["micro"])
+
+
+def test_no_cpu_fallback():
+    m = cm.WaveGlow(memory_efficient=True, bias=False, **fill.CONFIGS["micro"])
+    with pytest.raises(cm.WgError, match="no CPU fallback"):
+        m(torch.rand(2, 512), torch.randn(2, 20, 8))
+    with pytest.raises(cm.WgError):
+        m.infer(torch.randn(20, 8))
+    with pytest.raises(cm.WgError):
+        cm.WaveGlowLoss(0.7)(torch.randn(2, 16), torch.zeros(2))
+    with pytest.raises(cm.WgError):
+        cm.InvertibleConv1x1(4)(torch.rand(1, 4, 16))
+
+
+def test_shape_contract_assert():
+    m = cm.WaveGlow(memory_efficient=True, bias=False, **fill.CONFIGS["micro"])
+    with pytest.raises(AssertionError):                                  # mel shorter than the audio (waveglow.py:156)
+        m(torch.rand(1, 512 * 4), torch.randn(1, 20, 8))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "constant-memory-waveglow_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                for needle in ("wg_oracle", "import oracle", "from oracle", "libwgoracle"):
+                    assert needle not in text, (f, needle)

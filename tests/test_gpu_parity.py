@@ -1,0 +1,311 @@
+"""Parity tests proper (-m gpu): the HIP engine, called through the C ABI by the torch modules, against the CPU
+oracle on the same seeded inputs and against the golden vectors the upstream reference produced.
+
+Tolerances (BASELINE.json north_star: 1e-4 fp32):  z / x abs 1e-4;  loss 1e-6;  logdet rtol 1e-4 (+1e-7 per sample:
+the reference's own fp32 logdet sits ~1e-4 from fp64);  every parameter gradient within 1e-4 of
+that tensor's max-abs.  Block-level tolerances follow the reference's tests/test_fwd_bwd.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fill
+from make_golden import COUPLING_CASES
+from oracle import wg_oracle as orc
+import constant_memory_waveglow_amd as cm
+
+pytestmark = pytest.mark.gpu
+
+Z_ATOL, LOSS_ATOL, GRAD_RTOL = 1e-4, 1e-6, 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "the gpu suite needs the MI355X"
+    from constant_memory_waveglow_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH)
+    return torch.device("cuda:0")
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def relmax(a, b):
+    return float(np.abs(a - b).max() / max(float(np.abs(b).max()), 1e-30))
+
+
+def logdet_close(a, b, N):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return bool(np.all(np.abs(a - b) <= 1e-4 * np.abs(b) + 1e-7 * N))
+
+
+def build(name, dev, mem_eff=True):
+    cfg = fill.CONFIGS[name]
+    specs = fill.model_param_specs(cfg)
+    P = fill.fill_params(specs, name + "/")
+    m = cm.WaveGlow(memory_efficient=mem_eff, bias=False, **cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    return m.to(dev), cfg, specs, P
+
+
+@pytest.mark.parametrize("name", ["micro", "c1"])
+def test_model_step_vs_oracle_and_golden(dev, golden_dir, name):
+    m, cfg, specs, P = build(name, dev)
+    B, N, F = fill.SHAPES[name]
+    audio, h = fill.inputs(name, B, N, F, cfg["n_mels"])
+    ref = orc.train_step(orc.make_config(**cfg), fill.table(specs, P), audio, h, fill.SIGMA, need_dh=True)
+    gold = np.load(os.path.join(golden_dir, "model_%s.npz" % name))
+    x, ht = T(audio, dev), T(h, dev).requires_grad_(True)
+    z, logdet = m(x, ht)
+    loss = cm.WaveGlowLoss(fill.SIGMA)(z, logdet)
+    loss.backward()
+    for want in (ref, gold):
+        assert np.abs(npy(z) - want["z"]).max() < Z_ATOL
+        assert logdet_close(npy(logdet), want["logdet"], N)
+        assert abs(float(loss) - float(want["loss"])) < LOSS_ATOL
+        assert relmax(npy(ht.grad), want["dh"]) < GRAD_RTOL
+    named = dict(m.named_parameters())
+    for i, (n, _, _) in enumerate(specs):
+        g = npy(named[n].grad)
+        assert relmax(g, ref["grads"][i]) < GRAD_RTOL, n
+        nh = min(g.size, gold["grad_head"].shape[1])
+        assert np.abs(g.ravel()[:nh] - gold["grad_head"][i][:nh]).max() / max(float(gold["grad_max"][i]), 1e-30) < GRAD_RTOL, n
+        if "grad::" + n in gold:
+            assert relmax(g, gold["grad::" + n]) < GRAD_RTOL, n
+    assert torch.equal(x, T(audio, dev))                       # the caller's audio survives (waveglow.py:153 copies)
+
+
+@pytest.mark.parametrize("name", ["micro", "c1"])
+def test_model_inverse_and_infer(dev, golden_dir, name):
+    m, cfg, specs, P = build(name, dev)
+    B, N, F = fill.SHAPES[name]
+    audio, h = fill.inputs(name, B, N, F, cfg["n_mels"])
+    gold = np.load(os.path.join(golden_dir, "model_%s.npz" % name))
+    ht = T(h, dev)
+    with torch.no_grad():
+        x, ld = m.reverse(T(gold["z"], dev), ht)
+        zlat = fill.normal(name + "/latent", (B, N), fill.SIGMA)
+        xs, _ = m.reverse(T(zlat, dev), ht)
+    assert np.abs(npy(x) - gold["x_inv"]).max() < Z_ATOL
+    assert np.abs(npy(x) - audio).max() < Z_ATOL               # reverse(forward(x)) == x
+    assert logdet_close(npy(ld), gold["logdet_inv"], N)
+    assert np.abs(npy(xs) - gold["x_from_latent"]).max() < Z_ATOL * max(1.0, float(np.abs(gold["x_from_latent"]).max()))
+    torch.manual_seed(0)
+    y = m.infer(ht[0], sigma=0.6)                              # 2-D h is accepted (base.py:44-45)
+    assert y.shape == (F * cfg["hop_size"],) and bool(torch.isfinite(y).all())
+
+
+def test_c2_single_segment_vs_golden(dev, golden_dir):
+    """BASELINE.json configs[1] network (256ch, 12 flows) on one 16000-sample segment against the reference's numbers."""
+    m, cfg, specs, P = build("c2", dev)
+    B, N, F = fill.SHAPES["c2"]
+    audio, h = fill.inputs("c2", B, N, F, cfg["n_mels"])
+    gold = np.load(os.path.join(golden_dir, "model_c2.npz"))
+    x, ht = T(audio, dev), T(h, dev).requires_grad_(True)
+    z, logdet = m(x, ht)
+    loss = cm.WaveGlowLoss(fill.SIGMA)(z, logdet)
+    loss.backward()
+    assert np.abs(npy(z) - gold["z"]).max() < Z_ATOL
+    assert logdet_close(npy(logdet), gold["logdet"], N)
+    assert abs(float(loss) - float(gold["loss"])) < LOSS_ATOL
+    assert relmax(npy(ht.grad), gold["dh"]) < GRAD_RTOL
+    named = dict(m.named_parameters())
+    for i, (n, _, _) in enumerate(specs):
+        g = npy(named[n].grad).ravel()
+        nh = min(g.size, gold["grad_head"].shape[1])
+        scale = max(float(gold["grad_max"][i]), 1e-30)
+        assert np.abs(g[:nh] - gold["grad_head"][i][:nh]).max() / scale < GRAD_RTOL, n
+        nrm = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        assert abs(nrm - gold["grad_norm"][i]) <= 1e-3 * gold["grad_norm"][i] + 1e-12, n
+    with torch.no_grad():
+        xr, _ = m.reverse(z.detach(), ht.detach())
+    assert np.abs(npy(xr) - gold["x_inv"]).max() < Z_ATOL
+
+
+def test_full_size_properties(dev):
+    """BASELINE.json configs[1] at its full size (B=24): size-independent properties instead of an oracle run."""
+    m, cfg, specs, P = build("c2", dev)
+    B, N, F = 24, 16000, 63
+    audio, h = fill.inputs("c2full", B, N, F, cfg["n_mels"])
+    x, ht = T(audio, dev), T(h, dev)
+    crit = cm.WaveGlowLoss(fill.SIGMA)
+    z, logdet = m(x, ht)
+    loss = crit(z, logdet)
+    loss.backward()
+    g_full = {n: p.grad.clone() for n, p in m.named_parameters()}
+    with torch.no_grad():
+        xr, ldr = m.reverse(z.detach(), ht)
+    assert float((xr - x).abs().max()) < Z_ATOL                                    # forward o reverse = id
+    assert float((logdet.detach() + ldr).abs().max()) < 1e-4 * float(logdet.abs().max()) + 1e-2   # logdet_fwd = -logdet_rev
+    # batch items are independent units: item 5 alone gives the same z / logdet
+    with torch.no_grad():
+        z1, ld1 = m(x[5:6].clone(), ht[5:6])
+    assert float((z1 - z[5:6]).abs().max()) < 1e-5
+    assert abs(float(ld1[0] - logdet[5])) < 1e-4 * abs(float(logdet[5])) + 1e-3
+    # linearity of the gradient in the batch: mean of two half-batch gradients == full-batch gradient (DP semantics)
+    m.zero_grad()
+    for sl in (slice(0, 12), slice(12, 24)):
+        zz, ll = m(x[sl].clone(), ht[sl])
+        (0.5 * crit(zz, ll)).backward()
+    for n, p in m.named_parameters():
+        a, b = p.grad, g_full[n]
+        assert float((a - b).abs().max()) <= GRAD_RTOL * float(b.abs().max()) + 1e-12, n
+
+
+@pytest.mark.parametrize("c", [2, 4, 8])
+@pytest.mark.parametrize("batch", [1, 3])
+@pytest.mark.parametrize("rev", [False, True])
+def test_invconv_block(dev, golden_dir, c, batch, rev):
+    """InvertibleConv1x1 as upstream's test_conv1x1_fwd_bwd: outputs, logdet sign, freed input, re-materialised input, grads."""
+    gold = np.load(os.path.join(golden_dir, "block_invconv.npz"))
+    Tn = 64 if batch == 1 else 200
+    tag = "invconv/c%d_b%d_t%d" % (c, batch, Tn)
+    k = tag + ("/rev" if rev else "/fwd")
+    W = fill.orthogonal(tag + "/W", c)
+    x = fill.uniform(tag + "/x", (batch, c, Tn))
+    gz = fill.normal(tag + "/gz", (batch, c, Tn))
+    outs = []
+    for mem_eff in (False, True):
+        blk = cm.InvertibleConv1x1(c, memory_efficient=mem_eff).to(dev)
+        blk.weight.data.copy_(T(W, dev).unsqueeze(-1))
+        xt = T(x, dev).requires_grad_(True)
+        xin = xt.clone()
+        y, ld = blk.reverse(xin) if rev else blk(xin)
+        yrev = y.detach().clone()
+        xinv, ld2 = (blk(yrev) if rev else blk.reverse(yrev))
+        assert torch.equal(ld, -ld2)                                            # test_fwd_bwd.py:51
+        if mem_eff:
+            assert xin.untyped_storage().size() == 0 and yrev.untyped_storage().size() == 0   # :57-64
+        ((y * T(gz, dev)).sum() + ld * 0.37).backward()
+        assert np.abs(npy(xin) - x).max() < 1e-6                                # input re-materialised (:70)
+        assert np.abs(npy(xinv) - x).max() < 2e-6                               # :72
+        assert np.abs(npy(y) - gold[k + "/y"]).max() < 2e-6
+        assert abs(float(ld) - float(gold[k + "/logdet"])) < 1e-4 * max(1.0, abs(float(gold[k + "/logdet"])))
+        assert relmax(npy(xt.grad), gold[k + "/dx"]) < 1e-5
+        assert relmax(npy(blk.weight.grad)[:, :, 0], gold[k + "/dW"]) < 1e-5
+        outs.append((npy(y), npy(blk.weight.grad)))
+    assert np.allclose(outs[0][0], outs[1][0]) and np.allclose(outs[0][1], outs[1][1], atol=5e-7, rtol=0)   # :78-79
+
+
+def test_invconv_negative_det_is_nan(dev):
+    W = fill.orthogonal("negdet", 4)
+    W[:, 0] = -W[:, 0]
+    blk = cm.InvertibleConv1x1(4).to(dev)
+    blk.weight.data.copy_(T(W, dev).unsqueeze(-1))
+    _, ld = blk(T(fill.uniform("negdet/x", (1, 4, 8)), dev))
+    assert bool(torch.isnan(ld))                                                # efficient_modules.py:38
+
+
+@pytest.mark.parametrize("cname", list(COUPLING_CASES))
+@pytest.mark.parametrize("rev", [False, True])
+def test_coupling_block(dev, golden_dir, cname, rev):
+    """AffineCouplingBlock(WN) as upstream's test_affine_fwd_bwd, plus golden values from the reference."""
+    gold = np.load(os.path.join(golden_dir, "block_coupling.npz"))
+    cs = COUPLING_CASES[cname]
+    tag = "coupling/" + cname
+    k = tag + ("/rev" if rev else "/fwd")
+    wn = dict(in_channels=cs["c"] // 2, aux_channels=cs["aux"], residual_channels=cs["wn"], dilation_channels=cs["wn"],
+              skip_channels=cs["wn"], depth=cs["depth"], radix=3)
+    specs = fill.wn_param_specs("F.", cs["c"] // 2, cs["aux"], cs["wn"], cs["wn"], cs["wn"], cs["depth"], 3)
+    P = fill.fill_params(specs, tag + "/")
+    x = fill.uniform(tag + "/x", (cs["B"], cs["c"], cs["T"]))
+    y = fill.normal(tag + "/y", (cs["B"], cs["aux"], cs["T"]))
+    gz = fill.normal(tag + "/gz", x.shape)
+    gls = fill.normal(tag + "/gls", (cs["B"], cs["c"] // 2, cs["T"]))
+    res = []
+    for mem_eff in (False, True):
+        blk = cm.AffineCouplingBlock(cm.WN, mem_eff, zero_init=False, **wn)
+        blk.load_state_dict({n: torch.from_numpy(v) for n, v in P.items()})
+        blk = blk.to(dev)
+        xt, yt = T(x, dev).requires_grad_(True), T(y, dev).requires_grad_(True)
+        xin = xt.clone()
+        z, ls = blk.reverse(xin, yt) if rev else blk(xin, yt)
+        zrev = z.detach().clone()
+        xinv, ls2 = blk(zrev, yt.detach()) if rev else blk.reverse(zrev, yt.detach())
+        assert torch.equal(ls, -ls2)                                            # test_fwd_bwd.py:131
+        if mem_eff:
+            assert xin.untyped_storage().size() == 0 and zrev.untyped_storage().size() == 0   # :137-144
+            assert torch.equal(yt.detach(), T(y, dev))                          # h untouched (:145-146)
+        ((z * T(gz, dev)).sum() + (ls * T(gls, dev)).sum()).backward()
+        assert np.abs(npy(xin) - x).max() < 1e-5                                # re-materialised (:152)
+        assert np.abs(npy(xinv) - x).max() < 1e-5                               # round trip (:154)
+        assert np.abs(npy(z) - gold[k + "/z"]).max() < 1e-5
+        assert np.abs(npy(ls) - gold[k + "/log_s"]).max() < 1e-5
+        assert relmax(npy(xt.grad), gold[k + "/dx"]) < GRAD_RTOL
+        assert relmax(npy(yt.grad), gold[k + "/dy"]) < GRAD_RTOL
+        named = dict(blk.named_parameters())
+        for i, (n, _, _) in enumerate(specs):
+            g = npy(named[n].grad)
+            nrm = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
+            assert abs(nrm - gold[k + "/grad_norm"][i]) <= 1e-3 * gold[k + "/grad_norm"][i] + 1e-12, n
+            if k + "/grad::" + n in gold:
+                assert relmax(g, gold[k + "/grad::" + n]) < GRAD_RTOL, n
+        res.append([npy(named[n].grad) for n, _, _ in specs])
+    for a, b in zip(*res):
+        assert np.allclose(a, b)                                                # efficient == naive (:160)
+
+
+def test_wn_forward_standalone(dev):
+    wn = cm.WN(4, 80, 64, 64, 64, depth=4, zero_init=False).to(dev)
+    specs = fill.wn_param_specs("", 4, 80, 64, 64, 64, 4, 3)
+    P = fill.fill_params(specs, "wnalone/")
+    wn.load_state_dict({n: torch.from_numpy(v) for n, v in P.items()})
+    x = fill.uniform("wnalone/x", (2, 4, 333))
+    y = fill.normal("wnalone/y", (2, 80, 333))
+    with torch.no_grad():
+        ls, t = wn(T(x, dev), T(y, dev))
+    xx = np.concatenate([x, np.zeros_like(x)], 1)
+    z, lso = orc.coupling_apply(dict(in_channels=4, aux_channels=80, residual_channels=64, dilation_channels=64,
+                                     skip_channels=64, depth=4, radix=3), fill.table(specs, P), xx, y)
+    assert np.abs(npy(ls) - lso).max() < 1e-5
+    assert np.abs(npy(t) - z[:, 4:]).max() < 1e-5                               # xb = 0  =>  zb = t
+
+
+def test_weight_norm_removed_model_matches(dev):
+    """inference.py:17 upstream: model.apply(remove_weight_norms) must not change the function."""
+    m, cfg, specs, P = build("micro", dev)
+    B, N, F = fill.SHAPES["micro"]
+    audio, h = fill.inputs("micro", B, N, F, cfg["n_mels"])
+    with torch.no_grad():
+        z0, l0 = m(T(audio, dev), T(h, dev))
+        m.apply(cm.remove_weight_norms)
+        z1, l1 = m(T(audio, dev), T(h, dev))
+    assert float((z0 - z1).abs().max()) < 1e-5 and float((l0 - l1).abs().max()) < 1e-3
+
+
+def test_loss_kernel(dev):
+    z = fill.normal("loss/z", (3, 4000))
+    ld = fill.normal("loss/ld", (3,))
+    zt, lt = T(z, dev).requires_grad_(True), T(ld, dev).requires_grad_(True)
+    for mean in (True, False):
+        zt.grad = lt.grad = None
+        loss = cm.WaveGlowLoss(0.7, elementwise_mean=mean)(zt, lt)
+        loss.backward()
+        want = float(np.mean(0.5 * (z.astype(np.float64) ** 2).sum(1) / 0.49 - ld)) / (4000 if mean else 1)
+        assert abs(float(loss) - want) < 1e-5 * max(1.0, abs(want))
+        sc = 1.0 / 3 / (4000 if mean else 1)
+        assert np.allclose(npy(zt.grad), z / 0.49 * sc, rtol=1e-5, atol=1e-9)
+        assert np.allclose(npy(lt.grad), -sc, rtol=1e-6)
+
+
+def test_trainer_step_matches_autograd(dev):
+    """FlowTrainer (the bench's step: engine calls + flat gradient buffer) == the autograd path."""
+    from constant_memory_waveglow_amd.parallel import FlowTrainer
+    m, cfg, specs, P = build("c1", dev)
+    B, N, F = fill.SHAPES["c1"]
+    audio, h = fill.inputs("c1", B, N, F, cfg["n_mels"])
+    x, ht = T(audio, dev), T(h, dev)
+    z, logdet = m(x, ht)
+    cm.WaveGlowLoss(fill.SIGMA)(z, logdet).backward()
+    ga = [p.grad.clone() for p in m.parameters()]
+    m.zero_grad(set_to_none=True)
+    loss, z2, ld2 = FlowTrainer(m, fill.SIGMA).step(x, ht)
+    assert torch.equal(z, z2) and torch.equal(logdet, ld2)
+    for a, p in zip(ga, m.parameters()):
+        assert torch.equal(a, p.grad)
