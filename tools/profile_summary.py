@@ -1,0 +1,65 @@
+"""Condenses rocprofv3 CSV output (gpurun_out/...) into the small summaries committed under profiles/.
+
+    python tools/profile_summary.py <round-tag> <kernel_stats.csv> [<fetch_counter.csv> <write_counter.csv>]
+
+Writes profiles/<tag>_kernel_stats.csv (our kernels only, torch RNG/fill kernels dropped, names shortened) and, when the
+two PMC passes are given, profiles/<tag>_hbm_traffic.json with per-kernel HBM bytes per launch:
+    bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
+(FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read stream --
+MI355X_MICROARCH.md, "HBM" -- hence the factor 2; the two counters need separate passes: TCC has 4 slots)."""
+import csv
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    name = re.sub(r"\(.*", "", name).replace("void ", "")
+    return name.strip()
+
+
+def ours(name):
+    return not ("at::native" in name or "rocclr" in name)
+
+
+def main():
+    tag, stats = sys.argv[1], sys.argv[2]
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    rows = list(csv.DictReader(open(stats)))
+    total = sum(float(r["TotalDurationNs"]) for r in rows)
+    out = os.path.join(ROOT, "profiles", "%s_kernel_stats.csv" % tag)
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_ms", "avg_us", "pct_of_gpu_time", "min_us", "max_us"])
+        for r in rows:
+            if ours(r["Name"]):
+                w.writerow([short(r["Name"]), r["Calls"], "%.3f" % (float(r["TotalDurationNs"]) / 1e6),
+                            "%.2f" % (float(r["AverageNs"]) / 1e3), "%.2f" % (100 * float(r["TotalDurationNs"]) / total),
+                            "%.2f" % (float(r["MinNs"]) / 1e3), "%.2f" % (float(r["MaxNs"]) / 1e3)])
+    print("wrote", out)
+    if len(sys.argv) >= 5:
+        acc = {}
+        for key, path in (("FETCH_SIZE", sys.argv[3]), ("WRITE_SIZE", sys.argv[4])):
+            sums, cnt = defaultdict(float), defaultdict(int)
+            for r in csv.DictReader(open(path)):
+                if r["Counter_Name"] == key and ours(r["Kernel_Name"]):
+                    k = short(r["Kernel_Name"])
+                    sums[k] += float(r["Counter_Value"])
+                    cnt[k] += 1
+            acc[key] = {k: (sums[k] / cnt[k], cnt[k]) for k in sums}
+        res = {}
+        for k in sorted(acc["FETCH_SIZE"]):
+            f, n = acc["FETCH_SIZE"][k]
+            wv = acc["WRITE_SIZE"].get(k, (0.0, 0))[0]
+            res[k] = {"launches": n, "fetch_kib_raw": f, "write_kib": wv, "hbm_bytes_per_launch": (2 * f + wv) * 1024}
+        out = os.path.join(ROOT, "profiles", "%s_hbm_traffic.json" % tag)
+        json.dump({"formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes, averaged over launches", "kernels": res}, open(out, "w"), indent=1)
+        print("wrote", out)
+
+
+if __name__ == "__main__":
+    main()
