@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libwgflow.so")
+LIB_PATH = os.environ.get("WGFLOW_LIB") or os.path.join(_HERE, "csrc", "libwgflow.so")   # WGFLOW_LIB: developer A/B builds
 _LIB = None
 
 ABI_SYMBOLS = [
@@ -24,11 +24,24 @@ K_CONV_STORE, K_CONV_GATE, K_CONV_RESSKIP, K_CONV_DGATE, K_WGRAD = range(5)
 class WgConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n_flows", "n_group", "n_early_every", "n_early_size", "n_mels",
-        "up_stride", "up_kernel", "up_pad", "res_ch", "dil_ch", "skip_ch", "depth", "radix")]
+        "up_stride", "up_kernel", "up_pad", "res_ch", "dil_ch", "skip_ch", "depth", "radix", "precision")]
 
 
 class WgWnDims(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("in_ch", "aux_ch", "res_ch", "dil_ch", "skip_ch", "depth", "radix")]
+    _fields_ = [(n, C.c_int32) for n in ("in_ch", "aux_ch", "res_ch", "dil_ch", "skip_ch", "depth", "radix", "precision")]
+
+
+PREC_F32, PREC_BF16X3 = 0, 1
+
+
+def default_precision():
+    """WG_PRECISION=f32|bf16x3 selects the arithmetic of the MFMA contractions (include/wgflow.h, WG_PREC_*)."""
+    v = os.environ.get("WG_PRECISION", "f32").lower()
+    if v in ("f32", "fp32", "0"):
+        return PREC_F32
+    if v in ("bf16x3", "1"):
+        return PREC_BF16X3
+    raise WgError("WG_PRECISION must be f32 or bf16x3 (got %r)" % v)
 
 
 class WgError(RuntimeError):

@@ -28,15 +28,17 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in SOURCES)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+def build(force=False, verbose=False, defines=(), out=None):
+    """defines / out: developer A/B builds (tools/kbench.py), e.g. build(True, defines=["WG_OPT_X=1"], out="/tmp/x.so")"""
+    if out is None and not force and not needs_build():
         return OUT
+    out = out or OUT
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-pass-failed", "-o", OUT, os.path.join(CSRC, "wgflow.hip")]
+           "-Wno-pass-failed"] + ["-D" + d for d in defines] + ["-o", out, os.path.join(CSRC, "wgflow.hip")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

@@ -1,0 +1,328 @@
+// wg_gemm16.h -- split-precision ("bf16x3") variants of the two MFMA kernels.
+//
+// fp32 operands are split on the fly into hi = bf16(x), lo = bf16(x - hi) and every product is evaluated as
+//     a*b ~= a_lo*b_hi + a_hi*b_lo + a_hi*b_hi        (three v_mfma_f32_32x32x16_bf16, fp32 accumulate)
+// which drops only the a_lo*b_lo term (2^-16 relative to the product; measured 2e-7 rms of sum|ab| at K = 848, see
+// tools/experiments/split_mfma.hip), has fp32 range (bf16 exponent) and runs on the 16x faster bf16 matrix pipe.
+// All tensors in HBM stay fp32: activations are converted when a tile is staged into LDS, weights are pre-split
+// once per step by wg_pack_weights into chunked [chunk][m][32] hi/lo images.
+//
+// LDS image of every operand tile: [row][32 k + 8 pad] bf16 (80-byte rows): a fragment of v_mfma_f32_32x32x16_bf16
+// (lane l: row l&31, k = 8*(l>>5) .. +7) is one conflict-free ds_read_b128.
+#pragma once
+#include "wg_gemm.h"
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define WG16_BK 32                    // k per chunk (two MFMA k-steps)
+#define WG16_ROWB 80                  // bytes per LDS row (32 bf16 + 16 B pad)
+#define WG16_IMG (WG_TILE * WG16_ROWB)  // one 128-row image
+
+__device__ __forceinline__ unsigned short bf16_rn(float x)
+{
+    unsigned u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_tof(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+// split two floats: returns packed hi pair and lo pair (element 0 in the low half)
+__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo)
+{
+    const unsigned short ha = bf16_rn(a), hb = bf16_rn(b);
+    hi = (unsigned)ha | ((unsigned)hb << 16);
+    lo = (unsigned)bf16_rn(a - bf16_tof(ha)) | ((unsigned)bf16_rn(b - bf16_tof(hb)) << 16);
+}
+
+// acc[mi][ni] += A(rows wr*64+mi*32..) x B(rows wc*64+ni*32..) over nk16 k-steps of 16
+__device__ __forceinline__ void mma16_chunk(const char *Ahi, const char *Alo, const char *Bhi, const char *Blo,
+                                            int wr, int wc, int lane, int nk16, f32x16 (&acc)[2][2])
+{
+    const int r = lane & 31, h = lane >> 5;
+    const int ao = (wr * 64 + r) * WG16_ROWB + h * 16, bo = (wc * 64 + r) * WG16_ROWB + h * 16;
+    for (int s = 0; s < nk16; ++s) {
+        bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ah[i] = *reinterpret_cast<const bf16x8 *>(Ahi + ao + i * 32 * WG16_ROWB + s * 32);
+            al[i] = *reinterpret_cast<const bf16x8 *>(Alo + ao + i * 32 * WG16_ROWB + s * 32);
+            bh[i] = *reinterpret_cast<const bf16x8 *>(Bhi + bo + i * 32 * WG16_ROWB + s * 32);
+            bl[i] = *reinterpret_cast<const bf16x8 *>(Blo + bo + i * 32 * WG16_ROWB + s * 32);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// convgemm16: same contract and epilogues as convgemm_kernel; A comes from the pre-split images
+//   img_hi[chunk][lda][32], img_lo = img_hi + nchunks_total*lda*32 (bf16)
+// chunks never straddle a segment; a segment whose channel count is 16 mod 32 ends with a half chunk (nk16 = 1).
+// ------------------------------------------------------------------------------------------------
+struct ConvGemm16Args {
+    const unsigned short *img;   // hi image; lo image follows at + img_stride
+    size_t img_stride;           // elements between hi and lo images
+    ConvGemmArgs c;              // geometry, segments, epilogue (c.A unused)
+};
+
+template <int EPI>
+__global__ __launch_bounds__(256) void convgemm16_kernel(const ConvGemm16Args aa)
+{
+    __shared__ __attribute__((aligned(16))) char smem[2 * 4 * WG16_IMG];   // 2 buffers x 4 images (80 KB)
+    const ConvGemmArgs &a = aa.c;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int t0 = blockIdx.x * WG_TILE, m0 = blockIdx.y * WG_TILE, b = blockIdx.z;
+    const Geo g = a.g;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int nchunks = 0;
+    for (int s = 0; s < a.nseg; ++s) nchunks += (a.seg[s].nch + WG16_BK - 1) / WG16_BK;
+
+    // staging registers: A 2 x (hi,lo) 16-B pieces, B 16 floats
+    u32x4 ra_hi[2], ra_lo[2];
+    float rb[16];
+    int cur_seg = 0, cur_c = 0, chunk = 0;      // next chunk to load
+    int nk_loaded = 0;                          // k16 steps of the chunk sitting in the staging registers
+    const int bt = tid & 127, bk = (tid >> 7) * 16;   // B staging: time column, first of 16 k rows
+
+    auto load_chunk = [&]() {
+        const ConvSeg sg = a.seg[cur_seg];
+        const int nvalid = min(WG16_BK, sg.nch - cur_c);
+        nk_loaded = nvalid >> 4;
+        // A: 512 pieces of 16 B per image: piece p -> row p>>2, part p&3
+        const unsigned short *ih = aa.img + ((size_t)chunk * a.lda + m0) * WG16_BK;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int p = tid + 256 * j;
+            ra_hi[j] = *reinterpret_cast<const u32x4 *>(ih + (size_t)p * 8);
+            ra_lo[j] = *reinterpret_cast<const u32x4 *>(ih + aa.img_stride + (size_t)p * 8);
+        }
+        const float *base = sg.src + ((size_t)b * sg.Cp + sg.ch0 + cur_c + bk) * g.P + g.H + t0 + sg.shift + bt;
+        if (bk < nvalid) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) rb[j] = base[(size_t)j * g.P];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) rb[j] = 0.f;
+        }
+        ++chunk;
+        cur_c += WG16_BK;
+        if (cur_c >= sg.nch) { cur_c = 0; ++cur_seg; }
+    };
+    auto store_chunk = [&](int buf) {
+        char *sb = smem + buf * 4 * WG16_IMG;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int p = tid + 256 * j;
+            const int off = (p >> 2) * WG16_ROWB + (p & 3) * 16;
+            *reinterpret_cast<u32x4 *>(sb + off) = ra_hi[j];
+            *reinterpret_cast<u32x4 *>(sb + WG16_IMG + off) = ra_lo[j];
+        }
+        char *bh = sb + 2 * WG16_IMG + bt * WG16_ROWB + bk * 2, *bl = bh + WG16_IMG;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            u32x4 vh, vl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned hh, ll;
+                split2(rb[8 * q + 2 * e], rb[8 * q + 2 * e + 1], hh, ll);
+                vh[e] = hh; vl[e] = ll;
+            }
+            *reinterpret_cast<u32x4 *>(bh + q * 16) = vh;
+            *reinterpret_cast<u32x4 *>(bl + q * 16) = vl;
+        }
+    };
+
+    load_chunk();
+    int nk_cur = nk_loaded;
+    store_chunk(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) load_chunk();
+        const char *sb = smem + buf * 4 * WG16_IMG;
+        mma16_chunk(sb, sb + WG16_IMG, sb + 2 * WG16_IMG, sb + 3 * WG16_IMG, wr, wc, lane, nk_cur, acc);
+        if (c + 1 < nchunks) { store_chunk(buf ^ 1); nk_cur = nk_loaded; }
+        __syncthreads();
+    }
+    conv_epilogue<EPI>(a, acc, t0, m0, b, wr, wc, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad16: same contract as wgrad_kernel, k = time (32 steps per chunk), both operands converted on the fly
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a)
+{
+    __shared__ __attribute__((aligned(16))) char smem[2 * 4 * WG16_IMG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int n0 = blockIdx.x * WG_TILE, m0 = blockIdx.y * WG_TILE;
+    const int zs = blockIdx.z;
+    const int ts = zs % a.nts, bs = zs / a.nts;
+    const Geo g = a.g;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int lrow = tid >> 3, k4 = (tid & 7) * 4;
+    const float *pa[4];
+    const float *pb[4];
+    bool bal[4];
+    size_t sba[4], sbb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ma = m0 + lrow + 32 * j;
+        const WgSeg &sa = find_seg(a.sa, a.nseg_a, ma >> 5);
+        const int ca = ma - sa.blk0 * 32;
+        pa[j] = (ma < a.Mp && ca < sa.nch) ? sa.src + ((size_t)sa.ch0 + ca) * g.P + g.H + k4 : nullptr;
+        sba[j] = (size_t)sa.Cp * g.P;
+        const int nb = n0 + lrow + 32 * j;
+        const WgSeg &sb = find_seg(a.sb, a.nseg_b, nb >> 5);
+        const int cb = nb - sb.blk0 * 32;
+        pb[j] = (nb < a.Np && cb < sb.nch) ? sb.src + ((size_t)sb.ch0 + cb) * g.P + g.H + sb.shift + k4 : nullptr;
+        sbb[j] = (size_t)sb.Cp * g.P;
+        bal[j] = (sb.shift & 3) == 0;
+    }
+    const int t_begin = ts * a.t_per_split;
+    int t_end = t_begin + a.t_per_split;
+    if (t_end > g.Tt) t_end = g.Tt;
+    const int chunks_per_b = (t_end - t_begin + WG16_BK - 1) / WG16_BK;
+    const int b_begin = bs * a.b_per_split;
+    int b_end = b_begin + a.b_per_split;
+    if (b_end > g.B) b_end = g.B;
+    const int nchunks = chunks_per_b * (b_end - b_begin);
+
+    f32x4 ra[4], rb[4];
+    int lb = b_begin, lt = t_begin;
+    auto load_chunk = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (pa[j]) v = *reinterpret_cast<const f32x4 *>(pa[j] + lb * sba[j] + lt);
+            ra[j] = v;
+            f32x4 w = {0.f, 0.f, 0.f, 0.f};
+            if (pb[j]) {
+                const float *q = pb[j] + lb * sbb[j] + lt;
+                if (bal[j]) w = *reinterpret_cast<const f32x4 *>(q);
+                else { w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; w[3] = q[3]; }
+            }
+            rb[j] = w;
+        }
+        lt += WG16_BK;
+        if (lt >= t_end) { lt = t_begin; ++lb; }
+    };
+    auto store_chunk = [&](int buf) {
+        char *sb = smem + buf * 4 * WG16_IMG;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int off = (lrow + 32 * j) * WG16_ROWB + k4 * 2;
+            u32x2 h, l;
+            unsigned hh, ll;
+            split2(ra[j][0], ra[j][1], hh, ll); h[0] = hh; l[0] = ll;
+            split2(ra[j][2], ra[j][3], hh, ll); h[1] = hh; l[1] = ll;
+            *reinterpret_cast<u32x2 *>(sb + off) = h;
+            *reinterpret_cast<u32x2 *>(sb + WG16_IMG + off) = l;
+            split2(rb[j][0], rb[j][1], hh, ll); h[0] = hh; l[0] = ll;
+            split2(rb[j][2], rb[j][3], hh, ll); h[1] = hh; l[1] = ll;
+            *reinterpret_cast<u32x2 *>(sb + 2 * WG16_IMG + off) = h;
+            *reinterpret_cast<u32x2 *>(sb + 3 * WG16_IMG + off) = l;
+        }
+    };
+
+    if (nchunks > 0) {
+        load_chunk();
+        store_chunk(0);
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            const int buf = c & 1;
+            if (c + 1 < nchunks) load_chunk();
+            const char *sb = smem + buf * 4 * WG16_IMG;
+            mma16_chunk(sb, sb + WG16_IMG, sb + 2 * WG16_IMG, sb + 3 * WG16_IMG, wr, wc, lane, 2, acc);
+            if (c + 1 < nchunks) store_chunk(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    float *out = a.slab + (size_t)zs * a.Mp * a.Np;
+    const int col = lane & 31;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int n = n0 + wc * 64 + ni * 32 + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * 64 + mi * 32 + acc_row(r, lane);
+                if (m < a.Mp && n < a.Np) out[(size_t)m * a.Np + n] = acc[mi][ni][r];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pre-split weight images: A32 [K][lda] (k-major fp32, segments of nch rows) -> [chunk][lda][32] hi | lo
+// one block per (chunk, 64 columns)
+// ------------------------------------------------------------------------------------------------
+struct ImgJob {
+    const float *A32;
+    unsigned short *img;      // hi; lo at + nchunks*lda*32
+    int lda, nseg, nchunks;
+    int nch[WG_MAX_SEG];
+};
+#define WG_IMG_JOBS 48
+struct ImgArgs {
+    int n;
+    ImgJob job[WG_IMG_JOBS];
+};
+__global__ __launch_bounds__(256) void img_kernel(const ImgArgs a)
+{
+    __shared__ float tile[32][65];
+    const ImgJob j = a.job[blockIdx.z];
+    const int ci = blockIdx.y, mb = blockIdx.x * 64;
+    if (ci >= j.nchunks || mb >= j.lda) return;
+    // locate chunk ci
+    int seg = 0, c0 = 0, row0 = 0, left = ci;
+    for (seg = 0; seg < j.nseg; ++seg) {
+        const int nc = (j.nch[seg] + 31) / 32;
+        if (left < nc) { c0 = left * 32; break; }
+        left -= nc;
+        row0 += j.nch[seg];
+    }
+    const int nvalid = min(32, j.nch[seg] - c0);
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 32 * 64; e += 256) {
+        const int kk = e >> 6, m = e & 63;
+        tile[kk][m] = (kk < nvalid) ? j.A32[(size_t)(row0 + c0 + kk) * j.lda + mb + m] : 0.f;
+    }
+    __syncthreads();
+    // thread -> (m = tid>>2, 8 k values (tid&3)*8..)
+    const int m = tid >> 2, k8 = (tid & 3) * 8;
+    u32x4 vh, vl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        unsigned hh, ll;
+        split2(tile[k8 + 2 * e][m], tile[k8 + 2 * e + 1][m], hh, ll);
+        vh[e] = hh; vl[e] = ll;
+    }
+    const size_t o = ((size_t)ci * j.lda + mb + m) * 32 + k8;
+    *reinterpret_cast<u32x4 *>(j.img + o) = vh;
+    *reinterpret_cast<u32x4 *>(j.img + (size_t)j.nchunks * j.lda * 32 + o) = vl;
+}

@@ -3,6 +3,7 @@
 // comes from the caller (packed-weight buffer + workspace), carved by the deterministic layouts below.
 #include "../../include/wgflow.h"
 #include "wg_small.h"
+#include "wg_gemm16.h"
 
 #include <algorithm>
 #include <atomic>
@@ -20,6 +21,7 @@ inline size_t rupz(size_t x, size_t m) { return (x + m - 1) / m * m; }
 struct Ctx {
     hipStream_t st;
     int err;
+    int prec;   // 0: exact fp32 MFMA; 1: split bf16x3 MFMA (wg_gemm16.h)
 };
 #define WG_LAUNCH(ctx, kern, grid, block, shmem, ...)                         \
     do {                                                                      \
@@ -55,6 +57,7 @@ struct TimerScope {
 // ------------------------------------------------------------------------------------------------
 struct WnD {
     int ic, aux, C, Cd, Cs, depth, radix;
+    int prec = 0;
     int auxp() const { return rup(aux, WG_BK); }
     int wo_rows(int i) const { return i == depth - 1 ? Cs : C + Cs; }
     int nparams() const { return 4 + 4 * depth + 1; }
@@ -94,6 +97,10 @@ struct WnPack {
     size_t total;
 };
 
+// floats taken by an fp32 k-major matrix plus its split image ([chunk][ld][32] bf16 hi, then lo)
+inline size_t mat_floats(int K, int ld) { return rupz((size_t)K * ld, 64) + (size_t)(K / WG16_BK + WG_MAX_SEG + 1) * ld * WG16_BK; }
+inline unsigned short *mat_img(const float *A32, int K, int ld) { return (unsigned short *)(A32 + rupz((size_t)K * ld, 64)); }
+
 WnPack wn_pack_layout(const WnD &d)
 {
     WnPack L;
@@ -112,17 +119,19 @@ WnPack wn_pack_layout(const WnD &d)
     L.ld_WoN = rup(d.Cd, WG_TILE);
     L.ld_WT = rup(d.C, WG_TILE);
     L.ld_VN = rup(d.aux, WG_TILE);
-    L.startT = take((size_t)L.kp_start * L.ld_startT);
-    L.startN = take((size_t)d.C * L.ld_startN);
+    // a matrix = fp32 k-major [K][ld] followed by its split bf16 image (mat_img)
+    auto take_mat = [&](int K, int ld) { return take(mat_floats(K, ld)); };
+    L.startT = take_mat(L.kp_start, L.ld_startT);
+    L.startN = take_mat(d.C, L.ld_startN);
     L.endT = take((size_t)d.Cs * 32);
-    L.endN = take((size_t)L.kp_end * L.ld_endN);
+    L.endN = take_mat(L.kp_end, L.ld_endN);
     for (int i = 0; i < d.depth; ++i) {
         L.ld_WoT[i] = rup(d.wo_rows(i), WG_TILE);
-        L.Acat[i] = take((size_t)L.kcat * L.ld_Acat);
-        L.WoT[i] = take((size_t)d.Cd * L.ld_WoT[i]);
-        L.WoN[i] = take((size_t)d.wo_rows(i) * L.ld_WoN);
-        L.WT[i] = take((size_t)d.radix * 2 * d.Cd * L.ld_WT);
-        L.VN[i] = take((size_t)2 * d.Cd * L.ld_VN);
+        L.Acat[i] = take_mat(L.kcat, L.ld_Acat);
+        L.WoT[i] = take_mat(d.Cd, L.ld_WoT[i]);
+        L.WoN[i] = take_mat(d.wo_rows(i), L.ld_WoN);
+        L.WT[i] = take_mat(d.radix * 2 * d.Cd, L.ld_WT);
+        L.VN[i] = take_mat(2 * d.Cd, L.ld_VN);
     }
     L.total = off;
     return L;
@@ -199,6 +208,52 @@ void wn_pack_mats(JobBatch &jb, const WnD &d, const WnPack &L, const float *cons
                     pk + L.scale_W[i], d.C * d.radix, d.radix, kt);
         jb.pack(pk + L.VN[i], L.ld_VN, 2 * d.Cd, L.ld_VN, 1, 2 * d.Cd, d.aux, 0, vV + (size_t)i * 2 * d.Cd * d.aux,
                 pk + L.scale_V + (size_t)i * 2 * d.Cd, d.aux, 1, 0);
+    }
+}
+
+struct ImgBatch {
+    Ctx *ctx;
+    ImgArgs ia;
+    ImgBatch(Ctx *c) : ctx(c) { ia.n = 0; }
+    void add(float *A32, int ld, const int *nch, int nseg)
+    {
+        if (ia.n == WG_IMG_JOBS) flush();
+        ImgJob &j = ia.job[ia.n++];
+        int K = 0, nc = 0;
+        for (int s = 0; s < nseg; ++s) { j.nch[s] = nch[s]; K += nch[s]; nc += (nch[s] + WG16_BK - 1) / WG16_BK; }
+        j.A32 = A32; j.img = mat_img(A32, K, ld); j.lda = ld; j.nseg = nseg; j.nchunks = nc;
+    }
+    void flush()
+    {
+        if (!ia.n) return;
+        int mx = 0, my = 0;
+        for (int i = 0; i < ia.n; ++i) { mx = std::max(mx, ia.job[i].lda / 64); my = std::max(my, ia.job[i].nchunks); }
+        WG_LAUNCH(*ctx, img_kernel, dim3(mx, my, ia.n), dim3(256), 0, ia);
+        ia.n = 0;
+    }
+};
+// split images of every matrix convgemm reads (after the fp32 matrices have been packed)
+void wn_pack_images(ImgBatch &ib, const WnD &d, const WnPack &L, float *pk)
+{
+    int one[WG_MAX_SEG];
+    one[0] = L.kp_start; ib.add(pk + L.startT, L.ld_startT, one, 1);
+    one[0] = d.C;        ib.add(pk + L.startN, L.ld_startN, one, 1);
+    one[0] = L.kp_end;   ib.add(pk + L.endN, L.ld_endN, one, 1);
+    for (int i = 0; i < d.depth; ++i) {
+        int sg[WG_MAX_SEG];
+        int ns = 0;
+        for (int kt = 0; kt < d.radix; ++kt) sg[ns++] = d.C;
+        sg[ns++] = d.auxp();
+        ib.add(pk + L.Acat[i], L.ld_Acat, sg, ns);
+        one[0] = d.Cd; ib.add(pk + L.WoT[i], L.ld_WoT[i], one, 1);
+        ns = 0;
+        if (i < d.depth - 1) sg[ns++] = d.C;
+        sg[ns++] = d.Cs;
+        ib.add(pk + L.WoN[i], L.ld_WoN, sg, ns);
+        ns = 0;
+        for (int kt = 0; kt < d.radix; ++kt) sg[ns++] = 2 * d.Cd;
+        ib.add(pk + L.WT[i], L.ld_WT, sg, ns);
+        one[0] = 2 * d.Cd; ib.add(pk + L.VN[i], L.ld_VN, one, 1);
     }
 }
 
@@ -377,6 +432,21 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
     const int mrows = epi == EPI_GATE ? M : M;
     dim3 grid(g.Tt / WG_TILE, rup(mrows, WG_TILE) / WG_TILE, g.B), block(256);
     TimerScope ts(WG_K_CONV_STORE + epi, cx.st);
+    if (cx.prec) {
+        ConvGemm16Args a16;
+        int K = 0, nc = 0;
+        for (int s = 0; s < nseg; ++s) { K += segs[s].nch; nc += (segs[s].nch + WG16_BK - 1) / WG16_BK; }
+        a16.img = mat_img(A, K, lda);
+        a16.img_stride = (size_t)nc * lda * WG16_BK;
+        a16.c = a;
+        switch (epi) {
+        case EPI_STORE: WG_LAUNCH(cx, convgemm16_kernel<EPI_STORE>, grid, block, 0, a16); break;
+        case EPI_GATE: WG_LAUNCH(cx, convgemm16_kernel<EPI_GATE>, grid, block, 0, a16); break;
+        case EPI_RESSKIP: WG_LAUNCH(cx, convgemm16_kernel<EPI_RESSKIP>, grid, block, 0, a16); break;
+        case EPI_DGATE: WG_LAUNCH(cx, convgemm16_kernel<EPI_DGATE>, grid, block, 0, a16); break;
+        }
+        return;
+    }
     switch (epi) {
     case EPI_STORE: WG_LAUNCH(cx, convgemm_kernel<EPI_STORE>, grid, block, 0, a); break;
     case EPI_GATE: WG_LAUNCH(cx, convgemm_kernel<EPI_GATE>, grid, block, 0, a); break;
@@ -421,7 +491,8 @@ WgradOut run_wgrad(Ctx &cx, const Geo &g, const WSegSpec *sa, int nsa, const WSe
     if ((size_t)p.nsplit * a.Mp * a.Np > slab_cap) { if (!cx.err) cx.err = WG_EWORKSPACE; return o; }
     dim3 grid(a.Np / WG_TILE, a.Mp / WG_TILE, p.nsplit), block(256);
     TimerScope ts(WG_K_WGRAD, cx.st);
-    WG_LAUNCH(cx, wgrad_kernel, grid, block, 0, a);
+    if (cx.prec) WG_LAUNCH(cx, wgrad16_kernel, grid, block, 0, a);
+    else WG_LAUNCH(cx, wgrad_kernel, grid, block, 0, a);
     return o;
 }
 
@@ -690,7 +761,7 @@ int wg_wn_pack_weights(const wg_wn_dims *dd, const void *const *params, void *pa
     const WnD d = wnd_from(dd);
     int rc = wn_check(d);
     if (rc) return rc;
-    Ctx cx = {(hipStream_t)stream, 0};
+    Ctx cx = {(hipStream_t)stream, 0, 0};
     float *pk = (float *)packed;
     float *ones = pk;
     float *wn = pk + rupz(WG_ONES, 64);
@@ -701,6 +772,9 @@ int wg_wn_pack_weights(const wg_wn_dims *dd, const void *const *params, void *pa
     jb.flush_norm();
     wn_pack_mats(jb, d, L, (const float *const *)params, wn, ones);
     jb.flush_pack();
+    ImgBatch ib(&cx);
+    wn_pack_images(ib, d, L, wn);
+    ib.flush();
     return cx.err;
 }
 
@@ -709,7 +783,7 @@ int wg_pack_weights(const wg_config *cf, const void *const *params, void *packed
     int rc = cfg_check(cf);
     if (rc) return rc;
     if (!params || !packed) return WG_EINVAL;
-    Ctx cx = {(hipStream_t)stream, 0};
+    Ctx cx = {(hipStream_t)stream, 0, 0};
     const float *const *p = (const float *const *)params;
     float *pk = (float *)packed;
     const ModelPack M = model_pack_layout(cf);
@@ -734,6 +808,12 @@ int wg_pack_weights(const wg_config *cf, const void *const *params, void *packed
         wn_pack_mats(jb, d, wn_pack_layout(d), p + wn_table_off(cf, k), pk + M.wn[k], ones);
     }
     jb.flush_pack();
+    ImgBatch ib(&cx);
+    for (int k = 0; k < cf->n_flows; ++k) {
+        const WnD d = flow_wn(cf, k);
+        wn_pack_images(ib, d, wn_pack_layout(d), pk + M.wn[k]);
+    }
+    ib.flush();
     return cx.err;
 }
 
@@ -750,7 +830,7 @@ static int model_run_fwd_or_inv(const wg_config *cf, const void *packed, const f
     if (!packed || !in || !h || !out || !logdet || !wsv) return WG_EINVAL;
     const ModelWs W = model_ws_layout(cf, B, T, 0);
     if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
-    Ctx cx = {(hipStream_t)stream, 0};
+    Ctx cx = {(hipStream_t)stream, 0, cf->precision ? 1 : 0};
     const float *pk = (const float *)packed;
     const ModelPack M = model_pack_layout(cf);
     float *ws = (float *)wsv;
@@ -817,7 +897,7 @@ int wg_backward(const wg_config *cf, const void *const *params, const void *pack
     if (!params || !packed || !z || !h || !dz || !dlogdet || !grads || !wsv) return WG_EINVAL;
     const ModelWs W = model_ws_layout(cf, B, T, 1);
     if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
-    Ctx cx = {(hipStream_t)stream, 0};
+    Ctx cx = {(hipStream_t)stream, 0, cf->precision ? 1 : 0};
     const float *pk = (const float *)packed;
     const float *const *p = (const float *const *)params;
     float *const *gr = (float *const *)grads;
@@ -846,7 +926,10 @@ int wg_backward(const wg_config *cf, const void *const *params, const void *pack
         run_mix(cx, g, Xk, c, lu + WG_MAXC * WG_MAXC, 0);                                     // x = W^-1 z   :235-237
         {
             WSegSpec sa = {dXk.p, dXk.Cp, dXk.ch0, c, 0}, sb = {Xk.p, Xk.Cp, Xk.ch0, c, 0};
+            const int prec_keep = cx.prec;
+            cx.prec = 0;                                                                         // tiny c x c product: keep it exact
             WgradOut wo = run_wgrad(cx, g, &sa, 1, &sb, 1, ws + W.wn.slab, W.wn.slab_floats);   // dW = dz x^T     :240
+            cx.prec = prec_keep;
             run_finalize(cx, ws + W.wn.slab, wo, 0, c, c, 1, 0, 1, 0, nullptr, nullptr, nullptr, gr[3 + k],
                          lu + WG_MAXC * WG_MAXC, dlogdet, B, (float)T);                         // + W^-T dlogdet T :242
         }
@@ -864,7 +947,7 @@ int wg_backward(const wg_config *cf, const void *const *params, const void *pack
 int wg_nll_loss(const float *z, const float *logdet, int B, int N, float sigma, int elementwise_mean, float *loss, void *stream)
 {
     if (!z || !logdet || !loss || B < 1 || N < 1 || !(sigma > 0.f)) return WG_EINVAL;
-    Ctx cx = {(hipStream_t)stream, 0};
+    Ctx cx = {(hipStream_t)stream, 0, 0};
     WG_LAUNCH(cx, nll_loss_kernel, dim3(1), dim3(1024), 0, z, logdet, B, N, 1.0f / (sigma * sigma), elementwise_mean, loss);
     return cx.err;
 }
@@ -872,7 +955,7 @@ int wg_nll_loss_backward(const float *z, int B, int N, float sigma, int elementw
                          float *dlogdet, void *stream)
 {
     if (!z || !dz || !dlogdet || B < 1 || N < 1 || !(sigma > 0.f)) return WG_EINVAL;
-    Ctx cx = {(hipStream_t)stream, 0};
+    Ctx cx = {(hipStream_t)stream, 0, 0};
     const size_t n = (size_t)B * N;
     WG_LAUNCH(cx, nll_loss_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, z, B, N, 1.0f / (sigma * sigma), elementwise_mean,
               dloss, dz, dlogdet);
@@ -886,7 +969,7 @@ int wg_upsample(const wg_config *cf, const void *packed, const float *h, int B, 
     if (!packed || !h || !y || B < 1 || F < 1 || T < 1) return WG_EINVAL;
     const long L = (long)(F - 1) * cf->up_stride - 2 * cf->up_pad + cf->up_kernel;
     if (T > L) return WG_ESHAPE;
-    Ctx cx = {(hipStream_t)stream, 0};
+    Ctx cx = {(hipStream_t)stream, 0, 0};
     const float *pk = (const float *)packed;
     const ModelPack M = model_pack_layout(cf);
     const Geo g = make_geo(B, T, 0);
@@ -926,7 +1009,7 @@ int wg_invconv_apply(const float *Wm, int c, const float *x, int B, int T, int r
     if (!Wm || !x || !z || !logdet || !wsv || c < 1 || c > WG_MAXC || B < 1 || T < 1) return WG_EINVAL;
     const InvWs W = inv_ws_layout(c, B, T);
     if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
-    Ctx cx = {(hipStream_t)stream, 0};
+    Ctx cx = {(hipStream_t)stream, 0, 0};
     float *ws = (float *)wsv;
     LuArgs lu;
     lu.n = 1; lu.out = ws + W.lu; lu.ostride = WG_LU_STRIDE; lu.job[0].W = Wm; lu.job[0].c = c;
@@ -945,7 +1028,7 @@ int wg_invconv_backward(const float *Wm, int c, const float *z, const float *dz,
     if (!Wm || !z || !dz || !dlogdet || !x || !dx || !dW || !wsv || c < 1 || c > WG_MAXC || B < 1 || T < 1) return WG_EINVAL;
     const InvWs W = inv_ws_layout(c, B, T);
     if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
-    Ctx cx = {(hipStream_t)stream, 0};
+    Ctx cx = {(hipStream_t)stream, 0, 0};
     float *ws = (float *)wsv;
     const Geo g = W.g;
     LuArgs lu;
@@ -1015,7 +1098,7 @@ int wg_coupling_apply(const wg_wn_dims *dd, const void *packed, const float *x, 
     if (rc) return rc;
     const CplWs W = cpl_ws_layout(d, B, T, 0);
     if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
-    Ctx cx = {(hipStream_t)stream, 0};
+    Ctx cx = {(hipStream_t)stream, 0, dd->precision ? 1 : 0};
     float *ws = (float *)wsv;
     const Geo g = W.g;
     PRef X = pref(ws + W.X, W.Xp);
@@ -1039,7 +1122,7 @@ int wg_wn_apply(const wg_wn_dims *dd, const void *packed, const float *x, const 
     if (rc) return rc;
     const CplWs W = cpl_ws_layout(d, B, T, 0);
     if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
-    Ctx cx = {(hipStream_t)stream, 0};
+    Ctx cx = {(hipStream_t)stream, 0, dd->precision ? 1 : 0};
     float *ws = (float *)wsv;
     const Geo g = W.g;
     PRef X = pref(ws + W.X, W.Xp);
@@ -1067,7 +1150,7 @@ int wg_coupling_backward(const wg_wn_dims *dd, const void *const *params, const 
     if (rc) return rc;
     const CplWs W = cpl_ws_layout(d, B, T, 1);
     if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
-    Ctx cx = {(hipStream_t)stream, 0};
+    Ctx cx = {(hipStream_t)stream, 0, dd->precision ? 1 : 0};
     float *ws = (float *)wsv;
     const Geo g = W.g;
     PRef X = pref(ws + W.X, W.Xp), dX = pref(ws + W.dX, W.Xp);

@@ -13,7 +13,7 @@ from torch import Tensor, nn
 from torch.autograd import Function
 
 from . import engine
-from ._lib import WgWnDims, WgError
+from ._lib import WgWnDims, WgError, default_precision as _default_precision
 from .base import Reversible
 
 __all__ = ["InvertibleConv1x1", "AffineCouplingBlock"]
@@ -111,7 +111,7 @@ class AffineCouplingBlock(Reversible):
             raise WgError("AffineCouplingBlock runs on the fused HIP WN kernels; transform_type must be "
                           "constant_memory_waveglow_amd.WN (got %r)" % (transform_type,))
         self._memory_efficient = bool(memory_efficient)
-        self._engine = engine.CouplingEngine(WgWnDims(*self.F.hip_dims()))
+        self._engine = engine.CouplingEngine(WgWnDims(*self.F.hip_dims(), _default_precision()))
 
     def _run(self, x: Tensor, y: Tensor, reverse: bool) -> Tuple[Tensor, Tensor]:
         z, log_s = _Coupling.apply(x, y, self, reverse, *self.F.parameters())

@@ -85,8 +85,8 @@ class WN(nn.Module):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             warnings.warn("WN.forward on its own runs without autograd; gradients flow through AffineCouplingBlock", stacklevel=2)
         if self._engine is None:
-            from ._lib import WgWnDims
-            self._engine = engine.CouplingEngine(WgWnDims(*self.hip_dims()))
+            from ._lib import WgWnDims, default_precision
+            self._engine = engine.CouplingEngine(WgWnDims(*self.hip_dims(), default_precision()))
         return self._engine.wn([None if t is None else t.detach() for t in self.param_table()], x.detach(), y.detach())
 
 

@@ -40,17 +40,26 @@ extern "C" {
 #define WG_ELAUNCH (-4)     /* a HIP launch failed */
 #define WG_EWORKSPACE (-5)  /* workspace too small */
 
+/* Arithmetic of the matrix contractions; every tensor in memory is fp32 in both modes.
+ *   WG_PREC_F32    v_mfma_f32_32x32x2_f32: bit-exact fp32 fma chains.
+ *   WG_PREC_BF16X3 each fp32 operand is split into bf16 hi + lo and a*b is evaluated as a_lo*b_hi + a_hi*b_lo + a_hi*b_hi
+ *                  on the bf16 matrix pipe with fp32 accumulation (drops a_lo*b_lo, 2^-16 of a product). */
+#define WG_PREC_F32 0
+#define WG_PREC_BF16X3 1
+
 /* Constructor arguments of model.WaveGlow (model/waveglow.py:109-118) after the arithmetic of
  * :125-129 (upsampler geometry).  WN arguments are the **kwargs forwarded to WN (waveglow.py:50-59). */
 typedef struct wg_config {
     int32_t n_flows, n_group, n_early_every, n_early_size, n_mels;
     int32_t up_stride, up_kernel, up_pad;            /* ConvTranspose1d(n_mels,n_mels,K,stride,pad,groups=n_mels) */
     int32_t res_ch, dil_ch, skip_ch, depth, radix;   /* WN: residual/dilation/skip channels, layers, kernel size */
+    int32_t precision;                               /* WG_PREC_* : arithmetic of the MFMA contractions (not upstream) */
 } wg_config;
 
 /* Dimensions of one WN as AffineCouplingBlock builds it (efficient_modules.py:58-65, waveglow.py:50-59). */
 typedef struct wg_wn_dims {
     int32_t in_ch, aux_ch, res_ch, dil_ch, skip_ch, depth, radix;
+    int32_t precision;                               /* WG_PREC_* */
 } wg_wn_dims;
 
 const char *wg_strerror(int code);
