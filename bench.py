@@ -35,6 +35,7 @@ C2 = dict(flows=12, n_group=8, n_early_every=4, n_early_size=2, hop_size=256, n_
           dilation_channels=256, residual_channels=256, skip_channels=256, depth=8, radix=3)   # configs/waveglow_LJ_speech.json:6-19
 SEG, FRAMES, SIGMA = 16000, 63, 0.7
 FP32_MFMA_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0           # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA" (dense)
 FWD_FLOP_PER_SAMPLE = 13_376_372         # SURVEY.md 2.1 (forward = inverse)
 STEP_FLOP_PER_SAMPLE = 40_129_116        # fwd + dgrad + wgrad (algorithmic; the recompute is not credited)
 
@@ -47,6 +48,21 @@ def build_model(dev, seed=0):
         for blk in model.WNs:
             blk.F.end.weight.normal_(0.0, 0.02)
     return model.to(dev)
+
+
+def _traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (profiles/*_hbm_traffic.json, produced by
+    tools/profile_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command); None if absent."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
+        try:
+            k = json.load(open(f))["kernels"]
+        except Exception:
+            continue
+        if kernel in k:
+            best = k[kernel]["hbm_bytes_per_launch"]
+    return best
 
 
 def cpu_baseline():
@@ -135,18 +151,25 @@ def main():
         kcat = C2["radix"] * C2["residual_channels"] + C2["n_mels"]
         gate_flop = 2.0 * kcat * 2 * C2["dilation_channels"] * B * T     # algorithmic FLOPs of one launch
         achieved = gate_flop / (gate_ms * 1e-3) / 1e12
+        split = _lib.default_precision() == _lib.PREC_BF16X3
+        # bf16x3: every fp32 product costs three bf16 MFMAs; the roofline is the bf16 matrix pipe and only the
+        # algorithmic FLOPs are credited (the 3x is overhead, not work) -- SURVEY.md 8d
+        peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
         out = {
             "metric": "audio samples/sec (fwd+bwd) WaveGlow-256ch seg=16000",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 (contractions as split bf16x3 MFMA, fp32 accumulate)" if split else "f32", "data": "synthetic",
             "config": {"workload": "WaveGlow 256ch, 12 flows, seg=16000, batch=%d per GPU (waveglow_LJ_speech.json), "
                                    "forward + NLL + constant-memory backward%s" % (B, " + RCCL grad all-reduce" if world > 1 else ""),
                        "global_batch": B * world, "segment": SEG, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "convgemm_kernel<EPI_GATE> (dilated k=3 conv + mel conditioning + gate)",
-                         "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "launch_ms": gate_ms, "launches_timed": n, "flop_per_launch": gate_flop},
+            "roofline": {"bound": "mfma", "kernel": "%s<EPI_GATE> (dilated k=3 conv + mel conditioning + gate)"
+                                                    % ("convgemm16_kernel" if split else "convgemm_kernel"),
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": _traffic("convgemm16_kernel<1, 4>" if split else "convgemm_kernel<1>"),
+                         "launch_ms": gate_ms, "launches_timed": n, "flop_per_launch": gate_flop,
+                         "mfma_tflops_issued": achieved * (3 if split else 1),
+                         "x_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS},
             "step_tflops_algorithmic": value * STEP_FLOP_PER_SAMPLE / 1e12 / world,
             "step_frac_of_fp32_mfma_peak": value * STEP_FLOP_PER_SAMPLE / 1e12 / world / FP32_MFMA_PEAK_TFLOPS,
             "loss": float(loss),

@@ -36,7 +36,7 @@ PREC_F32, PREC_BF16X3 = 0, 1
 
 def default_precision():
     """WG_PRECISION=f32|bf16x3 selects the arithmetic of the MFMA contractions (include/wgflow.h, WG_PREC_*)."""
-    v = os.environ.get("WG_PRECISION", "f32").lower()
+    v = os.environ.get("WG_PRECISION", "bf16x3").lower()
     if v in ("f32", "fp32", "0"):
         return PREC_F32
     if v in ("bf16x3", "1"):

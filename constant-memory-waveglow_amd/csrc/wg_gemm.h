@@ -97,7 +97,11 @@ __device__ __forceinline__ void mma_chunk(const float *__restrict__ As, const fl
 #endif
 }
 
-// gate nonlinearities.  WG_OPT_FASTGATE: hardware exp2/rcp based forms (|err| ~1e-7, well inside the 1e-4 parity budget)
+// gate nonlinearities: hardware exp2/rcp based forms (|err| ~1e-7, well inside the 1e-4 parity budget); the libm
+// forms cost ~4x the VALU work, which is visible once the contraction runs on the bf16 pipe.  -DWG_EXACT_GATE restores them.
+#if !defined(WG_EXACT_GATE)
+#define WG_OPT_FASTGATE 1
+#endif
 __device__ __forceinline__ float wg_sigmoid(float x)
 {
 #if defined(WG_OPT_FASTGATE)

@@ -11,6 +11,7 @@
 // (lane l: row l&31, k = 8*(l>>5) .. +7) is one conflict-free ds_read_b128.
 #pragma once
 #include "wg_gemm.h"
+#include <type_traits>
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -20,45 +21,50 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define WG16_ROWB 80                  // bytes per LDS row (32 bf16 + 16 B pad)
 #define WG16_IMG (WG_TILE * WG16_ROWB)  // one 128-row image
 
-__device__ __forceinline__ unsigned short bf16_rn(float x)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// two floats -> packed bf16 pair (round to nearest even): one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b)
 {
-    unsigned u = __float_as_uint(x);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+    f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
-__device__ __forceinline__ float bf16_tof(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
-// split two floats: returns packed hi pair and lo pair (element 0 in the low half)
+// split two floats: packed hi pair and packed lo pair (element 0 in the low half)
 __device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo)
 {
-    const unsigned short ha = bf16_rn(a), hb = bf16_rn(b);
-    hi = (unsigned)ha | ((unsigned)hb << 16);
-    lo = (unsigned)bf16_rn(a - bf16_tof(ha)) | ((unsigned)bf16_rn(b - bf16_tof(hb)) << 16);
+    hi = cvt_pk_bf16(a, b);
+    lo = cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
 }
 
-// acc[mi][ni] += A(rows wr*64+mi*32..) x B(rows wc*64+ni*32..) over nk16 k-steps of 16
+// one k-step of 16: acc[mi][ni] += A(rows wr*64+mi*32..) x B(rows wc*64+ni*32..)
+__device__ __forceinline__ void mma16_step(const char *Ahi, const char *Alo, const char *Bhi, const char *Blo,
+                                           int ao, int bo, f32x16 (&acc)[2][2])
+{
+    bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        ah[i] = *reinterpret_cast<const bf16x8 *>(Ahi + ao + i * 32 * WG16_ROWB);
+        al[i] = *reinterpret_cast<const bf16x8 *>(Alo + ao + i * 32 * WG16_ROWB);
+        bh[i] = *reinterpret_cast<const bf16x8 *>(Bhi + bo + i * 32 * WG16_ROWB);
+        bl[i] = *reinterpret_cast<const bf16x8 *>(Blo + bo + i * 32 * WG16_ROWB);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+        }
+}
+// a chunk = nk16 (1 or 2) k-steps
 __device__ __forceinline__ void mma16_chunk(const char *Ahi, const char *Alo, const char *Bhi, const char *Blo,
                                             int wr, int wc, int lane, int nk16, f32x16 (&acc)[2][2])
 {
     const int r = lane & 31, h = lane >> 5;
     const int ao = (wr * 64 + r) * WG16_ROWB + h * 16, bo = (wc * 64 + r) * WG16_ROWB + h * 16;
-    for (int s = 0; s < nk16; ++s) {
-        bf16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            ah[i] = *reinterpret_cast<const bf16x8 *>(Ahi + ao + i * 32 * WG16_ROWB + s * 32);
-            al[i] = *reinterpret_cast<const bf16x8 *>(Alo + ao + i * 32 * WG16_ROWB + s * 32);
-            bh[i] = *reinterpret_cast<const bf16x8 *>(Bhi + bo + i * 32 * WG16_ROWB + s * 32);
-            bl[i] = *reinterpret_cast<const bf16x8 *>(Blo + bo + i * 32 * WG16_ROWB + s * 32);
-        }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-            }
-    }
+    mma16_step(Ahi, Alo, Bhi, Blo, ao, bo, acc);
+    if (nk16 == 2) mma16_step(Ahi, Alo, Bhi, Blo, ao + 32, bo + 32, acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -72,14 +78,20 @@ struct ConvGemm16Args {
     ConvGemmArgs c;              // geometry, segments, epilogue (c.A unused)
 };
 
-template <int EPI>
-__global__ __launch_bounds__(256) void convgemm16_kernel(const ConvGemm16Args aa)
+// MT = 64-row wave rows per workgroup: 2 -> 128x128 tile, 4 waves;  4 -> 256x128 tile, 8 waves (the B tile is converted once
+// for twice the MFMA work).  LDS: 2 buffers x (MT*64 + MT*64 + 128 + 128) rows x 80 B.
+template <int EPI, int MT>
+__global__ __launch_bounds__(128 * MT) void convgemm16_kernel(const ConvGemm16Args aa)
 {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 4 * WG16_IMG];   // 2 buffers x 4 images (80 KB)
+    constexpr int NT = 128 * MT;                 // threads
+    constexpr int AIMG = MT * 64 * WG16_ROWB;    // one A image (hi or lo)
+    constexpr int BUF = 2 * AIMG + 2 * WG16_IMG; // A_hi, A_lo, B_hi, B_lo
+    constexpr int KPT = 32 / (NT / 128);         // k rows of the B tile converted per thread (16 or 8)
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
     const ConvGemmArgs &a = aa.c;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int t0 = blockIdx.x * WG_TILE, m0 = blockIdx.y * WG_TILE, b = blockIdx.z;
+    const int t0 = blockIdx.x * WG_TILE, m0 = blockIdx.y * (64 * MT), b = blockIdx.z;
     const Geo g = a.g;
 
     f32x16 acc[2][2];
@@ -93,49 +105,50 @@ __global__ __launch_bounds__(256) void convgemm16_kernel(const ConvGemm16Args aa
     int nchunks = 0;
     for (int s = 0; s < a.nseg; ++s) nchunks += (a.seg[s].nch + WG16_BK - 1) / WG16_BK;
 
-    // staging registers: A 2 x (hi,lo) 16-B pieces, B 16 floats
+    // staging registers: A 2 x (hi,lo) 16-B pieces, B KPT floats
     u32x4 ra_hi[2], ra_lo[2];
-    float rb[16];
+    float rb[KPT];
     int cur_seg = 0, cur_c = 0, chunk = 0;      // next chunk to load
     int nk_loaded = 0;                          // k16 steps of the chunk sitting in the staging registers
-    const int bt = tid & 127, bk = (tid >> 7) * 16;   // B staging: time column, first of 16 k rows
+    const int bt = tid & 127;                                            // B staging: time column
+    const int bk = __builtin_amdgcn_readfirstlane(tid >> 7) * KPT;       // first k row (wave uniform)
 
     auto load_chunk = [&]() {
         const ConvSeg sg = a.seg[cur_seg];
         const int nvalid = min(WG16_BK, sg.nch - cur_c);
         nk_loaded = nvalid >> 4;
-        // A: 512 pieces of 16 B per image: piece p -> row p>>2, part p&3
+        // A: MT*256 pieces of 16 B per image: piece p -> row p>>2, part p&3
         const unsigned short *ih = aa.img + ((size_t)chunk * a.lda + m0) * WG16_BK;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int p = tid + 256 * j;
+            const int p = tid + NT * j;
             ra_hi[j] = *reinterpret_cast<const u32x4 *>(ih + (size_t)p * 8);
             ra_lo[j] = *reinterpret_cast<const u32x4 *>(ih + aa.img_stride + (size_t)p * 8);
         }
-        const float *base = sg.src + ((size_t)b * sg.Cp + sg.ch0 + cur_c + bk) * g.P + g.H + t0 + sg.shift + bt;
+        const float *base = sg.src + ((size_t)b * sg.Cp + sg.ch0 + cur_c + bk) * g.P + g.H + t0 + sg.shift;   // wave uniform
         if (bk < nvalid) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) rb[j] = base[(size_t)j * g.P];
+            for (int j = 0; j < KPT; ++j) rb[j] = base[(size_t)j * g.P + bt];
         } else {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) rb[j] = 0.f;
+            for (int j = 0; j < KPT; ++j) rb[j] = 0.f;
         }
         ++chunk;
         cur_c += WG16_BK;
         if (cur_c >= sg.nch) { cur_c = 0; ++cur_seg; }
     };
     auto store_chunk = [&](int buf) {
-        char *sb = smem + buf * 4 * WG16_IMG;
+        char *sb = smem + buf * BUF;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int p = tid + 256 * j;
+            const int p = tid + NT * j;
             const int off = (p >> 2) * WG16_ROWB + (p & 3) * 16;
             *reinterpret_cast<u32x4 *>(sb + off) = ra_hi[j];
-            *reinterpret_cast<u32x4 *>(sb + WG16_IMG + off) = ra_lo[j];
+            *reinterpret_cast<u32x4 *>(sb + AIMG + off) = ra_lo[j];
         }
-        char *bh = sb + 2 * WG16_IMG + bt * WG16_ROWB + bk * 2, *bl = bh + WG16_IMG;
+        char *bh = sb + 2 * AIMG + bt * WG16_ROWB + bk * 2, *bl = bh + WG16_IMG;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < KPT / 8; ++q) {
             u32x4 vh, vl;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -155,8 +168,8 @@ __global__ __launch_bounds__(256) void convgemm16_kernel(const ConvGemm16Args aa
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
         if (c + 1 < nchunks) load_chunk();
-        const char *sb = smem + buf * 4 * WG16_IMG;
-        mma16_chunk(sb, sb + WG16_IMG, sb + 2 * WG16_IMG, sb + 3 * WG16_IMG, wr, wc, lane, nk_cur, acc);
+        const char *sb = smem + buf * BUF;
+        mma16_chunk(sb, sb + AIMG, sb + 2 * AIMG, sb + 2 * AIMG + WG16_IMG, wr, wc, lane, nk_cur, acc);
         if (c + 1 < nchunks) { store_chunk(buf ^ 1); nk_cur = nk_loaded; }
         __syncthreads();
     }

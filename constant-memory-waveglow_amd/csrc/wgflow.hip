@@ -439,11 +439,26 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
         a16.img = mat_img(A, K, lda);
         a16.img_stride = (size_t)nc * lda * WG16_BK;
         a16.c = a;
-        switch (epi) {
-        case EPI_STORE: WG_LAUNCH(cx, convgemm16_kernel<EPI_STORE>, grid, block, 0, a16); break;
-        case EPI_GATE: WG_LAUNCH(cx, convgemm16_kernel<EPI_GATE>, grid, block, 0, a16); break;
-        case EPI_RESSKIP: WG_LAUNCH(cx, convgemm16_kernel<EPI_RESSKIP>, grid, block, 0, a16); break;
-        case EPI_DGATE: WG_LAUNCH(cx, convgemm16_kernel<EPI_DGATE>, grid, block, 0, a16); break;
+#if defined(WG_OPT_MT2ONLY)
+        const bool big = false;
+#else
+        const bool big = (rup(mrows, WG_TILE) % 256) == 0;      // 256-row tiles when M allows it
+#endif
+        if (big) {
+            dim3 grid4(g.Tt / WG_TILE, rup(mrows, WG_TILE) / 256, g.B), block4(512);
+            switch (epi) {
+            case EPI_STORE: WG_LAUNCH(cx, (convgemm16_kernel<EPI_STORE, 4>), grid4, block4, 0, a16); break;
+            case EPI_GATE: WG_LAUNCH(cx, (convgemm16_kernel<EPI_GATE, 4>), grid4, block4, 0, a16); break;
+            case EPI_RESSKIP: WG_LAUNCH(cx, (convgemm16_kernel<EPI_RESSKIP, 4>), grid4, block4, 0, a16); break;
+            case EPI_DGATE: WG_LAUNCH(cx, (convgemm16_kernel<EPI_DGATE, 4>), grid4, block4, 0, a16); break;
+            }
+        } else {
+            switch (epi) {
+            case EPI_STORE: WG_LAUNCH(cx, (convgemm16_kernel<EPI_STORE, 2>), grid, block, 0, a16); break;
+            case EPI_GATE: WG_LAUNCH(cx, (convgemm16_kernel<EPI_GATE, 2>), grid, block, 0, a16); break;
+            case EPI_RESSKIP: WG_LAUNCH(cx, (convgemm16_kernel<EPI_RESSKIP, 2>), grid, block, 0, a16); break;
+            case EPI_DGATE: WG_LAUNCH(cx, (convgemm16_kernel<EPI_DGATE, 2>), grid, block, 0, a16); break;
+            }
         }
         return;
     }
