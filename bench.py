@@ -151,7 +151,8 @@ def main():
         kcat = C2["radix"] * C2["residual_channels"] + C2["n_mels"]
         gate_flop = 2.0 * kcat * 2 * C2["dilation_channels"] * B * T     # algorithmic FLOPs of one launch
         achieved = gate_flop / (gate_ms * 1e-3) / 1e12
-        split = _lib.default_precision() == _lib.PREC_BF16X3
+        split = _lib.default_precision() != _lib.PREC_F32
+        kname = {0: 'convgemm_kernel', 1: 'convgemm16_kernel', 2: 'convgemm16p_kernel'}[_lib.default_precision()]
         # bf16x3: every fp32 product costs three bf16 MFMAs; the roofline is the bf16 matrix pipe and only the
         # algorithmic FLOPs are credited (the 3x is overhead, not work) -- SURVEY.md 8d
         peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
@@ -163,10 +164,9 @@ def main():
             "config": {"workload": "WaveGlow 256ch, 12 flows, seg=16000, batch=%d per GPU (waveglow_LJ_speech.json), "
                                    "forward + NLL + constant-memory backward%s" % (B, " + RCCL grad all-reduce" if world > 1 else ""),
                        "global_batch": B * world, "segment": SEG, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "%s<EPI_GATE> (dilated k=3 conv + mel conditioning + gate)"
-                                                    % ("convgemm16_kernel" if split else "convgemm_kernel"),
+            "roofline": {"bound": "mfma", "kernel": "%s<EPI_GATE> (dilated k=3 conv + mel conditioning + gate)" % kname,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": _traffic("convgemm16_kernel<1, 4>" if split else "convgemm_kernel<1>"),
+                         "traffic": _traffic(kname + ("<1, 4>" if kname == "convgemm16_kernel" else "<1>")),
                          "launch_ms": gate_ms, "launches_timed": n, "flop_per_launch": gate_flop,
                          "mfma_tflops_issued": achieved * (3 if split else 1),
                          "x_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS},

@@ -31,16 +31,18 @@ class WgWnDims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("in_ch", "aux_ch", "res_ch", "dil_ch", "skip_ch", "depth", "radix", "precision")]
 
 
-PREC_F32, PREC_BF16X3 = 0, 1
+PREC_F32, PREC_BF16X3, PREC_BF16X3_PLANES = 0, 1, 2
 
 
 def default_precision():
-    """WG_PRECISION=f32|bf16x3 selects the arithmetic of the MFMA contractions (include/wgflow.h, WG_PREC_*)."""
-    v = os.environ.get("WG_PRECISION", "bf16x3").lower()
+    """WG_PRECISION=f32|bf16x3|bf16x3p selects the arithmetic of the MFMA contractions (include/wgflow.h, WG_PREC_*)."""
+    v = os.environ.get("WG_PRECISION", "bf16x3p").lower()
     if v in ("f32", "fp32", "0"):
         return PREC_F32
     if v in ("bf16x3", "1"):
         return PREC_BF16X3
+    if v in ("bf16x3p", "bf16x3_planes", "2"):
+        return PREC_BF16X3_PLANES
     raise WgError("WG_PRECISION must be f32 or bf16x3 (got %r)" % v)
 
 

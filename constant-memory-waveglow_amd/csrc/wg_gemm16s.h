@@ -1,0 +1,452 @@
+// wg_gemm16s.h -- bf16x3 kernels fed from PRE-SPLIT activation planes ("S-planes"): no conversion work in the main loops.
+//
+// An S-plane holds a tensor as two bf16 arrays (hi, then lo = x - hi) in a channel-interleaved layout
+//     S[b][c/8][p][8]      p = H + t, same pitch P and zero-halo invariant as the fp32 planes,
+// i.e. one 16-byte unit = 8 consecutive channels at one time step.  Consequences:
+//   * the conv B-tile image [t][k] is filled with plain 16-byte copies and ANY time shift (dilation tap) stays
+//     16-byte aligned (a shift moves whole units);
+//   * the wgrad operand image [t][c] is filled the same way and read with ds_read_b64_tr_b16 (hardware transpose),
+//     which hands each lane 4 consecutive time steps of its channel;
+//   * producers write it straight from the MFMA accumulator layout: a lane owns 4 consecutive channels of one time
+//     step (8 bytes), a wave store covers 512 contiguous bytes.
+// Producers (epilogues below, to_splane_kernel) do the fp32 -> hi/lo split ONCE per element; with the on-the-fly kernels
+// of wg_gemm16.h every consumer workgroup repeated it (12x for the dilated conv).
+#pragma once
+#include "wg_gemm16.h"
+
+struct SRef {
+    unsigned short *hi;   // lo array at hi + lo_off
+    size_t lo_off;        // = B * Cp * P elements
+    int Cp, ch0;          // channel rows per item (multiple of 8), first channel (multiple of 8)
+};
+__device__ __forceinline__ size_t s_index(const SRef &r, const Geo &g, int b, int c, int t)
+{
+    const int cc = r.ch0 + c;
+    return (((size_t)b * (r.Cp >> 3) + (cc >> 3)) * g.P + g.H + t) * 8 + (cc & 7);
+}
+// 4 consecutive channels (c multiple of 4) of one time step
+__device__ __forceinline__ void s_store4(const SRef &r, const Geo &g, int b, int c, int t, const float (&v)[4])
+{
+    u32x2 h, l;
+    unsigned hh, ll;
+    split2(v[0], v[1], hh, ll); h[0] = hh; l[0] = ll;
+    split2(v[2], v[3], hh, ll); h[1] = hh; l[1] = ll;
+    const size_t i = s_index(r, g, b, c, t);
+    *reinterpret_cast<u32x2 *>(r.hi + i) = h;
+    *reinterpret_cast<u32x2 *>(r.hi + r.lo_off + i) = l;
+}
+
+// fp32 plane channels [ch0, ch0+nvalid) -> S-plane channels [0, Cp_dst) (zero filled beyond nvalid)
+__global__ void to_splane_kernel(PRef src, int nvalid, SRef dst, Geo g)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, cg = blockIdx.y, b = blockIdx.z;
+    if (t >= g.T) return;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (cg * 8 + e < nvalid) ? *paddr(src, g, b, cg * 8 + e, t) : 0.f;
+    u32x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        unsigned hh, ll;
+        split2(v[2 * e], v[2 * e + 1], hh, ll);
+        h[e] = hh; l[e] = ll;
+    }
+    const size_t i = s_index(dst, g, b, cg * 8, t);
+    *reinterpret_cast<u32x4 *>(dst.hi + i) = h;
+    *reinterpret_cast<u32x4 *>(dst.hi + dst.lo_off + i) = l;
+}
+
+// ------------------------------------------------------------------------------------------------
+// epilogues with optional fp32 and S-plane outputs
+// ------------------------------------------------------------------------------------------------
+// All auxiliary loads of a thread (residual input, skip accumulator, tanh/sigmoid) are issued first, into registers that
+// overwrite the accumulators they are combined with, and only then the stores: the epilogue is HBM/latency bound at two
+// waves per SIMD, so memory-level parallelism (64-128 loads in flight per lane) is what matters.
+template <int EPI>
+__device__ __forceinline__ void conv_epilogue_s(const ConvGemmArgs &a, const SRef &s0, f32x16 (&acc)[2][2], int t0, int m0, int b,
+                                                int wr, int wc, int lane)
+{
+    const Geo g = a.g;
+    const int col = lane & 31, h = lane >> 5;
+    if (EPI == EPI_GATE) {
+        const int chb = (m0 >> 1) + wr * 32;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int t = t0 + wc * 64 + ni * 32 + col;
+            if (t >= g.T) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ch = chb + 8 * q + 4 * h;
+                if (2 * ch >= a.M) continue;
+                float gv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float tw = wg_tanh(acc[0][ni][4 * q + e]);
+                    const float sf = wg_sigmoid(acc[1][ni][4 * q + e]);
+                    gv[e] = tw * sf;
+                    if (a.out0.p) *paddr(a.out0, g, b, ch + e, t) = gv[e];
+                    if (a.out1.p) {
+                        *paddr(a.out1, g, b, ch + e, t) = tw;
+                        *paddr(a.out2, g, b, ch + e, t) = sf;
+                    }
+                }
+                s_store4(s0, g, b, ch, t, gv);
+            }
+        }
+        return;
+    }
+    // ---- phase 1: loads ----
+    f32x16 ax[2][2];                 // aux0 / skip accumulator
+    f32x16 ay[2][2];                 // aux1 (DGATE only)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int t = t0 + wc * 64 + ni * 32 + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * 64 + mi * 32 + acc_row(r, lane);
+                float x = 0.f, y = 0.f;
+                if (t < g.T && m < a.M) {
+                    if (EPI == EPI_STORE) {
+                        if (a.aux0.p) x = *paddr(a.aux0, g, b, m, t);
+                    } else if (EPI == EPI_RESSKIP) {
+                        if (m < a.nsplit) x = *paddr(a.aux0, g, b, m, t);
+                        else if (a.accumulate) x = *paddr(a.out1, g, b, m - a.nsplit, t);
+                    } else if (EPI == EPI_DGATE) {
+                        x = *paddr(a.aux0, g, b, m, t);
+                        y = *paddr(a.aux1, g, b, m, t);
+                    }
+                }
+                ax[mi][ni][r] = x;
+                if (EPI == EPI_DGATE) ay[mi][ni][r] = y;
+            }
+        }
+    // ---- phase 2: combine + stores ----
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int t = t0 + wc * 64 + ni * 32 + col;
+            if (t >= g.T) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = m0 + wr * 64 + mi * 32 + 8 * q + 4 * h;
+                if (m >= a.M) continue;
+                float o[4];
+                if (EPI == EPI_STORE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[e] = acc[mi][ni][4 * q + e] + ax[mi][ni][4 * q + e];
+                        if (m + e < a.M && a.out0.p) *paddr(a.out0, g, b, m + e, t) = o[e];
+                    }
+                    if (s0.hi) s_store4(s0, g, b, m, t, o);
+                } else if (EPI == EPI_RESSKIP) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = acc[mi][ni][4 * q + e] + ax[mi][ni][4 * q + e];
+                    if (m < a.nsplit) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) *paddr(a.out0, g, b, m + e, t) = o[e];
+                        if (s0.hi) s_store4(s0, g, b, m, t, o);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) *paddr(a.out1, g, b, m + e - a.nsplit, t) = o[e];
+                    }
+                } else if (EPI == EPI_DGATE) {
+                    float o2[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = acc[mi][ni][4 * q + e];
+                        const float tw = ax[mi][ni][4 * q + e], sf = ay[mi][ni][4 * q + e];
+                        o[e] = v * sf * (1.0f - tw * tw);
+                        o2[e] = v * tw * sf * (1.0f - sf);
+                        if (a.out0.p) {
+                            *paddr(a.out0, g, b, m + e, t) = o[e];
+                            *paddr(a.out0, g, b, a.nsplit + m + e, t) = o2[e];
+                        }
+                    }
+                    s_store4(s0, g, b, m, t, o);
+                    s_store4(s0, g, b, a.nsplit + m, t, o2);
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// convgemm16s: A from the pre-split weight images, B from S-planes
+// ------------------------------------------------------------------------------------------------
+struct SSeg {
+    const unsigned short *hi;
+    size_t lo_off;
+    int Cp, ch0;
+};
+struct ConvGemm16sArgs {
+    const unsigned short *img;
+    size_t img_stride;
+    ConvGemmArgs c;               // geometry, seg[].nch / shift, epilogue operands (seg[].src unused)
+    SSeg sseg[WG_MAX_SEG];
+    SRef s0;                      // S-plane output (hi == nullptr: none)
+};
+
+template <int EPI, int MT>
+__global__ __launch_bounds__(128 * MT) void convgemm16s_kernel(const ConvGemm16sArgs aa)
+{
+    constexpr int NT = 128 * MT;
+    constexpr int AIMG = MT * 64 * WG16_ROWB;
+    constexpr int BUF = 2 * AIMG + 2 * WG16_IMG;
+    constexpr int UPT = 512 / NT;                 // 16-byte units of the B tile per thread and image (2 or 1)
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+    const ConvGemmArgs &a = aa.c;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int t0 = blockIdx.x * WG_TILE, m0 = blockIdx.y * (64 * MT), b = blockIdx.z;
+    const Geo g = a.g;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int nchunks = 0;
+    for (int s = 0; s < a.nseg; ++s) nchunks += (a.seg[s].nch + WG16_BK - 1) / WG16_BK;
+
+    u32x4 ra_hi[2], ra_lo[2], rb_hi[UPT], rb_lo[UPT];
+    int cur_seg = 0, cur_c = 0, chunk = 0, nk_loaded = 0;
+    const int bt = tid & 127;
+
+    auto load_chunk = [&]() {
+        const int nch = a.seg[cur_seg].nch, shift = a.seg[cur_seg].shift;
+        const SSeg ss = aa.sseg[cur_seg];
+        const int nvalid = min(WG16_BK, nch - cur_c);
+        nk_loaded = nvalid >> 4;
+        const unsigned short *ih = aa.img + ((size_t)chunk * a.lda + m0) * WG16_BK;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int p = tid + NT * j;
+            ra_hi[j] = *reinterpret_cast<const u32x4 *>(ih + (size_t)p * 8);
+            ra_lo[j] = *reinterpret_cast<const u32x4 *>(ih + aa.img_stride + (size_t)p * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < UPT; ++j) {
+            const int cg = (tid + NT * j) >> 7;                                  // 0..3
+            u32x4 vh = {0u, 0u, 0u, 0u}, vl = {0u, 0u, 0u, 0u};
+            if (cg * 8 < nvalid) {
+                const unsigned short *p = ss.hi + (((size_t)b * (ss.Cp >> 3) + ((ss.ch0 + cur_c) >> 3) + cg) * g.P + g.H + t0 + shift + bt) * 8;
+                vh = *reinterpret_cast<const u32x4 *>(p);
+                vl = *reinterpret_cast<const u32x4 *>(p + ss.lo_off);
+            }
+            rb_hi[j] = vh; rb_lo[j] = vl;
+        }
+        ++chunk;
+        cur_c += WG16_BK;
+        if (cur_c >= nch) { cur_c = 0; ++cur_seg; }
+    };
+    auto store_chunk = [&](int buf) {
+        char *sb = smem + buf * BUF;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int p = tid + NT * j;
+            const int off = (p >> 2) * WG16_ROWB + (p & 3) * 16;
+            *reinterpret_cast<u32x4 *>(sb + off) = ra_hi[j];
+            *reinterpret_cast<u32x4 *>(sb + AIMG + off) = ra_lo[j];
+        }
+#pragma unroll
+        for (int j = 0; j < UPT; ++j) {
+            const int cg = (tid + NT * j) >> 7;
+            char *q = sb + 2 * AIMG + bt * WG16_ROWB + cg * 16;
+            *reinterpret_cast<u32x4 *>(q) = rb_hi[j];
+            *reinterpret_cast<u32x4 *>(q + WG16_IMG) = rb_lo[j];
+        }
+    };
+
+    load_chunk();
+    int nk_cur = nk_loaded;
+    store_chunk(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) load_chunk();
+        const char *sb = smem + buf * BUF;
+        mma16_chunk(sb, sb + AIMG, sb + 2 * AIMG, sb + 2 * AIMG + WG16_IMG, wr, wc, lane, nk_cur, acc);
+        if (c + 1 < nchunks) { store_chunk(buf ^ 1); nk_cur = nk_loaded; }
+        __syncthreads();
+    }
+    conv_epilogue_s<EPI>(a, aa.s0, acc, t0, m0, b, wr, wc, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// convgemm16p: software-pipelined 128x128 variant (4 waves, two workgroups per CU).
+// Every chunk runs two k-steps (half chunks are zero padded in LDS); inside a chunk the fragment reads of step 1 are
+// issued between the MFMAs of step 0 and the LDS writes of the NEXT chunk between the MFMAs of step 1, so a wave keeps
+// the matrix pipe fed by itself; sched_group_barrier pins that interleave.
+// ------------------------------------------------------------------------------------------------
+struct Frags16 {
+    bf16x8 ah[2], al[2], bh[2], bl[2];
+};
+__device__ __forceinline__ void read_frags16(Frags16 &f, const char *Ahi, const char *Alo, const char *Bhi, const char *Blo, int ao, int bo)
+{
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        f.ah[i] = *reinterpret_cast<const bf16x8 *>(Ahi + ao + i * 32 * WG16_ROWB);
+        f.al[i] = *reinterpret_cast<const bf16x8 *>(Alo + ao + i * 32 * WG16_ROWB);
+        f.bh[i] = *reinterpret_cast<const bf16x8 *>(Bhi + bo + i * 32 * WG16_ROWB);
+        f.bl[i] = *reinterpret_cast<const bf16x8 *>(Blo + bo + i * 32 * WG16_ROWB);
+    }
+}
+__device__ __forceinline__ void mfma12(const Frags16 &f, f32x16 (&acc)[2][2])
+{
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[mi], f.bh[ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mi], f.bl[ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mi], f.bh[ni], acc[mi][ni], 0, 0, 0);
+        }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void convgemm16p_kernel(const ConvGemm16sArgs aa)
+{
+    constexpr int AIMG = WG16_IMG;
+    constexpr int BUF = 4 * WG16_IMG;
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+    const ConvGemmArgs &a = aa.c;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int t0 = blockIdx.x * WG_TILE, m0 = blockIdx.y * WG_TILE, b = blockIdx.z;
+    const Geo g = a.g;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int nchunks = 0;
+    for (int s = 0; s < a.nseg; ++s) nchunks += (a.seg[s].nch + WG16_BK - 1) / WG16_BK;
+
+#if defined(WG_OPT_PIPE_DEPTH2)
+    constexpr int NSET = 2;       // global loads run two chunks ahead of the MFMAs (two staging register sets)
+#else
+    constexpr int NSET = 1;
+#endif
+    u32x4 ra_hi[NSET][2], ra_lo[NSET][2], rb_hi[NSET][2], rb_lo[NSET][2];
+    int cur_seg = 0, cur_c = 0, chunk = 0;
+    const int bt = tid & 127, cg0 = tid >> 7;          // B units: (cg0, bt) and (cg0 + 2, bt)
+
+    auto load_chunk = [&](auto SET) {
+        constexpr int S = decltype(SET)::value;
+        const int nch = a.seg[cur_seg].nch, shift = a.seg[cur_seg].shift;
+        const SSeg ss = aa.sseg[cur_seg];
+        const int nvalid = min(WG16_BK, nch - cur_c);
+        const unsigned short *ih = aa.img + ((size_t)chunk * a.lda + m0) * WG16_BK;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int p = tid + 256 * j;
+            ra_hi[S][j] = *reinterpret_cast<const u32x4 *>(ih + (size_t)p * 8);
+            ra_lo[S][j] = *reinterpret_cast<const u32x4 *>(ih + aa.img_stride + (size_t)p * 8);
+        }
+        const unsigned short *p0 = ss.hi + (((size_t)b * (ss.Cp >> 3) + ((ss.ch0 + cur_c) >> 3) + cg0) * g.P + g.H + t0 + shift + bt) * 8;
+        rb_hi[S][0] = *reinterpret_cast<const u32x4 *>(p0);           // cg0 in {0,1}: always valid (chunks hold >= 16 channels)
+        rb_lo[S][0] = *reinterpret_cast<const u32x4 *>(p0 + ss.lo_off);
+        u32x4 vh = {0u, 0u, 0u, 0u}, vl = {0u, 0u, 0u, 0u};
+        if (nvalid > 16) {
+            const unsigned short *p1 = p0 + (size_t)2 * g.P * 8;
+            vh = *reinterpret_cast<const u32x4 *>(p1);
+            vl = *reinterpret_cast<const u32x4 *>(p1 + ss.lo_off);
+        }
+        rb_hi[S][1] = vh; rb_lo[S][1] = vl;
+        ++chunk;
+        cur_c += WG16_BK;
+        if (cur_c >= nch) { cur_c = 0; ++cur_seg; }
+    };
+    auto store_chunk = [&](auto SET, int buf) {
+        constexpr int S = decltype(SET)::value;
+        char *sb = smem + buf * BUF;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int p = tid + 256 * j;
+            const int off = (p >> 2) * WG16_ROWB + (p & 3) * 16;
+            *reinterpret_cast<u32x4 *>(sb + off) = ra_hi[S][j];
+            *reinterpret_cast<u32x4 *>(sb + AIMG + off) = ra_lo[S][j];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            char *q = sb + 2 * AIMG + bt * WG16_ROWB + (cg0 + 2 * j) * 16;
+            *reinterpret_cast<u32x4 *>(q) = rb_hi[S][j];
+            *reinterpret_cast<u32x4 *>(q + WG16_IMG) = rb_lo[S][j];
+        }
+    };
+
+    const int r = lane & 31, h = lane >> 5;
+    const int ao = (wr * 64 + r) * WG16_ROWB + h * 16, bo = (wc * 64 + r) * WG16_ROWB + h * 16;
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, NSET - 1>;
+
+    // one steady-state iteration: multiply chunk c (buffer c&1) while chunk c+1 goes registers -> LDS and (DEPTH2) chunk c+2
+    // goes global -> registers.  LSET: register set loaded in this iteration, WSET: set written to LDS.
+    auto iter = [&](auto LSET, auto WSET, int c, bool do_load) {
+        const char *sb = smem + (c & 1) * BUF;
+        Frags16 f0, f1;
+#if !defined(WG_ABL_NOLOAD)
+        if (do_load) load_chunk(LSET);
+#endif
+        read_frags16(f0, sb, sb + AIMG, sb + 2 * AIMG, sb + 3 * AIMG, ao, bo);
+        read_frags16(f1, sb, sb + AIMG, sb + 2 * AIMG, sb + 3 * AIMG, ao + 32, bo + 32);
+#if defined(WG_ABL_NOMFMA)
+        asm volatile("" ::"v"(f0.ah[0]), "v"(f0.al[1]), "v"(f0.bh[0]), "v"(f0.bl[1]), "v"(f1.ah[1]), "v"(f1.al[0]), "v"(f1.bh[1]), "v"(f1.bl[0]));
+#else
+        mfma12(f0, acc);
+#endif
+#if !defined(WG_ABL_NOLOAD) && !defined(WG_ABL_NOSTORE)
+        store_chunk(WSET, (c & 1) ^ 1);
+#endif
+#if !defined(WG_ABL_NOMFMA)
+        mfma12(f1, acc);
+#endif
+        // pin the interleave: loads, step-0 fragments, then {3 MFMA, 2 DS reads} x4, {3 MFMA, 2 DS writes} x4
+        __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+        }
+        __syncthreads();
+    };
+
+    load_chunk(S0{});
+    store_chunk(S0{}, 0);
+#if defined(WG_OPT_PIPE_DEPTH2)
+    if (nchunks > 1) load_chunk(S1{});             // chunk 1 -> set 1
+    __syncthreads();
+    // iteration c: loads chunk c+2 into set c&1 (free: chunk c is already in LDS), writes chunk c+1 from set (c+1)&1
+    for (int c = 0; c + 1 < nchunks; c += 2) {
+        iter(S0{}, S1{}, c, c + 2 < nchunks);
+        if (c + 2 < nchunks) iter(S1{}, S0{}, c + 1, c + 3 < nchunks);
+    }
+#else
+    __syncthreads();
+    for (int c = 0; c + 1 < nchunks; ++c) iter(S0{}, S0{}, c, true);
+#endif
+    {
+        const char *sb = smem + ((nchunks - 1) & 1) * BUF;
+        Frags16 f0, f1;
+        read_frags16(f0, sb, sb + AIMG, sb + 2 * AIMG, sb + 3 * AIMG, ao, bo);
+        read_frags16(f1, sb, sb + AIMG, sb + 2 * AIMG, sb + 3 * AIMG, ao + 32, bo + 32);
+        mfma12(f0, acc);
+        mfma12(f1, acc);
+    }
+    conv_epilogue_s<EPI>(a, aa.s0, acc, t0, m0, b, wr, wc, lane);
+}

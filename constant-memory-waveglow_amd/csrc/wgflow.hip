@@ -4,6 +4,7 @@
 #include "../../include/wgflow.h"
 #include "wg_small.h"
 #include "wg_gemm16.h"
+#include "wg_gemm16s.h"
 
 #include <algorithm>
 #include <atomic>
@@ -21,7 +22,7 @@ inline size_t rupz(size_t x, size_t m) { return (x + m - 1) / m * m; }
 struct Ctx {
     hipStream_t st;
     int err;
-    int prec;   // 0: exact fp32 MFMA; 1: split bf16x3 MFMA (wg_gemm16.h)
+    int prec;   // 0: exact fp32 MFMA; 1: bf16x3, operands split on the fly (wg_gemm16.h); 2: bf16x3 from pre-split S-planes (wg_gemm16s.h)
 };
 #define WG_LAUNCH(ctx, kern, grid, block, shmem, ...)                         \
     do {                                                                      \
@@ -275,6 +276,7 @@ WnD flow_wn(const wg_config *cf, int k)
     WnD d;
     d.ic = flow_channels(cf, k) / 2;
     d.aux = cf->n_mels; d.C = cf->res_ch; d.Cd = cf->dil_ch; d.Cs = cf->skip_ch; d.depth = cf->depth; d.radix = cf->radix;
+    d.prec = cf->precision;
     return d;
 }
 int wn_table_off(const wg_config *cf, int k) { return 3 + cf->n_flows + k * (4 + 4 * cf->depth + 1); }
@@ -342,6 +344,7 @@ size_t slab_floats(const Geo &g, int Mp, int Np)
 
 struct WnWs {               // plane bases (float offsets) of one WN's activations
     size_t H[16], tw[16], sf[16], gate[16], skip, G, dS, dH, dxy, slab;
+    size_t HS[16], gateS[16], XaS, GS, dSS, dHS, dxyS;   // S-planes (precision 2), sized like the fp32 plane of the same tensor
     int nH;                 // 2 (ping-pong) or depth
     size_t slab_floats;
 };
@@ -349,9 +352,21 @@ struct Bump {
     size_t off = 0;
     size_t take(size_t n) { size_t o = off; off += rupz(n, 64); return o; }
 };
-void wn_ws_layout(Bump &bp, const WnD &d, int ic_max, const Geo &g, int mode, WnWs &w)
+void wn_ws_layout(Bump &bp, const WnD &d, int ic_max, const Geo &g, int mode, int prec, WnWs &w)
 {
     const size_t pC = (size_t)g.B * d.C * g.P, pD = (size_t)g.B * d.Cd * g.P, pS = (size_t)g.B * d.Cs * g.P;
+    if (prec == 2) {
+        const int nHS = mode ? d.depth : 2;
+        for (int i = 0; i < nHS; ++i) w.HS[i] = bp.take(pC);
+        for (int i = 0; i < d.depth; ++i) w.gateS[i] = (mode || i == 0) ? bp.take(pD) : w.gateS[0];
+        w.XaS = bp.take((size_t)g.B * rup(ic_max, WG_BK) * g.P);
+        if (mode) {
+            w.GS = bp.take((size_t)g.B * rup(2 * ic_max, WG_BK) * g.P);
+            w.dSS = bp.take(pS);
+            w.dHS = bp.take(pC);
+            w.dxyS = bp.take(2 * pD);
+        }
+    }
     w.nH = mode ? d.depth : 2;
     for (int i = 0; i < w.nH; ++i) w.H[i] = bp.take(pC);
     for (int i = 0; i < d.depth; ++i) {
@@ -381,7 +396,7 @@ void wn_ws_layout(Bump &bp, const WnD &d, int ic_max, const Geo &g, int mode, Wn
 struct ModelWs {
     Geo g;
     int Gp, auxp, ntile;
-    size_t X, dX, Y, dY, partial, total;
+    size_t X, dX, Y, dY, YS, partial, total;
     WnWs wn;
 };
 ModelWs model_ws_layout(const wg_config *cf, int B, int T, int mode)
@@ -401,7 +416,8 @@ ModelWs model_ws_layout(const wg_config *cf, int B, int T, int mode)
         w.dX = bp.take((size_t)B * w.Gp * w.g.P);
         w.dY = bp.take((size_t)B * w.auxp * w.g.P);
     }
-    wn_ws_layout(bp, d0, cf->n_group / 2, w.g, mode, w.wn);
+    w.YS = cf->precision == 2 ? bp.take((size_t)B * w.auxp * w.g.P) : 0;
+    wn_ws_layout(bp, d0, cf->n_group / 2, w.g, mode, cf->precision, w.wn);
     w.total = bp.off + 4096;   // slack
     return w;
 }
@@ -415,10 +431,23 @@ PRef pnull() { PRef r; r.p = nullptr; r.Cp = 0; r.ch0 = 0; return r; }
 struct SegSpec {
     const float *src;
     int Cp, ch0, nch, shift;
+    const float *s;      // S-plane base of the same tensor (precision 2), its rows per item and first row
+    int sCp, sch0;
 };
+SRef sref(const Geo &g, const float *base, int Cp, int ch0 = 0)
+{
+    SRef r;
+    r.hi = (unsigned short *)base; r.lo_off = (size_t)g.B * Cp * g.P; r.Cp = Cp; r.ch0 = ch0;
+    return r;
+}
+SRef snull() { SRef r; r.hi = nullptr; r.lo_off = 0; r.Cp = 8; r.ch0 = 0; return r; }
+void run_to_splane(Ctx &cx, const Geo &g, PRef src, int nvalid, const float *dst, int Cp_dst)
+{
+    WG_LAUNCH(cx, to_splane_kernel, dim3((g.T + 255) / 256, Cp_dst / 8, g.B), dim3(256), 0, src, nvalid, sref(g, dst, Cp_dst), g);
+}
 
 void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const SegSpec *segs, int nseg, int epi,
-                  PRef out0, PRef out1, PRef out2, PRef aux0, PRef aux1, int nsplit, int accumulate)
+                  PRef out0, PRef out1, PRef out2, PRef aux0, PRef aux1, int nsplit, int accumulate, SRef s0 = snull())
 {
     ConvGemmArgs a;
     memset(&a, 0, sizeof(a));
@@ -439,6 +468,46 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
         a16.img = mat_img(A, K, lda);
         a16.img_stride = (size_t)nc * lda * WG16_BK;
         a16.c = a;
+        if (cx.prec == 2) {
+            ConvGemm16sArgs as;
+            as.img = a16.img; as.img_stride = a16.img_stride; as.c = a; as.s0 = s0;
+            for (int s = 0; s < nseg; ++s) {
+                as.sseg[s].hi = (const unsigned short *)segs[s].s;
+                as.sseg[s].lo_off = (size_t)g.B * segs[s].sCp * g.P;
+                as.sseg[s].Cp = segs[s].sCp; as.sseg[s].ch0 = segs[s].sch0;
+                if (!segs[s].s && !cx.err) cx.err = WG_EINVAL;
+            }
+#if !defined(WG_OPT_NOPIPE)     // software-pipelined 128x128 kernel (default); -DWG_OPT_NOPIPE: plain double-buffered tiles
+            switch (epi) {
+            case EPI_STORE: WG_LAUNCH(cx, convgemm16p_kernel<EPI_STORE>, grid, block, 0, as); break;
+            case EPI_GATE: WG_LAUNCH(cx, convgemm16p_kernel<EPI_GATE>, grid, block, 0, as); break;
+            case EPI_RESSKIP: WG_LAUNCH(cx, convgemm16p_kernel<EPI_RESSKIP>, grid, block, 0, as); break;
+            case EPI_DGATE: WG_LAUNCH(cx, convgemm16p_kernel<EPI_DGATE>, grid, block, 0, as); break;
+            }
+            return;
+#endif
+#if defined(WG_OPT_MT2ONLY)
+            if (false) {
+#else
+            if ((rup(mrows, WG_TILE) % 256) == 0) {
+#endif
+                dim3 grid4(g.Tt / WG_TILE, rup(mrows, WG_TILE) / 256, g.B), block4(512);
+                switch (epi) {
+                case EPI_STORE: WG_LAUNCH(cx, (convgemm16s_kernel<EPI_STORE, 4>), grid4, block4, 0, as); break;
+                case EPI_GATE: WG_LAUNCH(cx, (convgemm16s_kernel<EPI_GATE, 4>), grid4, block4, 0, as); break;
+                case EPI_RESSKIP: WG_LAUNCH(cx, (convgemm16s_kernel<EPI_RESSKIP, 4>), grid4, block4, 0, as); break;
+                case EPI_DGATE: WG_LAUNCH(cx, (convgemm16s_kernel<EPI_DGATE, 4>), grid4, block4, 0, as); break;
+                }
+            } else {
+                switch (epi) {
+                case EPI_STORE: WG_LAUNCH(cx, (convgemm16s_kernel<EPI_STORE, 2>), grid, block, 0, as); break;
+                case EPI_GATE: WG_LAUNCH(cx, (convgemm16s_kernel<EPI_GATE, 2>), grid, block, 0, as); break;
+                case EPI_RESSKIP: WG_LAUNCH(cx, (convgemm16s_kernel<EPI_RESSKIP, 2>), grid, block, 0, as); break;
+                case EPI_DGATE: WG_LAUNCH(cx, (convgemm16s_kernel<EPI_DGATE, 2>), grid, block, 0, as); break;
+                }
+            }
+            return;
+        }
 #if defined(WG_OPT_MT2ONLY)
         const bool big = false;
 #else
@@ -548,6 +617,7 @@ struct WnRun {
     WnWs w;
     PRef X;              // flow state at ch0 = first channel of this flow
     const float *Y;      // aux plane base (auxp rows per item)
+    const float *YS;     // its S-plane (precision 2)
     int save;            // keep all layers (backward) or ping-pong
 };
 
@@ -557,25 +627,30 @@ void wn_forward(Ctx &cx, const WnRun &r)
     const Geo &g = r.g;
     float *ws = r.ws;
     const int mid = (d.radix - 1) / 2;
-    SegSpec s0 = {r.X.p, r.X.Cp, r.X.ch0, r.L.kp_start, 0};
+    const bool sp = cx.prec == 2;
+    if (sp) run_to_splane(cx, g, r.X, d.ic, ws + r.w.XaS, r.L.kp_start);      // xa -> S-plane (re-based to channel 0)
+    SegSpec s0 = {r.X.p, r.X.Cp, r.X.ch0, r.L.kp_start, 0, ws + r.w.XaS, r.L.kp_start, 0};
     run_convgemm(cx, g, r.pk + r.L.startT, r.L.ld_startT, d.C, &s0, 1, EPI_STORE, pref(ws + r.w.H[0], d.C), pnull(), pnull(),
-                 pnull(), pnull(), 0, 0);                                                       // waveglow.py:99
+                 pnull(), pnull(), 0, 0, sp ? sref(g, ws + r.w.HS[0], d.C) : snull());             // waveglow.py:99
     for (int i = 0; i < d.depth; ++i) {
         const int dil = 1 << i;
-        float *Hin = ws + r.w.H[r.save ? i : (i & 1)];
-        float *Hout = ws + r.w.H[r.save ? std::min(i + 1, d.depth - 1) : ((i + 1) & 1)];
+        const int hin = r.save ? i : (i & 1), hout = r.save ? std::min(i + 1, d.depth - 1) : ((i + 1) & 1);
+        float *Hin = ws + r.w.H[hin], *Hout = ws + r.w.H[hout];
         float *gate = ws + r.w.gate[r.save ? i : 0];
+        const float *gateS = ws + r.w.gateS[r.save ? i : 0];
         SegSpec sg[WG_MAX_SEG];
         int ns = 0;
-        for (int kt = 0; kt < d.radix; ++kt) sg[ns++] = {Hin, d.C, 0, d.C, (kt - mid) * dil};
-        sg[ns++] = {r.Y, d.auxp(), 0, d.auxp(), 0};
-        run_convgemm(cx, g, r.pk + r.L.Acat[i], r.L.ld_Acat, 2 * d.Cd, sg, ns, EPI_GATE, pref(gate, d.Cd),
+        for (int kt = 0; kt < d.radix; ++kt) sg[ns++] = {Hin, d.C, 0, d.C, (kt - mid) * dil, ws + r.w.HS[hin], d.C, 0};
+        sg[ns++] = {r.Y, d.auxp(), 0, d.auxp(), 0, r.YS, d.auxp(), 0};
+        // fp32 gate plane: only the on-the-fly weight-gradient kernel still reads it (backward); the S-plane feeds W_o
+        run_convgemm(cx, g, r.pk + r.L.Acat[i], r.L.ld_Acat, 2 * d.Cd, sg, ns, EPI_GATE, (sp && !r.save) ? pnull() : pref(gate, d.Cd),
                      r.save ? pref(ws + r.w.tw[i], d.Cd) : pnull(), r.save ? pref(ws + r.w.sf[i], d.Cd) : pnull(),
-                     pnull(), pnull(), 0, 0);                                                   // waveglow.py:42-44
-        SegSpec so = {gate, d.Cd, 0, d.Cd, 0};
+                     pnull(), pnull(), 0, 0, sp ? sref(g, gateS, d.Cd) : snull());                 // waveglow.py:42-44
+        SegSpec so = {gate, d.Cd, 0, d.Cd, 0, gateS, d.Cd, 0};
         const int last = i == d.depth - 1;
         run_convgemm(cx, g, r.pk + r.L.WoT[i], r.L.ld_WoT[i], d.wo_rows(i), &so, 1, EPI_RESSKIP, pref(Hout, d.C),
-                     pref(ws + r.w.skip, d.Cs), pnull(), pref(Hin, d.C), pnull(), last ? 0 : d.C, i > 0);   // :45-46,104
+                     pref(ws + r.w.skip, d.Cs), pnull(), pref(Hin, d.C), pnull(), last ? 0 : d.C, i > 0,
+                     (sp && !last) ? sref(g, ws + r.w.HS[hout], d.C) : snull());                   // :45-46,104
     }
 }
 
@@ -607,13 +682,16 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
     const size_t cap = r.w.slab_floats;
     float *G = ws + r.w.G, *dS = ws + r.w.dS, *dH = ws + r.w.dH, *dxy = ws + r.w.dxy, *skip = ws + r.w.skip;
     const int Gc = r.L.kp_end;
+    const bool sp = cx.prec == 2;
     // end: dW_end = sum G (x) S ; dS = W_end^T G
     {
         WSegSpec sa = {G, Gc, 0, 2 * d.ic, 0}, sb = {skip, d.Cs, 0, d.Cs, 0};
         WgradOut wo = run_wgrad(cx, g, &sa, 1, &sb, 1, slab, cap);
         run_finalize(cx, slab, wo, 0, 2 * d.ic, d.Cs, 1, 0, 1, 0, nullptr, nullptr, nullptr, grads[4 + 4 * nd]);
-        SegSpec s = {G, Gc, 0, Gc, 0};
-        run_convgemm(cx, g, r.pk + r.L.endN, r.L.ld_endN, d.Cs, &s, 1, EPI_STORE, pref(dS, d.Cs), pnull(), pnull(), pnull(), pnull(), 0, 0);
+        if (sp) run_to_splane(cx, g, pref(G, Gc), Gc, ws + r.w.GS, Gc);
+        SegSpec s = {G, Gc, 0, Gc, 0, ws + r.w.GS, Gc, 0};
+        run_convgemm(cx, g, r.pk + r.L.endN, r.L.ld_endN, d.Cs, &s, 1, EPI_STORE, pref(dS, d.Cs), pnull(), pnull(), pnull(), pnull(), 0, 0,
+                     sp ? sref(g, ws + r.w.dSS, d.Cs) : snull());
     }
     for (int i = nd - 1; i >= 0; --i) {
         const int dil = 1 << i, rows = d.wo_rows(i), last = i == nd - 1;
@@ -632,10 +710,10 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
         {
             SegSpec s[2];
             int ns = 0;
-            if (!last) s[ns++] = {dH, d.C, 0, d.C, 0};
-            s[ns++] = {dS, d.Cs, 0, d.Cs, 0};
+            if (!last) s[ns++] = {dH, d.C, 0, d.C, 0, ws + r.w.dHS, d.C, 0};
+            s[ns++] = {dS, d.Cs, 0, d.Cs, 0, ws + r.w.dSS, d.Cs, 0};
             run_convgemm(cx, g, r.pk + r.L.WoN[i], r.L.ld_WoN, d.Cd, s, ns, EPI_DGATE, pref(dxy, 2 * d.Cd), pnull(), pnull(),
-                         pref(ws + r.w.tw[i], d.Cd), pref(ws + r.w.sf[i], d.Cd), d.Cd, 0);
+                         pref(ws + r.w.tw[i], d.Cd), pref(ws + r.w.sf[i], d.Cd), d.Cd, 0, sp ? sref(g, ws + r.w.dxyS, 2 * d.Cd) : snull());
         }
         // dW (taps) and dV (conditioning) in one wgrad
         {
@@ -653,7 +731,7 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
         }
         // dy += V_i^T dxy
         if (dY) {
-            SegSpec s = {dxy, 2 * d.Cd, 0, 2 * d.Cd, 0};
+            SegSpec s = {dxy, 2 * d.Cd, 0, 2 * d.Cd, 0, ws + r.w.dxyS, 2 * d.Cd, 0};
             run_convgemm(cx, g, r.pk + r.L.VN[i], r.L.ld_VN, d.aux, &s, 1, EPI_STORE, pref(dY, d.auxp()), pnull(), pnull(),
                          pref(dY, d.auxp()), pnull(), 0, 0);
         }
@@ -661,9 +739,9 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
         {
             SegSpec s[WG_MAX_SEG];
             int ns = 0;
-            for (int kt = 0; kt < d.radix; ++kt) s[ns++] = {dxy, 2 * d.Cd, 0, 2 * d.Cd, -(kt - mid) * dil};
+            for (int kt = 0; kt < d.radix; ++kt) s[ns++] = {dxy, 2 * d.Cd, 0, 2 * d.Cd, -(kt - mid) * dil, ws + r.w.dxyS, 2 * d.Cd, 0};
             run_convgemm(cx, g, r.pk + r.L.WT[i], r.L.ld_WT, d.C, s, ns, EPI_STORE, pref(dH, d.C), pnull(), pnull(),
-                         last ? pnull() : pref(dH, d.C), pnull(), 0, 0);
+                         last ? pnull() : pref(dH, d.C), pnull(), 0, 0, sp ? sref(g, ws + r.w.dHS, d.C) : snull());
         }
     }
     // start: dW_start = sum dh_0 (x) xa ; dxa += W_start^T dh_0
@@ -671,7 +749,7 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
         WSegSpec sa = {dH, d.C, 0, d.C, 0}, sb = {r.X.p, r.X.Cp, r.X.ch0, d.ic, 0};
         WgradOut wo = run_wgrad(cx, g, &sa, 1, &sb, 1, slab, cap);
         run_finalize(cx, slab, wo, 0, d.C, d.ic, 1, 0, 1, 0, p[2], p[3], grads[2], grads[3]);
-        SegSpec s = {dH, d.C, 0, d.C, 0};
+        SegSpec s = {dH, d.C, 0, d.C, 0, ws + r.w.dHS, d.C, 0};
         run_convgemm(cx, g, r.pk + r.L.startN, r.L.ld_startN, d.ic, &s, 1, EPI_STORE, dX, pnull(), pnull(), dX, pnull(), 0, 0);
     }
 }
@@ -761,6 +839,7 @@ static WnD wnd_from(const wg_wn_dims *d)
 {
     WnD w;
     w.ic = d->in_ch; w.aux = d->aux_ch; w.C = d->res_ch; w.Cd = d->dil_ch; w.Cs = d->skip_ch; w.depth = d->depth; w.radix = d->radix;
+    w.prec = d->precision;
     return w;
 }
 int wg_wn_param_count(const wg_wn_dims *d) { return d ? 4 + 4 * d->depth + 1 : WG_EINVAL; }
@@ -845,7 +924,7 @@ static int model_run_fwd_or_inv(const wg_config *cf, const void *packed, const f
     if (!packed || !in || !h || !out || !logdet || !wsv) return WG_EINVAL;
     const ModelWs W = model_ws_layout(cf, B, T, 0);
     if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
-    Ctx cx = {(hipStream_t)stream, 0, cf->precision ? 1 : 0};
+    Ctx cx = {(hipStream_t)stream, 0, cf->precision};
     const float *pk = (const float *)packed;
     const ModelPack M = model_pack_layout(cf);
     float *ws = (float *)wsv;
@@ -854,9 +933,10 @@ static int model_run_fwd_or_inv(const wg_config *cf, const void *packed, const f
     PRef X = pref(ws + W.X, W.Gp);
     WG_LAUNCH(cx, squeeze_kernel, dim3((T + 255) / 256, B), dim3(256), 0, in, X, g, G, N);           // waveglow.py:153 / :184
     run_upsample(cx, cf, pk + M.up_w, pk + M.up_bias, h, F, g, pref(ws + W.Y, W.auxp), nullptr);                // :151,157
+    if (cx.prec == 2) run_to_splane(cx, g, pref(ws + W.Y, W.auxp), cf->n_mels, ws + W.YS, W.auxp);
     float *partial = ws + W.partial;
     WnRun r;
-    r.g = g; r.ws = ws; r.w = W.wn; r.Y = ws + W.Y; r.save = 0;
+    r.g = g; r.ws = ws; r.w = W.wn; r.Y = ws + W.Y; r.YS = ws + W.YS; r.save = 0;
     if (!inverse) {
         int base = 0;
         for (int k = 0; k < cf->n_flows; ++k) {
@@ -912,7 +992,7 @@ int wg_backward(const wg_config *cf, const void *const *params, const void *pack
     if (!params || !packed || !z || !h || !dz || !dlogdet || !grads || !wsv) return WG_EINVAL;
     const ModelWs W = model_ws_layout(cf, B, T, 1);
     if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
-    Ctx cx = {(hipStream_t)stream, 0, cf->precision ? 1 : 0};
+    Ctx cx = {(hipStream_t)stream, 0, cf->precision};
     const float *pk = (const float *)packed;
     const float *const *p = (const float *const *)params;
     float *const *gr = (float *const *)grads;
@@ -924,9 +1004,10 @@ int wg_backward(const wg_config *cf, const void *const *params, const void *pack
     WG_LAUNCH(cx, squeeze_kernel, dim3((T + 255) / 256, B), dim3(256), 0, z, X, g, G, N);
     WG_LAUNCH(cx, squeeze_kernel, dim3((T + 255) / 256, B), dim3(256), 0, dz, dX, g, G, N);
     run_upsample(cx, cf, pk + M.up_w, pk + M.up_bias, h, F, g, pref(ws + W.Y, W.auxp), nullptr);
+    if (cx.prec == 2) run_to_splane(cx, g, pref(ws + W.Y, W.auxp), cf->n_mels, ws + W.YS, W.auxp);
     if (cx.err == 0 && hipMemsetAsync(ws + W.dY, 0, (size_t)B * W.auxp * g.P * sizeof(float), cx.st) != hipSuccess) cx.err = WG_ELAUNCH;
     WnRun r;
-    r.g = g; r.ws = ws; r.w = W.wn; r.Y = ws + W.Y; r.save = 1;
+    r.g = g; r.ws = ws; r.w = W.wn; r.Y = ws + W.Y; r.YS = ws + W.YS; r.save = 1;
     int base = G - flow_channels(cf, cf->n_flows - 1);
     for (int k = cf->n_flows - 1; k >= 0; --k) {
         const int c = flow_channels(cf, k);
@@ -1077,7 +1158,7 @@ int wg_invconv_backward(const float *Wm, int c, const float *z, const float *dz,
 struct CplWs {
     Geo g;
     int Xp, auxp;
-    size_t X, dX, Y, dY, total;
+    size_t X, dX, Y, dY, YS, total;
     WnWs wn;
 };
 static CplWs cpl_ws_layout(const WnD &d, int B, int T, int mode)
@@ -1094,7 +1175,8 @@ static CplWs cpl_ws_layout(const WnD &d, int B, int T, int mode)
         w.dX = bp.take((size_t)B * w.Xp * w.g.P);
         w.dY = bp.take((size_t)B * w.auxp * w.g.P);
     }
-    wn_ws_layout(bp, d, d.ic, w.g, mode, w.wn);
+    w.YS = d.prec == 2 ? bp.take((size_t)B * w.auxp * w.g.P) : 0;
+    wn_ws_layout(bp, d, d.ic, w.g, mode, d.prec, w.wn);
     w.total = bp.off + 4096;
     return w;
 }
@@ -1113,15 +1195,16 @@ int wg_coupling_apply(const wg_wn_dims *dd, const void *packed, const float *x, 
     if (rc) return rc;
     const CplWs W = cpl_ws_layout(d, B, T, 0);
     if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
-    Ctx cx = {(hipStream_t)stream, 0, dd->precision ? 1 : 0};
+    Ctx cx = {(hipStream_t)stream, 0, dd->precision};
     float *ws = (float *)wsv;
     const Geo g = W.g;
     PRef X = pref(ws + W.X, W.Xp);
     WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, 2 * d.ic, B), dim3(256), 0, x, X, g, 2 * d.ic);
     WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, d.aux, B), dim3(256), 0, y, pref(ws + W.Y, W.auxp), g, d.aux);
+    if (cx.prec == 2) run_to_splane(cx, g, pref(ws + W.Y, W.auxp), d.aux, ws + W.YS, W.auxp);
     WnRun r;
     r.d = d; r.L = wn_pack_layout(d); r.pk = (const float *)packed + rupz(WG_ONES, 64); r.g = g; r.ws = ws; r.w = W.wn;
-    r.X = X; r.Y = ws + W.Y; r.save = 0;
+    r.X = X; r.Y = ws + W.Y; r.YS = ws + W.YS; r.save = 0;
     wn_forward(cx, r);
     run_end_affine(cx, r, reverse ? AFF_REV : AFF_FWD, pnull(), log_s, nullptr, nullptr, nullptr);
     WG_LAUNCH(cx, export_kernel, dim3((T + 255) / 256, 2 * d.ic, B), dim3(256), 0, X, z, g, 2 * d.ic, 1.0f);
@@ -1137,15 +1220,16 @@ int wg_wn_apply(const wg_wn_dims *dd, const void *packed, const float *x, const 
     if (rc) return rc;
     const CplWs W = cpl_ws_layout(d, B, T, 0);
     if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
-    Ctx cx = {(hipStream_t)stream, 0, dd->precision ? 1 : 0};
+    Ctx cx = {(hipStream_t)stream, 0, dd->precision};
     float *ws = (float *)wsv;
     const Geo g = W.g;
     PRef X = pref(ws + W.X, W.Xp);
     WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, d.ic, B), dim3(256), 0, x, X, g, d.ic);
     WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, d.aux, B), dim3(256), 0, y, pref(ws + W.Y, W.auxp), g, d.aux);
+    if (cx.prec == 2) run_to_splane(cx, g, pref(ws + W.Y, W.auxp), d.aux, ws + W.YS, W.auxp);
     WnRun r;
     r.d = d; r.L = wn_pack_layout(d); r.pk = (const float *)packed + rupz(WG_ONES, 64); r.g = g; r.ws = ws; r.w = W.wn;
-    r.X = X; r.Y = ws + W.Y; r.save = 0;
+    r.X = X; r.Y = ws + W.Y; r.YS = ws + W.YS; r.save = 0;
     wn_forward(cx, r);
     AffineArgs a;
     memset(&a, 0, sizeof(a));
@@ -1165,17 +1249,18 @@ int wg_coupling_backward(const wg_wn_dims *dd, const void *const *params, const 
     if (rc) return rc;
     const CplWs W = cpl_ws_layout(d, B, T, 1);
     if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
-    Ctx cx = {(hipStream_t)stream, 0, dd->precision ? 1 : 0};
+    Ctx cx = {(hipStream_t)stream, 0, dd->precision};
     float *ws = (float *)wsv;
     const Geo g = W.g;
     PRef X = pref(ws + W.X, W.Xp), dX = pref(ws + W.dX, W.Xp);
     WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, 2 * d.ic, B), dim3(256), 0, z, X, g, 2 * d.ic);
     WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, 2 * d.ic, B), dim3(256), 0, dz, dX, g, 2 * d.ic);
     WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, d.aux, B), dim3(256), 0, y, pref(ws + W.Y, W.auxp), g, d.aux);
+    if (cx.prec == 2) run_to_splane(cx, g, pref(ws + W.Y, W.auxp), d.aux, ws + W.YS, W.auxp);
     if (dy && cx.err == 0 && hipMemsetAsync(ws + W.dY, 0, (size_t)B * W.auxp * g.P * sizeof(float), cx.st) != hipSuccess) cx.err = WG_ELAUNCH;
     WnRun r;
     r.d = d; r.L = wn_pack_layout(d); r.pk = (const float *)packed + rupz(WG_ONES, 64); r.g = g; r.ws = ws; r.w = W.wn;
-    r.X = X; r.Y = ws + W.Y; r.save = 1;
+    r.X = X; r.Y = ws + W.Y; r.YS = ws + W.YS; r.save = 1;
     wn_forward(cx, r);
     run_end_affine(cx, r, reverse ? AFF_BWD_REV : AFF_BWD, dX, nullptr, dlog_s, nullptr, nullptr);
     wn_backward(cx, r, (const float *const *)params, (float *const *)grads, dX, dy ? ws + W.dY : nullptr);

@@ -43,9 +43,12 @@ extern "C" {
 /* Arithmetic of the matrix contractions; every tensor in memory is fp32 in both modes.
  *   WG_PREC_F32    v_mfma_f32_32x32x2_f32: bit-exact fp32 fma chains.
  *   WG_PREC_BF16X3 each fp32 operand is split into bf16 hi + lo and a*b is evaluated as a_lo*b_hi + a_hi*b_lo + a_hi*b_hi
- *                  on the bf16 matrix pipe with fp32 accumulation (drops a_lo*b_lo, 2^-16 of a product). */
+ *                  on the bf16 matrix pipe with fp32 accumulation (drops a_lo*b_lo, 2^-16 of a product).
+ *   WG_PREC_BF16X3_PLANES  same arithmetic; producers additionally keep every MFMA operand tensor pre-split in bf16 hi/lo
+ *                  "S-planes" (wg_gemm16s.h), so the contraction kernels do no conversion work. */
 #define WG_PREC_F32 0
 #define WG_PREC_BF16X3 1
+#define WG_PREC_BF16X3_PLANES 2
 
 /* Constructor arguments of model.WaveGlow (model/waveglow.py:109-118) after the arithmetic of
  * :125-129 (upsampler geometry).  WN arguments are the **kwargs forwarded to WN (waveglow.py:50-59). */
