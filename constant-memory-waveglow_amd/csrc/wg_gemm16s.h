@@ -450,3 +450,170 @@ __global__ __launch_bounds__(256) void convgemm16p_kernel(const ConvGemm16sArgs 
     }
     conv_epilogue_s<EPI>(a, aa.s0, acc, t0, m0, b, wr, wc, lane);
 }
+
+// ------------------------------------------------------------------------------------------------
+// wgrad16s: weight gradients from S-planes.  dW[m][n] = sum_b sum_t A[b][m][t] * B[b][n][t + shift]
+// LDS images are [t (32 rows)][c (128 channels)] bf16 with 320-byte rows, filled by 16-byte unit copies; an MFMA fragment
+// (8 consecutive time steps of one channel) is two ds_read_b64_tr_b16 (4x16 hardware transposes), conflict free.
+// ------------------------------------------------------------------------------------------------
+#define WG16_ROWT 320
+struct WgSSeg {
+    const unsigned short *hi;
+    size_t lo_off;
+    int Cp, ch0, nch, shift, blk0;
+};
+struct WgradSArgs {
+    int nseg_a, nseg_b;
+    WgSSeg sa[2];
+    WgSSeg sb[WG_MAX_SEG];
+    Geo g;
+    int t_per_split, nts, b_per_split;
+    float *slab;
+    int Mp, Np;
+};
+typedef short s4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 tr_frag(const char *img, int off)
+{
+    typedef __attribute__((address_space(3))) s4v *lds_s4p;
+    const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(img + off));
+    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(img + off + 4 * WG16_ROWT));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+__device__ __forceinline__ const WgSSeg &find_sseg(const WgSSeg *s, int n, int blk)
+{
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j < WG_MAX_SEG; ++j)
+        if (j < n && blk >= s[j].blk0) i = j;
+    return s[i];
+}
+
+__global__ __launch_bounds__(256) void wgrad16s_kernel(const WgradSArgs a)
+{
+    constexpr int IMG = 32 * WG16_ROWT;     // 10240
+    constexpr int BUF = 4 * IMG;
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int n0 = blockIdx.x * WG_TILE, m0 = blockIdx.y * WG_TILE;
+    const int zs = blockIdx.z;
+    const int ts = zs % a.nts, bs = zs / a.nts;
+    const Geo g = a.g;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // staging: unit u = tid + 256*j -> t = 2*(u>>5) + (u&1), channel group cg = (u>>1)&15
+    const unsigned short *pa[2], *pb[2];
+    size_t la[2], lb_[2], sba[2], sbb[2];
+    int loff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int u = tid + 256 * j;
+        const int tl = 2 * (u >> 5) + (u & 1), cg = (u >> 1) & 15;
+        loff[j] = tl * WG16_ROWT + cg * 16;
+        const int ma = m0 + 8 * cg;
+        const WgSSeg &sa = find_sseg(a.sa, a.nseg_a, ma >> 5);
+        const int ca = ma - sa.blk0 * 32;
+        pa[j] = (ma < a.Mp && ca < sa.nch) ? sa.hi + (((size_t)((sa.ch0 + ca) >> 3)) * g.P + g.H + tl) * 8 : nullptr;
+        la[j] = sa.lo_off; sba[j] = (size_t)(sa.Cp >> 3) * g.P * 8;
+        const int nb = n0 + 8 * cg;
+        const WgSSeg &sb = find_sseg(a.sb, a.nseg_b, nb >> 5);
+        const int cb = nb - sb.blk0 * 32;
+        pb[j] = (nb < a.Np && cb < sb.nch) ? sb.hi + (((size_t)((sb.ch0 + cb) >> 3)) * g.P + g.H + sb.shift + tl) * 8 : nullptr;
+        lb_[j] = sb.lo_off; sbb[j] = (size_t)(sb.Cp >> 3) * g.P * 8;
+    }
+    const int t_begin = ts * a.t_per_split;
+    int t_end = t_begin + a.t_per_split;
+    if (t_end > g.Tt) t_end = g.Tt;
+    const int chunks_per_b = (t_end - t_begin + WG16_BK - 1) / WG16_BK;
+    const int b_begin = bs * a.b_per_split;
+    int b_end = b_begin + a.b_per_split;
+    if (b_end > g.B) b_end = g.B;
+    const int nchunks = chunks_per_b * (b_end - b_begin);
+
+    u32x4 rah[2], ral[2], rbh[2], rbl[2];
+    int lb = b_begin, lt = t_begin;
+    auto load_chunk = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            u32x4 z = {0u, 0u, 0u, 0u};
+            rah[j] = z; ral[j] = z; rbh[j] = z; rbl[j] = z;
+            if (pa[j]) {
+                const unsigned short *q = pa[j] + lb * sba[j] + (size_t)lt * 8;
+                rah[j] = *reinterpret_cast<const u32x4 *>(q);
+                ral[j] = *reinterpret_cast<const u32x4 *>(q + la[j]);
+            }
+            if (pb[j]) {
+                const unsigned short *q = pb[j] + lb * sbb[j] + (size_t)lt * 8;
+                rbh[j] = *reinterpret_cast<const u32x4 *>(q);
+                rbl[j] = *reinterpret_cast<const u32x4 *>(q + lb_[j]);
+            }
+        }
+        lt += WG16_BK;
+        if (lt >= t_end) { lt = t_begin; ++lb; }
+    };
+    auto store_chunk = [&](int buf) {
+        char *sb = smem + buf * BUF;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            *reinterpret_cast<u32x4 *>(sb + loff[j]) = rah[j];
+            *reinterpret_cast<u32x4 *>(sb + IMG + loff[j]) = ral[j];
+            *reinterpret_cast<u32x4 *>(sb + 2 * IMG + loff[j]) = rbh[j];
+            *reinterpret_cast<u32x4 *>(sb + 3 * IMG + loff[j]) = rbl[j];
+        }
+    };
+    // fragment addressing: lane supplies row q = (l&15)>>2 of its 4x16 block, columns 4*(l&3)..; block = rows 8h (+4), cols 16*((l>>4)&1)
+    const int fq = (lane & 15) >> 2, fp = lane & 3, fh = lane >> 5, fg = (lane >> 4) & 1;
+    const int fa = (8 * fh + fq) * WG16_ROWT + (wr * 64 + 16 * fg + 4 * fp) * 2;
+    const int fb = (8 * fh + fq) * WG16_ROWT + (wc * 64 + 16 * fg + 4 * fp) * 2;
+    auto compute = [&](int buf) {
+        const char *sb = smem + buf * BUF;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            Frags16 f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f.ah[i] = tr_frag(sb, fa + s * 16 * WG16_ROWT + i * 64);
+                f.al[i] = tr_frag(sb + IMG, fa + s * 16 * WG16_ROWT + i * 64);
+                f.bh[i] = tr_frag(sb + 2 * IMG, fb + s * 16 * WG16_ROWT + i * 64);
+                f.bl[i] = tr_frag(sb + 3 * IMG, fb + s * 16 * WG16_ROWT + i * 64);
+            }
+            mfma12(f, acc);
+        }
+    };
+
+    if (nchunks > 0) {
+        load_chunk();
+        store_chunk(0);
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            const int buf = c & 1;
+            if (c + 1 < nchunks) load_chunk();
+            compute(buf);
+            if (c + 1 < nchunks) store_chunk(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    float *out = a.slab + (size_t)zs * a.Mp * a.Np;
+    const int col = lane & 31;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int n = n0 + wc * 64 + ni * 32 + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * 64 + mi * 32 + acc_row(r, lane);
+                if (m < a.Mp && n < a.Np) out[(size_t)m * a.Np + n] = acc[mi][ni][r];
+            }
+        }
+}

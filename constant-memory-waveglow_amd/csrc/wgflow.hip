@@ -542,6 +542,8 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
 struct WSegSpec {
     const float *src;
     int Cp, ch0, nch, shift;
+    const float *s;      // S-plane of the same tensor (precision 2) or nullptr
+    int sCp, sch0;
 };
 // returns the plan used (finalize needs nsplit / strides)
 struct WgradOut {
@@ -575,7 +577,24 @@ WgradOut run_wgrad(Ctx &cx, const Geo &g, const WSegSpec *sa, int nsa, const WSe
     if ((size_t)p.nsplit * a.Mp * a.Np > slab_cap) { if (!cx.err) cx.err = WG_EWORKSPACE; return o; }
     dim3 grid(a.Np / WG_TILE, a.Mp / WG_TILE, p.nsplit), block(256);
     TimerScope ts(WG_K_WGRAD, cx.st);
-    if (cx.prec) WG_LAUNCH(cx, wgrad16_kernel, grid, block, 0, a);
+    bool all_s = cx.prec == 2;
+    for (int s = 0; s < nsa; ++s) all_s = all_s && sa[s].s;
+    for (int s = 0; s < nsb; ++s) all_s = all_s && sb[s].s;
+    if (all_s) {
+        WgradSArgs q;
+        memset(&q, 0, sizeof(q));
+        q.nseg_a = nsa; q.nseg_b = nsb; q.g = g;
+        q.t_per_split = a.t_per_split; q.nts = a.nts; q.b_per_split = a.b_per_split; q.slab = slab; q.Mp = a.Mp; q.Np = a.Np;
+        for (int s = 0; s < nsa; ++s) {
+            q.sa[s].hi = (const unsigned short *)sa[s].s; q.sa[s].lo_off = (size_t)g.B * sa[s].sCp * g.P;
+            q.sa[s].Cp = sa[s].sCp; q.sa[s].ch0 = sa[s].sch0; q.sa[s].nch = sa[s].nch; q.sa[s].shift = 0; q.sa[s].blk0 = a.sa[s].blk0;
+        }
+        for (int s = 0; s < nsb; ++s) {
+            q.sb[s].hi = (const unsigned short *)sb[s].s; q.sb[s].lo_off = (size_t)g.B * sb[s].sCp * g.P;
+            q.sb[s].Cp = sb[s].sCp; q.sb[s].ch0 = sb[s].sch0; q.sb[s].nch = sb[s].nch; q.sb[s].shift = sb[s].shift; q.sb[s].blk0 = a.sb[s].blk0;
+        }
+        WG_LAUNCH(cx, wgrad16s_kernel, grid, block, 0, q);
+    } else if (cx.prec) WG_LAUNCH(cx, wgrad16_kernel, grid, block, 0, a);
     else WG_LAUNCH(cx, wgrad_kernel, grid, block, 0, a);
     return o;
 }
@@ -643,7 +662,7 @@ void wn_forward(Ctx &cx, const WnRun &r)
         for (int kt = 0; kt < d.radix; ++kt) sg[ns++] = {Hin, d.C, 0, d.C, (kt - mid) * dil, ws + r.w.HS[hin], d.C, 0};
         sg[ns++] = {r.Y, d.auxp(), 0, d.auxp(), 0, r.YS, d.auxp(), 0};
         // fp32 gate plane: only the on-the-fly weight-gradient kernel still reads it (backward); the S-plane feeds W_o
-        run_convgemm(cx, g, r.pk + r.L.Acat[i], r.L.ld_Acat, 2 * d.Cd, sg, ns, EPI_GATE, (sp && !r.save) ? pnull() : pref(gate, d.Cd),
+        run_convgemm(cx, g, r.pk + r.L.Acat[i], r.L.ld_Acat, 2 * d.Cd, sg, ns, EPI_GATE, sp ? pnull() : pref(gate, d.Cd),
                      r.save ? pref(ws + r.w.tw[i], d.Cd) : pnull(), r.save ? pref(ws + r.w.sf[i], d.Cd) : pnull(),
                      pnull(), pnull(), 0, 0, sp ? sref(g, gateS, d.Cd) : snull());                 // waveglow.py:42-44
         SegSpec so = {gate, d.Cd, 0, d.Cd, 0, gateS, d.Cd, 0};
@@ -685,12 +704,13 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
     const bool sp = cx.prec == 2;
     // end: dW_end = sum G (x) S ; dS = W_end^T G
     {
-        WSegSpec sa = {G, Gc, 0, 2 * d.ic, 0}, sb = {skip, d.Cs, 0, d.Cs, 0};
+        // skip (fp32 only: it feeds the fp32 end conv) has no S-plane -> this small product runs on the on-the-fly kernel
+        WSegSpec sa = {G, Gc, 0, 2 * d.ic, 0, nullptr, 0, 0}, sb = {skip, d.Cs, 0, d.Cs, 0, nullptr, 0, 0};
         WgradOut wo = run_wgrad(cx, g, &sa, 1, &sb, 1, slab, cap);
         run_finalize(cx, slab, wo, 0, 2 * d.ic, d.Cs, 1, 0, 1, 0, nullptr, nullptr, nullptr, grads[4 + 4 * nd]);
         if (sp) run_to_splane(cx, g, pref(G, Gc), Gc, ws + r.w.GS, Gc);
         SegSpec s = {G, Gc, 0, Gc, 0, ws + r.w.GS, Gc, 0};
-        run_convgemm(cx, g, r.pk + r.L.endN, r.L.ld_endN, d.Cs, &s, 1, EPI_STORE, pref(dS, d.Cs), pnull(), pnull(), pnull(), pnull(), 0, 0,
+        run_convgemm(cx, g, r.pk + r.L.endN, r.L.ld_endN, d.Cs, &s, 1, EPI_STORE, sp ? pnull() : pref(dS, d.Cs), pnull(), pnull(), pnull(), pnull(), 0, 0,
                      sp ? sref(g, ws + r.w.dSS, d.Cs) : snull());
     }
     for (int i = nd - 1; i >= 0; --i) {
@@ -700,9 +720,9 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
         {
             WSegSpec sa[2];
             int nsa = 0;
-            if (!last) sa[nsa++] = {dH, d.C, 0, d.C, 0};
-            sa[nsa++] = {dS, d.Cs, 0, d.Cs, 0};
-            WSegSpec sb = {gate, d.Cd, 0, d.Cd, 0};
+            if (!last) sa[nsa++] = {dH, d.C, 0, d.C, 0, sp ? ws + r.w.dHS : nullptr, d.C, 0};
+            sa[nsa++] = {dS, d.Cs, 0, d.Cs, 0, sp ? ws + r.w.dSS : nullptr, d.Cs, 0};
+            WSegSpec sb = {gate, d.Cd, 0, d.Cd, 0, sp ? ws + r.w.gateS[i] : nullptr, d.Cd, 0};
             WgradOut wo = run_wgrad(cx, g, sa, nsa, &sb, 1, slab, cap);
             run_finalize(cx, slab, wo, 0, rows, d.Cd, 1, 0, 1, 0, p[6 + 4 * i], p[7 + 4 * i], grads[6 + 4 * i], grads[7 + 4 * i]);
         }
@@ -712,16 +732,16 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
             int ns = 0;
             if (!last) s[ns++] = {dH, d.C, 0, d.C, 0, ws + r.w.dHS, d.C, 0};
             s[ns++] = {dS, d.Cs, 0, d.Cs, 0, ws + r.w.dSS, d.Cs, 0};
-            run_convgemm(cx, g, r.pk + r.L.WoN[i], r.L.ld_WoN, d.Cd, s, ns, EPI_DGATE, pref(dxy, 2 * d.Cd), pnull(), pnull(),
+            run_convgemm(cx, g, r.pk + r.L.WoN[i], r.L.ld_WoN, d.Cd, s, ns, EPI_DGATE, sp ? pnull() : pref(dxy, 2 * d.Cd), pnull(), pnull(),
                          pref(ws + r.w.tw[i], d.Cd), pref(ws + r.w.sf[i], d.Cd), d.Cd, 0, sp ? sref(g, ws + r.w.dxyS, 2 * d.Cd) : snull());
         }
         // dW (taps) and dV (conditioning) in one wgrad
         {
-            WSegSpec sa = {dxy, 2 * d.Cd, 0, 2 * d.Cd, 0};
+            WSegSpec sa = {dxy, 2 * d.Cd, 0, 2 * d.Cd, 0, sp ? ws + r.w.dxyS : nullptr, 2 * d.Cd, 0};
             WSegSpec sb[WG_MAX_SEG];
             int nsb = 0;
-            for (int kt = 0; kt < d.radix; ++kt) sb[nsb++] = {Hi, d.C, 0, d.C, (kt - mid) * dil};
-            sb[nsb++] = {r.Y, d.auxp(), 0, d.aux, 0};
+            for (int kt = 0; kt < d.radix; ++kt) sb[nsb++] = {Hi, d.C, 0, d.C, (kt - mid) * dil, sp ? ws + r.w.HS[i] : nullptr, d.C, 0};
+            sb[nsb++] = {r.Y, d.auxp(), 0, d.aux, 0, sp ? r.YS : nullptr, d.auxp(), 0};
             WgradOut wo = run_wgrad(cx, g, &sa, 1, sb, nsb, slab, cap);
             const int C32 = rup(d.C, 32);
             run_finalize(cx, slab, wo, 0, 2 * d.Cd, d.C, d.radix, 0, 1, C32, p[4 + 4 * i], p[5 + 4 * i], grads[4 + 4 * i], grads[5 + 4 * i]);
@@ -746,7 +766,8 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
     }
     // start: dW_start = sum dh_0 (x) xa ; dxa += W_start^T dh_0
     {
-        WSegSpec sa = {dH, d.C, 0, d.C, 0}, sb = {r.X.p, r.X.Cp, r.X.ch0, d.ic, 0};
+        WSegSpec sa = {dH, d.C, 0, d.C, 0, sp ? ws + r.w.dHS : nullptr, d.C, 0};
+        WSegSpec sb = {r.X.p, r.X.Cp, r.X.ch0, d.ic, 0, sp ? ws + r.w.XaS : nullptr, r.L.kp_start, 0};
         WgradOut wo = run_wgrad(cx, g, &sa, 1, &sb, 1, slab, cap);
         run_finalize(cx, slab, wo, 0, d.C, d.ic, 1, 0, 1, 0, p[2], p[3], grads[2], grads[3]);
         SegSpec s = {dH, d.C, 0, d.C, 0, ws + r.w.dHS, d.C, 0};
@@ -1021,7 +1042,7 @@ int wg_backward(const wg_config *cf, const void *const *params, const void *pack
         // Conv1x1Func.backward (efficient_modules.py:230-244)
         run_mix(cx, g, Xk, c, lu + WG_MAXC * WG_MAXC, 0);                                     // x = W^-1 z   :235-237
         {
-            WSegSpec sa = {dXk.p, dXk.Cp, dXk.ch0, c, 0}, sb = {Xk.p, Xk.Cp, Xk.ch0, c, 0};
+            WSegSpec sa = {dXk.p, dXk.Cp, dXk.ch0, c, 0, nullptr, 0, 0}, sb = {Xk.p, Xk.Cp, Xk.ch0, c, 0, nullptr, 0, 0};
             const int prec_keep = cx.prec;
             cx.prec = 0;                                                                         // tiny c x c product: keep it exact
             WgradOut wo = run_wgrad(cx, g, &sa, 1, &sb, 1, ws + W.wn.slab, W.wn.slab_floats);   // dW = dz x^T     :240
@@ -1134,7 +1155,7 @@ int wg_invconv_backward(const float *Wm, int c, const float *z, const float *dz,
     PRef X = pref(ws + W.X, W.Cp), dX = pref(ws + W.dX, W.Cp);
     WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, c, B), dim3(256), 0, z, X, g, c);
     WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, c, B), dim3(256), 0, dz, dX, g, c);
-    WSegSpec sa = {dX.p, dX.Cp, 0, c, 0}, sb = {X.p, X.Cp, 0, c, 0};
+    WSegSpec sa = {dX.p, dX.Cp, 0, c, 0, nullptr, 0, 0}, sb = {X.p, X.Cp, 0, c, 0, nullptr, 0, 0};
     if (!reverse) {                      // Conv1x1Func.backward  (efficient_modules.py:230-244)
         run_mix(cx, g, X, c, Wi, 0);                                                          // x = W^-1 z
         WgradOut wo = run_wgrad(cx, g, &sa, 1, &sb, 1, ws + W.slab, W.slab_floats);           // dz x^T
