@@ -342,6 +342,20 @@ struct WgradArgs {
     int Mp, Np;
 };
 
+// XCD-aware block order for the weight-gradient kernels: the dispatcher deals consecutive workgroup ids round-robin over the 8
+// XCDs (private L2s), so the 28 tiles that share one batch item's operands would land on 8 different L2s and every tile would
+// be fetched from HBM 4-7 times.  Re-labelling id -> (id % 8) * (n / 8) + id / 8 gives each XCD a contiguous range of logical
+// blocks (= whole batch items).  Speed only; falls back to the identity when the grid is not a multiple of 8.
+__device__ __forceinline__ void xcd_remap(int &bx, int &by, int &bz)
+{
+    const int gx = gridDim.x, gy = gridDim.y, n = gx * gy * gridDim.z;
+    int id = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    if ((n & 7) == 0) id = (id & 7) * (n >> 3) + (id >> 3);
+    bx = id % gx;
+    by = (id / gx) % gy;
+    bz = id / (gx * gy);
+}
+
 #define WG_WLD 129   // odd LDS row stride: transposed stores are <= 2-way conflicted, reads conflict free
 
 __device__ __forceinline__ const WgSeg &find_seg(const WgSeg *s, int n, int blk)
@@ -359,8 +373,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
     __shared__ float Bs[2][WG_WBK][WG_WLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int n0 = blockIdx.x * WG_TILE, m0 = blockIdx.y * WG_TILE;
-    const int zs = blockIdx.z;
+    int bx, by, zs;
+    xcd_remap(bx, by, zs);
+    const int n0 = bx * WG_TILE, m0 = by * WG_TILE;
     const int ts = zs % a.nts, bs = zs / a.nts;
     const Geo g = a.g;
 

@@ -184,8 +184,9 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a)
     __shared__ __attribute__((aligned(16))) char smem[2 * 4 * WG16_IMG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int n0 = blockIdx.x * WG_TILE, m0 = blockIdx.y * WG_TILE;
-    const int zs = blockIdx.z;
+    int bx, by, zs;
+    xcd_remap(bx, by, zs);
+    const int n0 = bx * WG_TILE, m0 = by * WG_TILE;
     const int ts = zs % a.nts, bs = zs / a.nts;
     const Geo g = a.g;
 

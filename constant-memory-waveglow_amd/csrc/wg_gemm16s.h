@@ -498,8 +498,9 @@ __global__ __launch_bounds__(256) void wgrad16s_kernel(const WgradSArgs a)
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int n0 = blockIdx.x * WG_TILE, m0 = blockIdx.y * WG_TILE;
-    const int zs = blockIdx.z;
+    int bx, by, zs;
+    xcd_remap(bx, by, zs);
+    const int n0 = bx * WG_TILE, m0 = by * WG_TILE;
     const int ts = zs % a.nts, bs = zs / a.nts;
     const Geo g = a.g;
 

@@ -459,14 +459,28 @@ __global__ __launch_bounds__(256) void finalize_kernel(const FinJob j)
         for (int i = 0; i < j.n_extra; ++i) esc += j.extra_scale_src[i];
         esc *= j.extra_mul;
     }
+    // pass 1: sum the split-K slabs walking the slab row in MEMORY order (coalesced), scatter into tensor order in LDS.
+    // slab column of tensor element (i, r) is col0 + r*cr + i*ci; ci == 1 for every caller.
+    const float *row = j.slab + (size_t)(j.row0 + o) * j.ldn + j.col0;
+    for (int r = 0; r < j.R; ++r)
+        for (int i = tid; i < j.I; i += 256) {
+            const size_t off = (size_t)r * j.cr + (size_t)i * j.ci;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int sp = 0;
+            for (; sp + 3 < j.nsplit; sp += 4) {
+                s0 += row[(size_t)sp * j.sstride + off];
+                s1 += row[(size_t)(sp + 1) * j.sstride + off];
+                s2 += row[(size_t)(sp + 2) * j.sstride + off];
+                s3 += row[(size_t)(sp + 3) * j.sstride + off];
+            }
+            for (; sp < j.nsplit; ++sp) s0 += row[(size_t)sp * j.sstride + off];
+            dw[i * j.R + r] = (s0 + s1) + (s2 + s3);
+        }
+    __syncthreads();
     float dot = 0.f, ss = 0.f;
     for (int e = tid; e < cols; e += 256) {
-        const int i = e / j.R, r = e % j.R;
-        const size_t off = (size_t)(j.row0 + o) * j.ldn + j.col0 + r * j.cr + i * j.ci;
-        float s = 0.f;
-        for (int sp = 0; sp < j.nsplit; ++sp) s += j.slab[sp * j.sstride + off];
-        if (j.extra) s += j.extra[(size_t)e * j.rows + o] * esc;
-        dw[e] = s;
+        float s = dw[e];
+        if (j.extra) { s += j.extra[(size_t)e * j.rows + o] * esc; dw[e] = s; }
         if (j.g) { const float vv = j.v[(size_t)o * cols + e]; dot += s * vv; ss += vv * vv; }
     }
     if (!j.g) {
