@@ -73,7 +73,8 @@ def cpu_baseline():
     specs = fill.model_param_specs(C2)
     tab = fill.table(specs, fill.fill_params(specs, "c2/"))
     audio, h = fill.inputs("c2", 1, SEG, FRAMES, C2["n_mels"])
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    # the oracle's loops expose 64-128 independent row blocks: cap the OpenMP team there (measured: more threads are slower)
+    cores = orc.set_threads(min(int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)), 64))
     oc = orc.make_config(**C2)
     t0 = time.time()
     orc.train_step(oc, tab, audio, h, SIGMA)

@@ -576,19 +576,13 @@ __global__ __launch_bounds__(256) void wgrad16s_kernel(const WgradSArgs a)
     const int fq = (lane & 15) >> 2, fp = lane & 3, fh = lane >> 5, fg = (lane >> 4) & 1;
     const int fa = (8 * fh + fq) * WG16_ROWT + (wr * 64 + 16 * fg + 4 * fp) * 2;
     const int fb = (8 * fh + fq) * WG16_ROWT + (wc * 64 + 16 * fg + 4 * fp) * 2;
-    auto compute = [&](int buf) {
-        const char *sb = smem + buf * BUF;
+    auto read_step = [&](Frags16 &f, const char *sb, int s) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            Frags16 f;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                f.ah[i] = tr_frag(sb, fa + s * 16 * WG16_ROWT + i * 64);
-                f.al[i] = tr_frag(sb + IMG, fa + s * 16 * WG16_ROWT + i * 64);
-                f.bh[i] = tr_frag(sb + 2 * IMG, fb + s * 16 * WG16_ROWT + i * 64);
-                f.bl[i] = tr_frag(sb + 3 * IMG, fb + s * 16 * WG16_ROWT + i * 64);
-            }
-            mfma12(f, acc);
+        for (int i = 0; i < 2; ++i) {
+            f.ah[i] = tr_frag(sb, fa + s * 16 * WG16_ROWT + i * 64);
+            f.al[i] = tr_frag(sb + IMG, fa + s * 16 * WG16_ROWT + i * 64);
+            f.bh[i] = tr_frag(sb + 2 * IMG, fb + s * 16 * WG16_ROWT + i * 64);
+            f.bl[i] = tr_frag(sb + 3 * IMG, fb + s * 16 * WG16_ROWT + i * 64);
         }
     };
 
@@ -596,12 +590,38 @@ __global__ __launch_bounds__(256) void wgrad16s_kernel(const WgradSArgs a)
         load_chunk();
         store_chunk(0);
         __syncthreads();
-        for (int c = 0; c < nchunks; ++c) {
-            const int buf = c & 1;
-            if (c + 1 < nchunks) load_chunk();
-            compute(buf);
-            if (c + 1 < nchunks) store_chunk(buf ^ 1);
+        // steady state (same software pipeline as convgemm16p): step-1 fragments are read between the MFMAs of step 0, the next
+        // chunk's LDS writes between the MFMAs of step 1
+        for (int c = 0; c + 1 < nchunks; ++c) {
+            const char *sb = smem + (c & 1) * BUF;
+            Frags16 f0, f1;
+            load_chunk();
+            read_step(f0, sb, 0);
+            read_step(f1, sb, 1);
+            mfma12(f0, acc);
+            store_chunk((c & 1) ^ 1);
+            mfma12(f1, acc);
+            __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+            }
             __syncthreads();
+        }
+        {
+            const char *sb = smem + ((nchunks - 1) & 1) * BUF;
+            Frags16 f0, f1;
+            read_step(f0, sb, 0);
+            read_step(f1, sb, 1);
+            mfma12(f0, acc);
+            mfma12(f1, acc);
         }
     }
     float *out = a.slab + (size_t)zs * a.Mp * a.Np;

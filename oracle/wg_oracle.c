@@ -1020,3 +1020,11 @@ WGO_API int wgo_upsample(const wgo_config *cf, const float *bias, const float *g
 }
 
 WGO_API int wgo_real_bytes(void) { return (int)sizeof(real); }
+
+#ifdef _OPENMP
+#include <omp.h>
+/* cap the OpenMP team (the loops expose ~64-128 independent row blocks; more threads only add fork/join cost) */
+WGO_API int wgo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }
+#else
+WGO_API int wgo_set_threads(int n) { (void)n; return 1; }
+#endif

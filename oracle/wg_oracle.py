@@ -51,6 +51,11 @@ def _lib(double=False):
     return _LIBS[key]
 
 
+def set_threads(n, double=False):
+    """Caps the oracle's OpenMP team; returns the team size in effect."""
+    return int(_lib(double).wgo_set_threads(int(n)))
+
+
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 

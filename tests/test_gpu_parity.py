@@ -20,6 +20,14 @@ pytestmark = pytest.mark.gpu
 Z_ATOL, LOSS_ATOL, GRAD_RTOL = 1e-4, 1e-6, 1e-4
 
 
+@pytest.fixture(params=["f32", "bf16x3", "bf16x3p"], autouse=True)
+def precision(request, monkeypatch):
+    """Every parity test runs in the three arithmetic modes of the contraction kernels (include/wgflow.h WG_PREC_*):
+    exact fp32 MFMA, bf16x3 split on the fly, bf16x3 from pre-split S-planes (the default).  Same tolerances for all."""
+    monkeypatch.setenv("WG_PRECISION", request.param)
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def dev():
     assert torch.cuda.is_available(), "the gpu suite needs the MI355X"
