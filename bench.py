@@ -96,8 +96,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("WG_BENCH_FORCE_DIST") == "1"      # FORCE_DIST: exercise the RCCL path with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -115,7 +119,7 @@ def main():
     h = torch.randn(B, C2["n_mels"], FRAMES, device=dev, generator=g)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -135,7 +139,7 @@ def main():
     if timer:
         L.wg_timer_attach(None)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
@@ -190,7 +194,7 @@ def main():
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -308,16 +308,20 @@ __device__ __forceinline__ void mfma12(const Frags16 &f, f32x16 (&acc)[2][2])
         }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256) void convgemm16p_kernel(const ConvGemm16sArgs aa)
+// MT = 2: 128x128 tile, 4 waves, two workgroups per CU;  MT = 4: 256x128 tile, 8 waves, one workgroup per CU (25 % fewer operand
+// bytes per FLOP from L2).
+template <int EPI, int MT>
+__global__ __launch_bounds__(128 * MT) void convgemm16p_kernel(const ConvGemm16sArgs aa)
 {
-    constexpr int AIMG = WG16_IMG;
-    constexpr int BUF = 4 * WG16_IMG;
+    constexpr int NT = 128 * MT;
+    constexpr int AIMG = MT * 64 * WG16_ROWB;
+    constexpr int BUF = 2 * AIMG + 2 * WG16_IMG;
+    constexpr int UPT = 512 / NT;                // B units per thread and image
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
     const ConvGemmArgs &a = aa.c;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int t0 = blockIdx.x * WG_TILE, m0 = blockIdx.y * WG_TILE, b = blockIdx.z;
+    const int t0 = blockIdx.x * WG_TILE, m0 = blockIdx.y * (64 * MT), b = blockIdx.z;
     const Geo g = a.g;
 
     f32x16 acc[2][2];
@@ -336,9 +340,9 @@ __global__ __launch_bounds__(256) void convgemm16p_kernel(const ConvGemm16sArgs 
 #else
     constexpr int NSET = 1;
 #endif
-    u32x4 ra_hi[NSET][2], ra_lo[NSET][2], rb_hi[NSET][2], rb_lo[NSET][2];
+    u32x4 ra_hi[NSET][2], ra_lo[NSET][2], rb_hi[NSET][UPT], rb_lo[NSET][UPT];
     int cur_seg = 0, cur_c = 0, chunk = 0;
-    const int bt = tid & 127, cg0 = tid >> 7;          // B units: (cg0, bt) and (cg0 + 2, bt)
+    const int bt = tid & 127, cg0 = tid >> 7;          // B units: MT=2: (cg0, bt) and (cg0 + 2, bt); MT=4: (cg0, bt), cg0 = 0..3
 
     auto load_chunk = [&](auto SET) {
         constexpr int S = decltype(SET)::value;
@@ -348,20 +352,29 @@ __global__ __launch_bounds__(256) void convgemm16p_kernel(const ConvGemm16sArgs 
         const unsigned short *ih = aa.img + ((size_t)chunk * a.lda + m0) * WG16_BK;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int p = tid + 256 * j;
+            const int p = tid + NT * j;
             ra_hi[S][j] = *reinterpret_cast<const u32x4 *>(ih + (size_t)p * 8);
             ra_lo[S][j] = *reinterpret_cast<const u32x4 *>(ih + aa.img_stride + (size_t)p * 8);
         }
         const unsigned short *p0 = ss.hi + (((size_t)b * (ss.Cp >> 3) + ((ss.ch0 + cur_c) >> 3) + cg0) * g.P + g.H + t0 + shift + bt) * 8;
-        rb_hi[S][0] = *reinterpret_cast<const u32x4 *>(p0);           // cg0 in {0,1}: always valid (chunks hold >= 16 channels)
-        rb_lo[S][0] = *reinterpret_cast<const u32x4 *>(p0 + ss.lo_off);
-        u32x4 vh = {0u, 0u, 0u, 0u}, vl = {0u, 0u, 0u, 0u};
-        if (nvalid > 16) {
-            const unsigned short *p1 = p0 + (size_t)2 * g.P * 8;
-            vh = *reinterpret_cast<const u32x4 *>(p1);
-            vl = *reinterpret_cast<const u32x4 *>(p1 + ss.lo_off);
+        if (UPT == 2) {
+            rb_hi[S][0] = *reinterpret_cast<const u32x4 *>(p0);       // cg0 in {0,1}: always valid (chunks hold >= 16 channels)
+            rb_lo[S][0] = *reinterpret_cast<const u32x4 *>(p0 + ss.lo_off);
+            u32x4 vh = {0u, 0u, 0u, 0u}, vl = {0u, 0u, 0u, 0u};
+            if (nvalid > 16) {
+                const unsigned short *p1 = p0 + (size_t)2 * g.P * 8;
+                vh = *reinterpret_cast<const u32x4 *>(p1);
+                vl = *reinterpret_cast<const u32x4 *>(p1 + ss.lo_off);
+            }
+            rb_hi[S][UPT - 1] = vh; rb_lo[S][UPT - 1] = vl;
+        } else {
+            u32x4 vh = {0u, 0u, 0u, 0u}, vl = {0u, 0u, 0u, 0u};
+            if (cg0 * 8 < nvalid) {
+                vh = *reinterpret_cast<const u32x4 *>(p0);
+                vl = *reinterpret_cast<const u32x4 *>(p0 + ss.lo_off);
+            }
+            rb_hi[S][0] = vh; rb_lo[S][0] = vl;
         }
-        rb_hi[S][1] = vh; rb_lo[S][1] = vl;
         ++chunk;
         cur_c += WG16_BK;
         if (cur_c >= nch) { cur_c = 0; ++cur_seg; }
@@ -371,13 +384,13 @@ __global__ __launch_bounds__(256) void convgemm16p_kernel(const ConvGemm16sArgs 
         char *sb = smem + buf * BUF;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int p = tid + 256 * j;
+            const int p = tid + NT * j;
             const int off = (p >> 2) * WG16_ROWB + (p & 3) * 16;
             *reinterpret_cast<u32x4 *>(sb + off) = ra_hi[S][j];
             *reinterpret_cast<u32x4 *>(sb + AIMG + off) = ra_lo[S][j];
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < UPT; ++j) {
             char *q = sb + 2 * AIMG + bt * WG16_ROWB + (cg0 + 2 * j) * 16;
             *reinterpret_cast<u32x4 *>(q) = rb_hi[S][j];
             *reinterpret_cast<u32x4 *>(q + WG16_IMG) = rb_lo[S][j];
@@ -397,8 +410,8 @@ __global__ __launch_bounds__(256) void convgemm16p_kernel(const ConvGemm16sArgs 
 #if !defined(WG_ABL_NOLOAD)
         if (do_load) load_chunk(LSET);
 #endif
-        read_frags16(f0, sb, sb + AIMG, sb + 2 * AIMG, sb + 3 * AIMG, ao, bo);
-        read_frags16(f1, sb, sb + AIMG, sb + 2 * AIMG, sb + 3 * AIMG, ao + 32, bo + 32);
+        read_frags16(f0, sb, sb + AIMG, sb + 2 * AIMG, sb + 2 * AIMG + WG16_IMG, ao, bo);
+        read_frags16(f1, sb, sb + AIMG, sb + 2 * AIMG, sb + 2 * AIMG + WG16_IMG, ao + 32, bo + 32);
 #if defined(WG_ABL_NOMFMA)
         asm volatile("" ::"v"(f0.ah[0]), "v"(f0.al[1]), "v"(f0.bh[0]), "v"(f0.bl[1]), "v"(f1.ah[1]), "v"(f1.al[0]), "v"(f1.bh[1]), "v"(f1.bl[0]));
 #else
@@ -411,18 +424,22 @@ __global__ __launch_bounds__(256) void convgemm16p_kernel(const ConvGemm16sArgs 
         mfma12(f1, acc);
 #endif
         // pin the interleave: loads, step-0 fragments, then {3 MFMA, 2 DS reads} x4, {3 MFMA, 2 DS writes} x4
-        __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 4 + 2 * UPT, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
-        }
+        // LDS writes of the next chunk: 4 (A) + 2*UPT (B) per thread, two per MFMA group
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        if (UPT == 2) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
         __syncthreads();
     };
 
@@ -443,8 +460,8 @@ __global__ __launch_bounds__(256) void convgemm16p_kernel(const ConvGemm16sArgs 
     {
         const char *sb = smem + ((nchunks - 1) & 1) * BUF;
         Frags16 f0, f1;
-        read_frags16(f0, sb, sb + AIMG, sb + 2 * AIMG, sb + 3 * AIMG, ao, bo);
-        read_frags16(f1, sb, sb + AIMG, sb + 2 * AIMG, sb + 3 * AIMG, ao + 32, bo + 32);
+        read_frags16(f0, sb, sb + AIMG, sb + 2 * AIMG, sb + 2 * AIMG + WG16_IMG, ao, bo);
+        read_frags16(f1, sb, sb + AIMG, sb + 2 * AIMG, sb + 2 * AIMG + WG16_IMG, ao + 32, bo + 32);
         mfma12(f0, acc);
         mfma12(f1, acc);
     }

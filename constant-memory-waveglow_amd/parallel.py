@@ -59,9 +59,11 @@ class GradSync:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         backend = dist.get_backend(process_group) if dist.is_initialized() else None
         self._avg = backend == "nccl"          # RCCL has a native AVG; gloo does not
+        import os
+        self._force = dist.is_initialized() and os.environ.get("WG_BENCH_FORCE_DIST") == "1"   # 1-rank smoke of the collective path
 
     def all_reduce(self, fg: FlatGrads, order: Sequence[int] = None):
-        if self.world == 1:
+        if self.world == 1 and not self._force:
             return
         order = list(order) if order is not None else list(range(len(fg.bucket_ranges) - 1, -1, -1))
         works = []
@@ -78,7 +80,7 @@ class GradSync:
 
     def broadcast_params(self, params: Sequence[torch.Tensor], src: int = 0):
         """replicas start identical (what DDP does when it wraps the module)"""
-        if self.world == 1:
+        if self.world == 1 and not self._force:
             return
         for p in params:
             dist.broadcast(p.data, src=src, group=self.pg)
