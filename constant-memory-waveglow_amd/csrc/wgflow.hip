@@ -970,29 +970,50 @@ static int model_run_fwd_or_inv(const wg_config *cf, const void *packed, const f
     float *partial = ws + W.partial;
     WnRun r;
     r.g = g; r.ws = ws; r.w = W.wn; r.Y = ws + W.Y; r.YS = ws + W.YS; r.save = 0;
-    if (!inverse) {
-        int base = 0;
-        for (int k = 0; k < cf->n_flows; ++k) {
-            if (k % cf->n_early_every == 0 && k) base += cf->n_early_size;                            // :164-170
-            const int c = flow_channels(cf, k);
-            const float *lu = pk + M.lu + (size_t)k * WG_LU_STRIDE;
-            PRef Xk = pref(ws + W.X, W.Gp, base);
-            run_mix(cx, g, Xk, c, lu, 0);                                                             // :172
-            r.d = flow_wn(cf, k); r.L = wn_pack_layout(r.d); r.pk = pk + M.wn[k]; r.X = Xk;
-            wn_forward(cx, r);
-            run_end_affine(cx, r, AFF_FWD, pnull(), nullptr, nullptr, nullptr, partial + (size_t)k * B * W.ntile);   // :173
+    // one coupling (WN + affine, forward or inverse formulas) and one 1x1 mix on the channels [base, base + c_k)
+    auto coupling = [&](int k, int base, int aff_mode) {
+        r.d = flow_wn(cf, k); r.L = wn_pack_layout(r.d); r.pk = pk + M.wn[k]; r.X = pref(ws + W.X, W.Gp, base);
+        wn_forward(cx, r);
+        run_end_affine(cx, r, aff_mode, pnull(), nullptr, nullptr, nullptr, partial + (size_t)k * B * W.ntile);
+    };
+    auto mix = [&](int k, int base, bool inv) {
+        const float *lu = pk + M.lu + (size_t)k * WG_LU_STRIDE;
+        run_mix(cx, g, pref(ws + W.X, W.Gp, base), flow_channels(cf, k), lu + (inv ? WG_MAXC * WG_MAXC : 0), 0);
+    };
+    const int c_last = flow_channels(cf, cf->n_flows - 1);
+    if (!cf->reverse_mode) {
+        if (!inverse) {                                   // waveglow.py:150-179
+            int base = 0;
+            for (int k = 0; k < cf->n_flows; ++k) {
+                if (k % cf->n_early_every == 0 && k) base += cf->n_early_size;                        // :164-170
+                mix(k, base, false);                                                                  // :172
+                coupling(k, base, AFF_FWD);                                                           // :173
+            }
+        } else {                                          // waveglow.py:181-208
+            int base = G - c_last;
+            for (int k = cf->n_flows - 1; k >= 0; --k) {
+                coupling(k, base, AFF_REV);                                                           // :199
+                mix(k, base, true);                                                                   // :200
+                if (k % cf->n_early_every == 0 && k) base -= cf->n_early_size;                        // :204-205
+            }
         }
     } else {
-        int base = G - flow_channels(cf, cf->n_flows - 1);
-        for (int k = cf->n_flows - 1; k >= 0; --k) {
-            const int c = flow_channels(cf, k);
-            const float *lu = pk + M.lu + (size_t)k * WG_LU_STRIDE;
-            PRef Xk = pref(ws + W.X, W.Gp, base);
-            r.d = flow_wn(cf, k); r.L = wn_pack_layout(r.d); r.pk = pk + M.wn[k]; r.X = Xk;
-            wn_forward(cx, r);
-            run_end_affine(cx, r, AFF_REV, pnull(), nullptr, nullptr, nullptr, partial + (size_t)k * B * W.ntile);   // :199
-            run_mix(cx, g, Xk, c, lu + WG_MAXC * WG_MAXC, 0);                                          // :200
-            if (k % cf->n_early_every == 0 && k) base -= cf->n_early_size;                             // :204-205
+        // reverse_mode=True (base.py:20-28): model.forward runs the loop of :181-208 with the blocks' FORWARD formulas,
+        // model.reverse the loop of :150-179 with their inverse formulas.
+        if (!inverse) {
+            int base = G - c_last;
+            for (int k = cf->n_flows - 1; k >= 0; --k) {
+                coupling(k, base, AFF_FWD);
+                mix(k, base, false);
+                if (k % cf->n_early_every == 0 && k) base -= cf->n_early_size;
+            }
+        } else {
+            int base = 0;
+            for (int k = 0; k < cf->n_flows; ++k) {
+                if (k % cf->n_early_every == 0 && k) base += cf->n_early_size;
+                mix(k, base, true);
+                coupling(k, base, AFF_REV);
+            }
         }
     }
     WG_LAUNCH(cx, unsqueeze_kernel, dim3((T + 255) / 256, B), dim3(256), 0, X, out, g, G, N);          // :179 / :207
@@ -1041,29 +1062,43 @@ int wg_backward(const wg_config *cf, const void *const *params, const void *pack
     if (cx.err == 0 && hipMemsetAsync(ws + W.dY, 0, (size_t)B * W.auxp * g.P * sizeof(float), cx.st) != hipSuccess) cx.err = WG_ELAUNCH;
     WnRun r;
     r.g = g; r.ws = ws; r.w = W.wn; r.Y = ws + W.Y; r.YS = ws + W.YS; r.save = 1;
-    int base = G - flow_channels(cf, cf->n_flows - 1);
-    for (int k = cf->n_flows - 1; k >= 0; --k) {
-        const int c = flow_channels(cf, k);
-        const float *lu = pk + M.lu + (size_t)k * WG_LU_STRIDE;
+    // AffineCouplingFunc.backward (efficient_modules.py:118-154) on channels [base, base + c_k)
+    auto coupling_bwd = [&](int k, int base) {
         PRef Xk = pref(ws + W.X, W.Gp, base), dXk = pref(ws + W.dX, W.Gp, base);
         r.d = flow_wn(cf, k); r.L = wn_pack_layout(r.d); r.pk = pk + M.wn[k]; r.X = Xk;
-        // AffineCouplingFunc.backward (efficient_modules.py:118-154)
         wn_forward(cx, r);                                                                   // recompute :127-130
         run_end_affine(cx, r, AFF_BWD, dXk, nullptr, nullptr, dlogdet, nullptr);              // :132-148 (log_s.sum feeds logdet[b], waveglow.py:175)
         wn_backward(cx, r, p + wn_table_off(cf, k), gr + wn_table_off(cf, k), dXk, ws + W.dY);
-        // Conv1x1Func.backward (efficient_modules.py:230-244)
+    };
+    // Conv1x1Func.backward (efficient_modules.py:230-244)
+    auto invconv_bwd = [&](int k, int base) {
+        const int c = flow_channels(cf, k);
+        const float *lu = pk + M.lu + (size_t)k * WG_LU_STRIDE;
+        PRef Xk = pref(ws + W.X, W.Gp, base), dXk = pref(ws + W.dX, W.Gp, base);
         run_mix(cx, g, Xk, c, lu + WG_MAXC * WG_MAXC, 0);                                     // x = W^-1 z   :235-237
-        {
-            WSegSpec sa = {dXk.p, dXk.Cp, dXk.ch0, c, 0, nullptr, 0, 0}, sb = {Xk.p, Xk.Cp, Xk.ch0, c, 0, nullptr, 0, 0};
-            const int prec_keep = cx.prec;
-            cx.prec = 0;                                                                         // tiny c x c product: keep it exact
-            WgradOut wo = run_wgrad(cx, g, &sa, 1, &sb, 1, ws + W.wn.slab, W.wn.slab_floats);   // dW = dz x^T     :240
-            cx.prec = prec_keep;
-            run_finalize(cx, ws + W.wn.slab, wo, 0, c, c, 1, 0, 1, 0, nullptr, nullptr, nullptr, gr[3 + k],
-                         lu + WG_MAXC * WG_MAXC, dlogdet, B, (float)T);                         // + W^-T dlogdet T :242
-        }
+        WSegSpec sa = {dXk.p, dXk.Cp, dXk.ch0, c, 0, nullptr, 0, 0}, sb = {Xk.p, Xk.Cp, Xk.ch0, c, 0, nullptr, 0, 0};
+        const int prec_keep = cx.prec;
+        cx.prec = 0;                                                                          // tiny c x c product: keep it exact
+        WgradOut wo = run_wgrad(cx, g, &sa, 1, &sb, 1, ws + W.wn.slab, W.wn.slab_floats);     // dW = dz x^T     :240
+        cx.prec = prec_keep;
+        run_finalize(cx, ws + W.wn.slab, wo, 0, c, c, 1, 0, 1, 0, nullptr, nullptr, nullptr, gr[3 + k],
+                     lu + WG_MAXC * WG_MAXC, dlogdet, B, (float)T);                           // + W^-T dlogdet T :242
         run_mix(cx, g, dXk, c, lu, 1);                                                        // dx = W^T dz  :239
-        if (k % cf->n_early_every == 0 && k) base -= cf->n_early_size;
+    };
+    if (!cf->reverse_mode) {
+        int base = G - flow_channels(cf, cf->n_flows - 1);
+        for (int k = cf->n_flows - 1; k >= 0; --k) {
+            coupling_bwd(k, base);
+            invconv_bwd(k, base);
+            if (k % cf->n_early_every == 0 && k) base -= cf->n_early_size;
+        }
+    } else {                                              // reverse_mode architecture: per flow the 1x1 came last, flows ran n-1..0
+        int base = 0;
+        for (int k = 0; k < cf->n_flows; ++k) {
+            if (k % cf->n_early_every == 0 && k) base += cf->n_early_size;
+            invconv_bwd(k, base);
+            coupling_bwd(k, base);
+        }
     }
     if (x_rebuilt) WG_LAUNCH(cx, unsqueeze_kernel, dim3((T + 255) / 256, B), dim3(256), 0, X, x_rebuilt, g, G, N);
     if (dx) WG_LAUNCH(cx, unsqueeze_kernel, dim3((T + 255) / 256, B), dim3(256), 0, dX, dx, g, G, N);

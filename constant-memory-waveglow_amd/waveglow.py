@@ -118,9 +118,6 @@ class WaveGlow(FlowBase):
     def __init__(self, flows, n_group, n_early_every, n_early_size, hop_size, n_mels, memory_efficient,
                  reverse_mode=False, **kwargs):
         super().__init__(hop_size, reverse_mode)
-        if reverse_mode:
-            raise WgError("WaveGlow(reverse_mode=True) (the architecture with flows applied in inverse order, "
-                          "SURVEY.md a14) is not built yet; every shipped reference config uses reverse_mode=false")
         self.n_group, self.n_early_every, self.n_early_size = n_group, n_early_every, n_early_size
         self.n_mels, self.mem_efficient = n_mels, memory_efficient
 
@@ -146,7 +143,7 @@ class WaveGlow(FlowBase):
         wn0 = self.WNs[0].F
         self._engine = engine.ModelEngine(engine.make_config(
             flows, n_group, n_early_every, n_early_size, hop_size, n_mels,
-            wn0.res_chs, wn0.dil_chs, wn0.skp_chs, len(wn0.layers), wn0.rdx))
+            wn0.res_chs, wn0.dil_chs, wn0.skp_chs, len(wn0.layers), wn0.rdx, reverse_mode=reverse_mode))
 
     def param_table(self):
         """C-ABI parameter table (include/wgflow.h): upsampler bias,g,v; 1x1 weights; per flow the WN table."""
@@ -163,16 +160,25 @@ class WaveGlow(FlowBase):
         up_len = (h.size(2) - 1) * self.upsample_factor - 2 * self.upsampler.padding[0] + self.upsampler.kernel_size[0]
         assert T <= up_len            # same contract as the reference's assert (waveglow.py:156,187)
 
-    def forward_computation(self, x: Tensor, h: Tensor) -> Tuple[Tensor, Tensor]:
+    # The engine's wg_forward is "what model.forward computes" and wg_inverse "what model.reverse computes" for the
+    # architecture selected by reverse_mode.  Reversible.forward dispatches to reverse_computation when reverse_mode is set
+    # (base.py:20-28 upstream), so the differentiable direction lives in whichever method model.forward lands on.
+    def _train_direction(self, x: Tensor, h: Tensor) -> Tuple[Tensor, Tensor]:
         self._check(x, h)
         return _WaveGlowFn.apply(self, x, h, *self.parameters())
 
-    def reverse_computation(self, z: Tensor, h: Tensor) -> Tuple[Tensor, Tensor]:
+    def _sample_direction(self, z: Tensor, h: Tensor) -> Tuple[Tensor, Tensor]:
         self._check(z, h)
         if torch.is_grad_enabled() and (z.requires_grad or h.requires_grad):
-            warnings.warn("WaveGlow.reverse runs without autograd in the HIP engine", stacklevel=2)
+            warnings.warn("WaveGlow.reverse runs without autograd in the HIP engine", stacklevel=3)
         table = [None if t is None else t.detach() for t in self.param_table()]
         return self._engine.run(table, z.detach(), h.detach(), True)
+
+    def forward_computation(self, x: Tensor, h: Tensor) -> Tuple[Tensor, Tensor]:
+        return self._sample_direction(x, h) if self._reverse_mode else self._train_direction(x, h)
+
+    def reverse_computation(self, z: Tensor, h: Tensor) -> Tuple[Tensor, Tensor]:
+        return self._train_direction(z, h) if self._reverse_mode else self._sample_direction(z, h)
 
     def _upsample_h(self, h):
         T = (h.size(2) - 1) * self.upsample_factor - 2 * self.upsampler.padding[0] + self.upsampler.kernel_size[0]

@@ -57,6 +57,8 @@ typedef struct wg_config {
     int32_t up_stride, up_kernel, up_pad;            /* ConvTranspose1d(n_mels,n_mels,K,stride,pad,groups=n_mels) */
     int32_t res_ch, dil_ch, skip_ch, depth, radix;   /* WN: residual/dilation/skip channels, layers, kernel size */
     int32_t precision;                               /* WG_PREC_* : arithmetic of the MFMA contractions (not upstream) */
+    int32_t reverse_mode;                            /* WaveGlow(reverse_mode=...) (waveglow.py:116, base.py:20-28): wg_forward is what
+                                                        model.forward computes in that architecture, wg_inverse what model.reverse does */
 } wg_config;
 
 /* Dimensions of one WN as AffineCouplingBlock builds it (efficient_modules.py:58-65, waveglow.py:50-59). */

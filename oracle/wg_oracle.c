@@ -1005,6 +1005,179 @@ WGO_API int wgo_train_step(const wgo_config *cf, const float *const *params, con
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * reverse_mode=True architecture (model/base.py:20-28 double swap): model.forward runs the
+ * loop of waveglow.py:181-208 while every block's .reverse() resolves to its FORWARD formulas
+ * (base.py:25-28).  Per flow k = n-1..0 on the last c_k channels:  coupling forward, then z = W z;
+ * early channels are re-attached in front when k % n_early_every == 0.
+ * model.reverse / infer runs waveglow.py:150-179 with the blocks' inverse formulas: per flow k = 0..n-1
+ * (after the early split) x = W^-1 z, then the coupling inverse.
+ * ---------------------------------------------------------------------------------------- */
+static real model_forward_item_rm(const model_weights *m, const float *audio, const real *y, int T, real *Zs)
+{
+    const wgo_config *cf = m->cf;
+    const int G = cf->n_group;
+    real *tmp = ralloc((size_t)G * T), *out = ralloc((size_t)G * T);
+    for (int g = 0; g < G; ++g)
+        for (int t = 0; t < T; ++t) Zs[(long)g * T + t] = (real)audio[(long)t * G + g];   /* :183 */
+    real logdet = 0;
+    int base = G - flow_channels(cf, cf->n_flows - 1);                                    /* split :190-194 */
+    wn_saved s; wn_saved_alloc(&m->d[0], T, &s);
+    for (int k = cf->n_flows - 1; k >= 0; --k) {
+        const int c = flow_channels(cf, k), ic = c / 2;
+        real *cur = Zs + (long)base * T;
+        wn_forward(&m->d[k], &m->w[k], cur, y, T, &s, out);                               /* :199 -> block forward formulas */
+        real ls_sum = 0;
+        for (long j = 0; j < (long)ic * T; ++j) {
+            cur[(long)ic * T + j] = cur[(long)ic * T + j] * (real)exp((double)out[j]) + out[(long)ic * T + j];
+            ls_sum += out[j];
+        }
+        mix_channels(m->W[k], c, cur, T, tmp);                                            /* :200 */
+        memcpy(cur, tmp, sizeof(real) * c * T);
+        logdet += (real)T * m->logdetW[k] + ls_sum;                                       /* :202 */
+        if (k % cf->n_early_every == 0 && k) base -= cf->n_early_size;                    /* :204-205 */
+    }
+    wn_saved_free(&s);
+    free(tmp); free(out);
+    return logdet;
+}
+
+WGO_API int wgo_forward_rm(const wgo_config *cf, const float *const *params, const float *audio, const float *h,
+                           int B, int N, int F, float *z, float *logdet)
+{
+    int T, rc = check_dims(cf, N, F, &T);
+    if (rc) return rc;
+    model_weights m; model_weights_build(cf, params, &m);
+    real *y = ralloc((size_t)cf->n_mels * T), *Zs = ralloc((size_t)cf->n_group * T);
+    for (int b = 0; b < B; ++b) {
+        upsample_item(&m, params, h + (long)b * cf->n_mels * F, F, T, y);
+        const real ld = model_forward_item_rm(&m, audio + (long)b * N, y, T, Zs);
+        for (int g = 0; g < cf->n_group; ++g)
+            for (int t = 0; t < T; ++t) z[(long)b * N + (long)t * cf->n_group + g] = (float)Zs[(long)g * T + t];
+        logdet[b] = (float)ld;
+    }
+    free(y); free(Zs);
+    model_weights_free(&m);
+    return 0;
+}
+
+WGO_API int wgo_inverse_rm(const wgo_config *cf, const float *const *params, const float *z, const float *h,
+                           int B, int N, int F, float *x, float *logdet)
+{
+    int T, rc = check_dims(cf, N, F, &T);
+    if (rc) return rc;
+    const int G = cf->n_group;
+    model_weights m; model_weights_build(cf, params, &m);
+    real *y = ralloc((size_t)cf->n_mels * T), *Zs = ralloc((size_t)G * T);
+    real *tmp = ralloc((size_t)G * T), *out = ralloc((size_t)G * T);
+    wn_saved s; wn_saved_alloc(&m.d[0], T, &s);
+    for (int b = 0; b < B; ++b) {
+        upsample_item(&m, params, h + (long)b * cf->n_mels * F, F, T, y);
+        for (int g = 0; g < G; ++g)
+            for (int t = 0; t < T; ++t) Zs[(long)g * T + t] = (real)z[(long)b * N + (long)t * G + g];
+        real ld = 0;
+        int base = 0;
+        for (int k = 0; k < cf->n_flows; ++k) {
+            const int c = flow_channels(cf, k), ic = c / 2;
+            if (k % cf->n_early_every == 0 && k) base += cf->n_early_size;                /* waveglow.py:164-170 */
+            real *cur = Zs + (long)base * T;
+            mix_channels(m.Wi[k], c, cur, T, tmp);                                        /* :172 -> block reverse formulas */
+            memcpy(cur, tmp, sizeof(real) * c * T);
+            wn_forward(&m.d[k], &m.w[k], cur, y, T, &s, out);                             /* :173 */
+            real ls_sum = 0;
+            for (long j = 0; j < (long)ic * T; ++j) {
+                cur[(long)ic * T + j] = (cur[(long)ic * T + j] - out[(long)ic * T + j]) / (real)exp((double)out[j]);
+                ls_sum -= out[j];
+            }
+            ld += -(real)T * m.logdetW[k] + ls_sum;
+        }
+        for (int g = 0; g < G; ++g)
+            for (int t = 0; t < T; ++t) x[(long)b * N + (long)t * G + g] = (float)Zs[(long)g * T + t];
+        logdet[b] = (float)ld;
+    }
+    wn_saved_free(&s);
+    free(y); free(Zs); free(tmp); free(out);
+    model_weights_free(&m);
+    return 0;
+}
+
+/* training step of the reverse_mode architecture: forward above, NLL, constant-memory backward that walks the flows in
+ * the opposite order (k = 0..n-1): 1x1 backward first (rebuild u = W^-1 w), then the coupling backward. */
+WGO_API int wgo_train_step_rm(const wgo_config *cf, const float *const *params, const float *audio,
+                              const float *h, int B, int N, int F, float sigma,
+                              float *z, float *logdet, float *loss, float *const *grads, float *dh)
+{
+    int T, rc = check_dims(cf, N, F, &T);
+    if (rc) return rc;
+    const int G = cf->n_group, nf = cf->n_flows;
+    rc = wgo_forward_rm(cf, params, audio, h, B, N, F, z, logdet);
+    if (rc) return rc;
+    wgo_loss(z, logdet, B, N, sigma, loss);
+    model_weights m; model_weights_build(cf, params, &m);
+    wn_wgrads *wg = (wn_wgrads *)xmalloc(sizeof(wn_wgrads) * nf);
+    real **dW = (real **)xmalloc(sizeof(real *) * nf);
+    for (int k = 0; k < nf; ++k) { wn_wgrads_alloc(&m.d[k], &wg[k]); dW[k] = rzalloc((size_t)G * G); }
+    real *dup_w = rzalloc((size_t)cf->n_mels * cf->up_kernel), *dbias = rzalloc(cf->n_mels);
+    real *y = ralloc((size_t)cf->n_mels * T), *dy = ralloc((size_t)cf->n_mels * T);
+    real *Zs = ralloc((size_t)G * T), *dZ = ralloc((size_t)G * T);
+    real *out = ralloc((size_t)G * T), *Gr = ralloc((size_t)G * T), *dxa = ralloc((size_t)G * T);
+    real *xr = ralloc((size_t)G * T), *dxr = ralloc((size_t)G * T);
+    real *dhb = dh ? ralloc((size_t)cf->n_mels * F) : NULL;
+    wn_saved s; wn_saved_alloc(&m.d[0], T, &s);
+    const real inv_bn = (real)1 / ((real)B * (real)N);
+    const real dld = -inv_bn, dz_scale = inv_bn / ((real)sigma * (real)sigma);
+    for (int b = 0; b < B; ++b) {
+        upsample_item(&m, params, h + (long)b * cf->n_mels * F, F, T, y);
+        memset(dy, 0, sizeof(real) * cf->n_mels * T);
+        for (int g = 0; g < G; ++g)
+            for (int t = 0; t < T; ++t) {
+                const real zv = (real)z[(long)b * N + (long)t * G + g];
+                Zs[(long)g * T + t] = zv;
+                dZ[(long)g * T + t] = zv * dz_scale;
+            }
+        int base = 0;
+        for (int k = 0; k < nf; ++k) {
+            const int c = flow_channels(cf, k), ic = c / 2;
+            const long IT = (long)ic * T;
+            if (k % cf->n_early_every == 0 && k) base += cf->n_early_size;
+            real *cur = Zs + (long)base * T, *dcur = dZ + (long)base * T;
+            invconv_bwd_item(m.W[k], m.Wi[k], c, cur, dcur, T, xr, dxr, dW[k]);
+            memcpy(cur, xr, sizeof(real) * c * T);
+            memcpy(dcur, dxr, sizeof(real) * c * T);
+            wn_forward(&m.d[k], &m.w[k], cur, y, T, &s, out);
+            for (long j = 0; j < IT; ++j) {
+                const real sc = (real)exp((double)out[j]);
+                const real xb = (cur[IT + j] - out[IT + j]) / sc;
+                const real dzb = dcur[IT + j];
+                cur[IT + j] = xb;
+                Gr[j] = dzb * xb * sc + dld;
+                Gr[IT + j] = dzb;
+                dcur[IT + j] = dzb * sc;
+            }
+            wn_backward(&m.d[k], &m.w[k], &s, cur, y, Gr, T, &wg[k], dxa, dy);
+            for (long j = 0; j < IT; ++j) dcur[j] += dxa[j];
+        }
+        upsample_bwd(cf, m.up_w, h + (long)b * cf->n_mels * F, F, T, dy, dup_w, dbias, dhb);
+        if (dh) r2f(dhb, dh + (long)b * cf->n_mels * F, (long)cf->n_mels * F);
+    }
+    for (int c = 0; c < cf->n_mels; ++c) grads[0][c] = (float)dbias[c];
+    weight_norm_bwd(params[1], params[2], dup_w, cf->n_mels, cf->up_kernel, grads[1], grads[2]);
+    for (int k = 0; k < nf; ++k) {
+        const int c = flow_channels(cf, k);
+        const real gl = dld * (real)B * (real)T;
+        for (int i = 0; i < c; ++i)
+            for (int j = 0; j < c; ++j) grads[3 + k][i * c + j] = (float)(dW[k][i * c + j] + m.Wi[k][j * c + i] * gl);
+        wn_wgrads_emit(&m.d[k], params + wn_table_off(cf, k), &wg[k], grads + wn_table_off(cf, k));
+        wn_wgrads_free(&m.d[k], &wg[k]);
+        free(dW[k]);
+    }
+    wn_saved_free(&s);
+    free(wg); free(dW); free(dup_w); free(dbias); free(y); free(dy); free(Zs); free(dZ);
+    free(out); free(Gr); free(dxa); free(xr); free(dxr); free(dhb);
+    model_weights_free(&m);
+    return 0;
+}
+
 /* mel upsampler alone (for kernel-level parity tests): y = crop(upsampler(h), T) */
 WGO_API int wgo_upsample(const wgo_config *cf, const float *bias, const float *g, const float *v,
                          const float *h, int B, int F, int T, float *y)

@@ -79,25 +79,29 @@ def param_count(cfg):
     return _lib().wgo_param_count(C.byref(cfg))
 
 
-def forward(cfg, params, audio, h, double=False):
+def forward(cfg, params, audio, h, double=False, reverse_mode=False):
+    """model.forward(x, h); reverse_mode=True is the architecture WaveGlow(reverse_mode=True) builds."""
     audio, h = _f32(audio), _f32(h)
     B, N = audio.shape
     F = h.shape[2]
     tab, _keep = _table(params)
     z = np.empty((B, N), np.float32)
     logdet = np.empty((B,), np.float32)
-    _check(_lib(double).wgo_forward(C.byref(cfg), tab, _ptr(audio), _ptr(h), B, N, F, _ptr(z), _ptr(logdet)), "forward")
+    fn = _lib(double).wgo_forward_rm if reverse_mode else _lib(double).wgo_forward
+    _check(fn(C.byref(cfg), tab, _ptr(audio), _ptr(h), B, N, F, _ptr(z), _ptr(logdet)), "forward")
     return z, logdet
 
 
-def inverse(cfg, params, z, h, double=False):
+def inverse(cfg, params, z, h, double=False, reverse_mode=False):
+    """model.reverse(z, h)"""
     z, h = _f32(z), _f32(h)
     B, N = z.shape
     F = h.shape[2]
     tab, _keep = _table(params)
     x = np.empty((B, N), np.float32)
     logdet = np.empty((B,), np.float32)
-    _check(_lib(double).wgo_inverse(C.byref(cfg), tab, _ptr(z), _ptr(h), B, N, F, _ptr(x), _ptr(logdet)), "inverse")
+    fn = _lib(double).wgo_inverse_rm if reverse_mode else _lib(double).wgo_inverse
+    _check(fn(C.byref(cfg), tab, _ptr(z), _ptr(h), B, N, F, _ptr(x), _ptr(logdet)), "inverse")
     return x, logdet
 
 
@@ -108,7 +112,7 @@ def loss(z, logdet, sigma, double=False):
     return float(out.value)
 
 
-def train_step(cfg, params, audio, h, sigma, need_dh=False, double=False):
+def train_step(cfg, params, audio, h, sigma, need_dh=False, double=False, reverse_mode=False):
     """forward + NLL + backward.  Returns dict(z, logdet, loss, grads[list like params], dh)."""
     audio, h = _f32(audio), _f32(h)
     B, N = audio.shape
@@ -120,7 +124,8 @@ def train_step(cfg, params, audio, h, sigma, need_dh=False, double=False):
     logdet = np.empty((B,), np.float32)
     lossv = C.c_float()
     dh = np.empty_like(h) if need_dh else None
-    _check(_lib(double).wgo_train_step(C.byref(cfg), tab, _ptr(audio), _ptr(h), B, N, F, C.c_float(sigma),
+    fn = _lib(double).wgo_train_step_rm if reverse_mode else _lib(double).wgo_train_step
+    _check(fn(C.byref(cfg), tab, _ptr(audio), _ptr(h), B, N, F, C.c_float(sigma),
                                        _ptr(z), _ptr(logdet), C.byref(lossv), gtab, _ptr(dh)), "train_step")
     return dict(z=z, logdet=logdet, loss=float(lossv.value), grads=grads, dh=dh)
 

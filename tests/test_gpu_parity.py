@@ -53,11 +53,11 @@ def logdet_close(a, b, N):
     return bool(np.all(np.abs(a - b) <= 1e-4 * np.abs(b) + 1e-7 * N))
 
 
-def build(name, dev, mem_eff=True):
+def build(name, dev, mem_eff=True, reverse_mode=False):
     cfg = fill.CONFIGS[name]
     specs = fill.model_param_specs(cfg)
     P = fill.fill_params(specs, name + "/")
-    m = cm.WaveGlow(memory_efficient=mem_eff, bias=False, **cfg)
+    m = cm.WaveGlow(memory_efficient=mem_eff, bias=False, reverse_mode=reverse_mode, **cfg)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
     return m.to(dev), cfg, specs, P
 
@@ -106,6 +106,33 @@ def test_model_inverse_and_infer(dev, golden_dir, name):
     assert np.abs(npy(xs) - gold["x_from_latent"]).max() < Z_ATOL * max(1.0, float(np.abs(gold["x_from_latent"]).max()))
     torch.manual_seed(0)
     y = m.infer(ht[0], sigma=0.6)                              # 2-D h is accepted (base.py:44-45)
+    assert y.shape == (F * cfg["hop_size"],) and bool(torch.isfinite(y).all())
+
+
+def test_reverse_mode_model(dev, golden_dir):
+    """WaveGlow(reverse_mode=True): the architecture of SURVEY.md a14 (flows and early splits in the opposite order)."""
+    m, cfg, specs, P = build("micro", dev, reverse_mode=True)
+    B, N, F = fill.SHAPES["micro"]
+    audio, h = fill.inputs("micro", B, N, F, cfg["n_mels"])
+    gold = np.load(os.path.join(golden_dir, "model_micro_rm.npz"))
+    ref = orc.train_step(orc.make_config(**cfg), fill.table(specs, P), audio, h, fill.SIGMA, need_dh=True, reverse_mode=True)
+    x, ht = T(audio, dev), T(h, dev).requires_grad_(True)
+    z, logdet = m(x, ht)
+    loss = cm.WaveGlowLoss(fill.SIGMA)(z, logdet)
+    loss.backward()
+    for want in (ref, gold):
+        assert np.abs(npy(z) - want["z"]).max() < Z_ATOL
+        assert logdet_close(npy(logdet), want["logdet"], N)
+        assert abs(float(loss) - float(want["loss"])) < LOSS_ATOL
+        assert relmax(npy(ht.grad), want["dh"]) < GRAD_RTOL
+    named = dict(m.named_parameters())
+    for i, (n, _, _) in enumerate(specs):
+        assert relmax(npy(named[n].grad), gold["grad::" + n]) < GRAD_RTOL, n
+    with torch.no_grad():
+        xr, ldr = m.reverse(z.detach(), ht.detach())
+    assert np.abs(npy(xr) - gold["x_inv"]).max() < Z_ATOL and np.abs(npy(xr) - audio).max() < Z_ATOL
+    assert logdet_close(npy(ldr), gold["logdet_inv"], N)
+    y = m.infer(ht.detach()[0], sigma=0.6)
     assert y.shape == (F * cfg["hop_size"],) and bool(torch.isfinite(y).all())
 
 

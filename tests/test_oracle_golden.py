@@ -139,3 +139,27 @@ def test_coupling_block(golden_dir, cname, rev):
         assert abs(nrm - g[k + "/grad_norm"][i]) <= 2e-4 * g[k + "/grad_norm"][i] + 1e-12, n
         if k + "/grad::" + n in g:
             assert _relmax(gr, g[k + "/grad::" + n]) < GRAD_RTOL, n
+
+
+def test_reverse_mode_architecture(golden_dir):
+    """WaveGlow(reverse_mode=True) (model/base.py:20-28 double swap): forward, backward and inverse."""
+    name = "micro"
+    g = _load(golden_dir, "model_micro_rm.npz")
+    cfg = fill.CONFIGS[name]
+    B, N, F = fill.SHAPES[name]
+    specs = fill.model_param_specs(cfg)
+    tab = fill.table(specs, fill.fill_params(specs, name + "/"))
+    audio, h = fill.inputs(name, B, N, F, cfg["n_mels"])
+    oc = orc.make_config(**cfg)
+    r = orc.train_step(oc, tab, audio, h, fill.SIGMA, need_dh=True, reverse_mode=True)
+    assert np.abs(r["z"] - g["z"]).max() < Z_ATOL
+    assert _logdet_close(r["logdet"], g["logdet"], N)
+    assert abs(r["loss"] - float(g["loss"])) < 1e-6
+    assert _relmax(r["dh"], g["dh"]) < GRAD_RTOL
+    for i, (n, _, _) in enumerate(specs):
+        assert _relmax(r["grads"][i], g["grad::" + n]) < GRAD_RTOL, n
+    x, ld = orc.inverse(oc, tab, g["z"], h, reverse_mode=True)
+    assert np.abs(x - g["x_inv"]).max() < Z_ATOL and np.abs(x - audio).max() < 1e-5
+    assert _logdet_close(ld, g["logdet_inv"], N)
+    # it is a different function from the reverse_mode=False model
+    assert np.abs(g["z"] - _load(golden_dir, "model_micro.npz")["z"]).max() > 1e-2
