@@ -140,10 +140,15 @@ CONFIGS = {
     "c2": dict(flows=12, n_group=8, n_early_every=4, n_early_size=2, hop_size=256, n_mels=80,
                dilation_channels=256, residual_channels=256, skip_channels=256, depth=8, radix=3),
 }
+# the WaveGlow core of WSRGlow (model/wsrglow.py:22-25: n_group = hop = 8r, stride-1 upsampler, very wide conditioning), scaled
+# down: odd conditioning width (not a multiple of 8), 16 squeezed channels, upsample factor 1
+CONFIGS["wsr_like"] = dict(flows=4, n_group=16, n_early_every=2, n_early_size=2, hop_size=16, n_mels=83,
+                           dilation_channels=64, residual_channels=64, skip_channels=64, depth=3, radix=3)
 SHAPES = {  # (batch, samples, mel frames)
     "micro": (2, 512, 8),
     "c1": (2, 4000, 16),
     "c2": (1, 16000, 63),
+    "wsr_like": (2, 16 * 300, 300),
 }
 SIGMA = 0.7   # configs/waveglow_LJ_speech.json:47
 

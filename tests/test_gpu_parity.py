@@ -62,7 +62,7 @@ def build(name, dev, mem_eff=True, reverse_mode=False):
     return m.to(dev), cfg, specs, P
 
 
-@pytest.mark.parametrize("name", ["micro", "c1"])
+@pytest.mark.parametrize("name", ["micro", "c1", "wsr_like"])
 def test_model_step_vs_oracle_and_golden(dev, golden_dir, name):
     m, cfg, specs, P = build(name, dev)
     B, N, F = fill.SHAPES[name]

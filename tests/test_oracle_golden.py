@@ -28,7 +28,7 @@ def _relmax(a, b):
     return float(np.abs(a - b).max() / max(float(np.abs(b).max()), 1e-30))
 
 
-@pytest.mark.parametrize("name", ["micro", "c1", "c2"])
+@pytest.mark.parametrize("name", ["micro", "c1", "c2", "wsr_like"])
 @pytest.mark.parametrize("double", [False, True])
 def test_model_step_matches_reference(golden_dir, name, double):
     if name == "c2" and double:
