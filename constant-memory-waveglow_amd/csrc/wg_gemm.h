@@ -53,38 +53,6 @@ __device__ __forceinline__ void mma_chunk(const float *__restrict__ As, const fl
     const int kh = lane >> 5, r = lane & 31;
     const float *ap = As + kh * LDA + wr * 64 + r;
     const float *bp = Bs + kh * LDB + wc * 64 + r;
-#if defined(WG_OPT_FRAGPIPE)
-    // fragments of k-step s+1 are read while the MFMAs of step s issue (named double buffer, static indices)
-    float a0 = ap[0], a1 = ap[32], b0 = bp[0], b1 = bp[32];
-#pragma unroll
-    for (int kk = 0; kk < BKK; kk += 2) {
-        float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
-        if (kk + 2 < BKK) {
-            na0 = ap[(kk + 2) * LDA]; na1 = ap[(kk + 2) * LDA + 32];
-            nb0 = bp[(kk + 2) * LDB]; nb1 = bp[(kk + 2) * LDB + 32];
-        }
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
-    }
-#elif defined(WG_OPT_FRAGALL)
-    // all fragments of the chunk first, then a pure MFMA stream
-    float fa[BKK / 2][2], fb[BKK / 2][2];
-#pragma unroll
-    for (int s = 0; s < BKK / 2; ++s) {
-        fa[s][0] = ap[2 * s * LDA]; fa[s][1] = ap[2 * s * LDA + 32];
-        fb[s][0] = bp[2 * s * LDB]; fb[s][1] = bp[2 * s * LDB + 32];
-    }
-#pragma unroll
-    for (int s = 0; s < BKK / 2; ++s) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][0], fb[s][0], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][0], fb[s][1], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][1], fb[s][0], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][1], fb[s][1], acc[1][1], 0, 0, 0);
-    }
-#else
 #pragma unroll
     for (int kk = 0; kk < BKK; kk += 2) {
         const float a0 = ap[kk * LDA], a1 = ap[kk * LDA + 32];
@@ -94,7 +62,6 @@ __device__ __forceinline__ void mma_chunk(const float *__restrict__ As, const fl
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
     }
-#endif
 }
 
 // gate nonlinearities: hardware exp2/rcp based forms (|err| ~1e-7, well inside the 1e-4 parity budget); the libm
@@ -167,12 +134,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvGemmArgs &a, f32x16 (&ac
             for (int r = 0; r < 16; ++r) {
                 const int ch = chb + acc_row(r, lane);
                 if (2 * ch >= a.M) continue;
-#if defined(WG_OPT_NOEPI)
-                const float tw = acc[0][ni][r], sf = acc[1][ni][r];
-#else
                 const float tw = wg_tanh(acc[0][ni][r]);
                 const float sf = wg_sigmoid(acc[1][ni][r]);
-#endif
                 *paddr(a.out0, g, b, ch, t) = tw * sf;
                 if (a.out1.p) {
                     *paddr(a.out1, g, b, ch, t) = tw;
@@ -304,13 +267,7 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmArgs a)
             al_next = (a.seg[cur_seg].shift & 3) == 0;
             load_chunk();
         }
-#if defined(WG_OPT_SETPRIO)
-        __builtin_amdgcn_s_setprio(1);
-#endif
         mma_chunk<WG_BK, WG_TILE, WG_TILE>(&As[buf][0][0], &Bs[buf][0][0], wr, wc, lane, acc);
-#if defined(WG_OPT_SETPRIO)
-        __builtin_amdgcn_s_setprio(0);
-#endif
         if (c + 1 < nchunks) store_chunk(buf ^ 1, al_next);
         __syncthreads();
     }

@@ -188,95 +188,6 @@ struct ConvGemm16sArgs {
     SRef s0;                      // S-plane output (hi == nullptr: none)
 };
 
-template <int EPI, int MT>
-__global__ __launch_bounds__(128 * MT) void convgemm16s_kernel(const ConvGemm16sArgs aa)
-{
-    constexpr int NT = 128 * MT;
-    constexpr int AIMG = MT * 64 * WG16_ROWB;
-    constexpr int BUF = 2 * AIMG + 2 * WG16_IMG;
-    constexpr int UPT = 512 / NT;                 // 16-byte units of the B tile per thread and image (2 or 1)
-    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
-    const ConvGemmArgs &a = aa.c;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int t0 = blockIdx.x * WG_TILE, m0 = blockIdx.y * (64 * MT), b = blockIdx.z;
-    const Geo g = a.g;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    int nchunks = 0;
-    for (int s = 0; s < a.nseg; ++s) nchunks += (a.seg[s].nch + WG16_BK - 1) / WG16_BK;
-
-    u32x4 ra_hi[2], ra_lo[2], rb_hi[UPT], rb_lo[UPT];
-    int cur_seg = 0, cur_c = 0, chunk = 0, nk_loaded = 0;
-    const int bt = tid & 127;
-
-    auto load_chunk = [&]() {
-        const int nch = a.seg[cur_seg].nch, shift = a.seg[cur_seg].shift;
-        const SSeg ss = aa.sseg[cur_seg];
-        const int nvalid = min(WG16_BK, nch - cur_c);
-        nk_loaded = nvalid >> 4;
-        const unsigned short *ih = aa.img + ((size_t)chunk * a.lda + m0) * WG16_BK;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int p = tid + NT * j;
-            ra_hi[j] = *reinterpret_cast<const u32x4 *>(ih + (size_t)p * 8);
-            ra_lo[j] = *reinterpret_cast<const u32x4 *>(ih + aa.img_stride + (size_t)p * 8);
-        }
-#pragma unroll
-        for (int j = 0; j < UPT; ++j) {
-            const int cg = (tid + NT * j) >> 7;                                  // 0..3
-            u32x4 vh = {0u, 0u, 0u, 0u}, vl = {0u, 0u, 0u, 0u};
-            if (cg * 8 < nvalid) {
-                const unsigned short *p = ss.hi + (((size_t)b * (ss.Cp >> 3) + ((ss.ch0 + cur_c) >> 3) + cg) * g.P + g.H + t0 + shift + bt) * 8;
-                vh = *reinterpret_cast<const u32x4 *>(p);
-                vl = *reinterpret_cast<const u32x4 *>(p + ss.lo_off);
-            }
-            rb_hi[j] = vh; rb_lo[j] = vl;
-        }
-        ++chunk;
-        cur_c += WG16_BK;
-        if (cur_c >= nch) { cur_c = 0; ++cur_seg; }
-    };
-    auto store_chunk = [&](int buf) {
-        char *sb = smem + buf * BUF;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int p = tid + NT * j;
-            const int off = (p >> 2) * WG16_ROWB + (p & 3) * 16;
-            *reinterpret_cast<u32x4 *>(sb + off) = ra_hi[j];
-            *reinterpret_cast<u32x4 *>(sb + AIMG + off) = ra_lo[j];
-        }
-#pragma unroll
-        for (int j = 0; j < UPT; ++j) {
-            const int cg = (tid + NT * j) >> 7;
-            char *q = sb + 2 * AIMG + bt * WG16_ROWB + cg * 16;
-            *reinterpret_cast<u32x4 *>(q) = rb_hi[j];
-            *reinterpret_cast<u32x4 *>(q + WG16_IMG) = rb_lo[j];
-        }
-    };
-
-    load_chunk();
-    int nk_cur = nk_loaded;
-    store_chunk(0);
-    __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunks) load_chunk();
-        const char *sb = smem + buf * BUF;
-        mma16_chunk(sb, sb + AIMG, sb + 2 * AIMG, sb + 2 * AIMG + WG16_IMG, wr, wc, lane, nk_cur, acc);
-        if (c + 1 < nchunks) { store_chunk(buf ^ 1); nk_cur = nk_loaded; }
-        __syncthreads();
-    }
-    conv_epilogue_s<EPI>(a, aa.s0, acc, t0, m0, b, wr, wc, lane);
-}
-
 // ------------------------------------------------------------------------------------------------
 // convgemm16p: software-pipelined 128x128 variant (4 waves, two workgroups per CU).
 // Every chunk runs two k-steps (half chunks are zero padded in LDS); inside a chunk the fragment reads of step 1 are
@@ -308,11 +219,12 @@ __device__ __forceinline__ void mfma12(const Frags16 &f, f32x16 (&acc)[2][2])
         }
 }
 
-// MT = 2: 128x128 tile, 4 waves, two workgroups per CU;  MT = 4: 256x128 tile, 8 waves, one workgroup per CU (25 % fewer operand
-// bytes per FLOP from L2).
-template <int EPI, int MT>
-__global__ __launch_bounds__(128 * MT) void convgemm16p_kernel(const ConvGemm16sArgs aa)
+// (a 256x128 / 8-wave variant and a deeper register prefetch were measured and bought nothing: the kernel is bound by the
+// L2->LDS operand stream and by its epilogue traffic)
+template <int EPI>
+__global__ __launch_bounds__(256) void convgemm16p_kernel(const ConvGemm16sArgs aa)
 {
+    constexpr int MT = 2;
     constexpr int NT = 128 * MT;
     constexpr int AIMG = MT * 64 * WG16_ROWB;
     constexpr int BUF = 2 * AIMG + 2 * WG16_IMG;
@@ -335,11 +247,7 @@ __global__ __launch_bounds__(128 * MT) void convgemm16p_kernel(const ConvGemm16s
     int nchunks = 0;
     for (int s = 0; s < a.nseg; ++s) nchunks += (a.seg[s].nch + WG16_BK - 1) / WG16_BK;
 
-#if defined(WG_OPT_PIPE_DEPTH2)
-    constexpr int NSET = 2;       // global loads run two chunks ahead of the MFMAs (two staging register sets)
-#else
-    constexpr int NSET = 1;
-#endif
+    constexpr int NSET = 1;       // staging register sets (global loads run one chunk ahead of the MFMAs)
     u32x4 ra_hi[NSET][2], ra_lo[NSET][2], rb_hi[NSET][UPT], rb_lo[NSET][UPT];
     int cur_seg = 0, cur_c = 0, chunk = 0;
     const int bt = tid & 127, cg0 = tid >> 7;          // B units: MT=2: (cg0, bt) and (cg0 + 2, bt); MT=4: (cg0, bt), cg0 = 0..3
@@ -407,22 +315,12 @@ __global__ __launch_bounds__(128 * MT) void convgemm16p_kernel(const ConvGemm16s
     auto iter = [&](auto LSET, auto WSET, int c, bool do_load) {
         const char *sb = smem + (c & 1) * BUF;
         Frags16 f0, f1;
-#if !defined(WG_ABL_NOLOAD)
         if (do_load) load_chunk(LSET);
-#endif
         read_frags16(f0, sb, sb + AIMG, sb + 2 * AIMG, sb + 2 * AIMG + WG16_IMG, ao, bo);
         read_frags16(f1, sb, sb + AIMG, sb + 2 * AIMG, sb + 2 * AIMG + WG16_IMG, ao + 32, bo + 32);
-#if defined(WG_ABL_NOMFMA)
-        asm volatile("" ::"v"(f0.ah[0]), "v"(f0.al[1]), "v"(f0.bh[0]), "v"(f0.bl[1]), "v"(f1.ah[1]), "v"(f1.al[0]), "v"(f1.bh[1]), "v"(f1.bl[0]));
-#else
         mfma12(f0, acc);
-#endif
-#if !defined(WG_ABL_NOLOAD) && !defined(WG_ABL_NOSTORE)
         store_chunk(WSET, (c & 1) ^ 1);
-#endif
-#if !defined(WG_ABL_NOMFMA)
         mfma12(f1, acc);
-#endif
         // pin the interleave: loads, step-0 fragments, then {3 MFMA, 2 DS reads} x4, {3 MFMA, 2 DS writes} x4
         __builtin_amdgcn_sched_group_barrier(0x020, 4 + 2 * UPT, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
@@ -445,18 +343,8 @@ __global__ __launch_bounds__(128 * MT) void convgemm16p_kernel(const ConvGemm16s
 
     load_chunk(S0{});
     store_chunk(S0{}, 0);
-#if defined(WG_OPT_PIPE_DEPTH2)
-    if (nchunks > 1) load_chunk(S1{});             // chunk 1 -> set 1
-    __syncthreads();
-    // iteration c: loads chunk c+2 into set c&1 (free: chunk c is already in LDS), writes chunk c+1 from set (c+1)&1
-    for (int c = 0; c + 1 < nchunks; c += 2) {
-        iter(S0{}, S1{}, c, c + 2 < nchunks);
-        if (c + 2 < nchunks) iter(S1{}, S0{}, c + 1, c + 3 < nchunks);
-    }
-#else
     __syncthreads();
     for (int c = 0; c + 1 < nchunks; ++c) iter(S0{}, S0{}, c, true);
-#endif
     {
         const char *sb = smem + ((nchunks - 1) & 1) * BUF;
         Frags16 f0, f1;

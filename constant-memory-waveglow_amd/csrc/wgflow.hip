@@ -477,54 +477,15 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                 as.sseg[s].Cp = segs[s].sCp; as.sseg[s].ch0 = segs[s].sch0;
                 if (!segs[s].s && !cx.err) cx.err = WG_EINVAL;
             }
-#if !defined(WG_OPT_NOPIPE)     // software-pipelined kernels (default); -DWG_OPT_NOPIPE: plain double-buffered tiles
-#if defined(WG_OPT_PIPE_MT4)
-            if ((rup(mrows, WG_TILE) % 256) == 0) {
-                dim3 grid4(g.Tt / WG_TILE, rup(mrows, WG_TILE) / 256, g.B), block4(512);
-                switch (epi) {
-                case EPI_STORE: WG_LAUNCH(cx, (convgemm16p_kernel<EPI_STORE, 4>), grid4, block4, 0, as); break;
-                case EPI_GATE: WG_LAUNCH(cx, (convgemm16p_kernel<EPI_GATE, 4>), grid4, block4, 0, as); break;
-                case EPI_RESSKIP: WG_LAUNCH(cx, (convgemm16p_kernel<EPI_RESSKIP, 4>), grid4, block4, 0, as); break;
-                case EPI_DGATE: WG_LAUNCH(cx, (convgemm16p_kernel<EPI_DGATE, 4>), grid4, block4, 0, as); break;
-                }
-                return;
-            }
-#endif
             switch (epi) {
-            case EPI_STORE: WG_LAUNCH(cx, (convgemm16p_kernel<EPI_STORE, 2>), grid, block, 0, as); break;
-            case EPI_GATE: WG_LAUNCH(cx, (convgemm16p_kernel<EPI_GATE, 2>), grid, block, 0, as); break;
-            case EPI_RESSKIP: WG_LAUNCH(cx, (convgemm16p_kernel<EPI_RESSKIP, 2>), grid, block, 0, as); break;
-            case EPI_DGATE: WG_LAUNCH(cx, (convgemm16p_kernel<EPI_DGATE, 2>), grid, block, 0, as); break;
-            }
-            return;
-#endif
-#if defined(WG_OPT_MT2ONLY)
-            if (false) {
-#else
-            if ((rup(mrows, WG_TILE) % 256) == 0) {
-#endif
-                dim3 grid4(g.Tt / WG_TILE, rup(mrows, WG_TILE) / 256, g.B), block4(512);
-                switch (epi) {
-                case EPI_STORE: WG_LAUNCH(cx, (convgemm16s_kernel<EPI_STORE, 4>), grid4, block4, 0, as); break;
-                case EPI_GATE: WG_LAUNCH(cx, (convgemm16s_kernel<EPI_GATE, 4>), grid4, block4, 0, as); break;
-                case EPI_RESSKIP: WG_LAUNCH(cx, (convgemm16s_kernel<EPI_RESSKIP, 4>), grid4, block4, 0, as); break;
-                case EPI_DGATE: WG_LAUNCH(cx, (convgemm16s_kernel<EPI_DGATE, 4>), grid4, block4, 0, as); break;
-                }
-            } else {
-                switch (epi) {
-                case EPI_STORE: WG_LAUNCH(cx, (convgemm16s_kernel<EPI_STORE, 2>), grid, block, 0, as); break;
-                case EPI_GATE: WG_LAUNCH(cx, (convgemm16s_kernel<EPI_GATE, 2>), grid, block, 0, as); break;
-                case EPI_RESSKIP: WG_LAUNCH(cx, (convgemm16s_kernel<EPI_RESSKIP, 2>), grid, block, 0, as); break;
-                case EPI_DGATE: WG_LAUNCH(cx, (convgemm16s_kernel<EPI_DGATE, 2>), grid, block, 0, as); break;
-                }
+            case EPI_STORE: WG_LAUNCH(cx, convgemm16p_kernel<EPI_STORE>, grid, block, 0, as); break;
+            case EPI_GATE: WG_LAUNCH(cx, convgemm16p_kernel<EPI_GATE>, grid, block, 0, as); break;
+            case EPI_RESSKIP: WG_LAUNCH(cx, convgemm16p_kernel<EPI_RESSKIP>, grid, block, 0, as); break;
+            case EPI_DGATE: WG_LAUNCH(cx, convgemm16p_kernel<EPI_DGATE>, grid, block, 0, as); break;
             }
             return;
         }
-#if defined(WG_OPT_MT2ONLY)
-        const bool big = false;
-#else
         const bool big = (rup(mrows, WG_TILE) % 256) == 0;      // 256-row tiles when M allows it
-#endif
         if (big) {
             dim3 grid4(g.Tt / WG_TILE, rup(mrows, WG_TILE) / 256, g.B), block4(512);
             switch (epi) {
