@@ -80,7 +80,7 @@ def lib():
     L.wg_wn_pack_weights.argtypes = [wnp, vp, vp, vp]
     L.wg_forward.argtypes = [cfgp, vp, vp, vp, i, i, i, vp, vp, vp, sz, vp]
     L.wg_inverse.argtypes = [cfgp, vp, vp, vp, i, i, i, vp, vp, vp, sz, vp]
-    L.wg_backward.argtypes = [cfgp, vp, vp, vp, vp, vp, vp, i, i, i, vp, vp, vp, vp, vp, sz, vp]
+    L.wg_backward.argtypes = [cfgp, vp, vp, vp, vp, vp, vp, i, i, i, vp, vp, vp, vp, vp, sz, vp, vp]
     L.wg_nll_loss.argtypes = [vp, vp, i, i, f, i, vp, vp]
     L.wg_nll_loss_backward.argtypes = [vp, i, i, f, i, vp, vp, vp, vp]
     L.wg_invconv_apply.argtypes = [vp, i, vp, i, i, i, vp, vp, vp, sz, vp]

@@ -997,7 +997,7 @@ int wg_inverse(const wg_config *cf, const void *packed, const float *z, const fl
 
 int wg_backward(const wg_config *cf, const void *const *params, const void *packed, const float *z, const float *h,
                 const float *dz, const float *dlogdet, int B, int N, int F, void *const *grads, float *dh, float *dx,
-                float *x_rebuilt, void *wsv, size_t ws_bytes, void *stream)
+                float *x_rebuilt, void *wsv, size_t ws_bytes, void *stream, void *const *flow_events)
 {
     int rc = cfg_check(cf);
     if (rc) return rc;
@@ -1051,6 +1051,7 @@ int wg_backward(const wg_config *cf, const void *const *params, const void *pack
         for (int k = cf->n_flows - 1; k >= 0; --k) {
             coupling_bwd(k, base);
             invconv_bwd(k, base);
+            if (flow_events && flow_events[k] && !cx.err) (void)hipEventRecord((hipEvent_t)flow_events[k], cx.st);   // flow k's grads final
             if (k % cf->n_early_every == 0 && k) base -= cf->n_early_size;
         }
     } else {                                              // reverse_mode architecture: per flow the 1x1 came last, flows ran n-1..0
@@ -1059,6 +1060,7 @@ int wg_backward(const wg_config *cf, const void *const *params, const void *pack
             if (k % cf->n_early_every == 0 && k) base += cf->n_early_size;
             invconv_bwd(k, base);
             coupling_bwd(k, base);
+            if (flow_events && flow_events[k] && !cx.err) (void)hipEventRecord((hipEvent_t)flow_events[k], cx.st);
         }
     }
     if (x_rebuilt) WG_LAUNCH(cx, unsqueeze_kernel, dim3((T + 255) / 256, B), dim3(256), 0, X, x_rebuilt, g, G, N);
@@ -1066,6 +1068,7 @@ int wg_backward(const wg_config *cf, const void *const *params, const void *pack
     // upsampler backward (+ its weight norm)
     WG_LAUNCH(cx, upsample_bwd_kernel, dim3(cf->n_mels), dim3(256), (size_t)(cf->up_kernel + 256) * sizeof(float), h, pk + M.up_w,
               pref(ws + W.dY, W.auxp), g, cf->n_mels, F, cf->up_kernel, cf->up_stride, cf->up_pad, p[1], p[2], gr[0], gr[1], gr[2], dh);
+    if (flow_events && flow_events[cf->n_flows] && !cx.err) (void)hipEventRecord((hipEvent_t)flow_events[cf->n_flows], cx.st);
     return cx.err;
 }
 

@@ -125,7 +125,7 @@ class ModelEngine:
               "wg_inverse" if inverse else "wg_forward")
         return out, logdet
 
-    def backward(self, params, z, h, dz, dlogdet, need, need_dh, need_dx, want_x=False, grads_out=None):
+    def backward(self, params, z, h, dz, dlogdet, need, need_dh, need_dx, want_x=False, grads_out=None, flow_events=None):
         """need[i]: produce the gradient of params[i] (into grads_out[i] when given).  Returns (grads, dh, dx, x_rebuilt)."""
         require_device(z, h, dz, dlogdet)
         z, h, dz, dlogdet = z.contiguous(), h.contiguous(), dz.contiguous(), dlogdet.contiguous()
@@ -141,8 +141,19 @@ class ModelEngine:
         dx = torch.empty_like(z) if need_dx else None
         xr = torch.empty_like(z) if want_x else None
         check(_lib.lib().wg_backward(C.byref(self.cfg), _table(params), _p(pk), _p(z), _p(h), _p(dz), _p(dlogdet), B, N, F,
-                                     _table(grads), _p(dh), _p(dx), _p(xr), _p(ws), ws.numel(), _stream()), "wg_backward")
+                                     _table(grads), _p(dh), _p(dx), _p(xr), _p(ws), ws.numel(), _stream(),
+                                     self._events(flow_events)), "wg_backward")
         return grads, dh, dx, xr
+
+    @staticmethod
+    def _events(events):
+        """torch.cuda.Event list -> array of raw hipEvent_t (NULL when not given)"""
+        if not events:
+            return None
+        arr = (C.c_void_p * len(events))()
+        for i, e in enumerate(events):
+            arr[i] = e.cuda_event
+        return arr
 
     def upsample(self, params, h, T):
         require_device(h)

@@ -44,8 +44,8 @@ class FlatGrads:
 
 
 def waveglow_buckets(n_flows: int, depth: int) -> List[int]:
-    """bucket id per parameter-table entry: flow k -> bucket k; upsampler + 1x1 weights -> bucket n_flows."""
-    ids = [n_flows] * (3 + n_flows)
+    """bucket id per parameter-table entry: flow k (its WN and its 1x1 weight) -> bucket k; upsampler -> bucket n_flows."""
+    ids = [n_flows] * 3 + list(range(n_flows))
     for k in range(n_flows):
         ids += [k] * (4 + 4 * depth + 1)
     return ids
@@ -59,22 +59,36 @@ class GradSync:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         backend = dist.get_backend(process_group) if dist.is_initialized() else None
         self._avg = backend == "nccl"          # RCCL has a native AVG; gloo does not
+        self._comm = None
         import os
         self._force = dist.is_initialized() and os.environ.get("WG_BENCH_FORCE_DIST") == "1"   # 1-rank smoke of the collective path
 
-    def all_reduce(self, fg: FlatGrads, order: Sequence[int] = None):
+    def all_reduce(self, fg: FlatGrads, order: Sequence[int] = None, events=None):
+        """events[b] (torch.cuda.Event, optional): bucket b's gradients are final once the event has fired; its all-reduce is
+        enqueued behind that event on a side stream, so it overlaps whatever backward work is still queued on the main stream."""
         if self.world == 1 and not self._force:
             return
         order = list(order) if order is not None else list(range(len(fg.bucket_ranges) - 1, -1, -1))
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         works = []
-        for b in order:
-            t = fg.bucket(b)
-            if t.numel() == 0:
-                continue
-            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-            works.append((dist.all_reduce(t, op=op, group=self.pg, async_op=True), t))
+        if events is not None and fg.flat.is_cuda:
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(device=fg.flat.device)
+            with torch.cuda.stream(self._comm):
+                for b in order:
+                    t = fg.bucket(b)
+                    if t.numel() == 0:
+                        continue
+                    self._comm.wait_event(events[b])
+                    works.append((dist.all_reduce(t, op=op, group=self.pg, async_op=True), t))
+        else:
+            for b in order:
+                t = fg.bucket(b)
+                if t.numel() == 0:
+                    continue
+                works.append((dist.all_reduce(t, op=op, group=self.pg, async_op=True), t))
         for w, t in works:
-            w.wait()
+            w.wait()                      # the current (main) stream waits for the collective
             if not self._avg:
                 t.div_(self.world)
 
@@ -105,6 +119,12 @@ class FlowTrainer:
         it = iter(self.fg.views)
         self.grad_views = [next(it) if t is not None else None for t in self.table]
         self.sync.broadcast_params([t for t in self.table if t is not None])
+        self.n_flows = len(model.WNs)
+        self.events = None
+        if self.table[0].is_cuda and (self.sync.world > 1 or self.sync._force):
+            self.events = [torch.cuda.Event() for _ in range(self.n_flows + 1)]
+            for e in self.events:
+                e.record()                # materialise the underlying hipEvent_t so its handle can cross the C ABI
 
     @torch.no_grad()
     def step(self, x: torch.Tensor, h: torch.Tensor):
@@ -115,8 +135,10 @@ class FlowTrainer:
         one = torch.ones((), dtype=torch.float32, device=z.device)
         dz, dlogdet = E.nll_loss_backward(z, self.sigma, self.mean, one)
         need = [t is not None and t.requires_grad for t in self.table]
-        eng.backward(table, z, h, dz, dlogdet, need, False, False, grads_out=self.grad_views)
-        self.sync.all_reduce(self.fg)
+        eng.backward(table, z, h, dz, dlogdet, need, False, False, grads_out=self.grad_views, flow_events=self.events)
+        # buckets become final in the order backward retires the flows: last flow first (first flow first in reverse_mode), upsampler last
+        flows = range(self.n_flows) if self.model._reverse_mode else range(self.n_flows - 1, -1, -1)
+        self.sync.all_reduce(self.fg, order=list(flows) + [self.n_flows], events=self.events)
         for t, g in zip(self.table, self.grad_views):
             if t is not None:
                 t.grad = g

@@ -120,11 +120,15 @@ int wg_inverse(const wg_config *cfg, const void *packed, const float *z, const f
  * its output, recomputes that flow's WN activations into the workspace and produces the gradient of every
  * parameter.  dz[B,N], dlogdet[B] are the incoming gradients.  grads: table as params (written, not
  * accumulated).  dh[B,n_mels,F] and dx[B,N] (gradient wrt the audio) may be NULL.  x_rebuilt (nullable)
- * receives the re-materialised input audio [B,N]. */
+ * receives the re-materialised input audio [B,N].
+ * flow_events (nullable): n_flows+1 caller-created hipEvent_t; [k] is recorded on `stream` as soon as every parameter
+ * gradient of flow k (its WN and its 1x1 weight) is final, [n_flows] after the upsampler's -- lets a data-parallel caller
+ * all-reduce one flow's bucket over RCCL while the remaining flows are still in backward (what DDP's bucket hooks do
+ * for the reference, train.py:77). */
 int wg_backward(const wg_config *cfg, const void *const *params, const void *packed,
                 const float *z, const float *h, const float *dz, const float *dlogdet,
                 int B, int N, int F, void *const *grads, float *dh, float *dx, float *x_rebuilt,
-                void *ws, size_t ws_bytes, void *stream);
+                void *ws, size_t ws_bytes, void *stream, void *const *flow_events);
 
 /* WaveGlowLoss.forward (model/loss.py:10-15): loss = mean_b(0.5*sum z^2/sigma^2 - logdet_b) [/N].
  * loss is a device scalar.  The backward writes dz[B,N], dlogdet[B] for an upstream gradient dloss (device scalar,
