@@ -219,8 +219,9 @@ __device__ __forceinline__ void mfma12(const Frags16 &f, f32x16 (&acc)[2][2])
         }
 }
 
-// (a 256x128 / 8-wave variant and a deeper register prefetch were measured and bought nothing: the kernel is bound by the
-// L2->LDS operand stream and by its epilogue traffic)
+// (measured and dropped, each within +-5 %: a 256x128 / 8-wave tile, a two-chunk-deep register prefetch, and LDS-DMA staging
+// (global_load_lds with every 5th lane landing in the row pad).  The kernel is bound by the L2->LDS operand stream and by
+// its epilogue traffic)
 template <int EPI>
 __global__ __launch_bounds__(256) void convgemm16p_kernel(const ConvGemm16sArgs aa)
 {
