@@ -11,6 +11,14 @@ from . import _lib
 from ._lib import WgConfig, WgWnDims, WgError, check
 
 
+def _use_graphs():
+    """WG_GRAPHS=1 replays the inverse from a captured hipGraph.  Off by default: measured on MI355X the ~250 launches of one
+    synthesis call are NOT host bound (2.7 MHz for 16 128 samples either way) -- at one utterance every kernel is a single
+    partial wave of workgroups and the time is the serial chunk latency inside each workgroup."""
+    import os
+    return os.environ.get("WG_GRAPHS", "0") == "1"
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -49,18 +57,22 @@ def make_config(flows, n_group, n_early_every, n_early_size, hop_size, n_mels,
 
 class _Buffers:
     """Zero-initialised device workspaces keyed by (device, tag, shape...).  The kernels keep the zero halo of
-    every activation plane intact, so a workspace is zeroed once when it is allocated."""
+    every activation plane intact, so a workspace is zeroed once when it is allocated.  At most `keep` shapes stay
+    resident (least recently used goes first), so variable-length inference does not pile up multi-GB buffers."""
 
-    def __init__(self):
+    def __init__(self, keep=4):
         self._ws = {}
+        self._keep = keep
 
     def get(self, key, nbytes, device):
-        buf = self._ws.get(key)
+        buf = self._ws.pop(key, None)
         if buf is None or buf.numel() < nbytes or buf.device != device:
             if nbytes == 0:
                 raise WgError("configuration/shape rejected by the HIP engine (workspace query returned 0)")
+            while len(self._ws) >= self._keep:
+                self._ws.pop(next(iter(self._ws)))
             buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
-            self._ws[key] = buf
+        self._ws[key] = buf                      # (re)insert as most recently used
         return buf
 
     def clear(self):
@@ -90,6 +102,7 @@ class ModelEngine:
         self.buffers = _Buffers()
         self.packed = PackedWeights()
         self.n_params = None
+        self._graphs = {}                        # (device, B, N, F) -> captured inverse (hipGraph)
 
     def _pack(self, params, device):
         L = _lib.lib()
@@ -111,19 +124,45 @@ class ModelEngine:
         nbytes = _lib.lib().wg_workspace_bytes(C.byref(self.cfg), B, N, mode)
         return self.buffers.get((device, mode, B, N), nbytes, device)
 
+    def _launch(self, pk, ws, x, h, inverse):
+        B, N = x.shape
+        out = torch.empty_like(x)
+        logdet = torch.empty(B, dtype=torch.float32, device=x.device)
+        fn = _lib.lib().wg_inverse if inverse else _lib.lib().wg_forward
+        check(fn(C.byref(self.cfg), _p(pk), _p(x), _p(h), B, N, h.shape[2], _p(out), _p(logdet), _p(ws), ws.numel(), _stream()),
+              "wg_inverse" if inverse else "wg_forward")
+        return out, logdet
+
     def run(self, params, x, h, inverse):
         require_device(x, h, *params)
         x, h = x.contiguous(), h.contiguous()
         B, N = x.shape
-        F = h.shape[2]
         pk = self._pack(params, x.device)
         ws = self._ws(B, N, 0, x.device)
-        out = torch.empty_like(x)
-        logdet = torch.empty(B, dtype=torch.float32, device=x.device)
-        fn = _lib.lib().wg_inverse if inverse else _lib.lib().wg_forward
-        check(fn(C.byref(self.cfg), _p(pk), _p(x), _p(h), B, N, F, _p(out), _p(logdet), _p(ws), ws.numel(), _stream()),
-              "wg_inverse" if inverse else "wg_forward")
-        return out, logdet
+        if inverse and _use_graphs() and not torch.cuda.is_current_stream_capturing():
+            return self._replay_inverse(pk, ws, x, h)
+        return self._launch(pk, ws, x, h, inverse)
+
+    def _replay_inverse(self, pk, ws, z, h):
+        """Optional (WG_GRAPHS=1): the whole wg_inverse call (~250 launches) is captured once per shape into a hipGraph
+        (torch.cuda.CUDAGraph on the stream the C ABI enqueues on) and replayed."""
+        key = (z.device, tuple(z.shape), h.shape[2], pk.data_ptr(), ws.data_ptr())
+        ent = self._graphs.get(key)
+        if ent is None:
+            sz, sh = z.clone(), h.clone()
+            self._launch(pk, ws, sz, sh, True)                      # warm-up outside capture
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out, logdet = self._launch(pk, ws, sz, sh, True)
+            while len(self._graphs) >= 4:
+                self._graphs.pop(next(iter(self._graphs)))
+            ent = self._graphs[key] = (graph, sz, sh, out, logdet)
+        graph, sz, sh, out, logdet = ent
+        sz.copy_(z)
+        sh.copy_(h)
+        graph.replay()
+        return out.clone(), logdet.clone()
 
     def backward(self, params, z, h, dz, dlogdet, need, need_dh, need_dx, want_x=False, grads_out=None, flow_events=None):
         """need[i]: produce the gradient of params[i] (into grads_out[i] when given).  Returns (grads, dh, dx, x_rebuilt)."""

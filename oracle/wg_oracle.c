@@ -301,7 +301,6 @@ typedef struct {
 } wn_dims;
 
 /* number of parameter-table entries of one WN: V(g,v) start(g,v) depth*(W g,v ; W_o g,v) end */
-static int wn_nparams(const wn_dims *d) { return 4 + 4 * d->depth + 1; }
 static int wo_rows(const wn_dims *d, int i) { return i == d->depth - 1 ? d->Cs : d->C + d->Cs; }
 
 typedef struct {

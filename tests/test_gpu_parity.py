@@ -314,6 +314,19 @@ def test_weight_norm_removed_model_matches(dev):
     assert float((z0 - z1).abs().max()) < 1e-5 and float((l0 - l1).abs().max()) < 1e-3
 
 
+def test_inverse_graph_replay_matches_eager(dev, monkeypatch):
+    """WG_GRAPHS=1: wg_inverse captured into a hipGraph and replayed gives the same audio as the eager launches."""
+    m, cfg, specs, P = build("micro", dev)
+    B, N, F = fill.SHAPES["micro"]
+    _, h = fill.inputs("micro", B, N, F, cfg["n_mels"])
+    z1, z2 = T(fill.normal("g/z1", (B, N)), dev), T(fill.normal("g/z2", (B, N)), dev)
+    with torch.no_grad():
+        want = [m.reverse(z, T(h, dev))[0].clone() for z in (z1, z2)]
+        monkeypatch.setenv("WG_GRAPHS", "1")
+        got = [m.reverse(z, T(h, dev))[0].clone() for z in (z1, z2, z1)]      # capture, replay, replay
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and torch.equal(got[2], want[0])
+
+
 def test_loss_kernel(dev):
     z = fill.normal("loss/z", (3, 4000))
     ld = fill.normal("loss/ld", (3,))
