@@ -219,9 +219,14 @@ __device__ __forceinline__ void mfma12(const Frags16 &f, f32x16 (&acc)[2][2])
         }
 }
 
-// (measured and dropped, each within +-5 %: a 256x128 / 8-wave tile, a two-chunk-deep register prefetch, and LDS-DMA staging
-// (global_load_lds with every 5th lane landing in the row pad).  The kernel is bound by the L2->LDS operand stream and by
-// its epilogue traffic)
+// Measured and dropped (all within +-10 % of this kernel, several slower): a 256x128 / 8-wave tile; LDS-DMA staging
+// (global_load_lds with every 5th lane landing in the row pad); inline-asm loads with hand-counted s_waitcnt running one and
+// two FULL chunks ahead (hipcc's own waitcnt bookkeeping collapses to vmcnt(0) across the loop back edge, so compiler-managed
+// prefetch is only ~half a chunk deep -- but deeper prefetch bought nothing, i.e. L2 latency is not the limiter); and an
+// LDS-free, barrier-free variant in which every wave streams its own fragments straight into registers (both operand formats
+// are fragment shaped in memory) -- correct, 15 % slower.  Ablations: MFMA+LDS alone 92 us, operand staging alone 104 us (83 us
+// when every load hits L1), together 140 us per launch of the dilated conv: the per-CU vector-memory -> VGPR -> LDS path
+// (~31 B/clk/CU sustained) is as long as the matrix work and overlaps it poorly.  See DESIGN.md section 4.
 template <int EPI>
 __global__ __launch_bounds__(256) void convgemm16p_kernel(const ConvGemm16sArgs aa)
 {
