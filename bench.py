@@ -157,7 +157,7 @@ def main():
         gate_flop = 2.0 * kcat * 2 * C2["dilation_channels"] * B * T     # algorithmic FLOPs of one launch
         achieved = gate_flop / (gate_ms * 1e-3) / 1e12
         split = _lib.default_precision() != _lib.PREC_F32
-        kname = {0: 'convgemm_kernel', 1: 'convgemm16_kernel', 2: 'convgemm16p_kernel'}[_lib.default_precision()]
+        kname = {0: 'convgemm_kernel', 1: 'convgemm16_kernel', 2: 'convgemm16w_kernel'}[_lib.default_precision()]
         # bf16x3: every fp32 product costs three bf16 MFMAs; the roofline is the bf16 matrix pipe and only the
         # algorithmic FLOPs are credited (the 3x is overhead, not work) -- SURVEY.md 8d
         peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS

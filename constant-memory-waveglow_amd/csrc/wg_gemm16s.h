@@ -363,6 +363,149 @@ __global__ __launch_bounds__(256) void convgemm16p_kernel(const ConvGemm16sArgs 
 }
 
 // ------------------------------------------------------------------------------------------------
+// convgemm16w: wave-specialised variant.  A workgroup is 8 waves on one CU: waves 0-3 only multiply (ds_read + MFMA on the
+// 128x128 tile, one per SIMD), waves 4-7 only move operands (global -> registers -> LDS, two chunks in flight, counted
+// waits).  The two roles meet at one barrier per chunk.  The per-CU vector-memory -> VGPR -> LDS path and the matrix pipe are
+// both busy for about the same time per chunk; in the symmetric kernels every wave alternates between the two and the
+// phases overlap poorly, here the overlap is structural.
+// ------------------------------------------------------------------------------------------------
+struct Stage8 {
+    u32x4 ah[2], al[2], bh[2], bl[2];
+};
+#define WG_STAGE_REGS(s) "+v"(s.ah[0]), "+v"(s.ah[1]), "+v"(s.al[0]), "+v"(s.al[1]), "+v"(s.bh[0]), "+v"(s.bh[1]), "+v"(s.bl[0]), "+v"(s.bl[1])
+__device__ __forceinline__ void asm_wait_keep8(Stage8 &s) { asm volatile("s_waitcnt vmcnt(8)" : WG_STAGE_REGS(s)::"memory"); }
+
+template <int EPI>
+__global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs aa)
+{
+    constexpr int AIMG = WG16_IMG;
+    constexpr int BUF = 4 * WG16_IMG;
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+    const ConvGemmArgs &a = aa.c;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t0 = blockIdx.x * WG_TILE, m0 = blockIdx.y * WG_TILE, b = blockIdx.z;
+    const Geo g = a.g;
+    int nchunks = 0;
+    for (int s = 0; s < a.nseg; ++s) nchunks += (a.seg[s].nch + WG16_BK - 1) / WG16_BK;
+
+    if (wave >= 4) {
+        // ------------------------------- loader waves -------------------------------
+        const int lt = tid - 256, bt = lt & 127, cg0 = lt >> 7;
+        int cur_seg = 0, cur_c = 0, chunk = 0;
+        const unsigned voff_a = (unsigned)lt * 16u;
+        const unsigned voff_b = (unsigned)((cg0 * g.P + bt) * 16);
+#define WG_LD(dst, base, voff) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
+        const unsigned short *zsrc = aa.sseg[0].hi;           // plane position 0 of the first operand: always-zero halo
+        // Every call issues exactly 8 loads in straight-line code: past the last chunk, and for the missing half of a 16-channel
+        // chunk, base and offset are SELECTED to the zero halo.  No branch may sit between an asm load and its counted wait --
+        // the compiler treats an asm output as valid at once and is free to copy it on a branch arm before the data has landed
+        // (tools/check_asm_loads.py walks the ISA for exactly that).
+        auto issue = [&](Stage8 &st) {
+            const bool live = chunk < nchunks;
+            const int sg = min(cur_seg, a.nseg - 1);
+            const int nch = a.seg[sg].nch, shift = a.seg[sg].shift;
+            const SSeg ss = aa.sseg[sg];
+            const bool full = live && (nch - cur_c > 16);
+            const unsigned short *ih = aa.img + ((size_t)chunk * a.lda + m0) * WG16_BK, *il = ih + aa.img_stride;
+            const unsigned short *row0 = ss.hi + ((size_t)b * (ss.Cp >> 3) + ((ss.ch0 + cur_c) >> 3)) * g.P * 8;   // p = 0: zero halo
+            const unsigned short *b0 = row0 + (size_t)(g.H + t0 + shift) * 8, *b0l = b0 + ss.lo_off;
+            const unsigned short *b1 = b0 + (size_t)2 * g.P * 8, *b1l = b1 + ss.lo_off;
+            const unsigned short *pa0 = live ? ih : zsrc, *pa1 = live ? ih + 2048 : zsrc;
+            const unsigned short *pl0 = live ? il : zsrc, *pl1 = live ? il + 2048 : zsrc;
+            const unsigned short *pb0 = live ? b0 : zsrc, *pb0l = live ? b0l : zsrc;
+            const unsigned short *pb1 = full ? b1 : zsrc, *pb1l = full ? b1l : zsrc;
+            const unsigned va = live ? voff_a : 0u, vb = live ? voff_b : 0u, vb1 = full ? voff_b : 0u;
+            WG_LD(st.ah[0], pa0, va);   WG_LD(st.ah[1], pa1, va);
+            WG_LD(st.al[0], pl0, va);   WG_LD(st.al[1], pl1, va);
+            WG_LD(st.bh[0], pb0, vb);   WG_LD(st.bl[0], pb0l, vb);
+            WG_LD(st.bh[1], pb1, vb1);  WG_LD(st.bl[1], pb1l, vb1);
+            if (live) {
+                ++chunk;
+                cur_c += WG16_BK;
+                if (cur_c >= nch) { cur_c = 0; ++cur_seg; }
+            }
+        };
+#undef WG_LD
+        auto write = [&](const Stage8 &st, int buf) {
+            char *sb = smem + buf * BUF;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int p = lt + 256 * j;
+                const int off = (p >> 2) * WG16_ROWB + (p & 3) * 16;
+                *reinterpret_cast<u32x4 *>(sb + off) = st.ah[j];
+                *reinterpret_cast<u32x4 *>(sb + AIMG + off) = st.al[j];
+                char *q = sb + 2 * AIMG + bt * WG16_ROWB + (cg0 + 2 * j) * 16;
+                *reinterpret_cast<u32x4 *>(q) = st.bh[j];
+                *reinterpret_cast<u32x4 *>(q + WG16_IMG) = st.bl[j];
+            }
+        };
+        Stage8 s0, s1;
+        issue(s0);                                           // chunk 0
+        issue(s1);                                           // chunk 1
+        asm_wait_keep8(s0);
+        write(s0, 0);
+        issue(s0);                                           // chunk 2
+        __syncthreads();                                     // buffer 0 ready
+        // iteration c: compute waves multiply buffer c&1; we write chunk c+1 (landed) into the other buffer and issue chunk c+3
+        auto iter = [&](Stage8 &st, int c) {
+#if !defined(WG_ABL_W_NOLOAD)
+            asm_wait_keep8(st);
+            write(st, (c & 1) ^ 1);
+            issue(st);
+#endif
+            __syncthreads();
+        };
+        // always in pairs (an even chunk count ends with one spare write of zero-halo data into the idle buffer, and the compute
+        // waves take one matching extra barrier): the loop body stays branch-free between loads and waits
+        for (int c = 0; c + 1 < nchunks; c += 2) {
+            iter(s1, c);
+            iter(s0, c + 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the trailing zero-halo loads before the wave ends
+        return;
+    }
+    // ------------------------------- compute waves -------------------------------
+    const int wr = wave >> 1, wc = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    const int r = lane & 31, h = lane >> 5;
+    const int ao = (wr * 64 + r) * WG16_ROWB + h * 16, bo = (wc * 64 + r) * WG16_ROWB + h * 16;
+    __syncthreads();                                         // buffer 0 ready
+    for (int c = 0; c < nchunks; ++c) {
+        const char *sb = smem + (c & 1) * BUF;
+#if defined(WG_ABL_W_NOCOMPUTE)
+        (void)sb; (void)ao; (void)bo;
+#else
+        Frags16 f0, f1;
+#if defined(WG_ABL_W_NOLDSRD)
+        if (c == 0) {
+#endif
+        read_frags16(f0, sb, sb + AIMG, sb + 2 * AIMG, sb + 3 * AIMG, ao, bo);
+        read_frags16(f1, sb, sb + AIMG, sb + 2 * AIMG, sb + 3 * AIMG, ao + 32, bo + 32);
+#if defined(WG_ABL_W_NOLDSRD)
+        }
+#endif
+#if defined(WG_ABL_W_NOMFMA)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            asm volatile("" ::"v"(f0.ah[i]), "v"(f0.al[i]), "v"(f0.bh[i]), "v"(f0.bl[i]), "v"(f1.ah[i]), "v"(f1.al[i]), "v"(f1.bh[i]), "v"(f1.bl[i]));
+#else
+        mfma12(f0, acc);
+        mfma12(f1, acc);
+#endif
+#endif
+        if (c + 1 < nchunks || !(nchunks & 1)) __syncthreads();   // matches the loaders' barrier of iteration c (pairs: see there)
+    }
+    conv_epilogue_s<EPI>(a, aa.s0, acc, t0, m0, b, wr, wc, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
 // wgrad16s: weight gradients from S-planes.  dW[m][n] = sum_b sum_t A[b][m][t] * B[b][n][t + shift]
 // LDS images are [t (32 rows)][c (128 channels)] bf16 with 320-byte rows, filled by 16-byte unit copies; an MFMA fragment
 // (8 consecutive time steps of one channel) is two ds_read_b64_tr_b16 (4x16 hardware transposes), conflict free.

@@ -477,6 +477,15 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                 as.sseg[s].Cp = segs[s].sCp; as.sseg[s].ch0 = segs[s].sch0;
                 if (!segs[s].s && !cx.err) cx.err = WG_EINVAL;
             }
+#if !defined(WG_OPT_NO_WSPEC)                     // default: loader waves + compute waves (8 waves per workgroup)
+            switch (epi) {
+            case EPI_STORE: WG_LAUNCH(cx, convgemm16w_kernel<EPI_STORE>, grid, dim3(512), 0, as); break;
+            case EPI_GATE: WG_LAUNCH(cx, convgemm16w_kernel<EPI_GATE>, grid, dim3(512), 0, as); break;
+            case EPI_RESSKIP: WG_LAUNCH(cx, convgemm16w_kernel<EPI_RESSKIP>, grid, dim3(512), 0, as); break;
+            case EPI_DGATE: WG_LAUNCH(cx, convgemm16w_kernel<EPI_DGATE>, grid, dim3(512), 0, as); break;
+            }
+            return;
+#else                                             // A/B build: the symmetric software-pipelined kernel
             switch (epi) {
             case EPI_STORE: WG_LAUNCH(cx, convgemm16p_kernel<EPI_STORE>, grid, block, 0, as); break;
             case EPI_GATE: WG_LAUNCH(cx, convgemm16p_kernel<EPI_GATE>, grid, block, 0, as); break;
@@ -484,6 +493,7 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
             case EPI_DGATE: WG_LAUNCH(cx, convgemm16p_kernel<EPI_DGATE>, grid, block, 0, as); break;
             }
             return;
+#endif
         }
         const bool big = (rup(mrows, WG_TILE) % 256) == 0;      // 256-row tiles when M allows it
         if (big) {

@@ -110,3 +110,18 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 for needle in ("wg_oracle", "import oracle", "from oracle", "libwgoracle"):
                     assert needle not in text, (f, needle)
+
+
+def test_hand_issued_loads_are_never_touched_before_their_wait():
+    """The loader waves of convgemm16w_kernel issue global loads from inline asm and retire them with hand-counted waits.
+    tools/check_asm_loads.py compiles the device code to ISA and walks every control-flow path of those kernels: no
+    compiler-emitted instruction may read, copy or overwrite a staged register between its load and the wait that retires it."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("hipcc not available")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_loads.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("0 violations") == 4, r.stdout

@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Static check of the hand-issued global loads in the wave-specialised conv kernels (convgemm16w_kernel<*>).
+
+The loader waves issue `global_load_dwordx4` from inline asm and retire them with hand-counted `s_waitcnt vmcnt(N)`; the
+compiler believes an asm output is valid right after the asm statement, so nothing but OUR waits keeps it from reading, copying
+or overwriting a register whose data has not landed.  This script compiles the device code to ISA and walks every
+convgemm16w kernel along its control-flow graph (every path, every distinct in-flight state):
+
+  * an asm load puts its destination registers "in flight";
+  * an asm `s_waitcnt vmcnt(N)` retires all but the newest N in-flight loads;
+  * any compiler-emitted instruction that names an in-flight register is an error.
+
+    python tools/check_asm_loads.py [--defines WG_X,WG_Y] [--keep out.s]
+Exit code 0 = clean.  Used by tests/test_abi_cpu.py.
+"""
+import argparse
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "constant-memory-waveglow_amd", "csrc", "wgflow.hip")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def regs(tok):
+    m = re.match(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    if m:
+        return {int(m.group(1))}
+    return set()
+
+
+def parse(lines):
+    """-> (instructions, label -> index).  An instruction is (line_no, text, in_asm)."""
+    ins, labels, inasm = [], {}, False
+    for no, raw in enumerate(lines, 1):
+        t = raw.strip()
+        if t.startswith(";;#ASMSTART"):
+            inasm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            inasm = False
+            continue
+        m = re.match(r"^(\.LBB\w+):", t)
+        if m:
+            labels[m.group(1)] = len(ins)
+            continue
+        if not t or t[0] in ";.":
+            continue
+        t = t.split(";")[0].strip()
+        if t:
+            ins.append((no, t, inasm))
+    return ins, labels
+
+
+def check_kernel(name, lines):
+    """Walks the control-flow graph; the state is the ordered tuple of in-flight asm loads (their destination registers)."""
+    ins, labels = parse(lines)
+    errors, seen_err = [], set()
+    nload = sum(1 for _, t, a in ins if a and t.startswith("global_load"))
+    nwait = sum(1 for _, t, a in ins if a and t.startswith("s_waitcnt") and "vmcnt" in t)
+    work, visited = [(0, ())], set()
+    while work:
+        pc, st = work.pop()
+        while pc < len(ins):
+            if (pc, st) in visited:
+                break
+            visited.add((pc, st))
+            if len(visited) > 2_000_000:
+                errors.append("%s: state space too large" % name)
+                return nload, nwait, errors
+            no, t, inasm = ins[pc]
+            ops = [o for o in re.split(r"[ ,]+", t) if o]
+            op = ops[0]
+            if inasm and op.startswith("global_load"):
+                dst = frozenset(regs(ops[1]))
+                st = tuple(e for e in st if not (e[0] & dst)) + ((dst, no),)
+            elif inasm and op == "s_waitcnt":
+                m = re.search(r"vmcnt\((\d+)\)", t)
+                if m:
+                    keep = int(m.group(1))
+                    st = st[len(st) - keep:] if keep else ()
+            elif op == "s_endpgm":
+                if st and ("end", no) not in seen_err:
+                    seen_err.add(("end", no))
+                    errors.append("%s:%d: wave ends with %d asm loads in flight" % (name, no, len(st)))
+                break
+            else:
+                used = set()
+                for o in ops[1:]:
+                    used |= regs(o)
+                for dst, at in st:
+                    if used & dst and (no, at) not in seen_err:
+                        seen_err.add((no, at))
+                        errors.append("%s:%d: `%s` touches v%d.. loaded at line %d before its wait" % (name, no, t, min(dst), at))
+                if op == "s_branch":
+                    pc = labels[ops[1]]
+                    continue
+                if op.startswith("s_cbranch"):
+                    work.append((labels[ops[1]], st))
+            pc += 1
+    return nload, nwait, errors
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--defines", default="")
+    ap.add_argument("--keep", default=None)
+    a = ap.parse_args()
+    out = a.keep or os.path.join(tempfile.mkdtemp(prefix="wgisa"), "wgflow.s")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-w", "-o", out, SRC]
+    cmd += ["-D" + d for d in a.defines.split(",") if d]
+    subprocess.run(cmd, check=True)
+    text = open(out).read().split("\n")
+    starts = [i for i, l in enumerate(text) if re.match(r"^_Z\d+convgemm16w_kernel\w*:", l)]
+    if not starts:
+        print("no convgemm16w_kernel instantiation in the ISA")
+        return 1
+    bad = 0
+    for s in starts:
+        e = next(i for i in range(s, len(text)) if ".amdhsa_kernel" in text[i] or text[i].startswith(".Lfunc_end"))
+        kname = text[s].split(":")[0]
+        nload, nwait, errors = check_kernel(kname, text[s:e])
+        print("%s: %d asm loads, %d counted waits, %d violations" % (kname, nload, nwait, len(errors)))
+        for m in errors[:10]:
+            print("   ", m)
+        bad += len(errors)
+        if nload == 0:
+            bad += 1
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
