@@ -368,6 +368,16 @@ __global__ __launch_bounds__(256) void convgemm16p_kernel(const ConvGemm16sArgs 
 // waits).  The two roles meet at one barrier per chunk.  The per-CU vector-memory -> VGPR -> LDS path and the matrix pipe are
 // both busy for about the same time per chunk; in the symmetric kernels every wave alternates between the two and the
 // phases overlap poorly, here the overlap is structural.
+// Where the time of this kernel goes (gate conv, 27 chunks, 1536 tiles; rocprofv3 PMC: clock 2.06 GHz, matrix pipe 47 % busy):
+//   compute waves alone (loaders only take the barriers)            101 us = 2560 cycles per chunk and CU
+//     = 1536 cycles of MFMA (2 workgroups x 24 MFMA x 32 cycles per SIMD) + 1024 cycles of LDS reads (128 KB at 128 B/clk):
+//     the two do not overlap -- and LDS writes (64 KB, 512 cycles) + reads already fill the LDS pipe for as long as the MFMAs run,
+//     so at this tile shape (64x64 per wave, separate hi and lo images) the LDS port is co-critical with the matrix pipe;
+//   loader waves alone                                                82 us
+//   both                                                             129 us; loads served from L1/L2 only: no change; compute
+//   waves skipping their LDS reads: no change; s_setprio on the compute waves: no change.
+// The barrier of chunk c moved between its two k-steps (-DWG_OPT_W_MIDBAR: fragments of chunk c+1 fetched under the MFMAs of
+// k-step 1) needs 132 VGPRs, i.e. one workgroup per CU: 148 us.
 // ------------------------------------------------------------------------------------------------
 struct Stage8 {
     u32x4 ah[2], al[2], bh[2], bl[2];
@@ -391,8 +401,14 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
 
     if (wave >= 4) {
         // ------------------------------- loader waves -------------------------------
+#if defined(WG_OPT_W_PRIO)
+        __builtin_amdgcn_s_setprio(0);
+#endif
         const int lt = tid - 256, bt = lt & 127, cg0 = lt >> 7;
         int cur_seg = 0, cur_c = 0, chunk = 0;
+#if defined(WG_ABL_W_SAMECHUNK)
+        int fake = 0;
+#endif
         const unsigned voff_a = (unsigned)lt * 16u;
         const unsigned voff_b = (unsigned)((cg0 * g.P + bt) * 16);
 #define WG_LD(dst, base, voff) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
@@ -422,7 +438,11 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
             WG_LD(st.bh[1], pb1, vb1);  WG_LD(st.bl[1], pb1l, vb1);
             if (live) {
                 ++chunk;
+#if defined(WG_ABL_W_SAMECHUNK)
+                --chunk; if (++fake >= nchunks) chunk = nchunks;
+#else
                 cur_c += WG16_BK;
+#endif
                 if (cur_c >= nch) { cur_c = 0; ++cur_seg; }
             }
         };
@@ -466,6 +486,9 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
         return;
     }
     // ------------------------------- compute waves -------------------------------
+#if defined(WG_OPT_W_PRIO)
+    __builtin_amdgcn_s_setprio(3);
+#endif
     const int wr = wave >> 1, wc = wave & 1;
     f32x16 acc[2][2];
 #pragma unroll
@@ -477,30 +500,149 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
     const int r = lane & 31, h = lane >> 5;
     const int ao = (wr * 64 + r) * WG16_ROWB + h * 16, bo = (wc * 64 + r) * WG16_ROWB + h * 16;
     __syncthreads();                                         // buffer 0 ready
+#if !defined(WG_OPT_W_MIDBAR)
     for (int c = 0; c < nchunks; ++c) {
         const char *sb = smem + (c & 1) * BUF;
-#if defined(WG_ABL_W_NOCOMPUTE)
-        (void)sb; (void)ao; (void)bo;
-#else
         Frags16 f0, f1;
-#if defined(WG_ABL_W_NOLDSRD)
-        if (c == 0) {
-#endif
         read_frags16(f0, sb, sb + AIMG, sb + 2 * AIMG, sb + 3 * AIMG, ao, bo);
         read_frags16(f1, sb, sb + AIMG, sb + 2 * AIMG, sb + 3 * AIMG, ao + 32, bo + 32);
-#if defined(WG_ABL_W_NOLDSRD)
-        }
-#endif
-#if defined(WG_ABL_W_NOMFMA)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            asm volatile("" ::"v"(f0.ah[i]), "v"(f0.al[i]), "v"(f0.bh[i]), "v"(f0.bl[i]), "v"(f1.ah[i]), "v"(f1.al[i]), "v"(f1.bh[i]), "v"(f1.bl[i]));
-#else
         mfma12(f0, acc);
         mfma12(f1, acc);
-#endif
-#endif
         if (c + 1 < nchunks || !(nchunks & 1)) __syncthreads();   // matches the loaders' barrier of iteration c (pairs: see there)
+    }
+#else
+    // The barrier of chunk c ("chunk c+1 is written, buffer c&1 may be overwritten") sits in the MIDDLE of the chunk: both k-steps
+    // of chunk c are in registers by then, and the first k-step of chunk c+1 is fetched right behind it, under the twelve MFMAs
+    // of k-step 1.  A wave never starts a chunk by waiting for LDS.
+    Frags16 f0, f1;
+    read_frags16(f0, smem, smem + AIMG, smem + 2 * AIMG, smem + 3 * AIMG, ao, bo);
+    for (int c = 0; c < nchunks; ++c) {
+        const char *sb = smem + (c & 1) * BUF, *sn = smem + ((c & 1) ^ 1) * BUF;
+        read_frags16(f1, sb, sb + AIMG, sb + 2 * AIMG, sb + 3 * AIMG, ao + 32, bo + 32);
+        mfma12(f0, acc);
+        if (c + 1 < nchunks || !(nchunks & 1)) __syncthreads();   // matches the loaders' barrier of iteration c (pairs: see there)
+        if (c + 1 < nchunks) read_frags16(f0, sn, sn + AIMG, sn + 2 * AIMG, sn + 3 * AIMG, ao, bo);
+        mfma12(f1, acc);
+    }
+#endif
+    conv_epilogue_s<EPI>(a, aa.s0, acc, t0, m0, b, wr, wc, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// convgemm16d: LDS-DMA loader ring + register-pipelined compute waves.  Six waves per workgroup, two workgroups per CU:
+//   waves 0-3  multiply; fragments of the next k-step are fetched under the twelve MFMAs of the current one (the barrier of
+//              chunk c sits between its two k-steps, so a wave never starts a chunk by waiting for LDS);
+//   wave 4     streams the A images (weights hi|lo) of the next chunk global -> LDS with global_load_lds_dwordx4,
+//   wave 5     the B images (S-planes hi|lo): no staging VGPRs, no ds_write, nothing of the copy passes through a SIMD's
+//              register file while its matrix pipe works.
+// An LDS-DMA writes lane-linear (base + lane * 16 B), so the images are unpadded 64-byte rows and the bank-conflict-free
+// order is an XOR swizzle applied on BOTH sides: lane l of a DMA fetches k-group (l & 3) ^ ((row >> 2) & 3) of its row, and a
+// fragment read of k-group q of row r goes to slot q ^ ((r >> 2) & 3).
+// Ordering: a loader wave waits vmcnt(0) for its own DMAs, then takes the barrier; a compute wave reads only after that
+// barrier (cdna_hip_programming.md section 5, "Read a staged buffer one phase AFTER the wait that retires it").
+// MEASURED (opt-in build -DWG_OPT_DMA, parity identical): 232 us per launch of the dilated conv against 129-135 us for
+// convgemm16w.  With two 32 KB buffers per workgroup a DMA can only run ONE chunk ahead (its target is free only once the
+// compute waves hold the previous chunk in registers) and a chunk lasts ~1.5 us while a load under this kernel's own L2 traffic
+// (~10 TB/s aggregate) takes 2-3 us; convgemm16w's staging registers are the extra ~128 KB per CU of buffering that hides it.
+// A ring deep enough for DMA (>= 3 chunks ahead) does not fit 2 x 80 KB of LDS.  Kept as the reference point for that trade.
+// ------------------------------------------------------------------------------------------------
+#define WG16D_IMG (128 * 64)
+typedef __attribute__((address_space(3))) void wg_lds_void;
+typedef const __attribute__((address_space(1))) void wg_glb_void;
+__device__ __forceinline__ void dma16(const void *src, char *lds_dst)
+{
+    __builtin_amdgcn_global_load_lds((wg_glb_void *)src, (wg_lds_void *)lds_dst, 16, 0, 0);
+}
+__device__ __forceinline__ void read_frags16d(Frags16 &f, const char *buf, int ao, int bo)
+{
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        f.ah[i] = *reinterpret_cast<const bf16x8 *>(buf + ao + i * 2048);
+        f.al[i] = *reinterpret_cast<const bf16x8 *>(buf + WG16D_IMG + ao + i * 2048);
+        f.bh[i] = *reinterpret_cast<const bf16x8 *>(buf + 2 * WG16D_IMG + bo + i * 2048);
+        f.bl[i] = *reinterpret_cast<const bf16x8 *>(buf + 3 * WG16D_IMG + bo + i * 2048);
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(384, 3) void convgemm16d_kernel(const ConvGemm16sArgs aa)
+{
+    constexpr int IMG = WG16D_IMG, BUF = 4 * IMG;
+    __shared__ __attribute__((aligned(1024))) char smem[2 * BUF];
+    const ConvGemmArgs &a = aa.c;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t0 = blockIdx.x * WG_TILE, m0 = blockIdx.y * WG_TILE, b = blockIdx.z;
+    const Geo g = a.g;
+    int nchunks = 0;
+    for (int s = 0; s < a.nseg; ++s) nchunks += (a.seg[s].nch + WG16_BK - 1) / WG16_BK;
+
+    if (wave >= 4) {
+        // ------------------------------- loader waves -------------------------------
+        const int rsub = lane >> 2, kg = (lane & 3) ^ ((lane >> 4) & 3);     // row inside a 16-row piece, source k-group
+        int cur_seg = 0, cur_c = 0, chunk = 0;
+        auto issue = [&](int buf) {
+            char *dst = smem + buf * BUF;
+            if (wave == 4) {
+                const char *src = reinterpret_cast<const char *>(aa.img + ((size_t)chunk * a.lda + m0) * WG16_BK) + rsub * 64 + kg * 16;
+                const char *srcl = src + aa.img_stride * 2;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    dma16(src + j * 1024, dst + j * 1024);
+                    dma16(srcl + j * 1024, dst + IMG + j * 1024);
+                }
+            } else {
+                const int nch = a.seg[cur_seg].nch, shift = a.seg[cur_seg].shift;
+                const SSeg ss = aa.sseg[cur_seg];
+                const bool real = kg < 2 || nch - cur_c > 16;
+                const unsigned short *row0 = ss.hi + ((size_t)b * (ss.Cp >> 3) + ((ss.ch0 + cur_c) >> 3)) * g.P * 8;   // p = 0: zero halo
+                const unsigned short *ph = real ? row0 + ((size_t)kg * g.P + (g.H + t0 + shift) + rsub) * 8 : row0 + rsub * 8;
+                const unsigned short *pl = ph + ss.lo_off;
+                const int step = real ? 16 * 8 : 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    dma16(ph + j * step, dst + 2 * IMG + j * 1024);
+                    dma16(pl + j * step, dst + 3 * IMG + j * 1024);
+                }
+            }
+            ++chunk;
+            cur_c += WG16_BK;
+            if (cur_c >= a.seg[cur_seg].nch) { cur_c = 0; ++cur_seg; }
+        };
+        issue(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // buffer 0 ready
+        for (int c = 0; c < nchunks; ++c) {
+            if (c + 1 < nchunks) issue((c + 1) & 1);         // the compute waves hold chunk c-1 in registers since barrier c-1
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                    // barrier c: chunk c+1 has landed
+        }
+        return;
+    }
+    // ------------------------------- compute waves -------------------------------
+    const int wr = wave >> 1, wc = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    const int r = lane & 31, h = lane >> 5, swz = (r >> 2) & 3;
+    const int ao0 = (wr * 64 + r) * 64 + ((h ^ swz) << 4), ao1 = ao0 ^ 32;
+    const int bo0 = (wc * 64 + r) * 64 + ((h ^ swz) << 4), bo1 = bo0 ^ 32;
+    __syncthreads();                                         // buffer 0 ready
+    Frags16 f0, f1;
+    read_frags16d(f0, smem, ao0, bo0);
+    for (int c = 0; c < nchunks; ++c) {
+        const char *sb = smem + (c & 1) * BUF, *sn = smem + ((c & 1) ^ 1) * BUF;
+        read_frags16d(f1, sb, ao1, bo1);
+        mfma12(f0, acc);
+        __builtin_amdgcn_sched_barrier(0);                   // keep the twelve MFMAs between the reads of f1 and the barrier's lgkmcnt(0)
+        __syncthreads();                                     // barrier c: both k-steps of chunk c are in registers; chunk c+1 has landed
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < nchunks) read_frags16d(f0, sn, ao0, bo0);
+        mfma12(f1, acc);
     }
     conv_epilogue_s<EPI>(a, aa.s0, acc, t0, m0, b, wr, wc, lane);
 }

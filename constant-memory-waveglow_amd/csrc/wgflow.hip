@@ -477,7 +477,15 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                 as.sseg[s].Cp = segs[s].sCp; as.sseg[s].ch0 = segs[s].sch0;
                 if (!segs[s].s && !cx.err) cx.err = WG_EINVAL;
             }
-#if !defined(WG_OPT_NO_WSPEC)                     // default: loader waves + compute waves (8 waves per workgroup)
+#if defined(WG_OPT_DMA)                           // LDS-DMA loader ring (6 waves per workgroup)
+            switch (epi) {
+            case EPI_STORE: WG_LAUNCH(cx, convgemm16d_kernel<EPI_STORE>, grid, dim3(384), 0, as); break;
+            case EPI_GATE: WG_LAUNCH(cx, convgemm16d_kernel<EPI_GATE>, grid, dim3(384), 0, as); break;
+            case EPI_RESSKIP: WG_LAUNCH(cx, convgemm16d_kernel<EPI_RESSKIP>, grid, dim3(384), 0, as); break;
+            case EPI_DGATE: WG_LAUNCH(cx, convgemm16d_kernel<EPI_DGATE>, grid, dim3(384), 0, as); break;
+            }
+            return;
+#elif !defined(WG_OPT_NO_WSPEC)                   // default: loader waves + compute waves (8 waves per workgroup)
             switch (epi) {
             case EPI_STORE: WG_LAUNCH(cx, convgemm16w_kernel<EPI_STORE>, grid, dim3(512), 0, as); break;
             case EPI_GATE: WG_LAUNCH(cx, convgemm16w_kernel<EPI_GATE>, grid, dim3(512), 0, as); break;
