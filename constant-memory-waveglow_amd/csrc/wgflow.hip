@@ -5,6 +5,7 @@
 #include "wg_small.h"
 #include "wg_gemm16.h"
 #include "wg_gemm16s.h"
+#include "wg_wsr.h"
 
 #include <algorithm>
 #include <atomic>
@@ -1120,6 +1121,30 @@ int wg_upsample(const wg_config *cf, const void *packed, const float *h, int B, 
     const ModelPack M = model_pack_layout(cf);
     const Geo g = make_geo(B, T, 0);
     run_upsample(cx, cf, pk + M.up_w, pk + M.up_bias, h, F, g, pnull(), y);
+    return cx.err;
+}
+
+// ---- WSRGlow conditioning front-end ---------------------------------------------------------------
+int wg_wsr_cond(const float *c, int B, int L, const float *mu_table, const float *ang_table, float *cond, void *stream)
+{
+    if (!c || !mu_table || !ang_table || !cond || B < 1 || L < 8) return WG_EINVAL;
+    if (L % 8) return WG_ESHAPE;
+    Ctx cx = {(hipStream_t)stream, 0, 0};
+    const int F = L / 8, nslice = 32, per = (WSR_COND + nslice - 1) / nslice;
+    WG_LAUNCH(cx, wsr_cond_kernel, dim3((F + WSR_FT - 1) / WSR_FT, nslice, B), dim3(256), 0, c, L, mu_table, ang_table, cond, per);
+    return cx.err;
+}
+
+int wg_wsr_cond_backward(const float *c, int B, int L, const float *dcond, float *dmu_table, float *dang_table, void *stream)
+{
+    if (!c || !dcond || !dmu_table || !dang_table || B < 1 || L < 8) return WG_EINVAL;
+    if (L % 8) return WG_ESHAPE;
+    Ctx cx = {(hipStream_t)stream, 0, 0};
+    if (hipMemsetAsync(dmu_table, 0, sizeof(float) * WSR_MU * WSR_MU_DIM, cx.st) != hipSuccess ||
+        hipMemsetAsync(dang_table, 0, sizeof(float) * WSR_ANG * WSR_ANG_DIM, cx.st) != hipSuccess)
+        return WG_ELAUNCH;
+    WG_LAUNCH(cx, wsr_table_grad_kernel<false>, dim3((WSR_MU_DIM + 15) / 16, 8), dim3(256), 0, c, B, L, dcond, dmu_table);
+    WG_LAUNCH(cx, wsr_table_grad_kernel<true>, dim3((WSR_ANG_DIM + 15) / 16, WSR_BINS), dim3(256), 0, c, B, L, dcond, dang_table);
     return cx.err;
 }
 

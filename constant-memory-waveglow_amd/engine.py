@@ -317,3 +317,34 @@ def nll_loss_backward(z, sigma, elementwise_mean, dloss):
     check(_lib.lib().wg_nll_loss_backward(_p(z), B, N, float(sigma), int(elementwise_mean), _p(dloss.contiguous()), _p(dz),
                                           _p(dlogdet), _stream()), "wg_nll_loss_backward")
     return dz, dlogdet
+
+
+# ---- WSRGlow conditioning front-end (include/wgflow.h: wg_wsr_cond*) -----------------------------------------------------
+WSR_COND_CHANNELS = 8 * 400 + 9 * 51
+
+
+def wsr_cond(c, mu_table, ang_table):
+    """c[B,L] -> cond[B,3659,L/8]  (WSRGlow._get_cond, model/wsrglow.py:37-50; c is read clipped, not modified)."""
+    require_device(c, mu_table, ang_table)
+    if c.dim() != 2 or c.size(1) % 8 or c.size(1) < 8:
+        raise WgError("WSRGlow conditioning signal must be [B, L] with L a multiple of 8")
+    if tuple(mu_table.shape) != (256, 400) or tuple(ang_table.shape) != (120, 50):
+        raise WgError("WSRGlow embedding tables must be [256,400] and [120,50]")
+    c, mu_table, ang_table = c.contiguous(), mu_table.contiguous(), ang_table.contiguous()
+    B, L = c.shape
+    cond = torch.empty(B, WSR_COND_CHANNELS, L // 8, dtype=torch.float32, device=c.device)
+    check(_lib.lib().wg_wsr_cond(_p(c), B, L, _p(mu_table), _p(ang_table), _p(cond), _stream()), "wg_wsr_cond")
+    return cond
+
+
+def wsr_cond_backward(c, dcond):
+    """-> (d mu_table [256,400], d ang_table [120,50]) from dcond[B,3659,L/8]."""
+    require_device(c, dcond)
+    c, dcond = c.contiguous(), dcond.contiguous()
+    B, L = c.shape
+    if tuple(dcond.shape) != (B, WSR_COND_CHANNELS, L // 8):
+        raise WgError("dcond must be [B, 3659, L/8]")
+    dmu = torch.empty(256, 400, dtype=torch.float32, device=c.device)
+    dang = torch.empty(120, 50, dtype=torch.float32, device=c.device)
+    check(_lib.lib().wg_wsr_cond_backward(_p(c), B, L, _p(dcond), _p(dmu), _p(dang), _stream()), "wg_wsr_cond_backward")
+    return dmu, dang

@@ -167,6 +167,18 @@ int wg_coupling_backward(const wg_wn_dims *d, const void *const *params, const v
 /* mel upsampler alone (waveglow.py:126-130,210-212, cropped to T as :157): h[B,n_mels,F] -> y[B,n_mels,T] */
 int wg_upsample(const wg_config *cfg, const void *packed, const float *h, int B, int F, int T, float *y, void *stream);
 
+/* ---- WSRGlow conditioning front-end -------------------------------------------------------------
+ * Replaces WSRGlow._get_cond (model/wsrglow.py:37-50): c[B,L] (low-rate audio, L a multiple of 8) ->
+ * cond[B, WG_WSR_COND_CHANNELS, L/8] = cat(mu-law(256) embedding [8*400], |STFT16| [9], phase embedding [9*50]).
+ * mu_table is `mu_enc.1.weight` [256,400] (wsrglow.py:27-30), ang_table is `angle_embed.embed.weight` [120,50]
+ * (wsrglow.py:8-18,31).  c is read clipped to [-1,1] and NOT modified (the reference clips it in place, wsrglow.py:38:
+ * the Python mirror does that).  The result feeds wg_forward / wg_inverse as `h` of a WaveGlow with n_mels = 3659. */
+#define WG_WSR_COND_CHANNELS 3659
+int wg_wsr_cond(const float *c, int B, int L, const float *mu_table, const float *ang_table, float *cond, void *stream);
+/* Its backward: the two nn.Embedding weight gradients from dcond[B,3659,L/8] (c has no gradient path: wsrglow.py:39,48 go
+ * through integer indices, :47 has no parameters).  Outputs are overwritten. */
+int wg_wsr_cond_backward(const float *c, int B, int L, const float *dcond, float *dmu_table, float *dang_table, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,7 @@
  *   - invertible 1x1 convolution              model/efficient_modules.py:37-54,215-279
  *   - affine coupling fwd / inverse / bwd     model/efficient_modules.py:77-96,99-212
  *   - NLL loss                                model/loss.py:10-15
+ *   - WSRGlow conditioning front-end          model/wsrglow.py:8-18,27-50 (mu-law: torchaudio, restated)
  * The backward pass follows the reference's constant-memory protocol: nothing but the
  * flow outputs is kept; each block rebuilds its input from its output
  * (efficient_modules.py:127-136, 235-237) and that REBUILT input is what enters the
@@ -1188,6 +1189,131 @@ WGO_API int wgo_upsample(const wgo_config *cf, const float *bias, const float *g
         r2f(yb, y + (long)b * cf->n_mels * T, (long)cf->n_mels * T);
     }
     free(w); free(yb);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * WSRGlow conditioning front-end: WSRGlow._get_cond, model/wsrglow.py:37-50.
+ *   c      = clip(c, -1, 1)                                                              wsrglow.py:38
+ *   c_emb  = Embedding(256,400)(MuLawEncoding(256)(c)).view(B,-1,3200).transpose(1,2)     wsrglow.py:27-30,39
+ *   spec   = stft(reflect_pad(c,(4,4)), n_fft=16, hop=8, hann(16), center=False)          wsrglow.py:40-46
+ *   mag    = |spec| ; phase_emb = AngleEmbedding(120,50)(angle(spec)) as [B, 9*50, F]     wsrglow.py:8-18,47-49
+ *   cond   = cat([c_emb, mag, phase_emb], 1)        -> [B, 3200 + 9 + 450 = 3659, F = L/8] wsrglow.py:50
+ * MuLawEncoding lives in torchaudio (absent from /root/reference and from this image; the reference pins no
+ * version).  Its published algorithm (torchaudio.functional.mu_law_encoding, unchanged since 0.8):
+ *   mu = 255 ; x_mu = sign(x) * log1p(mu*|x|) / log1p(mu) ; q = int64((x_mu + 1) / 2 * mu + 0.5)   (truncation)
+ * AngleEmbedding: index = int64((angle / pi + 1) * 0.5 * (embed_num - 1))                  wsrglow.py:16-17
+ * The two index computations are done in float32 exactly as torch does them, whatever WGO_REAL is: they are
+ * quantisers, and a one-ulp difference at a bin edge selects another embedding row.
+ * Window: torch.hann_window(16) is periodic: w[n] = 0.5 - 0.5 cos(2 pi n / 16)             wsrglow.py:35
+ * ------------------------------------------------------------------------------------------------ */
+#define WSR_MU 256
+#define WSR_MU_DIM 400
+#define WSR_NFFT 16
+#define WSR_HOP 8
+#define WSR_BINS 9
+#define WSR_ANG 120
+#define WSR_ANG_DIM 50
+#define WSR_COND (8 * WSR_MU_DIM + WSR_BINS * (1 + WSR_ANG_DIM))
+
+static inline float clipf(float x) { return x < -1.f ? -1.f : (x > 1.f ? 1.f : x); }
+static inline int wsr_mu_index(float x)
+{
+    const float mu = 255.f;
+    const float sgn = (x > 0.f) - (x < 0.f);
+    const float x_mu = sgn * log1pf(mu * fabsf(x)) / log1pf(mu);
+    return (int)((x_mu + 1.f) / 2.f * mu + 0.5f);
+}
+static inline int wsr_angle_index(float ang)
+{
+    return (int)((ang / 3.14159274101257324f + 1.f) * 0.5f * (float)(WSR_ANG - 1));
+}
+/* padded signal of F.pad(c, (4,4), 'reflect'): position i in [0, L+8) */
+static inline float wsr_padded(const float *c, int L, int i)
+{
+    int j = i - 4;
+    if (j < 0) j = -j;
+    if (j >= L) j = 2 * (L - 1) - j;
+    return clipf(c[j]);
+}
+/* one frame of the 16-point STFT: re/im of bins 0..8 (real arithmetic), then the float32 magnitude / angle torch would hold */
+static void wsr_frame(const float *c, int L, int f, float *mag, float *ang)
+{
+    real x[WSR_NFFT];
+    for (int n = 0; n < WSR_NFFT; ++n) {
+        const real w = (real)0.5 - (real)0.5 * (real)cos(2.0 * M_PI * n / WSR_NFFT);
+        x[n] = w * (real)wsr_padded(c, L, WSR_HOP * f + n);
+    }
+    for (int k = 0; k < WSR_BINS; ++k) {
+        real re = 0, im = 0;
+        for (int n = 0; n < WSR_NFFT; ++n) {
+            const int m = (k * n) % WSR_NFFT;
+            re += x[n] * (real)cos(2.0 * M_PI * m / WSR_NFFT);
+            im -= x[n] * (real)sin(2.0 * M_PI * m / WSR_NFFT);
+        }
+        if (k == 0 || k == WSR_NFFT / 2) im = 0;     /* a real FFT returns exactly +0 there (DC, Nyquist) */
+        const float fre = (float)re, fim = (float)im;
+        mag[k] = hypotf(fre, fim);
+        ang[k] = atan2f(fim, fre);
+    }
+}
+
+/* cond[B][3659][F], F = L/8.  mu_idx[B][L] and ang_idx[B][9][F] are optional outputs (the quantiser decisions). */
+WGO_API int wgo_wsr_cond(const float *c, int B, int L, const float *mu_w, const float *ang_w, float *cond,
+                         int32_t *mu_idx, int32_t *ang_idx)
+{
+    if (L % WSR_HOP || L < 8) return -1;
+    const int F = L / WSR_HOP;
+    for (int b = 0; b < B; ++b) {
+        const float *cb = c + (long)b * L;
+        float *ob = cond + (long)b * WSR_COND * F;
+        for (int f = 0; f < F; ++f) {
+            for (int j = 0; j < 8; ++j) {
+                const int q = wsr_mu_index(clipf(cb[8 * f + j]));
+                if (mu_idx) mu_idx[(long)b * L + 8 * f + j] = q;
+                for (int e = 0; e < WSR_MU_DIM; ++e) ob[(long)(j * WSR_MU_DIM + e) * F + f] = mu_w[(long)q * WSR_MU_DIM + e];
+            }
+            float mag[WSR_BINS], ang[WSR_BINS];
+            wsr_frame(cb, L, f, mag, ang);
+            for (int k = 0; k < WSR_BINS; ++k) {
+                ob[(long)(8 * WSR_MU_DIM + k) * F + f] = mag[k];
+                const int q = wsr_angle_index(ang[k]);
+                if (ang_idx) ang_idx[((long)b * WSR_BINS + k) * F + f] = q;
+                for (int e = 0; e < WSR_ANG_DIM; ++e)
+                    ob[(long)(8 * WSR_MU_DIM + WSR_BINS + k * WSR_ANG_DIM + e) * F + f] = ang_w[(long)q * WSR_ANG_DIM + e];
+            }
+        }
+    }
+    return 0;
+}
+
+/* gradients of the two embedding tables given dcond[B][3659][F] (c itself carries no gradient: both paths from c to cond that
+ * have parameters go through integer indices; mag has no parameters).  nn.Embedding backward = scatter-add of rows. */
+WGO_API int wgo_wsr_cond_backward(const float *c, int B, int L, const float *dcond, float *dmu_w, float *dang_w)
+{
+    if (L % WSR_HOP || L < 8) return -1;
+    const int F = L / WSR_HOP;
+    real *gm = rzalloc((size_t)WSR_MU * WSR_MU_DIM), *ga = rzalloc((size_t)WSR_ANG * WSR_ANG_DIM);
+    for (int b = 0; b < B; ++b) {
+        const float *cb = c + (long)b * L;
+        const float *gb = dcond + (long)b * WSR_COND * F;
+        for (int f = 0; f < F; ++f) {
+            for (int j = 0; j < 8; ++j) {
+                const int q = wsr_mu_index(clipf(cb[8 * f + j]));
+                for (int e = 0; e < WSR_MU_DIM; ++e) gm[(long)q * WSR_MU_DIM + e] += (real)gb[(long)(j * WSR_MU_DIM + e) * F + f];
+            }
+            float mag[WSR_BINS], ang[WSR_BINS];
+            wsr_frame(cb, L, f, mag, ang);
+            for (int k = 0; k < WSR_BINS; ++k) {
+                const int q = wsr_angle_index(ang[k]);
+                for (int e = 0; e < WSR_ANG_DIM; ++e)
+                    ga[(long)q * WSR_ANG_DIM + e] += (real)gb[(long)(8 * WSR_MU_DIM + WSR_BINS + k * WSR_ANG_DIM + e) * F + f];
+            }
+        }
+    }
+    r2f(gm, dmu_w, (long)WSR_MU * WSR_MU_DIM);
+    r2f(ga, dang_w, (long)WSR_ANG * WSR_ANG_DIM);
+    free(gm); free(ga);
     return 0;
 }
 

@@ -199,3 +199,34 @@ def coupling_backward(wn, params, z, y, dz, dlog_s, need_dy=True, reverse=False,
     fn = _lib(double).wgo_coupling_reverse_backward if reverse else _lib(double).wgo_coupling_backward
     _check(fn(*_wn_args(wn), tab, _ptr(z), _ptr(y), _ptr(dz), _ptr(dlog_s), B, T, _ptr(x), _ptr(dx), _ptr(dy), gtab), "coupling_backward")
     return dict(x=x, dx=dx, dy=dy, grads=grads)
+
+
+# ---- WSRGlow conditioning front-end (model/wsrglow.py:37-50) -------------------------------------
+
+WSR_COND = 8 * 400 + 9 * 51
+
+
+def wsr_cond(c, mu_w, ang_w, double=False, return_idx=False):
+    """cond[B,3659,L/8] = cat(mu-law embedding, |STFT16|, phase embedding).  c is NOT modified (the reference clips it in place)."""
+    c, mu_w, ang_w = _f32(c), _f32(mu_w), _f32(ang_w)
+    B, L = c.shape
+    assert mu_w.shape == (256, 400) and ang_w.shape == (120, 50)
+    F = L // 8
+    cond = np.empty((B, WSR_COND, F), np.float32)
+    mi = np.empty((B, L), np.int32)
+    ai = np.empty((B, 9, F), np.int32)
+    ip = C.POINTER(C.c_int32)
+    _check(_lib(double).wgo_wsr_cond(_ptr(c), B, L, _ptr(mu_w), _ptr(ang_w), _ptr(cond),
+                                     mi.ctypes.data_as(ip), ai.ctypes.data_as(ip)), "wsr_cond")
+    return (cond, mi, ai) if return_idx else cond
+
+
+def wsr_cond_backward(c, dcond, double=False):
+    """-> (d mu_enc.1.weight [256,400], d angle_embed.embed.weight [120,50])."""
+    c, dcond = _f32(c), _f32(dcond)
+    B, L = c.shape
+    assert dcond.shape == (B, WSR_COND, L // 8)
+    dmu = np.empty((256, 400), np.float32)
+    dang = np.empty((120, 50), np.float32)
+    _check(_lib(double).wgo_wsr_cond_backward(_ptr(c), B, L, _ptr(dcond), _ptr(dmu), _ptr(dang)), "wsr_cond_backward")
+    return dmu, dang

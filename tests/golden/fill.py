@@ -144,14 +144,29 @@ CONFIGS = {
 # down: odd conditioning width (not a multiple of 8), 16 squeezed channels, upsample factor 1
 CONFIGS["wsr_like"] = dict(flows=4, n_group=16, n_early_every=2, n_early_size=2, hop_size=16, n_mels=83,
                            dilation_channels=64, residual_channels=64, skip_channels=64, depth=3, radix=3)
+# WSRGlow(upsample_rate=2, **WSR_KW): the WaveGlow underneath is fixed by model/wsrglow.py:23-26
+WSR_KW = dict(dilation_channels=32, residual_channels=32, skip_channels=32, depth=2, radix=3)
+CONFIGS["wsr"] = dict(flows=12, n_group=16, n_early_every=4, n_early_size=2, hop_size=16, n_mels=8 * 400 + 51 * 9, **WSR_KW)
+WSR_TABLES = [("mu_enc.1.weight", (256, 400)), ("angle_embed.embed.weight", (120, 50))]
 SHAPES = {  # (batch, samples, mel frames)
     "micro": (2, 512, 8),
     "c1": (2, 4000, 16),
     "c2": (1, 16000, 63),
     "wsr_like": (2, 16 * 300, 300),
+    "wsr": (2, 1024, 64),        # conditioning signal: [2, 512] low-rate samples -> 64 frames
 }
 SIGMA = 0.7   # configs/waveglow_LJ_speech.json:47
 
 
 def inputs(tag, B, N, F, n_mels):
     return uniform(tag + "/audio", (B, N), -1.0, 1.0), normal(tag + "/mel", (B, n_mels, F))
+
+
+def wsr_inputs(tag, B, N):
+    """(audio [B,N], low-rate conditioning signal c [B,N/2] in (-1.15, 1.15): exercises the clip and every mu-law level)."""
+    return uniform(tag + "/audio", (B, N), -1.0, 1.0), uniform(tag + "/lowres", (B, N // 2), -1.15, 1.15)
+
+
+def wsr_tables(tag):
+    """the two embedding tables, N(0,1) like nn.Embedding's default init"""
+    return {n: normal(tag + n, shp) for n, shp in WSR_TABLES}

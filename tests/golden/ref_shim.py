@@ -39,3 +39,39 @@ def load():
         InvertibleConv1x1=em.InvertibleConv1x1, AffineCouplingBlock=em.AffineCouplingBlock,
         WaveGlowLoss=ls.WaveGlowLoss)
     return ns
+
+
+def load_wsrglow():
+    """Returns the reference's WSRGlow class (model/wsrglow.py).
+
+    wsrglow.py:4 imports `MuLawEncoding` from torchaudio, which is not installed in this image and is not part of
+    /root/reference.  A stand-in module `torchaudio.transforms` exposing ONLY that class is registered for the import; it
+    restates torchaudio's published algorithm (torchaudio.functional.mu_law_encoding):
+        mu = quantization_channels - 1 ; x_mu = sign(x) * log1p(mu |x|) / log1p(mu) ; ((x_mu + 1) / 2 * mu + 0.5).to(int64)
+    Everything else on the WSRGlow path (embeddings, torch.stft, AngleEmbedding, the WaveGlow flow stack) is the reference's own
+    code, so the fixtures pin the path up to that one quantiser, which is pinned to the published formula only.
+    """
+    ns = load()
+    import importlib
+    import torch
+    if "torchaudio" not in sys.modules:
+        class MuLawEncoding(torch.nn.Module):
+            def __init__(self, quantization_channels: int = 256) -> None:
+                super().__init__()
+                self.quantization_channels = quantization_channels
+
+            def forward(self, x):
+                mu = torch.tensor(self.quantization_channels - 1.0, dtype=x.dtype)
+                x_mu = torch.sign(x) * torch.log1p(mu * torch.abs(x)) / torch.log1p(mu)
+                return ((x_mu + 1) / 2 * mu + 0.5).to(torch.int64)
+
+        ta = types.ModuleType("torchaudio")
+        tr = types.ModuleType("torchaudio.transforms")
+        tr.MuLawEncoding = MuLawEncoding
+        ta.transforms = tr
+        ta.__wg_standin__ = True
+        sys.modules["torchaudio"] = ta
+        sys.modules["torchaudio.transforms"] = tr
+    ws = importlib.import_module("model.wsrglow")
+    ns.WSRGlow = ws.WSRGlow
+    return ns

@@ -125,3 +125,18 @@ def test_hand_issued_loads_are_never_touched_before_their_wait():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_loads.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("0 violations") == 4, r.stdout
+
+
+def test_wsrglow_state_dict_layout_matches_reference(golden_dir):
+    """WSRGlow exposes the reference's names and shapes (model/wsrglow.py:21-35), recorded from the reference by
+    make_golden.wsrglow_fixture: 173 parameters incl. mu_enc.1.weight / angle_embed.embed.weight, plus the `window` buffer."""
+    import json
+    import numpy as np
+    gold = np.load(os.path.join(golden_dir, "model_wsr.npz"))
+    want = [(k, tuple(shp)) for k, shp in json.loads(str(gold["state_dict_layout"]))]
+    m = cm.WSRGlow(upsample_rate=2, memory_efficient=True, bias=False, **fill.WSR_KW)
+    got = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    assert got == want
+    assert m.n_group == 16 and m.n_mels == 3659 and m.z_split_sizes == [2, 2, 12]
+    with pytest.raises(cm.WgError):
+        m(torch.zeros(1, 1024), torch.zeros(1, 512))                   # CPU tensors: no fallback

@@ -357,3 +357,82 @@ def test_trainer_step_matches_autograd(dev):
     assert torch.equal(z, z2) and torch.equal(logdet, ld2)
     for a, p in zip(ga, m.parameters()):
         assert torch.equal(a, p.grad)
+
+
+# ---- WSRGlow: conditioning front-end kernels and the model ----------------------------------------
+
+def _wsr_tables():
+    t = fill.wsr_tables("wsr/")
+    return t["mu_enc.1.weight"], t["angle_embed.embed.weight"]
+
+
+@pytest.mark.parametrize("B,L", [(1, 8), (2, 512), (3, 1208)])
+def test_wsr_cond_kernel_vs_oracle(dev, B, L):
+    from constant_memory_waveglow_amd import engine
+    mu_w, ang_w = _wsr_tables()
+    c = fill.uniform("wsrk/c%d_%d" % (B, L), (B, L), -1.3, 1.3)
+    c[0, : min(L, 24)] = 0.0                                   # silence: atan2(0, 0), mu-law level 128
+    if L >= 64:
+        c[-1, 40:48] = 1.0
+        c[-1, 48:56] = -1.0                                    # full-scale plateaus: exact bin-edge style inputs
+    cond_ref, mi, ai = orc.wsr_cond(c, mu_w, ang_w, return_idx=True)
+    ct = T(c, dev)
+    cond = npy(engine.wsr_cond(ct, T(mu_w, dev), T(ang_w, dev)))
+    assert torch.equal(ct, T(c, dev))                          # the C ABI does not clip in place (the module does)
+    assert cond.shape == cond_ref.shape == (B, 3659, L // 8)
+    assert np.abs(cond[:, 3200:3209] - cond_ref[:, 3200:3209]).max() < 2e-6 * max(1.0, float(np.abs(cond_ref[:, 3200:3209]).max()))
+    # the embeddings are table rows: equal bit for bit wherever the quantiser decisions agree; a decision may differ from the
+    # oracle's only when the pre-rounding value sits within float noise of a bin edge -- allow a handful, never a pattern
+    diff = (cond != cond_ref)
+    diff[:, 3200:3209] = False
+    bad_frames = np.unique(np.argwhere(diff)[:, [0, 2]], axis=0) if diff.any() else np.zeros((0, 2), int)
+    assert len(bad_frames) <= max(1, (B * L // 8) // 500), "too many frames with a different quantiser decision: %d" % len(bad_frames)
+
+
+@pytest.mark.parametrize("B,L", [(1, 64), (3, 1208)])
+def test_wsr_cond_backward_vs_oracle(dev, B, L):
+    from constant_memory_waveglow_amd import engine
+    c = fill.uniform("wsrb/c%d_%d" % (B, L), (B, L), -1.1, 1.1)
+    dcond = fill.normal("wsrb/g%d_%d" % (B, L), (B, 3659, L // 8))
+    dmu_ref, dang_ref = orc.wsr_cond_backward(c, dcond, double=True)
+    dmu, dang = engine.wsr_cond_backward(T(c, dev), T(dcond, dev))
+    assert relmax(npy(dmu), dmu_ref) < 1e-5
+    assert relmax(npy(dang), dang_ref) < 1e-5
+
+
+def test_wsrglow_model_vs_reference_golden(dev, golden_dir):
+    name = "wsr"
+    cfg = fill.CONFIGS[name]
+    B, N, F = fill.SHAPES[name]
+    specs = fill.model_param_specs(cfg)
+    P = fill.fill_params(specs, name + "/")
+    P.update(fill.wsr_tables(name + "/"))
+    m = cm.WSRGlow(upsample_rate=2, memory_efficient=True, bias=False, **fill.WSR_KW)
+    sd = {k: torch.from_numpy(v) for k, v in P.items()}
+    sd["window"] = torch.hann_window(16)
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    audio, c = fill.wsr_inputs(name, B, N)
+    gold = np.load(os.path.join(golden_dir, "model_wsr.npz"))
+    ct = T(c, dev)
+    z, logdet = m(T(audio, dev), ct)
+    assert float(ct.abs().max()) <= 1.0                        # clipped in place, as upstream (wsrglow.py:38)
+    loss = cm.WaveGlowLoss(1.0)(z, logdet)
+    loss.backward()
+    assert np.abs(npy(z) - gold["z"]).max() < Z_ATOL
+    assert logdet_close(npy(logdet), gold["logdet"], N)
+    assert abs(float(loss) - float(gold["loss"])) < LOSS_ATOL
+    named = dict(m.named_parameters())
+    for i, (n, _, _) in enumerate(specs):
+        g = npy(named[n].grad)
+        nh = min(g.size, gold["grad_head"].shape[1])
+        assert np.abs(g.ravel()[:nh] - gold["grad_head"][i][:nh]).max() / max(float(gold["grad_max"][i]), 1e-30) < GRAD_RTOL, n
+        gn = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        assert abs(gn - float(gold["grad_norm"][i])) <= 1e-4 * float(gold["grad_norm"][i]) + 1e-12, n
+    for n, _ in fill.WSR_TABLES:
+        assert relmax(npy(named[n].grad), gold["grad::" + n]) < GRAD_RTOL, n
+    with torch.no_grad():
+        x, ld = m.reverse(T(gold["z"], dev), T(c, dev))
+    assert np.abs(npy(x) - gold["x_inv"]).max() < Z_ATOL
+    assert np.abs(npy(x) - audio).max() < Z_ATOL
+    assert logdet_close(npy(ld), gold["logdet_inv"], N)

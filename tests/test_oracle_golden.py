@@ -163,3 +163,53 @@ def test_reverse_mode_architecture(golden_dir):
     assert _logdet_close(ld, g["logdet_inv"], N)
     # it is a different function from the reverse_mode=False model
     assert np.abs(g["z"] - _load(golden_dir, "model_micro.npz")["z"]).max() > 1e-2
+
+
+# ---- WSRGlow ----------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("double", [False, True])
+def test_wsrglow_matches_reference(golden_dir, double):
+    """The oracle's conditioning front-end + flow stack against the reference's WSRGlow (model/wsrglow.py) run by
+    make_golden.wsrglow_fixture: quantiser decisions, |STFT|, z, logdet, loss, all gradient norms, both embedding-table grads."""
+    name = "wsr"
+    cfg = fill.CONFIGS[name]
+    B, N, F = fill.SHAPES[name]
+    specs = fill.model_param_specs(cfg)
+    P = fill.fill_params(specs, name + "/")
+    tabs = fill.wsr_tables(name + "/")
+    audio, c = fill.wsr_inputs(name, B, N)
+    G = np.load(os.path.join(golden_dir, "model_wsr.npz"))
+    cond, mi, ai = orc.wsr_cond(c, tabs["mu_enc.1.weight"], tabs["angle_embed.embed.weight"], double=double, return_idx=True)
+    assert cond.shape == (B, orc.WSR_COND, F)
+    assert np.array_equal(mi, G["mu_idx"]) and np.array_equal(ai, G["ang_idx"])
+    assert np.abs(cond[:, 3200:3209] - G["mag"]).max() < 2e-6
+    assert np.abs(cond[:, ::97, :4] - G["cond_head"]).max() < 2e-6
+    assert abs(np.sqrt((cond.astype(np.float64) ** 2).sum()) - float(G["cond_norm"])) < 1e-4 * float(G["cond_norm"])
+    r = orc.train_step(orc.make_config(**cfg), fill.table(specs, P), audio, cond, 1.0, need_dh=True, double=double)
+    assert np.abs(r["z"] - G["z"]).max() < 1e-5
+    assert _logdet_close(r["logdet"], G["logdet"], N)
+    assert abs(r["loss"] - float(G["loss"])) < 1e-6
+    gn = np.array([np.sqrt((g.astype(np.float64) ** 2).sum()) for g in r["grads"]])
+    assert np.all(np.abs(gn - G["grad_norm"]) <= 2e-5 * G["grad_norm"] + 1e-12)
+    dmu, dang = orc.wsr_cond_backward(c, r["dh"], double=double)
+    for n, g in (("mu_enc.1.weight", dmu), ("angle_embed.embed.weight", dang)):
+        assert np.abs(g - G["grad::" + n]).max() < 2e-5 * np.abs(G["grad::" + n]).max(), n
+    x, _ = orc.inverse(orc.make_config(**cfg), fill.table(specs, P), G["z"], cond, double=double)
+    assert np.abs(x - G["x_inv"]).max() < 1e-5
+
+
+def test_wsr_cond_edge_cases():
+    """Clip, silence and the shortest input: c beyond [-1,1] behaves as the clipped signal; an all-zero frame has |STFT| = 0 and
+    the phase index of angle 0; L = 8 is one frame whose reflect padding reads c[4..1] and c[6..3]."""
+    mu_w = fill.normal("edge/mu", (256, 400))
+    ang_w = fill.normal("edge/ang", (120, 50))
+    c = fill.uniform("edge/c", (2, 8), -2.0, 2.0)
+    a, mi, ai = orc.wsr_cond(c, mu_w, ang_w, return_idx=True)
+    b = orc.wsr_cond(np.clip(c, -1, 1), mu_w, ang_w)
+    assert a.shape == (2, orc.WSR_COND, 1) and np.array_equal(a, b)
+    assert mi.min() >= 0 and mi.max() <= 255 and ai.min() >= 0 and ai.max() <= 119
+    z, mi, ai = orc.wsr_cond(np.zeros((1, 64), np.float32), mu_w, ang_w, return_idx=True)
+    assert np.all(mi == 128) and np.all(ai == 59) and np.all(z[:, 3200:3209] == 0)
+    assert np.array_equal(z[0, :400, 0], mu_w[128]) and np.array_equal(z[0, 3209:3259, 0], ang_w[59])
+    with pytest.raises(RuntimeError):
+        orc.wsr_cond(np.zeros((1, 12), np.float32), mu_w, ang_w)       # L must be a multiple of 8
