@@ -436,3 +436,37 @@ def test_wsrglow_model_vs_reference_golden(dev, golden_dir):
     assert np.abs(npy(x) - gold["x_inv"]).max() < Z_ATOL
     assert np.abs(npy(x) - audio).max() < Z_ATOL
     assert logdet_close(npy(ld), gold["logdet_inv"], N)
+
+
+def test_wsrglow_full_width_vs_oracle(dev, precision):
+    """The shipped WSRGlow width (WN 256 channels x 8 layers, 229.7 M parameters, V = 3659 -> 4096 per flow) on one short segment
+    against the oracle: the conditioning GEMM segment with K = 3659 is the shape the small fixtures do not reach."""
+    if precision != "bf16x3p":
+        pytest.skip("full-width case runs in the default arithmetic only (CPU oracle time)")
+    name = "wsr_full"
+    cfg = dict(fill.CONFIGS["wsr"], dilation_channels=256, residual_channels=256, skip_channels=256, depth=8)
+    B, N = 1, 1024
+    specs = fill.model_param_specs(cfg)
+    P = fill.fill_params(specs, name + "/")
+    tabs = fill.wsr_tables(name + "/")
+    audio, c = fill.wsr_inputs(name, B, N)
+    cond = orc.wsr_cond(c, tabs["mu_enc.1.weight"], tabs["angle_embed.embed.weight"])
+    ref = orc.train_step(orc.make_config(**cfg), fill.table(specs, P), audio, cond, 1.0, need_dh=True)
+    dmu_ref, dang_ref = orc.wsr_cond_backward(c, ref["dh"])
+    m = cm.WSRGlow(upsample_rate=2, memory_efficient=True, bias=False)
+    sd = {k: torch.from_numpy(v) for k, v in P.items()}
+    sd.update({k: torch.from_numpy(v) for k, v in tabs.items()})
+    sd["window"] = torch.hann_window(16)
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    z, logdet = m(T(audio, dev), T(c, dev))
+    loss = cm.WaveGlowLoss(1.0)(z, logdet)
+    loss.backward()
+    assert np.abs(npy(z) - ref["z"]).max() < Z_ATOL
+    assert logdet_close(npy(logdet), ref["logdet"], N)
+    assert abs(float(loss) - ref["loss"]) < LOSS_ATOL
+    named = dict(m.named_parameters())
+    for i, (n, _, _) in enumerate(specs):
+        assert relmax(npy(named[n].grad), ref["grads"][i]) < GRAD_RTOL, n
+    assert relmax(npy(named["mu_enc.1.weight"].grad), dmu_ref) < GRAD_RTOL
+    assert relmax(npy(named["angle_embed.embed.weight"].grad), dang_ref) < GRAD_RTOL
