@@ -663,7 +663,7 @@ struct WgradSArgs {
     WgSSeg sa[2];
     WgSSeg sb[WG_MAX_SEG];
     Geo g;
-    int t_per_split, nts, b_per_split;
+    int cpb, total_chunks, nsplit;      // 32-step chunks per batch item, B * cpb, blocks per tile (each takes an even share of the range)
     float *slab;
     int Mp, Np;
 };
@@ -697,7 +697,6 @@ __global__ __launch_bounds__(256) void wgrad16s_kernel(const WgradSArgs a)
     int bx, by, zs;
     xcd_remap(bx, by, zs);
     const int n0 = bx * WG_TILE, m0 = by * WG_TILE;
-    const int ts = zs % a.nts, bs = zs / a.nts;
     const Geo g = a.g;
 
     f32x16 acc[2][2];
@@ -728,17 +727,12 @@ __global__ __launch_bounds__(256) void wgrad16s_kernel(const WgradSArgs a)
         pb[j] = (nb < a.Np && cb < sb.nch) ? sb.hi + (((size_t)((sb.ch0 + cb) >> 3)) * g.P + g.H + sb.shift + tl) * 8 : nullptr;
         lb_[j] = sb.lo_off; sbb[j] = (size_t)(sb.Cp >> 3) * g.P * 8;
     }
-    const int t_begin = ts * a.t_per_split;
-    int t_end = t_begin + a.t_per_split;
-    if (t_end > g.Tt) t_end = g.Tt;
-    const int chunks_per_b = (t_end - t_begin + WG16_BK - 1) / WG16_BK;
-    const int b_begin = bs * a.b_per_split;
-    int b_end = b_begin + a.b_per_split;
-    if (b_end > g.B) b_end = g.B;
-    const int nchunks = chunks_per_b * (b_end - b_begin);
+    // this block's share of the flattened (batch item, chunk) range
+    const int c_begin = (int)((long)zs * a.total_chunks / a.nsplit), c_end = (int)((long)(zs + 1) * a.total_chunks / a.nsplit);
+    const int nchunks = c_end - c_begin;
 
     u32x4 rah[2], ral[2], rbh[2], rbl[2];
-    int lb = b_begin, lt = t_begin;
+    int lb = c_begin / a.cpb, lt = (c_begin - lb * a.cpb) * WG16_BK;
     auto load_chunk = [&]() {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -756,7 +750,7 @@ __global__ __launch_bounds__(256) void wgrad16s_kernel(const WgradSArgs a)
             }
         }
         lt += WG16_BK;
-        if (lt >= t_end) { lt = t_begin; ++lb; }
+        if (lt >= g.Tt) { lt = 0; ++lb; }
     };
     auto store_chunk = [&](int buf) {
         char *sb = smem + buf * BUF;
