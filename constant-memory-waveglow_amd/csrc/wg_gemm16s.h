@@ -376,6 +376,10 @@ __global__ __launch_bounds__(256) void convgemm16p_kernel(const ConvGemm16sArgs 
 //   loader waves alone                                                82 us
 //   both                                                             129 us; loads served from L1/L2 only: no change; compute
 //   waves skipping their LDS reads: no change; s_setprio on the compute waves: no change.
+// A persistent form (2 workgroups per CU walking tiles w, w+512, ...; the loaders treat all their tiles as one chunk stream, so
+// the next tile's first chunks land during the epilogue) was measured too: no gain for the gate conv (the second workgroup of the
+// CU already covers a tile's prologue and epilogue) and the tile loop around the epilogue costs registers (177-239 VGPRs for
+// three of the four epilogues -> one workgroup per CU): 99.9 ms per step against 89.9.  Not kept.
 // The barrier of chunk c moved between its two k-steps (-DWG_OPT_W_MIDBAR: fragments of chunk c+1 fetched under the MFMAs of
 // k-step 1) needs 132 VGPRs, i.e. one workgroup per CU: 148 us.
 // ------------------------------------------------------------------------------------------------
