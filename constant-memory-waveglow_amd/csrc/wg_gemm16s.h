@@ -376,6 +376,12 @@ __global__ __launch_bounds__(256) void convgemm16p_kernel(const ConvGemm16sArgs 
 //   loader waves alone                                                82 us
 //   both                                                             129 us; loads served from L1/L2 only: no change; compute
 //   waves skipping their LDS reads: no change; s_setprio on the compute waves: no change.
+// A 256(M) x 128(T) workgroup tile at ONE workgroup per CU (4 compute waves with 128x64 tiles = 0.75x the LDS and L1 bytes per
+// MFMA, fragments double-buffered in the 256-register budget, barrier between the two k-steps, same asm loaders with 12 loads per
+// lane) was built and is bit-identical in results: 145 us for the gate conv against 128 us (compute waves alone 124 us, loaders
+// alone 101 us).  With a single workgroup on the CU nothing runs under a tile's epilogue (tanh/sigmoid + 64-192 KB of stores) or
+// its first loads; two co-resident workgroups hide exactly that, and two workgroups cap a wave at 128 registers, i.e. at the
+// 64x64 wave tile used here.
 // A persistent form (2 workgroups per CU walking tiles w, w+512, ...; the loaders treat all their tiles as one chunk stream, so
 // the next tile's first chunks land during the epilogue) was measured too: no gain for the gate conv (the second workgroup of the
 // CU already covers a tile's prologue and epilogue) and the tile loop around the epilogue costs registers (177-239 VGPRs for
