@@ -376,6 +376,12 @@ __global__ __launch_bounds__(256) void convgemm16p_kernel(const ConvGemm16sArgs 
 //   loader waves alone                                                82 us
 //   both                                                             129 us; loads served from L1/L2 only: no change; compute
 //   waves skipping their LDS reads: no change; s_setprio on the compute waves: no change.
+// Register note: only the gate instantiation (124 VGPRs) runs two workgroups per CU.  The store / residual+skip / gate-backward
+// epilogues hold all their auxiliary loads at once (64-128 values per lane; 162 / 158 / 220 VGPRs), so those launches run one
+// workgroup per CU -- deliberately: splitting the epilogue per 32x32 block and capping the kernel at 128 VGPRs restores two
+// workgroups per CU but leaves 16-32 loads in flight per lane, and these launches are bound by their epilogue's HBM traffic
+// (residual+skip 92 -> 102 us, gate backward 87 -> 119 us).  A 4-stage (4 chunks in flight) loader for launches with fewer
+// tiles than CUs (single-utterance synthesis) was also measured: 2.85 -> 2.70 MHz, not kept.
 // A 256(M) x 128(T) workgroup tile at ONE workgroup per CU (4 compute waves with 128x64 tiles = 0.75x the LDS and L1 bytes per
 // MFMA, fragments double-buffered in the 256-register budget, barrier between the two k-steps, same asm loaders with 12 loads per
 // lane) was built and is bit-identical in results: 145 us for the gate conv against 128 us (compute waves alone 124 us, loaders
