@@ -191,6 +191,18 @@ def main():
                     cost = time.perf_counter() - t1
                     out["inverse_khz_%d" % xs.numel()] = xs.numel() / cost / 1000.0
             out["inverse_khz"] = out["inverse_khz_%d" % (862 * 256)]
+        if world == 1:
+            # outside the metric (SURVEY.md 8d excludes the optimizer): one Adam step over all 53.66 M parameters on the flat buffers
+            from constant_memory_waveglow_amd.parallel import FlatAdam
+            opt = FlatAdam(trainer, lr=1e-4)
+            trainer.optimizer = None                          # timed stand-alone; trainer.step would run it per bucket
+            opt.step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                opt.step()
+            torch.cuda.synchronize()
+            out["adam_step_ms"] = (time.perf_counter() - t1) / 5 * 1e3
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

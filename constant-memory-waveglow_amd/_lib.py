@@ -15,7 +15,7 @@ ABI_SYMBOLS = [
     "wg_wn_param_count", "wg_wn_packed_bytes", "wg_coupling_workspace_bytes", "wg_invconv_workspace_bytes",
     "wg_workspace_init", "wg_pack_weights", "wg_wn_pack_weights", "wg_forward", "wg_inverse", "wg_backward",
     "wg_nll_loss", "wg_nll_loss_backward", "wg_invconv_apply", "wg_invconv_backward", "wg_coupling_apply",
-    "wg_coupling_backward", "wg_upsample", "wg_wn_apply", "wg_wsr_cond", "wg_wsr_cond_backward",
+    "wg_coupling_backward", "wg_upsample", "wg_wn_apply", "wg_wsr_cond", "wg_wsr_cond_backward", "wg_adam_step",
     "wg_timer_create", "wg_timer_attach", "wg_timer_count", "wg_timer_read", "wg_timer_destroy",
 ]
 K_CONV_STORE, K_CONV_GATE, K_CONV_RESSKIP, K_CONV_DGATE, K_WGRAD = range(5)
@@ -91,6 +91,7 @@ def lib():
     L.wg_wn_apply.argtypes = [wnp, vp, vp, vp, i, i, vp, vp, vp, sz, vp]
     L.wg_wsr_cond.argtypes = [vp, i, i, vp, vp, vp, vp]
     L.wg_wsr_cond_backward.argtypes = [vp, i, i, vp, vp, vp, vp]
+    L.wg_adam_step.argtypes = [vp, vp, vp, vp, sz, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, i, vp]
     L.wg_timer_create.restype = vp
     L.wg_timer_create.argtypes = [i, i]
     L.wg_timer_attach.argtypes = [vp]

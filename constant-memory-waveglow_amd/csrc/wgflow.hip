@@ -9,6 +9,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 
@@ -1120,6 +1122,29 @@ int wg_nll_loss_backward(const float *z, int B, int N, float sigma, int elementw
     const size_t n = (size_t)B * N;
     WG_LAUNCH(cx, nll_loss_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, z, B, N, 1.0f / (sigma * sigma), elementwise_mean,
               dloss, dz, dlogdet);
+    return cx.err;
+}
+
+int wg_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, double lr, double beta1, double beta2,
+                 double eps, double weight_decay, int step, void *stream)
+{
+    if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1 || !(lr >= 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) ||
+        !(beta2 >= 0.0 && beta2 < 1.0))
+        return WG_EINVAL;
+    if (n == 0) return WG_OK;
+    if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return WG_EINVAL;   // float4 access
+    Ctx cx = {(hipStream_t)stream, 0, 0};
+    AdamArgs a;
+    a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = n;
+    // hyper-parameters arrive as doubles and every derived scalar is rounded to fp32 once, as torch does with its Python floats
+    const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
+    a.one_minus_b1 = (float)(1.0 - beta1); a.b2 = (float)beta2; a.one_minus_b2 = (float)(1.0 - beta2); a.eps = (float)eps;
+    a.wd = (float)weight_decay;
+    a.step_size = (float)(lr / bc1);
+    a.inv_bc2_sqrt = (float)(1.0 / std::sqrt(bc2));
+    const size_t n4 = (n + 3) / 4;
+    const unsigned blocks = (unsigned)std::min<size_t>((n4 + 255) / 256, 256 * 16);
+    WG_LAUNCH(cx, adam_kernel, dim3(blocks), dim3(256), 0, a);
     return cx.err;
 }
 

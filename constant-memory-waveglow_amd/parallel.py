@@ -63,12 +63,17 @@ class GradSync:
         import os
         self._force = dist.is_initialized() and os.environ.get("WG_BENCH_FORCE_DIST") == "1"   # 1-rank smoke of the collective path
 
-    def all_reduce(self, fg: FlatGrads, order: Sequence[int] = None, events=None):
+    def all_reduce(self, fg: FlatGrads, order: Sequence[int] = None, events=None, after_bucket=None):
         """events[b] (torch.cuda.Event, optional): bucket b's gradients are final once the event has fired; its all-reduce is
-        enqueued behind that event on a side stream, so it overlaps whatever backward work is still queued on the main stream."""
-        if self.world == 1 and not self._force:
-            return
+        enqueued behind that event on a side stream, so it overlaps whatever backward work is still queued on the main stream.
+        after_bucket(b) (optional) runs right behind bucket b's reduction -- on the side stream when there is one -- which is
+        where FlatAdam puts the optimizer step of that bucket."""
         order = list(order) if order is not None else list(range(len(fg.bucket_ranges) - 1, -1, -1))
+        if self.world == 1 and not self._force:
+            if after_bucket is not None:
+                for b in order:
+                    after_bucket(b)
+            return
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         works = []
         if events is not None and fg.flat.is_cuda:
@@ -80,17 +85,31 @@ class GradSync:
                     if t.numel() == 0:
                         continue
                     self._comm.wait_event(events[b])
-                    works.append((dist.all_reduce(t, op=op, group=self.pg, async_op=True), t))
+                    w = dist.all_reduce(t, op=op, group=self.pg, async_op=True)
+                    if after_bucket is not None:
+                        w.wait()                                  # the SIDE stream waits for the collective ...
+                        if not self._avg:
+                            t.div_(self.world)
+                        after_bucket(b)                           # ... and runs the bucket's optimizer step behind it
+                    else:
+                        works.append((w, t))
+            if after_bucket is not None:
+                torch.cuda.current_stream(fg.flat.device).wait_stream(self._comm)
+                return
         else:
             for b in order:
                 t = fg.bucket(b)
                 if t.numel() == 0:
                     continue
                 works.append((dist.all_reduce(t, op=op, group=self.pg, async_op=True), t))
-        for w, t in works:
+        for i, (w, t) in enumerate(works):
             w.wait()                      # the current (main) stream waits for the collective
             if not self._avg:
                 t.div_(self.world)
+        if after_bucket is not None:
+            for b in order:
+                if fg.bucket(b).numel():
+                    after_bucket(b)
 
     def broadcast_params(self, params: Sequence[torch.Tensor], src: int = 0):
         """replicas start identical (what DDP does when it wraps the module)"""
@@ -120,6 +139,7 @@ class FlowTrainer:
         self.grad_views = [next(it) if t is not None else None for t in self.table]
         self.sync.broadcast_params([t for t in self.table if t is not None])
         self.n_flows = len(model.WNs)
+        self.optimizer = None             # a FlatAdam attaches itself here; step() then updates the weights as well
         self.events = None
         if self.table[0].is_cuda and (self.sync.world > 1 or self.sync._force):
             self.events = [torch.cuda.Event() for _ in range(self.n_flows + 1)]
@@ -138,8 +158,104 @@ class FlowTrainer:
         eng.backward(table, z, h, dz, dlogdet, need, False, False, grads_out=self.grad_views, flow_events=self.events)
         # buckets become final in the order backward retires the flows: last flow first (first flow first in reverse_mode), upsampler last
         flows = range(self.n_flows) if self.model._reverse_mode else range(self.n_flows - 1, -1, -1)
-        self.sync.all_reduce(self.fg, order=list(flows) + [self.n_flows], events=self.events)
+        opt = self.optimizer
+        self.sync.all_reduce(self.fg, order=list(flows) + [self.n_flows], events=self.events,
+                             after_bucket=opt.step_bucket if opt is not None else None)
+        if opt is not None:
+            opt.finish_step()
         for t, g in zip(self.table, self.grad_views):
             if t is not None:
                 t.grad = g
         return loss, z, logdet
+
+
+class FlatAdam:
+    """torch.optim.Adam for a FlowTrainer, run by `wg_adam_step` on flat buffers.
+
+    The reference builds `torch.optim.Adam(self.parameters(), **optimizer.args)` (model/lightning.py:41-44; lr 1e-4 in
+    configs/waveglow_LJ_speech.json).  Here the parameters of the trainer's table are re-pointed to views of ONE flat fp32
+    buffer laid out like the gradient buffer (one bucket per flow), so the update of a bucket is a single HBM-bound launch over a
+    contiguous range, issued right behind that bucket's gradient all-reduce on the communication stream: the optimizer step of the
+    last flows overlaps the backward of the first ones.  `state_dict()` / `load_state_dict()` use torch's per-parameter layout
+    (`exp_avg`, `exp_avg_sq`, `step`), so optimizer checkpoints interchange with torch.optim.Adam.
+    """
+
+    def __init__(self, trainer: "FlowTrainer", lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        from . import _lib
+        self._lib = _lib
+        self.trainer = trainer
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        fg = trainer.fg
+        live = [t for t in trainer.table if t is not None]
+        if not live[0].is_cuda:
+            raise _lib.WgError("FlatAdam runs on the HIP device only (no CPU fallback)")
+        self.flat = torch.empty_like(fg.flat)
+        for t, o, n in zip(live, fg.offsets, fg.sizes):
+            view = self.flat[o:o + n].view_as(t)
+            view.copy_(t.data)
+            t.data = view                                   # the module's parameters now live in the flat buffer
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.step_count = 0
+        self._live = live
+        trainer.optimizer = self
+
+    def step_bucket(self, b: int):
+        """Adam on bucket b (called by GradSync behind the bucket's all-reduce, on whatever stream is current there)."""
+        import ctypes as C
+        s, e = self.trainer.fg.bucket_ranges[b]
+        if e == s:
+            return
+        off = 4 * s
+        L = self._lib.lib()
+        st = C.c_void_p(torch.cuda.current_stream(self.flat.device).cuda_stream)
+        self._lib.check(L.wg_adam_step(C.c_void_p(self.flat.data_ptr() + off), C.c_void_p(self.trainer.fg.flat.data_ptr() + off),
+                                       C.c_void_p(self.exp_avg.data_ptr() + off), C.c_void_p(self.exp_avg_sq.data_ptr() + off),
+                                       C.c_size_t(e - s), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                                       self.step_count + 1, st), "wg_adam_step")
+
+    def finish_step(self):
+        self.step_count += 1
+        self.trainer.model._engine.packed.key = None        # weights changed behind torch's version counters: re-pack next step
+
+    def step(self):
+        """stand-alone use (gradients already reduced): all buckets on the current stream"""
+        for b in range(len(self.trainer.fg.bucket_ranges)):
+            self.step_bucket(b)
+        self.finish_step()
+
+    # ---- checkpoints: torch.optim.Adam's layout --------------------------------------------------------------------------
+    def state_dict(self):
+        fg = self.trainer.fg
+        state = {}
+        for i, (t, o, n) in enumerate(zip(self._live, fg.offsets, fg.sizes)):
+            state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.exp_avg[o:o + n].view_as(t).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[o:o + n].view_as(t).clone()}
+        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
+                 "maximize": False, "params": list(range(len(self._live)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        fg = self.trainer.fg
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps, self.weight_decay = float(g["lr"]), tuple(float(b) for b in g["betas"]), float(g["eps"]), float(g["weight_decay"])
+        steps = set()
+        for i, (t, o, n) in enumerate(zip(self._live, fg.offsets, fg.sizes)):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            self.exp_avg[o:o + n].view_as(t).copy_(st["exp_avg"])
+            self.exp_avg_sq[o:o + n].view_as(t).copy_(st["exp_avg_sq"])
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise self._lib.WgError("FlatAdam keeps one step counter; the checkpoint has several: %s" % sorted(steps))
+        self.step_count = steps.pop() if steps else 0
+
+
+def load_reference_checkpoint(model, checkpoint, prefix="model."):
+    """Loads the flow's weights from a checkpoint written by the reference's LightModel (pytorch-lightning layout:
+    checkpoint["state_dict"] with the flow under `model.` next to the conditioner's buffers -- model/lightning.py:38-40,
+    inference.py:17).  Accepts the checkpoint dict or a bare state dict; returns load_state_dict's result."""
+    sd = checkpoint.get("state_dict", checkpoint)
+    own = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)} if any(k.startswith(prefix) for k in sd) else dict(sd)
+    return model.load_state_dict(own)

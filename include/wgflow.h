@@ -179,6 +179,14 @@ int wg_wsr_cond(const float *c, int B, int L, const float *mu_table, const float
  * through integer indices, :47 has no parameters).  Outputs are overwritten. */
 int wg_wsr_cond_backward(const float *c, int B, int L, const float *dcond, float *dmu_table, float *dang_table, void *stream);
 
+/* ---- optimizer step (trainer parity) ---------------------------------------------------------------
+ * torch.optim.Adam (amsgrad = false, maximize = false) on one contiguous fp32 range: what the reference's
+ * configure_optimizers builds from `optimizer` in its configs (model/lightning.py:41-44; configs/waveglow_LJ_speech.json:
+ * lr 1e-4; configs/wsrglow_vctk_2x.json: betas (0.9, 0.98)).  `step` is 1-based.  All four ranges must be 16-byte aligned.
+ * Hyper-parameters are doubles (Python floats upstream): 1 - beta is formed in double before it is rounded to fp32. */
+int wg_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, double lr, double beta1, double beta2,
+                 double eps, double weight_decay, int step, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -140,3 +140,22 @@ def test_wsrglow_state_dict_layout_matches_reference(golden_dir):
     assert m.n_group == 16 and m.n_mels == 3659 and m.z_split_sizes == [2, 2, 12]
     with pytest.raises(cm.WgError):
         m(torch.zeros(1, 1024), torch.zeros(1, 512))                   # CPU tensors: no fallback
+
+
+def test_load_reference_checkpoint_strips_the_lightning_prefix():
+    """A checkpoint written by the reference's LightModel keeps the flow under `model.` next to conditioner buffers
+    (model/lightning.py:38-40); load_reference_checkpoint takes exactly that layout."""
+    from constant_memory_waveglow_amd.parallel import load_reference_checkpoint
+    cfg = fill.CONFIGS["micro"]
+    src = cm.WaveGlow(memory_efficient=True, bias=False, **cfg)
+    with torch.no_grad():
+        for p in src.parameters():
+            p.uniform_(-0.5, 0.5)
+    ckpt = {"epoch": 3, "state_dict": {"model." + k: v.clone() for k, v in src.state_dict().items()}}
+    ckpt["state_dict"]["conditioner.mel.1.spectrogram.window"] = torch.hann_window(1024)
+    dst = cm.WaveGlow(memory_efficient=True, bias=False, **cfg)
+    res = load_reference_checkpoint(dst, ckpt)
+    assert not res.missing_keys and not res.unexpected_keys
+    for (k, a), (_, b) in zip(src.state_dict().items(), dst.state_dict().items()):
+        assert torch.equal(a, b), k
+    load_reference_checkpoint(dst, src.state_dict())            # a bare state dict is accepted too

@@ -470,3 +470,46 @@ def test_wsrglow_full_width_vs_oracle(dev, precision):
         assert relmax(npy(named[n].grad), ref["grads"][i]) < GRAD_RTOL, n
     assert relmax(npy(named["mu_enc.1.weight"].grad), dmu_ref) < GRAD_RTOL
     assert relmax(npy(named["angle_embed.embed.weight"].grad), dang_ref) < GRAD_RTOL
+
+
+# ---- trainer parity: Adam on the flat buffers vs torch.optim.Adam, the optimizer the reference instantiates ----
+
+@pytest.mark.parametrize("wd,betas", [(0.0, (0.9, 0.999)), (0.01, (0.9, 0.98))])
+def test_flat_adam_matches_torch_adam(dev, precision, wd, betas):
+    if precision != "bf16x3p":
+        pytest.skip("optimizer arithmetic does not depend on the contraction mode")
+    from constant_memory_waveglow_amd.parallel import FlowTrainer, FlatAdam
+    m, cfg, specs, P = build("micro", dev)
+    B, N, F = fill.SHAPES["micro"]
+    audio, h = fill.inputs("micro", B, N, F, cfg["n_mels"])
+    tr = FlowTrainer(m, fill.SIGMA)
+    names = [n for n, p in m.named_parameters()]
+    ref_params = [torch.nn.Parameter(torch.from_numpy(P[n]).clone()) for n in names]
+    ref_opt = torch.optim.Adam(ref_params, lr=1e-3, betas=betas, eps=1e-8, weight_decay=wd)
+    opt = FlatAdam(tr, lr=1e-3, betas=betas, eps=1e-8, weight_decay=wd)
+    named = dict(m.named_parameters())
+    assert all(named[n].data_ptr() >= opt.flat.data_ptr() for n in names)          # parameters live in the flat buffer now
+    losses = []
+    for step in range(3):
+        loss, _, _ = tr.step(T(audio, dev), T(h, dev))
+        losses.append(float(loss))
+        for n, rp in zip(names, ref_params):
+            rp.grad = named[n].grad.detach().cpu().clone()                        # same gradients: isolates the optimizer
+        ref_opt.step()
+        for n, rp in zip(names, ref_params):
+            got, want = npy(named[n]), rp.detach().numpy()
+            assert np.abs(got - want).max() <= 2e-6 * max(1.0, float(np.abs(want).max())), (step, n)
+    assert losses[2] < losses[0]                                                   # and the step actually trains
+    # optimizer checkpoints interchange with torch.optim.Adam
+    sd = opt.state_dict()
+    ref_sd = ref_opt.state_dict()
+    assert set(sd["state"].keys()) == set(ref_sd["state"].keys())
+    order = {id(p): i for i, p in enumerate(t for t in tr.table if t is not None)}
+    for i, n in enumerate(names):
+        j = order[id(named[n])]
+        assert relmax(sd["state"][j]["exp_avg"].cpu().numpy(), ref_sd["state"][i]["exp_avg"].numpy()) < 1e-5, n
+        assert relmax(sd["state"][j]["exp_avg_sq"].cpu().numpy(), ref_sd["state"][i]["exp_avg_sq"].numpy()) < 1e-5, n
+    opt2_trainer = FlowTrainer(m, fill.SIGMA)
+    opt2 = FlatAdam(opt2_trainer, lr=5e-4)
+    opt2.load_state_dict(sd)
+    assert opt2.step_count == 3 and opt2.lr == 1e-3 and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
