@@ -53,7 +53,13 @@ def _worker(rank, world, port, q):
     for v, g in zip(fg.views, r["grads"]):
         v.copy_(torch.from_numpy(g))
     sync = GradSync()
-    sync.all_reduce(fg)
+    # after_bucket is where FlatAdam hangs the optimizer step: it must see each bucket already averaged, in the order given
+    seen = []
+    half = [b.clone() for b in (fg.bucket(i) for i in range(len(fg.bucket_ranges)))]
+    order = list(range(cfg["flows"] - 1, -1, -1)) + [cfg["flows"]]
+    sync.all_reduce(fg, order=order, after_bucket=lambda b: seen.append((b, float((fg.bucket(b) - half[b]).abs().max()))))
+    assert [b for b, _ in seen] == order, seen
+    assert any(d > 0 for _, d in seen)                                  # the buckets had been reduced when the callback ran
     # replicas start identical
     probe = [torch.full((3,), float(rank))]
     sync.broadcast_params(probe)
