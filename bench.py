@@ -205,10 +205,18 @@ def main():
             out["adam_step_ms"] = (time.perf_counter() - t1) / 5 * 1e3
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if out is not None:
+        # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which would otherwise be flushed
+        # behind it at exit
+        sys.stdout.flush()
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
