@@ -513,3 +513,59 @@ def test_flat_adam_matches_torch_adam(dev, precision, wd, betas):
     opt2 = FlatAdam(opt2_trainer, lr=5e-4)
     opt2.load_state_dict(sd)
     assert opt2.step_count == 3 and opt2.lr == 1e-3 and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
+
+
+# ---- shape sweep: configurations the fixtures do not hit, HIP engine vs oracle --------------------------------------------
+
+SWEEP = [
+    # flows, n_group, n_early_every, n_early_size, hop, n_mels, channels (dil, res, skip), depth, radix, B, frames
+    dict(flows=2, n_group=4, n_early_every=1, n_early_size=2, hop_size=8, n_mels=8, ch=(32, 32, 32), depth=1, radix=3, B=1, F=5),
+    dict(flows=3, n_group=6, n_early_every=2, n_early_size=2, hop_size=24, n_mels=33, ch=(64, 32, 96), depth=2, radix=3, B=3, F=7),
+    dict(flows=5, n_group=12, n_early_every=2, n_early_size=4, hop_size=48, n_mels=17, ch=(32, 64, 32), depth=4, radix=3, B=2, F=9),
+    dict(flows=2, n_group=32, n_early_every=4, n_early_size=2, hop_size=32, n_mels=40, ch=(96, 96, 64), depth=3, radix=3, B=1, F=300),
+    dict(flows=4, n_group=8, n_early_every=3, n_early_size=2, hop_size=16, n_mels=80, ch=(32, 32, 32), depth=9, radix=3, B=5, F=70),
+    dict(flows=2, n_group=8, n_early_every=4, n_early_size=2, hop_size=64, n_mels=20, ch=(64, 64, 64), depth=2, radix=1, B=2, F=4),
+]
+
+
+@pytest.mark.parametrize("case", range(len(SWEEP)))
+def test_shape_sweep_vs_oracle(dev, case):
+    """Odd channel mixes (dilation != residual != skip), depth 1 and 9 (dilation 256 > T), n_group 4..32, early outputs every flow,
+    radix 1, a time axis shorter than one tile and one that is not a multiple of it, batch 1..5."""
+    c = SWEEP[case]
+    cfg = dict(flows=c["flows"], n_group=c["n_group"], n_early_every=c["n_early_every"], n_early_size=c["n_early_size"],
+               hop_size=c["hop_size"], n_mels=c["n_mels"], dilation_channels=c["ch"][0], residual_channels=c["ch"][1],
+               skip_channels=c["ch"][2], depth=c["depth"], radix=c["radix"])
+    tag = "sweep%d" % case
+    B, F = c["B"], c["F"]
+    N = F * c["hop_size"] - (c["hop_size"] // 2 if case % 2 else 0)         # odd cases: audio shorter than the mel covers
+    N -= N % c["n_group"]
+    specs = fill.model_param_specs(cfg)
+    P = fill.fill_params(specs, tag + "/")
+    audio, h = fill.inputs(tag, B, N, F, cfg["n_mels"])
+    ref = orc.train_step(orc.make_config(**cfg), fill.table(specs, P), audio, h, fill.SIGMA, need_dh=True)
+    m = cm.WaveGlow(memory_efficient=True, bias=False, **cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    m = m.to(dev)
+    assert m.z_split_sizes and sum(m.z_split_sizes) == cfg["n_group"]
+    ht = T(h, dev).requires_grad_(True)
+    z, logdet = m(T(audio, dev), ht)
+    loss = cm.WaveGlowLoss(fill.SIGMA)(z, logdet)
+    loss.backward()
+    assert np.abs(npy(z) - ref["z"]).max() < Z_ATOL
+    assert logdet_close(npy(logdet), ref["logdet"], N)
+    assert abs(float(loss) - ref["loss"]) < LOSS_ATOL
+    assert relmax(npy(ht.grad), ref["dh"]) < GRAD_RTOL
+    named = dict(m.named_parameters())
+    for i, (n, _, _) in enumerate(specs):
+        g = npy(named[n].grad)
+        if n.endswith("weight_v") and g[0].size == 1:
+            # fan-in 1 (start conv of a 2-channel flow): w = g * sign(v), so dL/dv is exactly zero and both sides hold rounding noise
+            gg = np.abs(npy(named[n[:-1] + "g"].grad)).max()
+            assert np.abs(g).max() < 1e-6 * gg and np.abs(ref["grads"][i]).max() < 1e-6 * gg, n
+            continue
+        assert relmax(g, ref["grads"][i]) < GRAD_RTOL, n
+    with torch.no_grad():
+        x, ld = m.reverse(z.detach(), ht.detach())
+    assert np.abs(npy(x) - audio).max() < Z_ATOL
+    assert logdet_close(-npy(ld), ref["logdet"], N)
