@@ -34,7 +34,7 @@ def make_config(flows, n_group, n_early_every, n_early_size, hop_size, n_mels,
 
 def build(force=False):
     """Compile the oracle with the Makefile next to this file (gcc only)."""
-    need = force or not all(os.path.exists(os.path.join(_HERE, f)) for f in ("libwgoracle.so", "libwgoracle64.so"))
+    need = force or not all(os.path.exists(os.path.join(_HERE, f)) for f in ("libwgoracle.so", "libwgoracle64.so", "libwforacle.so", "libwforacle64.so"))
     if need:
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
 

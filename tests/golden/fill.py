@@ -170,3 +170,37 @@ def wsr_inputs(tag, B, N):
 def wsr_tables(tag):
     """the two embedding tables, N(0,1) like nn.Embedding's default init"""
     return {n: normal(tag + n, shp) for n, shp in WSR_TABLES}
+
+
+# ---- WaveFlow (model/waveflow.py; SURVEY.md 8f rank 2) ------------------------------------------------------------------
+
+def waveflow_param_specs(cfg):
+    """(name, shape, kind) in the reference's named_parameters() order for WaveFlow(use_conv1x1=False, bias=False):
+    cfg has the ctor keywords of configs/waveflow_LJ_speech.json (flows, n_group, n_mels, *_channels)."""
+    M, H = cfg["n_mels"], cfg["n_group"]
+    s = 256 // H                                           # FlowBase hop is fixed to 256 (waveflow.py:160-163)
+    C, Cd, Cs = cfg["residual_channels"], cfg["dilation_channels"], cfg["skip_channels"]
+    specs = [("upsampler.1.bias", (M,), "bias"), ("upsampler.1.weight_g", (M, 1, 1), "g"), ("upsampler.1.weight_v", (M, M, 2 * s + 1), "v")]
+    for k in range(cfg["flows"]):
+        p = "WNs.%d." % k
+        specs += [(p + "V.weight_g", (16 * Cd, 1, 1), "g"), (p + "V.weight_v", (16 * Cd, M, 1), "v"),
+                  (p + "start.weight_g", (C, 1, 1, 1), "g"), (p + "start.weight_v", (C, 1, 1, 1), "v")]
+        for i in range(8):
+            rows = Cs if i == 7 else C + Cs
+            specs += [(p + "layers.%d.W.weight_g" % i, (2 * Cd, 1, 1, 1), "g"), (p + "layers.%d.W.weight_v" % i, (2 * Cd, C, 3, 3), "v"),
+                      (p + "layers.%d.W_o.weight_g" % i, (rows, 1, 1, 1), "g"), (p + "layers.%d.W_o.weight_v" % i, (rows, Cd, 1, 1), "v")]
+        specs.append((p + "end.weight", (2, Cs, 1, 1), "end"))
+    return specs
+
+
+WF_CONFIGS = {
+    # 8 rows (all height dilations 1), upsampling stride 32
+    "wf8": dict(flows=3, n_group=8, n_mels=12, dilation_channels=32, residual_channels=32, skip_channels=32),
+    # 64 rows: the shipped height-dilation pattern 1,2,4,8,16,1,2,4 (waveflow.py:85), stride 4, 3x3 taps reaching 32 rows up
+    "wf64": dict(flows=2, n_group=64, n_mels=10, dilation_channels=32, residual_channels=32, skip_channels=64),
+}
+WF_SHAPES = {"wf8": (2, 8 * 96, 3), "wf64": (2, 64 * 24, 6)}       # (batch, samples, mel frames)
+
+
+def waveflow_inputs(tag, B, N, F, n_mels):
+    return uniform(tag + "/audio", (B, N), -1.0, 1.0), normal(tag + "/mel", (B, n_mels, F))

@@ -213,3 +213,43 @@ def test_wsr_cond_edge_cases():
     assert np.array_equal(z[0, :400, 0], mu_w[128]) and np.array_equal(z[0, 3209:3259, 0], ang_w[59])
     with pytest.raises(RuntimeError):
         orc.wsr_cond(np.zeros((1, 12), np.float32), mu_w, ang_w)       # L must be a multiple of 8
+
+
+# ---- WaveFlow ---------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", ["wf8", "wf64"])
+@pytest.mark.parametrize("double", [False, True])
+def test_waveflow_matches_reference(golden_dir, name, double):
+    """oracle/wf_oracle.c against the reference's WaveFlow (model/waveflow.py) run by make_golden.waveflow_fixture:
+    z, logdet, loss, every parameter-gradient norm and head, d loss / d mel, and the row-by-row inverse."""
+    from oracle import wf_oracle as wfo
+    cfg = fill.WF_CONFIGS[name]
+    B, N, F = fill.WF_SHAPES[name]
+    specs = fill.waveflow_param_specs(cfg)
+    P = fill.fill_params(specs, name + "/")
+    audio, mel = fill.waveflow_inputs(name, B, N, F, cfg["n_mels"])
+    G = np.load(os.path.join(golden_dir, "model_%s.npz" % name))
+    oc = wfo.make_config(**cfg)
+    assert wfo.param_count(oc) == len(specs)
+    r = wfo.train_step(oc, fill.table(specs, P), audio, mel, fill.SIGMA, need_dmel=True, double=double)
+    assert np.abs(r["z"] - G["z"]).max() < 2e-6
+    assert _logdet_close(r["logdet"], G["logdet"], N)
+    assert abs(r["loss"] - float(G["loss"])) < 1e-6
+    assert np.abs(r["dmel"] - G["dmel"]).max() < 1e-5 * np.abs(G["dmel"]).max()
+    for i, (n, shape, _) in enumerate(specs):
+        g = r["grads"][i]
+        if n.endswith("start.weight_v"):
+            # Conv2d(1, C, 1) under weight norm: w = g * sign(v), the exact gradient w.r.t. v is zero; both sides hold rounding noise
+            assert np.abs(g).max() < 1e-6 * np.abs(r["grads"][i - 1]).max(), n
+            continue
+        gn = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        assert abs(gn - float(G["grad_norm"][i])) <= 2e-5 * float(G["grad_norm"][i]) + 1e-12, n
+        nh = min(g.size, G["grad_head"].shape[1])
+        assert np.abs(g.ravel()[:nh] - G["grad_head"][i][:nh]).max() <= 2e-5 * float(G["grad_max"][i]) + 1e-12, n
+        if "grad::" + n in G:
+            assert np.abs(g - G["grad::" + n]).max() <= 2e-5 * np.abs(G["grad::" + n]).max(), n
+    zf, ldf = wfo.forward(oc, fill.table(specs, P), audio, mel, double=double)
+    assert np.array_equal(zf, r["z"]) or np.abs(zf - r["z"]).max() < 1e-6
+    x, ld = wfo.inverse(oc, fill.table(specs, P), G["z"], mel, double=double)
+    assert np.abs(x - G["x_inv"]).max() < 2e-6 and np.abs(x - audio).max() < 2e-6
+    assert _logdet_close(ld, G["logdet_inv"], N)
