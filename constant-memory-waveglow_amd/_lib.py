@@ -16,6 +16,8 @@ ABI_SYMBOLS = [
     "wg_workspace_init", "wg_pack_weights", "wg_wn_pack_weights", "wg_forward", "wg_inverse", "wg_backward",
     "wg_nll_loss", "wg_nll_loss_backward", "wg_invconv_apply", "wg_invconv_backward", "wg_coupling_apply",
     "wg_coupling_backward", "wg_upsample", "wg_wn_apply", "wg_wsr_cond", "wg_wsr_cond_backward", "wg_adam_step",
+    "wg_wf_param_count", "wg_wf_packed_bytes", "wg_wf_workspace_bytes", "wg_wf_tape_bytes", "wg_wf_pack_weights", "wg_wf_forward",
+    "wg_wf_inverse", "wg_wf_backward",
     "wg_timer_create", "wg_timer_attach", "wg_timer_count", "wg_timer_read", "wg_timer_destroy",
 ]
 K_CONV_STORE, K_CONV_GATE, K_CONV_RESSKIP, K_CONV_DGATE, K_WGRAD = range(5)
@@ -25,6 +27,10 @@ class WgConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n_flows", "n_group", "n_early_every", "n_early_size", "n_mels",
         "up_stride", "up_kernel", "up_pad", "res_ch", "dil_ch", "skip_ch", "depth", "radix", "precision", "reverse_mode")]
+
+
+class WgWfConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("flows", "n_group", "n_mels", "res_ch", "dil_ch", "skip_ch", "precision")]
 
 
 class WgWnDims(C.Structure):
@@ -92,6 +98,18 @@ def lib():
     L.wg_wsr_cond.argtypes = [vp, i, i, vp, vp, vp, vp]
     L.wg_wsr_cond_backward.argtypes = [vp, i, i, vp, vp, vp, vp]
     L.wg_adam_step.argtypes = [vp, vp, vp, vp, sz, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, i, vp]
+    wfp = C.POINTER(WgWfConfig)
+    L.wg_wf_param_count.argtypes = [wfp]
+    L.wg_wf_packed_bytes.restype = sz
+    L.wg_wf_packed_bytes.argtypes = [wfp]
+    L.wg_wf_workspace_bytes.restype = sz
+    L.wg_wf_workspace_bytes.argtypes = [wfp, i, i, i]
+    L.wg_wf_tape_bytes.restype = sz
+    L.wg_wf_tape_bytes.argtypes = [wfp, i, i]
+    L.wg_wf_pack_weights.argtypes = [wfp, vp, vp, vp]
+    L.wg_wf_forward.argtypes = [wfp, vp, vp, vp, vp, i, i, i, vp, vp, vp, vp, sz, vp]
+    L.wg_wf_inverse.argtypes = [wfp, vp, vp, vp, vp, i, i, i, vp, vp, vp, sz, vp]
+    L.wg_wf_backward.argtypes = [wfp, vp, vp, vp, vp, vp, vp, i, i, i, vp, vp, vp, vp, sz, vp]
     L.wg_timer_create.restype = vp
     L.wg_timer_create.argtypes = [i, i]
     L.wg_timer_attach.argtypes = [vp]

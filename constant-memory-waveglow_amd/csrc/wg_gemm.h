@@ -23,6 +23,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Geo {
     int B, T, Tt, H, P;   // Tt = roundup(T,128); P = H + Tt + H
+    int rows;             // 0: every plane row is one batch item.  > 0 (WaveFlow): an item is `rows` consecutive plane rows (the height
+                          // axis), B = items * rows; taps may then reach other rows of the same item (SSeg::row_off)
 };
 
 // reference to channels [ch0, ch0+..) of a plane
@@ -39,7 +41,7 @@ __device__ __forceinline__ float *paddr(const PRef &r, const Geo &g, int b, int 
 #define WG_TILE 128        // output tile edge (M and N) of both kernels
 #define WG_BK 16           // channels per chunk (convgemm)
 #define WG_WBK 32          // time steps per chunk (wgrad)
-#define WG_MAX_SEG 4
+#define WG_MAX_SEG 10     // 3x3 taps + conditioning (WaveFlow); the 1-D WN uses 4
 
 // ------------------------------------------------------------------------------------------------
 // shared inner product: acc[mi][ni] += As[k][wr*64 + mi*32 + r] * Bs[k][wc*64 + ni*32 + c], k < BKK
@@ -115,6 +117,7 @@ struct ConvGemmArgs {
     Geo g;
     int epi, nsplit, accumulate;
     PRef out0, out1, out2, aux0, aux1;
+    int row_sel1;       // Geo::rows > 0: 0 = blockIdx.z is the plane row; r + 1 = blockIdx.z is the item and the tile is its height row r
 };
 
 // fused epilogues shared by the fp32 and the split-precision kernels

@@ -179,6 +179,8 @@ struct SSeg {
     const unsigned short *hi;
     size_t lo_off;
     int Cp, ch0;
+    int row_off;      // Geo::rows > 0: the tap reads plane row b + row_off; rows outside the tile's own item read as zero
+    int per_item;     // Geo::rows > 0: the operand has ONE plane row per item (conditioning broadcast over the height axis)
 };
 struct ConvGemm16sArgs {
     const unsigned short *img;
@@ -410,8 +412,9 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
     const ConvGemmArgs &a = aa.c;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int t0 = blockIdx.x * WG_TILE, m0 = blockIdx.y * WG_TILE, b = blockIdx.z;
     const Geo g = a.g;
+    const int t0 = blockIdx.x * WG_TILE, m0 = blockIdx.y * WG_TILE;
+    const int b = a.row_sel1 ? (int)blockIdx.z * g.rows + a.row_sel1 - 1 : (int)blockIdx.z;
     int nchunks = 0;
     for (int s = 0; s < a.nseg; ++s) nchunks += (a.seg[s].nch + WG16_BK - 1) / WG16_BK;
 
@@ -438,16 +441,24 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
             const int sg = min(cur_seg, a.nseg - 1);
             const int nch = a.seg[sg].nch, shift = a.seg[sg].shift;
             const SSeg ss = aa.sseg[sg];
-            const bool full = live && (nch - cur_c > 16);
+            // source plane row of this segment: the tile's own row, another row of the same item (2-D taps) or the item's single row
+            int bsrc = b;
+            bool rowok = true;
+            if (g.rows > 0) {
+                const int item = b / g.rows, r = b - item * g.rows + ss.row_off;
+                rowok = r >= 0 && r < g.rows;
+                bsrc = ss.per_item ? item : b + ss.row_off;
+            }
+            const bool blive = live && rowok, full = blive && (nch - cur_c > 16);
             const unsigned short *ih = aa.img + ((size_t)chunk * a.lda + m0) * WG16_BK, *il = ih + aa.img_stride;
-            const unsigned short *row0 = ss.hi + ((size_t)b * (ss.Cp >> 3) + ((ss.ch0 + cur_c) >> 3)) * g.P * 8;   // p = 0: zero halo
+            const unsigned short *row0 = ss.hi + ((size_t)bsrc * (ss.Cp >> 3) + ((ss.ch0 + cur_c) >> 3)) * g.P * 8;   // p = 0: zero halo
             const unsigned short *b0 = row0 + (size_t)(g.H + t0 + shift) * 8, *b0l = b0 + ss.lo_off;
             const unsigned short *b1 = b0 + (size_t)2 * g.P * 8, *b1l = b1 + ss.lo_off;
             const unsigned short *pa0 = live ? ih : zsrc, *pa1 = live ? ih + 2048 : zsrc;
             const unsigned short *pl0 = live ? il : zsrc, *pl1 = live ? il + 2048 : zsrc;
-            const unsigned short *pb0 = live ? b0 : zsrc, *pb0l = live ? b0l : zsrc;
+            const unsigned short *pb0 = blive ? b0 : zsrc, *pb0l = blive ? b0l : zsrc;
             const unsigned short *pb1 = full ? b1 : zsrc, *pb1l = full ? b1l : zsrc;
-            const unsigned va = live ? voff_a : 0u, vb = live ? voff_b : 0u, vb1 = full ? voff_b : 0u;
+            const unsigned va = live ? voff_a : 0u, vb = blive ? voff_b : 0u, vb1 = full ? voff_b : 0u;
             WG_LD(st.ah[0], pa0, va);   WG_LD(st.ah[1], pa1, va);
             WG_LD(st.al[0], pl0, va);   WG_LD(st.al[1], pl1, va);
             WG_LD(st.bh[0], pb0, vb);   WG_LD(st.bl[0], pb0l, vb);
@@ -673,6 +684,7 @@ struct WgSSeg {
     const unsigned short *hi;
     size_t lo_off;
     int Cp, ch0, nch, shift, blk0;
+    int row_off, per_item;      // as SSeg (B operand only)
 };
 struct WgradSArgs {
     int nseg_a, nseg_b;
@@ -726,7 +738,7 @@ __global__ __launch_bounds__(256) void wgrad16s_kernel(const WgradSArgs a)
     // staging: unit u = tid + 256*j -> t = 2*(u>>5) + (u&1), channel group cg = (u>>1)&15
     const unsigned short *pa[2], *pb[2];
     size_t la[2], lb_[2], sba[2], sbb[2];
-    int loff[2];
+    int loff[2], roff[2], pitem[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int u = tid + 256 * j;
@@ -742,6 +754,7 @@ __global__ __launch_bounds__(256) void wgrad16s_kernel(const WgradSArgs a)
         const int cb = nb - sb.blk0 * 32;
         pb[j] = (nb < a.Np && cb < sb.nch) ? sb.hi + (((size_t)((sb.ch0 + cb) >> 3)) * g.P + g.H + sb.shift + tl) * 8 : nullptr;
         lb_[j] = sb.lo_off; sbb[j] = (size_t)(sb.Cp >> 3) * g.P * 8;
+        roff[j] = sb.row_off; pitem[j] = sb.per_item;
     }
     // this block's share of the flattened (batch item, chunk) range
     const int c_begin = (int)((long)zs * a.total_chunks / a.nsplit), c_end = (int)((long)(zs + 1) * a.total_chunks / a.nsplit);
@@ -759,8 +772,16 @@ __global__ __launch_bounds__(256) void wgrad16s_kernel(const WgradSArgs a)
                 rah[j] = *reinterpret_cast<const u32x4 *>(q);
                 ral[j] = *reinterpret_cast<const u32x4 *>(q + la[j]);
             }
-            if (pb[j]) {
-                const unsigned short *q = pb[j] + lb * sbb[j] + (size_t)lt * 8;
+            // B operand row: the chunk's own plane row, another row of the same item (2-D taps, zero outside it) or the item's row
+            int bsrc = lb;
+            bool rowok = true;
+            if (g.rows > 0) {
+                const int item = lb / g.rows, r = lb - item * g.rows + roff[j];
+                rowok = r >= 0 && r < g.rows;
+                bsrc = pitem[j] ? item : lb + roff[j];
+            }
+            if (pb[j] && rowok) {
+                const unsigned short *q = pb[j] + bsrc * sbb[j] + (size_t)lt * 8;
                 rbh[j] = *reinterpret_cast<const u32x4 *>(q);
                 rbl[j] = *reinterpret_cast<const u32x4 *>(q + lb_[j]);
             }

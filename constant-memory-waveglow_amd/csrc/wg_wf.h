@@ -1,0 +1,207 @@
+// WaveFlow (model/waveflow.py) pieces that are not the WN2D stack: squeeze / unsqueeze in the [height][time] layout, the dense
+// transposed-conv upsampler with LeakyReLU, the autoregressive affine coupling along the height axis fused with WN2D.end, and
+// their backward.  All HBM-bound glue; the WN2D convolutions run on the conv / wgrad kernels of wg_gemm16s.h with 3x3 taps
+// expressed as 9 shifted K segments over "one height row per plane row" planes (Geo::rows = n_group).
+//
+// Plane row of (item b, height h) = b * H + h.  X planes have ONE channel (PRef::Cp = 1).
+#pragma once
+#include <hip/hip_runtime.h>
+
+// x[b][h][t] = audio[b][t * H + h]                                             (waveflow.py:186)
+__global__ void wf_squeeze_kernel(const float *__restrict__ audio, PRef X, Geo g, int N)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
+    if (t >= g.T) return;
+    const int H = g.rows, b = row / H, h = row - b * H;
+    *paddr(X, g, row, 0, t) = audio[(size_t)b * N + (size_t)t * H + h];
+}
+__global__ void wf_unsqueeze_kernel(PRef X, Geo g, int N, float *__restrict__ audio)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
+    if (t >= g.T) return;
+    const int H = g.rows, b = row / H, h = row - b * H;
+    audio[(size_t)b * N + (size_t)t * H + h] = *paddr(X, g, row, 0, t);
+}
+// row `r` of every item from / to the [B][N] layout (the row-by-row inverse)
+__global__ void wf_copy_row_kernel(PRef src, PRef dst, Geo g, int r_src, int r_dst)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (t >= g.T) return;
+    *paddr(dst, g, b * g.rows + r_dst, 0, t) = *paddr(src, g, b * g.rows + r_src, 0, t);
+}
+// z = z.flip(2) along the height axis (waveflow.py:222)
+__global__ void wf_flip_kernel(PRef src, PRef dst, Geo g)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
+    if (t >= g.T) return;
+    const int H = g.rows, b = row / H, h = row - b * H;
+    *paddr(dst, g, b * H + (H - 1 - h), 0, t) = *paddr(src, g, row, 0, t);
+}
+
+// ------------------------------------------------------------------------------------------------
+// upsampler (waveflow.py:163-169): y = LeakyReLU_0.4(bias + ConvTranspose1d(ReplicationPad1d((0,1))(mel)))[:, :, :W]
+//   y[o][j] = bias[o] + sum_c sum_i melpad[c][i] * w[c][o][j + pad - s i],  w[c] = g[c] v[c] / ||v[c]||  (weight norm over dim 0 =
+//   the INPUT channel of a transposed conv).  scale[c] = g[c] / ||v[c]|| comes from rownorm_kernel.
+// ------------------------------------------------------------------------------------------------
+struct WfUpArgs {
+    const float *mel, *v, *scale, *bias;
+    int M, F, K, s, pad;
+    PRef Y;             // [items][Mp][P]
+    Geo gi;             // per-item geometry (rows = 0)
+};
+__global__ void wf_upsample_fwd_kernel(const WfUpArgs a)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, o = blockIdx.y, b = blockIdx.z;
+    if (j >= a.gi.T) return;
+    float acc = a.bias[o];
+    const int ihi = min((j + a.pad) / a.s, a.F);                       // padded length F + 1
+    int ilo = j + a.pad - a.K + 1;
+    ilo = ilo <= 0 ? 0 : (ilo + a.s - 1) / a.s;
+    const float *mb = a.mel + (size_t)b * a.M * a.F;
+    for (int i = ilo; i <= ihi; ++i) {
+        const int k = j + a.pad - a.s * i, isrc = min(i, a.F - 1);
+        for (int c = 0; c < a.M; ++c) acc = fmaf(mb[(size_t)c * a.F + isrc] * a.scale[c], a.v[((size_t)c * a.M + o) * a.K + k], acc);
+    }
+    *paddr(a.Y, a.gi, b, o, j) = acc > 0.f ? acc : 0.4f * acc;
+}
+
+// gp[b][o][j] = (sum over the H rows of dYrow[b*H + h][o][j]) * LeakyReLU'(y): the conditioning is broadcast over the height axis
+__global__ void wf_rowsum_leaky_kernel(PRef dYrow, Geo g, PRef Y, Geo gi, int M, float *__restrict__ gp)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, o = blockIdx.y, b = blockIdx.z;
+    if (j >= g.T) return;
+    float acc = 0.f;
+    for (int h = 0; h < g.rows; ++h) acc += *paddr(dYrow, g, b * g.rows + h, o, j);
+    const float y = *paddr(Y, gi, b, o, j);
+    gp[((size_t)b * M + o) * g.T + j] = acc * (y > 0.f ? 1.f : 0.4f);
+}
+
+// effective-weight gradient dw[c][o*K + k] = sum_b sum_i melpad[b][c][i] gp[b][o][s i + k - pad]  (one block per input channel c),
+// dbias[o] = sum gp (block c == 0), dmel (optional, block-per-c as well).
+struct WfUpBwdArgs {
+    const float *mel, *v, *scale, *gp;
+    int B, M, F, K, s, pad, W;
+    float *dw, *dbias, *dmel;
+};
+__global__ __launch_bounds__(256) void wf_upsample_bwd_kernel(const WfUpBwdArgs a)
+{
+    const int c = blockIdx.x, tid = threadIdx.x;
+    for (int e = tid; e < a.M * a.K; e += 256) {
+        const int o = e / a.K, k = e - o * a.K;
+        float acc = 0.f;
+        for (int b = 0; b < a.B; ++b) {
+            const float *mb = a.mel + ((size_t)b * a.M + c) * a.F, *gb = a.gp + ((size_t)b * a.M + o) * a.W;
+            for (int i = 0; i <= a.F; ++i) {
+                const int j = a.s * i + k - a.pad;
+                if (j >= 0 && j < a.W) acc = fmaf(mb[min(i, a.F - 1)], gb[j], acc);
+            }
+        }
+        a.dw[(size_t)c * a.M * a.K + e] = acc;
+    }
+    if (c == 0 && a.dbias)
+        for (int o = tid; o < a.M; o += 256) {
+            float acc = 0.f;
+            for (int b = 0; b < a.B; ++b)
+                for (int j = 0; j < a.W; ++j) acc += a.gp[((size_t)b * a.M + o) * a.W + j];
+            a.dbias[o] = acc;
+        }
+    if (a.dmel)
+        for (int e = tid; e < a.B * a.F; e += 256) {
+            const int b = e / a.F, i = e - b * a.F;
+            float acc = 0.f;
+            for (int ii = i; ii <= (i == a.F - 1 ? a.F : i); ++ii)         // the last frame also feeds the replicated one
+                for (int o = 0; o < a.M; ++o) {
+                    const float *gb = a.gp + ((size_t)b * a.M + o) * a.W;
+                    const float *wv = a.v + ((size_t)c * a.M + o) * a.K;
+                    for (int k = 0; k < a.K; ++k) {
+                        const int j = a.s * ii + k - a.pad;
+                        if (j >= 0 && j < a.W) acc = fmaf(wv[k], gb[j], acc);
+                    }
+                }
+            a.dmel[((size_t)b * a.M + c) * a.F + i] = acc * a.scale[c];
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// WN2D.end (plain 1x1 conv Cs -> 2, waveflow.py:117,135) fused with the coupling (waveflow.py:196-206):
+//   (log_s, t)[r] = W_end S[r] ;  xout[r] = x[r+1] exp(log_s[r]) + t[r] ;  x_next = cat(flip(xout), x[0]) ;  logdet += sum log_s
+// grid = (plane rows); the block of WN row r = 0..H-2 of an item writes x_next row H-2-r, the block of row H-1 copies x[0].
+// mode 0: forward.  mode 1: backward seed (see below).  mode 2: one row of the inverse: x[r+1] = (z[r+1] - t[r]) / exp(log_s[r]).
+// ------------------------------------------------------------------------------------------------
+struct WfCoupleArgs {
+    const float *endw;      // [2][Cs]
+    PRef S;                 // cumulated skip [rows][Cs][P]
+    int Cs;
+    PRef X, Xn;             // current / next flow state (1 channel)
+    PRef dXn, dX;           // mode 1: gradient w.r.t. x_next (in), w.r.t. x (out: the coupling part; WN2D's start conv adds its part later)
+    PRef G;                 // mode 1: [rows][Gc][P], channel 0 = d log_s, channel 1 = d t (zero for row H-1)
+    const float *dld;       // mode 1: d loss / d logdet [items]
+    float *rowsum;          // modes 0, 2: sum of log_s per plane row (mode 2: of -log_s)
+    int row_sel;            // mode 2: the WN row being produced (grid.x = items)
+    Geo g;
+    int mode;
+};
+__global__ __launch_bounds__(256) void wf_couple_kernel(const WfCoupleArgs a)
+{
+    __shared__ float red[256];
+    const Geo g = a.g;
+    const int H = g.rows, tid = threadIdx.x;
+    const int row = a.mode == 2 ? blockIdx.x * H + a.row_sel : blockIdx.x;
+    const int b = row / H, r = row - b * H;
+    float lsum = 0.f;
+    if (r == H - 1) {                                          // not a WN output row: x_next[H-1] = x[0] and its gradient
+        for (int t = tid; t < g.T; t += 256) {
+            if (a.mode == 0) *paddr(a.Xn, g, row, 0, t) = *paddr(a.X, g, b * H, 0, t);
+            if (a.mode == 1) {
+                *paddr(a.dX, g, b * H, 0, t) = *paddr(a.dXn, g, row, 0, t);
+                *paddr(a.G, g, row, 0, t) = 0.f;
+                *paddr(a.G, g, row, 1, t) = 0.f;
+            }
+        }
+        if (tid == 0 && a.rowsum && a.mode == 0) a.rowsum[row] = 0.f;
+        return;
+    }
+    for (int t = tid; t < g.T; t += 256) {
+        float ls = 0.f, tt = 0.f;
+        for (int c = 0; c < a.Cs; ++c) {
+            const float s = *paddr(a.S, g, row, c, t);
+            ls = fmaf(a.endw[c], s, ls);
+            tt = fmaf(a.endw[a.Cs + c], s, tt);
+        }
+        const float es = expf(ls);
+        if (a.mode == 0) {
+            *paddr(a.Xn, g, b * H + (H - 2 - r), 0, t) = fmaf(*paddr(a.X, g, row + 1, 0, t), es, tt);
+            lsum += ls;
+        } else if (a.mode == 1) {
+            const float gout = *paddr(a.dXn, g, b * H + (H - 2 - r), 0, t);
+            const float xv = *paddr(a.X, g, row + 1, 0, t);
+            *paddr(a.dX, g, row + 1, 0, t) = gout * es;
+            *paddr(a.G, g, row, 0, t) = gout * xv * es + a.dld[b];
+            *paddr(a.G, g, row, 1, t) = gout;
+        } else {
+            *paddr(a.Xn, g, row + 1, 0, t) = (*paddr(a.X, g, row + 1, 0, t) - tt) / es;
+            lsum -= ls;
+        }
+    }
+    if (a.mode == 1 || !a.rowsum) return;
+    red[tid] = lsum;
+    __syncthreads();
+    for (int q = 128; q > 0; q >>= 1) {
+        if (tid < q) red[tid] += red[tid + q];
+        __syncthreads();
+    }
+    if (tid == 0) a.rowsum[row] = red[0];
+}
+// logdet[b] = sum over flows and rows of rowsum[k][b*H + h]
+__global__ void wf_logdet_kernel(const float *__restrict__ rowsum, int nflow, int items, int H, float *__restrict__ logdet)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= items) return;
+    float s = 0.f;
+    for (int k = 0; k < nflow; ++k) {
+        float q = 0.f;
+        for (int h = 0; h < H; ++h) q += rowsum[((size_t)k * items + b) * H + h];
+        s += q;
+    }
+    logdet[b] = s;
+}

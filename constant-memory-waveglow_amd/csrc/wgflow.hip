@@ -6,6 +6,7 @@
 #include "wg_gemm16.h"
 #include "wg_gemm16s.h"
 #include "wg_wsr.h"
+#include "wg_wf.h"
 
 #include <algorithm>
 #include <atomic>
@@ -26,6 +27,7 @@ struct Ctx {
     hipStream_t st;
     int err;
     int prec;   // 0: exact fp32 MFMA; 1: bf16x3, operands split on the fly (wg_gemm16.h); 2: bf16x3 from pre-split S-planes (wg_gemm16s.h)
+    int row_sel1;   // Geo::rows > 0 only: 0 = every plane row; r + 1 = the conv launches cover height row r of every item (WaveFlow's inverse)
 };
 #define WG_LAUNCH(ctx, kern, grid, block, shmem, ...)                         \
     do {                                                                      \
@@ -62,6 +64,16 @@ struct TimerScope {
 struct WnD {
     int ic, aux, C, Cd, Cs, depth, radix;
     int prec = 0;
+    // WaveFlow's WN2D (model/waveflow.py:70-135) is this same network with a 3x3 kernel over (height, time): radix 9, tap
+    // kt = 3 kh + kw reads plane row r + (kh - 2) * hd[layer] (causal along the height axis) at time shift (kw - 1) * 2^layer, and
+    // the conditioning has one plane row per item.  The planes then hold one height row per plane row (Geo::rows).
+    int mode2d = 0;
+    int hd[16] = {0};
+    void tap(int layer, int kt, int &tshift, int &row_off) const
+    {
+        if (!mode2d) { tshift = (kt - (radix - 1) / 2) * (1 << layer); row_off = 0; }
+        else { tshift = (kt % 3 - 1) * (1 << layer); row_off = (kt / 3 - 2) * hd[layer]; }
+    }
     int auxp() const { return rup(aux, WG_BK); }
     int wo_rows(int i) const { return i == depth - 1 ? Cs : C + Cs; }
     int nparams() const { return 4 + 4 * depth + 1; }
@@ -76,13 +88,14 @@ Geo make_geo(int B, int T, int halo_need)
     g.Tt = rup(T, WG_TILE);
     g.H = std::max(16, rup(halo_need, 16));
     g.P = g.H + g.Tt + g.H;
+    g.rows = 0;
     return g;
 }
 
 int wn_check(const WnD &d)
 {
     if (d.ic < 1 || d.aux < 1 || d.depth < 1 || d.depth > 16) return WG_EINVAL;
-    if (d.radix != 1 && d.radix != 3) return WG_EUNSUPPORTED;            // odd kernels only make sense upstream; 1 and 3 built
+    if (d.mode2d ? d.radix != 9 : (d.radix != 1 && d.radix != 3)) return WG_EUNSUPPORTED;   // 1-D: kernels 1 and 3; 2-D: 3x3
     if (d.C % 32 || d.Cd % 32 || d.Cs % 32) return WG_EUNSUPPORTED;       // MFMA tile granularity
     if (2 * d.ic > WG_MAXC) return WG_EUNSUPPORTED;                       // end-conv rows handled by one MFMA tile
     if (d.C * d.radix > WG_FIN_MAXCOLS || d.aux > WG_FIN_MAXCOLS || d.Cd > WG_FIN_MAXCOLS) return WG_EUNSUPPORTED;
@@ -445,6 +458,7 @@ struct SegSpec {
     int Cp, ch0, nch, shift;
     const float *s;      // S-plane base of the same tensor (precision 2), its rows per item and first row
     int sCp, sch0;
+    int row_off = 0, per_item = 0;   // Geo::rows > 0 only: see SSeg
 };
 SRef sref(const Geo &g, const float *base, int Cp, int ch0 = 0)
 {
@@ -472,6 +486,11 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
     a.out0 = out0; a.out1 = out1; a.out2 = out2; a.aux0 = aux0; a.aux1 = aux1;
     const int mrows = epi == EPI_GATE ? M : M;
     dim3 grid(g.Tt / WG_TILE, rup(mrows, WG_TILE) / WG_TILE, g.B), block(256);
+    if (cx.row_sel1) {
+        if (g.rows <= 0 || cx.prec != 2) { if (!cx.err) cx.err = WG_EINVAL; return; }
+        a.row_sel1 = cx.row_sel1;
+        grid.z = g.B / g.rows;
+    }
     TimerScope ts(WG_K_CONV_STORE + epi, cx.st);
     if (cx.prec) {
         ConvGemm16Args a16;
@@ -485,9 +504,11 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
             as.img = a16.img; as.img_stride = a16.img_stride; as.c = a; as.s0 = s0;
             for (int s = 0; s < nseg; ++s) {
                 as.sseg[s].hi = (const unsigned short *)segs[s].s;
-                as.sseg[s].lo_off = (size_t)g.B * segs[s].sCp * g.P;
+                as.sseg[s].lo_off = (size_t)(segs[s].per_item ? g.B / g.rows : g.B) * segs[s].sCp * g.P;
                 as.sseg[s].Cp = segs[s].sCp; as.sseg[s].ch0 = segs[s].sch0;
+                as.sseg[s].row_off = segs[s].row_off; as.sseg[s].per_item = segs[s].per_item;
                 if (!segs[s].s && !cx.err) cx.err = WG_EINVAL;
+                if ((segs[s].row_off || segs[s].per_item) && g.rows <= 0 && !cx.err) cx.err = WG_EINVAL;
             }
 #if defined(WG_OPT_DMA)                           // LDS-DMA loader ring (6 waves per workgroup)
             switch (epi) {
@@ -547,6 +568,7 @@ struct WSegSpec {
     int Cp, ch0, nch, shift;
     const float *s;      // S-plane of the same tensor (precision 2) or nullptr
     int sCp, sch0;
+    int row_off = 0, per_item = 0;   // Geo::rows > 0 only (B operand)
 };
 // returns the plan used (finalize needs nsplit / strides)
 struct WgradOut {
@@ -598,8 +620,9 @@ WgradOut run_wgrad(Ctx &cx, const Geo &g, const WSegSpec *sa, int nsa, const WSe
             q.sa[s].Cp = sa[s].sCp; q.sa[s].ch0 = sa[s].sch0; q.sa[s].nch = sa[s].nch; q.sa[s].shift = 0; q.sa[s].blk0 = a.sa[s].blk0;
         }
         for (int s = 0; s < nsb; ++s) {
-            q.sb[s].hi = (const unsigned short *)sb[s].s; q.sb[s].lo_off = (size_t)g.B * sb[s].sCp * g.P;
+            q.sb[s].hi = (const unsigned short *)sb[s].s; q.sb[s].lo_off = (size_t)(sb[s].per_item ? g.B / g.rows : g.B) * sb[s].sCp * g.P;
             q.sb[s].Cp = sb[s].sCp; q.sb[s].ch0 = sb[s].sch0; q.sb[s].nch = sb[s].nch; q.sb[s].shift = sb[s].shift; q.sb[s].blk0 = a.sb[s].blk0;
+            q.sb[s].row_off = sb[s].row_off; q.sb[s].per_item = sb[s].per_item;
         }
         WG_LAUNCH(cx, wgrad16s_kernel, grid, block, 0, q);
     } else if (cx.prec) WG_LAUNCH(cx, wgrad16_kernel, grid, block, 0, a);
@@ -653,22 +676,24 @@ void wn_forward(Ctx &cx, const WnRun &r)
     const WnD &d = r.d;
     const Geo &g = r.g;
     float *ws = r.ws;
-    const int mid = (d.radix - 1) / 2;
     const bool sp = cx.prec == 2;
     if (sp) run_to_splane(cx, g, r.X, d.ic, ws + r.w.XaS, r.L.kp_start);      // xa -> S-plane (re-based to channel 0)
     SegSpec s0 = {r.X.p, r.X.Cp, r.X.ch0, r.L.kp_start, 0, ws + r.w.XaS, r.L.kp_start, 0};
     run_convgemm(cx, g, r.pk + r.L.startT, r.L.ld_startT, d.C, &s0, 1, EPI_STORE, pref(ws + r.w.H[0], d.C), pnull(), pnull(),
                  pnull(), pnull(), 0, 0, sp ? sref(g, ws + r.w.HS[0], d.C) : snull());             // waveglow.py:99
     for (int i = 0; i < d.depth; ++i) {
-        const int dil = 1 << i;
         const int hin = r.save ? i : (i & 1), hout = r.save ? std::min(i + 1, d.depth - 1) : ((i + 1) & 1);
         float *Hin = ws + r.w.H[hin], *Hout = ws + r.w.H[hout];
         float *gate = ws + r.w.gate[r.save ? i : 0];
         const float *gateS = ws + r.w.gateS[r.save ? i : 0];
         SegSpec sg[WG_MAX_SEG];
         int ns = 0;
-        for (int kt = 0; kt < d.radix; ++kt) sg[ns++] = {Hin, d.C, 0, d.C, (kt - mid) * dil, ws + r.w.HS[hin], d.C, 0};
-        sg[ns++] = {r.Y, d.auxp(), 0, d.auxp(), 0, r.YS, d.auxp(), 0};
+        for (int kt = 0; kt < d.radix; ++kt) {
+            int ts, ro;
+            d.tap(i, kt, ts, ro);
+            sg[ns++] = {Hin, d.C, 0, d.C, ts, ws + r.w.HS[hin], d.C, 0, ro, 0};
+        }
+        sg[ns++] = {r.Y, d.auxp(), 0, d.auxp(), 0, r.YS, d.auxp(), 0, 0, d.mode2d};
         // fp32 gate plane: only the on-the-fly weight-gradient kernel still reads it (backward); the S-plane feeds W_o
         run_convgemm(cx, g, r.pk + r.L.Acat[i], r.L.ld_Acat, 2 * d.Cd, sg, ns, EPI_GATE, sp ? pnull() : pref(gate, d.Cd),
                      r.save ? pref(ws + r.w.tw[i], d.Cd) : pnull(), r.save ? pref(ws + r.w.sf[i], d.Cd) : pnull(),
@@ -704,7 +729,7 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
     const WnD &d = r.d;
     const Geo &g = r.g;
     float *ws = r.ws;
-    const int mid = (d.radix - 1) / 2, nd = d.depth;
+    const int nd = d.depth;
     float *slab = ws + r.w.slab;
     const size_t cap = r.w.slab_floats;
     float *G = ws + r.w.G, *dS = ws + r.w.dS, *dH = ws + r.w.dH, *dxy = ws + r.w.dxy, *skip = ws + r.w.skip;
@@ -722,7 +747,7 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
                      sp ? sref(g, ws + r.w.dSS, d.Cs) : snull());
     }
     for (int i = nd - 1; i >= 0; --i) {
-        const int dil = 1 << i, rows = d.wo_rows(i), last = i == nd - 1;
+        const int rows = d.wo_rows(i), last = i == nd - 1;
         float *Hi = ws + r.w.H[i], *gate = ws + r.w.gate[i];
         // dW_o = sum do (x) gate,  do = last ? dS : cat(dh_{i+1}, dS)
         {
@@ -748,8 +773,12 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
             WSegSpec sa = {dxy, 2 * d.Cd, 0, 2 * d.Cd, 0, sp ? ws + r.w.dxyS : nullptr, 2 * d.Cd, 0};
             WSegSpec sb[WG_MAX_SEG];
             int nsb = 0;
-            for (int kt = 0; kt < d.radix; ++kt) sb[nsb++] = {Hi, d.C, 0, d.C, (kt - mid) * dil, sp ? ws + r.w.HS[i] : nullptr, d.C, 0};
-            sb[nsb++] = {r.Y, d.auxp(), 0, d.aux, 0, sp ? r.YS : nullptr, d.auxp(), 0};
+            for (int kt = 0; kt < d.radix; ++kt) {
+                int ts, ro;
+                d.tap(i, kt, ts, ro);
+                sb[nsb++] = {Hi, d.C, 0, d.C, ts, sp ? ws + r.w.HS[i] : nullptr, d.C, 0, ro, 0};
+            }
+            sb[nsb++] = {r.Y, d.auxp(), 0, d.aux, 0, sp ? r.YS : nullptr, d.auxp(), 0, 0, d.mode2d};
             WgradOut wo = run_wgrad(cx, g, &sa, 1, sb, nsb, slab, cap);
             const int C32 = rup(d.C, 32);
             run_finalize(cx, slab, wo, 0, 2 * d.Cd, d.C, d.radix, 0, 1, C32, p[4 + 4 * i], p[5 + 4 * i], grads[4 + 4 * i], grads[5 + 4 * i]);
@@ -767,7 +796,11 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
         {
             SegSpec s[WG_MAX_SEG];
             int ns = 0;
-            for (int kt = 0; kt < d.radix; ++kt) s[ns++] = {dxy, 2 * d.Cd, 0, 2 * d.Cd, -(kt - mid) * dil, ws + r.w.dxyS, 2 * d.Cd, 0};
+            for (int kt = 0; kt < d.radix; ++kt) {
+                int ts, ro;
+                d.tap(i, kt, ts, ro);
+                s[ns++] = {dxy, 2 * d.Cd, 0, 2 * d.Cd, -ts, ws + r.w.dxyS, 2 * d.Cd, 0, -ro, 0};
+            }
             run_convgemm(cx, g, r.pk + r.L.WT[i], r.L.ld_WT, d.C, s, ns, EPI_STORE, pref(dH, d.C), pnull(), pnull(),
                          last ? pnull() : pref(dH, d.C), pnull(), 0, 0, sp ? sref(g, ws + r.w.dHS, d.C) : snull());
         }
@@ -800,6 +833,109 @@ int shape_check(const wg_config *cf, int B, int N, int F, int *T)
     return 0;
 }
 
+
+// ================================================================================================
+// WaveFlow (model/waveflow.py)
+// ================================================================================================
+WnD wf_wn(const wg_wf_config *cf)
+{
+    WnD d;
+    d.ic = 1; d.aux = cf->n_mels; d.C = cf->res_ch; d.Cd = cf->dil_ch; d.Cs = cf->skip_ch; d.depth = 8; d.radix = 9;
+    d.prec = cf->precision; d.mode2d = 1;
+    static const int d8[8] = {1, 1, 1, 1, 1, 1, 1, 1}, d32[8] = {1, 2, 4, 1, 2, 4, 1, 2}, d64[8] = {1, 2, 4, 8, 16, 1, 2, 4},
+                     d128[8] = {1, 2, 4, 8, 16, 32, 64, 1};                 // waveflow.py:81-87
+    const int *hd = cf->n_group == 32 ? d32 : cf->n_group == 64 ? d64 : cf->n_group == 128 ? d128 : d8;
+    for (int i = 0; i < 8; ++i) d.hd[i] = hd[i];
+    return d;
+}
+int wf_check(const wg_wf_config *cf)
+{
+    if (!cf || cf->flows < 1 || cf->flows > WG_MAX_FLOWS || cf->n_mels < 1) return WG_EINVAL;
+    const int H = cf->n_group;
+    if (H != 8 && H != 16 && H != 32 && H != 64 && H != 128) return WG_EUNSUPPORTED;     // the keys of dilation_dict (waveflow.py:81-87)
+    if (cf->precision != WG_PREC_BF16X3_PLANES) return WG_EUNSUPPORTED;                      // only the S-plane kernels know 2-D taps
+    return wn_check(wf_wn(cf));
+}
+struct WfPack {
+    size_t ones, up_scale, wn[WG_MAX_FLOWS], total;
+};
+WfPack wf_pack_layout(const wg_wf_config *cf)
+{
+    WfPack L;
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += rupz(n, 64); return o; };
+    L.ones = take(WG_ONES);
+    L.up_scale = take(cf->n_mels);
+    const size_t wn = wn_pack_layout(wf_wn(cf)).total;
+    for (int k = 0; k < cf->flows; ++k) L.wn[k] = take(wn);
+    L.total = off;
+    return L;
+}
+struct WfWs {
+    Geo g, gi;              // one plane row per (item, height row) / one per item
+    int auxp;
+    size_t Y, YS, X[2], rowsum, dX[2], dYrow, gp, dwup, total;
+    WnWs wn;
+};
+WfWs wf_ws_layout(const wg_wf_config *cf, int B, int Wd, int mode)
+{
+    WfWs w;
+    const WnD d = wf_wn(cf);
+    const int H = cf->n_group, s = 256 / H;
+    w.gi = make_geo(B, Wd, d.maxdil());
+    w.g = w.gi;
+    w.g.B = B * H;
+    w.g.rows = H;
+    w.auxp = d.auxp();
+    Bump bp;
+    const size_t xplane = (size_t)w.g.B * w.g.P;
+    w.Y = bp.take((size_t)B * w.auxp * w.gi.P);
+    w.YS = bp.take((size_t)B * w.auxp * w.gi.P);
+    w.X[0] = bp.take(xplane); w.X[1] = bp.take(xplane);
+    w.rowsum = bp.take((size_t)cf->flows * w.g.B);
+    w.dX[0] = w.dX[1] = w.dYrow = w.gp = w.dwup = 0;
+    if (mode) {
+        w.dX[0] = bp.take(xplane); w.dX[1] = bp.take(xplane);
+        w.dYrow = bp.take((size_t)w.g.B * w.auxp * w.g.P);
+        w.gp = bp.take((size_t)B * cf->n_mels * Wd);
+        w.dwup = bp.take((size_t)cf->n_mels * cf->n_mels * (2 * s + 1));
+    }
+    wn_ws_layout(bp, d, 1, w.g, mode, cf->precision, w.wn);
+    w.total = bp.off + 4096;
+    return w;
+}
+int wf_shape(const wg_wf_config *cf, int B, int N, int F, int *Wd)
+{
+    if (B < 1 || N < 1 || F < 1) return WG_EINVAL;
+    if (N % cf->n_group) return WG_ESHAPE;
+    *Wd = N / cf->n_group;
+    const int s = 256 / cf->n_group;
+    if (*Wd > F * s - 2 * (s / 2) + 2 * s + 1) return WG_ESHAPE;          // y[..., :W] needs W upsampled frames (waveflow.py:187)
+    return 0;
+}
+void wf_upsample(Ctx &cx, const wg_wf_config *cf, const float *const *p, const float *pk, const WfPack &L, const float *mel, int F,
+                 const WfWs &W, float *ws)
+{
+    const int s = 256 / cf->n_group;
+    WfUpArgs a;
+    a.mel = mel; a.v = p[2]; a.scale = pk + L.up_scale; a.bias = p[0];
+    a.M = cf->n_mels; a.F = F; a.K = 2 * s + 1; a.s = s; a.pad = s / 2;
+    a.Y = pref(ws + W.Y, W.auxp); a.gi = W.gi;
+    WG_LAUNCH(cx, wf_upsample_fwd_kernel, dim3((W.gi.T + 255) / 256, cf->n_mels, W.gi.B), dim3(256), 0, a);
+    run_to_splane(cx, W.gi, pref(ws + W.Y, W.auxp), cf->n_mels, ws + W.YS, W.auxp);
+}
+void wf_couple(Ctx &cx, const WnRun &r, const float *endw, int mode, PRef X, PRef Xn, PRef dXn, PRef dX, const float *dld,
+               float *rowsum, int row_sel)
+{
+    WfCoupleArgs a;
+    memset(&a, 0, sizeof(a));
+    a.endw = endw;
+    a.S = pref(r.ws + r.w.skip, r.d.Cs); a.Cs = r.d.Cs;
+    a.X = X; a.Xn = Xn; a.dXn = dXn; a.dX = dX;
+    a.G = pref(r.ws + r.w.G, r.L.kp_end);
+    a.dld = dld; a.rowsum = rowsum; a.row_sel = row_sel; a.g = r.g; a.mode = mode;
+    WG_LAUNCH(cx, wf_couple_kernel, dim3(mode == 2 ? r.g.B / r.g.rows : r.g.B), dim3(256), 0, a);
+}
 }  // namespace
 
 // ================================================================================================
@@ -1160,6 +1296,182 @@ int wg_upsample(const wg_config *cf, const void *packed, const float *h, int B, 
     const ModelPack M = model_pack_layout(cf);
     const Geo g = make_geo(B, T, 0);
     run_upsample(cx, cf, pk + M.up_w, pk + M.up_bias, h, F, g, pnull(), y);
+    return cx.err;
+}
+
+// ---- WaveFlow -------------------------------------------------------------------------------------
+int wg_wf_param_count(const wg_wf_config *cf) { return cf ? 3 + cf->flows * 37 : WG_EINVAL; }
+size_t wg_wf_packed_bytes(const wg_wf_config *cf) { return wf_check(cf) ? 0 : wf_pack_layout(cf).total * sizeof(float); }
+size_t wg_wf_workspace_bytes(const wg_wf_config *cf, int B, int N, int mode)
+{
+    if (wf_check(cf) || B < 1 || N < 1 || N % cf->n_group) return 0;
+    return wf_ws_layout(cf, B, N / cf->n_group, mode ? 1 : 0).total * sizeof(float);
+}
+size_t wg_wf_tape_bytes(const wg_wf_config *cf, int B, int N)
+{
+    if (wf_check(cf) || B < 1 || N < 1 || N % cf->n_group) return 0;
+    const WfWs W = wf_ws_layout(cf, B, N / cf->n_group, 0);
+    return (size_t)(cf->flows + 1) * W.g.B * W.g.P * sizeof(float);
+}
+
+int wg_wf_pack_weights(const wg_wf_config *cf, const void *const *params, void *packed, void *stream)
+{
+    int rc = wf_check(cf);
+    if (rc) return rc;
+    if (!params || !packed) return WG_EINVAL;
+    Ctx cx = {(hipStream_t)stream, 0, 0};
+    const float *const *p = (const float *const *)params;
+    float *pk = (float *)packed;
+    const WfPack L = wf_pack_layout(cf);
+    const WnD d = wf_wn(cf);
+    const WnPack WL = wn_pack_layout(d);
+    const int s = 256 / cf->n_group;
+    float *ones = pk + L.ones;
+    WG_LAUNCH(cx, fill_rows_kernel, dim3(WG_ONES / 256, 1, 1), dim3(256), 0, pref(ones, 1), Geo{1, WG_ONES, WG_ONES, 0, WG_ONES}, (const float *)nullptr, 1.0f);
+    JobBatch jb(&cx);
+    jb.norm(p[1], p[2], pk + L.up_scale, cf->n_mels, cf->n_mels * (2 * s + 1));      // ConvTranspose1d: dim 0 is the input channel
+    for (int k = 0; k < cf->flows; ++k) wn_pack_norms(jb, d, WL, p + 3 + 37 * k, pk + L.wn[k]);
+    jb.flush_norm();
+    for (int k = 0; k < cf->flows; ++k) wn_pack_mats(jb, d, WL, p + 3 + 37 * k, pk + L.wn[k], ones);
+    jb.flush_pack();
+    ImgBatch ib(&cx);
+    for (int k = 0; k < cf->flows; ++k) wn_pack_images(ib, d, WL, pk + L.wn[k]);
+    ib.flush();
+    return cx.err;
+}
+
+// WaveFlow.forward_computation (waveflow.py:182-208).  tape (optional, wg_wf_tape_bytes, zero-initialised once by the caller) receives
+// the input of every flow and the final state: what wg_wf_backward needs, since this flow has no cheap inverse to rebuild them from.
+int wg_wf_forward(const wg_wf_config *cf, const void *const *params, const void *packed, const float *audio, const float *mel,
+                  int B, int N, int F, float *z, float *logdet, void *tape, void *wsv, size_t ws_bytes, void *stream)
+{
+    int rc = wf_check(cf);
+    if (rc) return rc;
+    int Wd;
+    rc = wf_shape(cf, B, N, F, &Wd);
+    if (rc) return rc;
+    if (!params || !packed || !audio || !mel || !z || !logdet || !wsv) return WG_EINVAL;
+    const WfWs W = wf_ws_layout(cf, B, Wd, 0);
+    if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
+    Ctx cx = {(hipStream_t)stream, 0, cf->precision};
+    const float *const *p = (const float *const *)params;
+    const float *pk = (const float *)packed;
+    const WfPack L = wf_pack_layout(cf);
+    float *ws = (float *)wsv;
+    const Geo g = W.g;
+    const size_t xplane = (size_t)g.B * g.P;
+    auto xk = [&](int k) { return tape ? (float *)tape + (size_t)k * xplane : ws + W.X[k & 1]; };
+    WG_LAUNCH(cx, wf_squeeze_kernel, dim3((g.T + 255) / 256, g.B), dim3(256), 0, audio, pref(xk(0), 1), g, N);        // waveflow.py:186
+    wf_upsample(cx, cf, p, pk, L, mel, F, W, ws);                                                                    // :183,187
+    WnRun r;
+    r.d = wf_wn(cf); r.L = wn_pack_layout(r.d); r.g = g; r.ws = ws; r.w = W.wn; r.Y = ws + W.Y; r.YS = ws + W.YS; r.save = 0;
+    for (int k = 0; k < cf->flows; ++k) {
+        r.pk = pk + L.wn[k]; r.X = pref(xk(k), 1);
+        wn_forward(cx, r);                                                                                           // :197
+        wf_couple(cx, r, p[3 + 37 * k + 36], 0, pref(xk(k), 1), pref(xk(k + 1), 1), pnull(), pnull(), nullptr,
+                  ws + W.rowsum + (size_t)k * g.B, 0);                                                               // :198-206
+    }
+    WG_LAUNCH(cx, wf_logdet_kernel, dim3((B + 63) / 64), dim3(64), 0, ws + W.rowsum, cf->flows, B, g.rows, logdet);
+    WG_LAUNCH(cx, wf_unsqueeze_kernel, dim3((g.T + 255) / 256, g.B), dim3(256), 0, pref(xk(cf->flows), 1), g, N, z);  // :208
+    return cx.err;
+}
+
+// WaveFlow.reverse_computation (waveflow.py:210-253): per flow (last first) flip, then one height row at a time -- WN2D on row r
+// from rows <= r (what reverse_mode_forward's ring buffers hold), x[r+1] = (z[r+1] - t[r]) / exp(log_s[r]).
+int wg_wf_inverse(const wg_wf_config *cf, const void *const *params, const void *packed, const float *z, const float *mel,
+                  int B, int N, int F, float *x, float *logdet, void *wsv, size_t ws_bytes, void *stream)
+{
+    int rc = wf_check(cf);
+    if (rc) return rc;
+    int Wd;
+    rc = wf_shape(cf, B, N, F, &Wd);
+    if (rc) return rc;
+    if (!params || !packed || !z || !mel || !x || !logdet || !wsv) return WG_EINVAL;
+    const WfWs W = wf_ws_layout(cf, B, Wd, 1);
+    if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
+    Ctx cx = {(hipStream_t)stream, 0, cf->precision};
+    const float *const *p = (const float *const *)params;
+    const float *pk = (const float *)packed;
+    const WfPack L = wf_pack_layout(cf);
+    float *ws = (float *)wsv;
+    const Geo g = W.g;
+    const int H = g.rows;
+    const dim3 rgrid((g.T + 255) / 256, g.B), igrid((g.T + 255) / 256, B);
+    float *Z = ws + W.X[0], *Zf = ws + W.X[1], *Xb = ws + W.dX[0];
+    WG_LAUNCH(cx, wf_squeeze_kernel, rgrid, dim3(256), 0, z, pref(Z, 1), g, N);
+    wf_upsample(cx, cf, p, pk, L, mel, F, W, ws);
+    WnRun r;
+    r.d = wf_wn(cf); r.L = wn_pack_layout(r.d); r.g = g; r.ws = ws; r.w = W.wn; r.Y = ws + W.Y; r.YS = ws + W.YS; r.save = 1;
+    for (int k = cf->flows - 1; k >= 0; --k) {
+        WG_LAUNCH(cx, wf_flip_kernel, rgrid, dim3(256), 0, pref(Z, 1), pref(Zf, 1), g);                              // :222
+        WG_LAUNCH(cx, wf_copy_row_kernel, igrid, dim3(256), 0, pref(Zf, 1), pref(Xb, 1), g, 0, 0);                   // :228
+        r.pk = pk + L.wn[k]; r.X = pref(Xb, 1);
+        for (int row = 0; row < H - 1; ++row) {
+            cx.row_sel1 = row + 1;
+            wn_forward(cx, r);
+            wf_couple(cx, r, p[3 + 37 * k + 36], 2, pref(Zf, 1), pref(Xb, 1), pnull(), pnull(), nullptr,
+                      ws + W.rowsum + (size_t)k * g.B, row);                                                         // :236-243
+        }
+        cx.row_sel1 = 0;
+        std::swap(Z, Xb);
+    }
+    // rowsum rows H-1 are never written by mode 2: they were zeroed with the workspace
+    WG_LAUNCH(cx, wf_logdet_kernel, dim3((B + 63) / 64), dim3(64), 0, ws + W.rowsum, cf->flows, B, H, logdet);
+    WG_LAUNCH(cx, wf_unsqueeze_kernel, rgrid, dim3(256), 0, pref(Z, 1), g, N, x);
+    return cx.err;
+}
+
+// Backward of wg_wf_forward + NLL seed: dz [B][N], dlogdet [B] -> every parameter gradient (table order), optional dmel, optional dx.
+// Per flow (last first): recompute WN2D from the taped flow input keeping every layer, seed (d log_s, d t) from the coupling, walk
+// WN2D backwards.  The conditioning gradient is accumulated per plane row and summed over the height axis at the end.
+int wg_wf_backward(const wg_wf_config *cf, const void *const *params, const void *packed, const void *tape, const float *mel,
+                   const float *dz, const float *dlogdet, int B, int N, int F, void *const *grads, float *dmel, float *dx,
+                   void *wsv, size_t ws_bytes, void *stream)
+{
+    int rc = wf_check(cf);
+    if (rc) return rc;
+    int Wd;
+    rc = wf_shape(cf, B, N, F, &Wd);
+    if (rc) return rc;
+    if (!params || !packed || !tape || !mel || !dz || !dlogdet || !grads || !wsv) return WG_EINVAL;
+    const WfWs W = wf_ws_layout(cf, B, Wd, 1);
+    if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
+    Ctx cx = {(hipStream_t)stream, 0, cf->precision};
+    const float *const *p = (const float *const *)params;
+    float *const *gr = (float *const *)grads;
+    const float *pk = (const float *)packed;
+    const WfPack L = wf_pack_layout(cf);
+    float *ws = (float *)wsv;
+    const Geo g = W.g;
+    const int M = cf->n_mels, s = 256 / cf->n_group, K = 2 * s + 1;
+    const size_t xplane = (size_t)g.B * g.P;
+    const dim3 rgrid((g.T + 255) / 256, g.B);
+    float *dXn = ws + W.dX[0], *dXc = ws + W.dX[1];
+    WG_LAUNCH(cx, wf_squeeze_kernel, rgrid, dim3(256), 0, dz, pref(dXn, 1), g, N);
+    wf_upsample(cx, cf, p, pk, L, mel, F, W, ws);
+    if (cx.err == 0 && hipMemsetAsync(ws + W.dYrow, 0, (size_t)g.B * W.auxp * g.P * sizeof(float), cx.st) != hipSuccess) cx.err = WG_ELAUNCH;
+    WnRun r;
+    r.d = wf_wn(cf); r.L = wn_pack_layout(r.d); r.g = g; r.ws = ws; r.w = W.wn; r.Y = ws + W.Y; r.YS = ws + W.YS; r.save = 1;
+    for (int k = cf->flows - 1; k >= 0; --k) {
+        const float *Xk = (const float *)tape + (size_t)k * xplane;
+        r.pk = pk + L.wn[k]; r.X = pref((float *)Xk, 1);
+        wn_forward(cx, r);
+        wf_couple(cx, r, p[3 + 37 * k + 36], 1, pref((float *)Xk, 1), pnull(), pref(dXn, 1), pref(dXc, 1), dlogdet, nullptr, 0);
+        wn_backward(cx, r, p + 3 + 37 * k, gr + 3 + 37 * k, pref(dXc, 1), ws + W.dYrow);
+        std::swap(dXn, dXc);
+    }
+    if (dx) WG_LAUNCH(cx, wf_unsqueeze_kernel, rgrid, dim3(256), 0, pref(dXn, 1), g, N, dx);
+    // upsampler backward: sum the per-row conditioning gradient over the height axis, LeakyReLU', transposed conv, weight norm
+    WG_LAUNCH(cx, wf_rowsum_leaky_kernel, dim3((g.T + 255) / 256, M, B), dim3(256), 0, pref(ws + W.dYrow, W.auxp), g, pref(ws + W.Y, W.auxp),
+              W.gi, M, ws + W.gp);
+    WfUpBwdArgs a;
+    a.mel = mel; a.v = p[2]; a.scale = pk + L.up_scale; a.gp = ws + W.gp;
+    a.B = B; a.M = M; a.F = F; a.K = K; a.s = s; a.pad = s / 2; a.W = Wd;
+    a.dw = ws + W.dwup; a.dbias = gr[0]; a.dmel = dmel;
+    WG_LAUNCH(cx, wf_upsample_bwd_kernel, dim3(M), dim3(256), 0, a);
+    WgradOut wo;
+    wo.nsplit = 1; wo.Mp = M; wo.Np = M * K;
+    run_finalize(cx, ws + W.dwup, wo, 0, M, M * K, 1, 0, 1, 0, p[1], p[2], gr[1], gr[2]);
     return cx.err;
 }
 

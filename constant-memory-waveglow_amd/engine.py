@@ -348,3 +348,73 @@ def wsr_cond_backward(c, dcond):
     dang = torch.empty(120, 50, dtype=torch.float32, device=c.device)
     check(_lib.lib().wg_wsr_cond_backward(_p(c), B, L, _p(dcond), _p(dmu), _p(dang), _stream()), "wg_wsr_cond_backward")
     return dmu, dang
+
+
+# ---- WaveFlow (include/wgflow.h: wg_wf_*) ------------------------------------------------------------------------------------
+class WaveFlowEngine:
+    """Whole-model entry points of WaveFlow: wg_wf_pack_weights / wg_wf_forward / wg_wf_inverse / wg_wf_backward."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.buffers = _Buffers()
+        self.packed = PackedWeights()
+        self._tape = None
+
+    def _pack(self, params, device):
+        L = _lib.lib()
+        if len(params) != L.wg_wf_param_count(C.byref(self.cfg)):
+            raise WgError("WaveFlow parameter table has %d entries" % len(params))
+        if self.packed.stale(params) or self.packed.buf.device != device:
+            nbytes = L.wg_wf_packed_bytes(C.byref(self.cfg))
+            if nbytes == 0:
+                raise WgError("WaveFlow configuration not supported by the HIP kernels (n_group in {8,16,32,64,128}, channels "
+                              "multiples of 32, WG_PRECISION=bf16x3p)")
+            if self.packed.buf is None or self.packed.buf.numel() < nbytes or self.packed.buf.device != device:
+                self.packed.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            check(L.wg_wf_pack_weights(C.byref(self.cfg), _table(params), _p(self.packed.buf), _stream()), "wg_wf_pack_weights")
+        return self.packed.buf
+
+    def _ws(self, B, N, mode, device):
+        nbytes = _lib.lib().wg_wf_workspace_bytes(C.byref(self.cfg), B, N, mode)
+        return self.buffers.get((device, mode, B, N), nbytes, device)
+
+    def forward(self, params, x, mel, keep_tape):
+        require_device(x, mel, *params)
+        x, mel = x.contiguous(), mel.contiguous()
+        B, N = x.shape
+        pk = self._pack(params, x.device)
+        ws = self._ws(B, N, 0, x.device)
+        tape = None
+        if keep_tape:
+            nbytes = _lib.lib().wg_wf_tape_bytes(C.byref(self.cfg), B, N)
+            tape = self.buffers.get((x.device, "tape", B, N), nbytes, x.device)
+        z = torch.empty_like(x)
+        logdet = torch.empty(B, dtype=torch.float32, device=x.device)
+        check(_lib.lib().wg_wf_forward(C.byref(self.cfg), _table(params), _p(pk), _p(x), _p(mel), B, N, mel.shape[2], _p(z), _p(logdet),
+                                       _p(tape), _p(ws), ws.numel(), _stream()), "wg_wf_forward")
+        return z, logdet, tape
+
+    def inverse(self, params, z, mel):
+        require_device(z, mel, *params)
+        z, mel = z.contiguous(), mel.contiguous()
+        B, N = z.shape
+        pk = self._pack(params, z.device)
+        ws = self._ws(B, N, 1, z.device)
+        x = torch.empty_like(z)
+        logdet = torch.empty(B, dtype=torch.float32, device=z.device)
+        check(_lib.lib().wg_wf_inverse(C.byref(self.cfg), _table(params), _p(pk), _p(z), _p(mel), B, N, mel.shape[2], _p(x), _p(logdet),
+                                       _p(ws), ws.numel(), _stream()), "wg_wf_inverse")
+        return x, logdet
+
+    def backward(self, params, tape, mel, dz, dlogdet, need_dmel, need_dx):
+        require_device(mel, dz, dlogdet)
+        mel, dz, dlogdet = mel.contiguous(), dz.contiguous(), dlogdet.contiguous()
+        B, N = dz.shape
+        pk = self._pack(params, dz.device)
+        ws = self._ws(B, N, 1, dz.device)
+        grads = [torch.empty_like(p) for p in params]
+        dmel = torch.empty_like(mel) if need_dmel else None
+        dx = torch.empty_like(dz) if need_dx else None
+        check(_lib.lib().wg_wf_backward(C.byref(self.cfg), _table(params), _p(pk), _p(tape), _p(mel), _p(dz), _p(dlogdet), B, N,
+                                        mel.shape[2], _table(grads), _p(dmel), _p(dx), _p(ws), ws.numel(), _stream()), "wg_wf_backward")
+        return grads, dmel, dx

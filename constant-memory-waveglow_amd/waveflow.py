@@ -1,0 +1,147 @@
+"""WaveFlow on the HIP flow engine: same constructor, parameter names and forward/reverse/infer contract as the reference's
+model/waveflow.py (use_conv1x1=False, the shipped configuration).  Audio [B, N] is viewed as [B, n_group (height), N/n_group (time)];
+each flow runs WN2D (8 layers of 3x3 dilated convs, causal along the height axis) on rows 0..H-2 and transforms rows 1..H-1.
+
+Module tree (state dicts interchange with the reference):
+    upsampler.{0,1,2}     ReplicationPad1d((0,1)), ConvTranspose1d(n_mels, n_mels, 2s+1, s, padding s//2) + weight norm, LeakyReLU(0.4)
+    WNs.{k}               WN2D: V, start, layers.{i}.{W, W_o}, end
+"""
+import warnings
+from typing import Tuple
+
+import torch
+from torch import Tensor, nn
+from torch.autograd import Function
+
+from . import engine
+from ._lib import WgError, WgWfConfig, default_precision
+from .base import FlowBase
+from .utils import add_weight_norms, conv_gv
+
+
+class NonCausalLayer2D(nn.Module):
+    """Parameter container of one WN2D layer (waveflow.py:14-51): W = 3x3 conv with dilation (h_dilation, dilation), W_o = 1x1."""
+
+    def __init__(self, h_dilation, dilation, dilation_channels, residual_channels, skip_channels, radix, bias, last_layer=False):
+        super().__init__()
+        self.h_pad_size = h_dilation * (radix - 1)
+        self.pad_size = dilation * (radix - 1) // 2
+        self.W = nn.Conv2d(residual_channels, dilation_channels * 2, kernel_size=radix, dilation=(h_dilation, dilation), bias=bias)
+        self.chs_split = [skip_channels]
+        if last_layer:
+            self.W_o = nn.Conv2d(dilation_channels, skip_channels, 1, bias=bias)
+        else:
+            self.W_o = nn.Conv2d(dilation_channels, residual_channels + skip_channels, 1, bias=bias)
+            self.chs_split.insert(0, residual_channels)
+
+    def forward(self, x, y):
+        raise WgError("NonCausalLayer2D is executed inside the fused HIP kernels; call WaveFlow")
+
+
+class WN2D(nn.Module):
+    """Parameter container of WN2D (waveflow.py:70-135)."""
+
+    H_DILATIONS = {8: [1] * 8, 16: [1] * 8, 32: [1, 2, 4] * 2 + [1, 2], 64: [1, 2, 4, 8, 16, 1, 2, 4], 128: [1, 2, 4, 8, 16, 32, 64, 1]}
+
+    def __init__(self, n_group, aux_channels, dilation_channels=256, residual_channels=256, skip_channels=256, bias=False, zero_init=True):
+        super().__init__()
+        if bias:
+            raise WgError("WN2D(bias=True) is not built into the HIP kernels (the reference config uses bias=False)")
+        self.h_dilations = self.H_DILATIONS[n_group]
+        self.dilations = [2 ** i for i in range(8)]
+        self.n_group = n_group
+        self.res_chs, self.dil_chs, self.skp_chs, self.aux_chs = residual_channels, dilation_channels, skip_channels, aux_channels
+        self.r_field = sum(self.dilations) * 2 + 1
+        self.h_r_field = sum(self.h_dilations) * 2 + 1
+        self.V = nn.Conv1d(aux_channels, dilation_channels * 2 * 8, 1, bias=bias)
+        self.V.apply(add_weight_norms)
+        self.start = nn.Conv2d(1, residual_channels, 1, bias=bias)
+        self.start.apply(add_weight_norms)
+        self.layers = nn.ModuleList(
+            NonCausalLayer2D(hd, d, dilation_channels, residual_channels, skip_channels, 3, bias, last_layer=(i == 7))
+            for i, (hd, d) in enumerate(zip(self.h_dilations, self.dilations)))
+        self.layers.apply(add_weight_norms)
+        self.end = nn.Conv2d(skip_channels, 2, 1, bias=bias)
+        if zero_init:
+            self.end.weight.data.zero_()
+
+    def param_table(self):
+        tab = list(conv_gv(self.V)) + list(conv_gv(self.start))
+        for layer in self.layers:
+            tab += list(conv_gv(layer.W)) + list(conv_gv(layer.W_o))
+        tab.append(self.end.weight)
+        return tab
+
+    def forward(self, x, y):
+        raise WgError("WN2D is executed inside the fused HIP kernels; call WaveFlow")
+
+
+class _WaveFlowFn(Function):
+    """forward = wg_wf_forward (which tapes every flow's input), backward = wg_wf_backward (per-flow recompute from the tape)."""
+
+    @staticmethod
+    def forward(ctx, model, x, h, *params):
+        table = [t.detach() for t in model.param_table()]
+        z, logdet, tape = model._engine.forward(table, x.detach(), h.detach(), keep_tape=True)
+        ctx.model, ctx.tape = model, tape
+        ctx.save_for_backward(h)
+        return z, logdet
+
+    @staticmethod
+    def backward(ctx, dz, dlogdet):
+        (h,) = ctx.saved_tensors
+        model = ctx.model
+        table = model.param_table()
+        grads, dmel, dx = model._engine.backward([t.detach() for t in table], ctx.tape, h, dz, dlogdet,
+                                                 ctx.needs_input_grad[2], ctx.needs_input_grad[1])
+        by_id = {id(t): g for t, g in zip(table, grads)}
+        return (None, dx, dmel) + tuple(by_id.get(id(p)) for p in model.parameters())
+
+
+class WaveFlow(FlowBase):
+    def __init__(self, flows, n_group, n_mels, use_conv1x1, memory_efficient, reverse_mode=False, **kwargs):
+        super().__init__(256, reverse_mode)
+        if use_conv1x1:
+            raise WgError("WaveFlow(use_conv1x1=True) is not built into the HIP engine (the shipped config uses False)")
+        if reverse_mode:
+            raise WgError("WaveFlow(reverse_mode=True) is not built into the HIP engine")
+        self.flows, self.n_group, self.n_mels = flows, n_group, n_mels
+        self.sub_sr = self._hop_length // n_group
+        self.upsampler = nn.Sequential(
+            nn.ReplicationPad1d((0, 1)),
+            nn.ConvTranspose1d(n_mels, n_mels, self.sub_sr * 2 + 1, self.sub_sr, padding=self.sub_sr // 2),
+            nn.LeakyReLU(0.4, True))
+        self.upsampler.apply(add_weight_norms)
+        self.WNs = nn.ModuleList(WN2D(n_group, n_mels, **kwargs) for _ in range(flows))
+        wn0 = self.WNs[0]
+        self._engine = engine.WaveFlowEngine(WgWfConfig(flows, n_group, n_mels, wn0.res_chs, wn0.dil_chs, wn0.skp_chs, default_precision()))
+
+    def param_table(self):
+        """C-ABI parameter table (include/wgflow.h): upsampler.1 bias, g, v; per flow the WN2D table."""
+        up = self.upsampler[1]
+        g, v = conv_gv(up)
+        if g is None:
+            raise WgError("the WaveFlow engine needs the weight-normed parameterisation (do not call remove_weight_norms on it)")
+        tab = [up.bias, g, v]
+        for wn in self.WNs:
+            t = wn.param_table()
+            if any(p is None for p in t):
+                raise WgError("the WaveFlow engine needs the weight-normed parameterisation (do not call remove_weight_norms on it)")
+            tab += t
+        return tab
+
+    def _check(self, x: Tensor, h: Tensor):
+        if x.dim() != 2 or h.dim() != 3:
+            raise WgError("expected audio [B, N] and conditioning [B, n_mels, frames]")
+        s = self.sub_sr
+        assert x.size(1) // self.n_group <= h.size(2) * s - 2 * (s // 2) + 2 * s + 1
+
+    def forward_computation(self, x: Tensor, h: Tensor) -> Tuple[Tensor, Tensor]:
+        self._check(x, h)
+        return _WaveFlowFn.apply(self, x, h, *self.parameters())
+
+    def reverse_computation(self, z: Tensor, h: Tensor) -> Tuple[Tensor, Tensor]:
+        self._check(z, h)
+        if torch.is_grad_enabled() and (z.requires_grad or h.requires_grad):
+            warnings.warn("WaveFlow.reverse runs without autograd in the HIP engine", stacklevel=3)
+        return self._engine.inverse([t.detach() for t in self.param_table()], z.detach(), h.detach())

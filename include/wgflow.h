@@ -179,6 +179,35 @@ int wg_wsr_cond(const float *c, int B, int L, const float *mu_table, const float
  * through integer indices, :47 has no parameters).  Outputs are overwritten. */
 int wg_wsr_cond_backward(const float *c, int B, int L, const float *dcond, float *dmu_table, float *dang_table, void *stream);
 
+/* ---- WaveFlow (model/waveflow.py) -------------------------------------------------------------------
+ * WaveFlow(flows, n_group, n_mels, use_conv1x1=False, ..., dilation/residual/skip_channels, bias=False): audio [B,N] viewed as
+ * [B, n_group (height), N/n_group (time)], 8-layer WN2D with 3x3 dilated convs causal along the height axis, autoregressive
+ * affine coupling along the height axis, flip between flows.  Parameter table = named_parameters() order (3 + 37 per flow):
+ *   upsampler.1.{bias, weight_g, weight_v}; WNs.k.{V.g, V.v, start.g, start.v, layers.i.{W.g, W.v, W_o.g, W_o.v} x 8, end.weight}.
+ * Only WG_PREC_BF16X3_PLANES is built for this model.  The hop length is 256 (waveflow.py:160). */
+typedef struct wg_wf_config {
+    int32_t flows, n_group, n_mels;
+    int32_t res_ch, dil_ch, skip_ch;
+    int32_t precision;
+} wg_wf_config;
+int wg_wf_param_count(const wg_wf_config *cfg);
+size_t wg_wf_packed_bytes(const wg_wf_config *cfg);
+size_t wg_wf_workspace_bytes(const wg_wf_config *cfg, int B, int N, int mode);      /* 0: forward; 1: backward / inverse */
+size_t wg_wf_tape_bytes(const wg_wf_config *cfg, int B, int N);
+int wg_wf_pack_weights(const wg_wf_config *cfg, const void *const *params, void *packed, void *stream);
+/* WaveFlow.forward_computation (waveflow.py:182-208): z[B,N], logdet[B].  `tape` (nullable; zero-initialised once) receives every
+ * flow's input for wg_wf_backward. */
+int wg_wf_forward(const wg_wf_config *cfg, const void *const *params, const void *packed, const float *audio, const float *mel,
+                  int B, int N, int F, float *z, float *logdet, void *tape, void *ws, size_t ws_bytes, void *stream);
+/* WaveFlow.reverse_computation (waveflow.py:210-253): the row-by-row autoregressive inverse. */
+int wg_wf_inverse(const wg_wf_config *cfg, const void *const *params, const void *packed, const float *z, const float *mel,
+                  int B, int N, int F, float *x, float *logdet, void *ws, size_t ws_bytes, void *stream);
+/* What autograd computes upstream for z, logdet = model(x, mel) (the reference trains this model with memory_efficient=False):
+ * every parameter gradient (table order), d mel (nullable), d audio (nullable), from the tape wg_wf_forward wrote. */
+int wg_wf_backward(const wg_wf_config *cfg, const void *const *params, const void *packed, const void *tape, const float *mel,
+                   const float *dz, const float *dlogdet, int B, int N, int F, void *const *grads, float *dmel, float *dx,
+                   void *ws, size_t ws_bytes, void *stream);
+
 /* ---- optimizer step (trainer parity) ---------------------------------------------------------------
  * torch.optim.Adam (amsgrad = false, maximize = false) on one contiguous fp32 range: what the reference's
  * configure_optimizers builds from `optimizer` in its configs (model/lightning.py:41-44; configs/waveglow_LJ_speech.json:

@@ -569,3 +569,49 @@ def test_shape_sweep_vs_oracle(dev, case):
         x, ld = m.reverse(z.detach(), ht.detach())
     assert np.abs(npy(x) - audio).max() < Z_ATOL
     assert logdet_close(-npy(ld), ref["logdet"], N)
+
+
+# ---- WaveFlow ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", ["wf8", "wf64"])
+def test_waveflow_model_vs_reference_golden(dev, golden_dir, precision, name):
+    """WaveFlow forward + NLL + backward + row-by-row inverse against the reference's own run (model_wf*.npz) and the oracle."""
+    if precision != "bf16x3p":
+        pytest.skip("WaveFlow's 2-D taps are built for the S-plane kernels only")
+    from oracle import wf_oracle as wfo
+    cfg = fill.WF_CONFIGS[name]
+    B, N, F = fill.WF_SHAPES[name]
+    specs = fill.waveflow_param_specs(cfg)
+    P = fill.fill_params(specs, name + "/")
+    audio, mel = fill.waveflow_inputs(name, B, N, F, cfg["n_mels"])
+    gold = np.load(os.path.join(golden_dir, "model_%s.npz" % name))
+    ref = wfo.train_step(wfo.make_config(**cfg), fill.table(specs, P), audio, mel, fill.SIGMA, need_dmel=True)
+    m = cm.WaveFlow(use_conv1x1=False, memory_efficient=False, bias=False, **cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    m = m.to(dev)
+    ht = T(mel, dev).requires_grad_(True)
+    z, logdet = m(T(audio, dev), ht)
+    loss = cm.WaveGlowLoss(fill.SIGMA)(z, logdet)
+    loss.backward()
+    for want in (ref, gold):
+        assert np.abs(npy(z) - want["z"]).max() < Z_ATOL
+        assert logdet_close(npy(logdet), want["logdet"], N)
+        assert abs(float(loss) - float(want["loss"])) < LOSS_ATOL
+        assert relmax(npy(ht.grad), want["dmel"]) < GRAD_RTOL
+    named = dict(m.named_parameters())
+    for i, (n, _, _) in enumerate(specs):
+        g = npy(named[n].grad)
+        if n.endswith("start.weight_v"):
+            # Conv2d(1, C, 1) under weight norm: the exact gradient w.r.t. v is zero (w = g * sign(v)); rounding noise on every side
+            assert np.abs(g).max() < 1e-5 * np.abs(npy(named[n[:-1] + "g"].grad)).max(), n
+            continue
+        assert relmax(g, ref["grads"][i]) < GRAD_RTOL, n
+        nh = min(g.size, gold["grad_head"].shape[1])
+        assert np.abs(g.ravel()[:nh] - gold["grad_head"][i][:nh]).max() / max(float(gold["grad_max"][i]), 1e-30) < GRAD_RTOL, n
+        if "grad::" + n in gold:
+            assert relmax(g, gold["grad::" + n]) < GRAD_RTOL, n
+    with torch.no_grad():
+        x, ld = m.reverse(T(gold["z"], dev), ht.detach())
+    assert np.abs(npy(x) - gold["x_inv"]).max() < Z_ATOL
+    assert np.abs(npy(x) - audio).max() < Z_ATOL
+    assert logdet_close(npy(ld), gold["logdet_inv"], N)
