@@ -615,3 +615,36 @@ def test_waveflow_model_vs_reference_golden(dev, golden_dir, precision, name):
     assert np.abs(npy(x) - gold["x_inv"]).max() < Z_ATOL
     assert np.abs(npy(x) - audio).max() < Z_ATOL
     assert logdet_close(npy(ld), gold["logdet_inv"], N)
+
+
+def test_waveflow_shipped_width_vs_oracle(dev, precision):
+    """The shipped WaveFlow width (8 flows, 64 rows, 80 mels, 64 channels: one 128-row tile, K = 9*64 + 96) on a short segment."""
+    if precision != "bf16x3p":
+        pytest.skip("WaveFlow's 2-D taps are built for the S-plane kernels only")
+    from oracle import wf_oracle as wfo
+    name = "wf_full"
+    cfg = dict(flows=8, n_group=64, n_mels=80, dilation_channels=64, residual_channels=64, skip_channels=64)
+    B, N, F = 1, 64 * 10, 2
+    specs = fill.waveflow_param_specs(cfg)
+    P = fill.fill_params(specs, name + "/")
+    audio, mel = fill.waveflow_inputs(name, B, N, F, cfg["n_mels"])
+    ref = wfo.train_step(wfo.make_config(**cfg), fill.table(specs, P), audio, mel, fill.SIGMA, need_dmel=True)
+    m = cm.WaveFlow(use_conv1x1=False, memory_efficient=False, bias=False, **cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    m = m.to(dev)
+    ht = T(mel, dev).requires_grad_(True)
+    z, logdet = m(T(audio, dev), ht)
+    loss = cm.WaveGlowLoss(fill.SIGMA)(z, logdet)
+    loss.backward()
+    assert np.abs(npy(z) - ref["z"]).max() < Z_ATOL
+    assert logdet_close(npy(logdet), ref["logdet"], N)
+    assert abs(float(loss) - ref["loss"]) < LOSS_ATOL
+    assert relmax(npy(ht.grad), ref["dmel"]) < GRAD_RTOL
+    named = dict(m.named_parameters())
+    for i, (n, _, _) in enumerate(specs):
+        if n.endswith("start.weight_v"):
+            continue
+        assert relmax(npy(named[n].grad), ref["grads"][i]) < GRAD_RTOL, n
+    with torch.no_grad():
+        x, _ = m.reverse(z.detach(), ht.detach())
+    assert np.abs(npy(x) - audio).max() < Z_ATOL
