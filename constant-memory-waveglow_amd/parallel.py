@@ -111,6 +111,23 @@ class GradSync:
                 if fg.bucket(b).numel():
                     after_bucket(b)
 
+    def all_reduce_params(self, params: Sequence[torch.Tensor]):
+        """Mean all-reduce of `p.grad` for models trained through autograd (WSRGlow, WaveFlow): the gradients are copied into one
+        flat buffer, reduced with ONE collective (WaveFlow: 5.95 M parameters = 24 MB) and copied back."""
+        if self.world == 1 and not self._force:
+            return
+        grads = [p.grad for p in params if p.grad is not None]
+        if not grads:
+            return
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, group=self.pg)
+        if not self._avg:
+            flat.div_(self.world)
+        off = 0
+        for g in grads:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+
     def broadcast_params(self, params: Sequence[torch.Tensor], src: int = 0):
         """replicas start identical (what DDP does when it wraps the module)"""
         if self.world == 1 and not self._force:

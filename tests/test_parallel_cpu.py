@@ -60,6 +60,13 @@ def _worker(rank, world, port, q):
     sync.all_reduce(fg, order=order, after_bucket=lambda b: seen.append((b, float((fg.bucket(b) - half[b]).abs().max()))))
     assert [b for b, _ in seen] == order, seen
     assert any(d > 0 for _, d in seen)                                  # the buckets had been reduced when the callback ran
+    # autograd-trained models (WSRGlow, WaveFlow): one coalesced mean all-reduce of p.grad
+    ps = [torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2, 3)), torch.nn.Parameter(torch.zeros(1))]
+    ps[0].grad = torch.full((5,), float(rank + 1))
+    ps[1].grad = torch.arange(6, dtype=torch.float32).view(2, 3) * (rank + 1)
+    sync.all_reduce_params(ps)
+    assert torch.allclose(ps[0].grad, torch.full((5,), 1.5)) and torch.allclose(ps[1].grad, torch.arange(6, dtype=torch.float32).view(2, 3) * 1.5)
+    assert ps[2].grad is None
     # replicas start identical
     probe = [torch.full((3,), float(rank))]
     sync.broadcast_params(probe)
