@@ -7,6 +7,7 @@
 #include "wg_gemm16s.h"
 #include "wg_wsr.h"
 #include "wg_wf.h"
+#include "wg_mel.h"
 
 #include <algorithm>
 #include <atomic>
@@ -1472,6 +1473,27 @@ int wg_wf_backward(const wg_wf_config *cf, const void *const *params, const void
     WgradOut wo;
     wo.nsplit = 1; wo.Mp = M; wo.Np = M * K;
     run_finalize(cx, ws + W.dwup, wo, 0, M, M * K, 1, 0, 1, 0, p[1], p[2], gr[1], gr[2]);
+    return cx.err;
+}
+
+// ---- log-mel conditioner --------------------------------------------------------------------------
+int wg_melspec_frames(int N, int n_fft, int hop) { return (N < 1 || hop < 1) ? WG_EINVAL : N / hop + 1; }
+int wg_melspec(const float *audio, int B, int N, int sr, int n_fft, int hop, double f_min, double f_max, int n_mels, float *mel, void *stream)
+{
+    if (!audio || !mel || B < 1 || N < 2 || sr < 2 || hop < 1 || n_mels < 1) return WG_EINVAL;
+    if (n_fft < 2 || n_fft > WG_MEL_MAXFFT || (n_fft & (n_fft - 1)) || n_mels > 256 || hop > n_fft) return WG_EUNSUPPORTED;
+    if (n_fft / 2 + hop / 2 >= N) return WG_ESHAPE;                      // reflection padding needs pad < length
+    if (f_max <= 0.0) f_max = (double)(sr / 2);
+    if (!(f_min >= 0.0) || !(f_max > f_min)) return WG_EINVAL;
+    Ctx cx = {(hipStream_t)stream, 0, 0};
+    MelArgs a;
+    a.audio = audio; a.mel = mel; a.N = N; a.n_fft = n_fft; a.hop = hop; a.n_mels = n_mels;
+    a.frames = N / hop + 1;                                               // (N + n_fft - n_fft) / hop + 1 with center=False
+    a.pad_left = n_fft / 2 - hop / 2;
+    a.sr_half = sr / 2;
+    a.m_min = (float)(2595.0 * std::log10(1.0 + f_min / 700.0));
+    a.m_max = (float)(2595.0 * std::log10(1.0 + f_max / 700.0));
+    WG_LAUNCH(cx, melspec_kernel, dim3(a.frames, B), dim3(256), 0, a);
     return cx.err;
 }
 

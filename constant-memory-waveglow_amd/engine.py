@@ -418,3 +418,18 @@ class WaveFlowEngine:
         check(_lib.lib().wg_wf_backward(C.byref(self.cfg), _table(params), _p(pk), _p(tape), _p(mel), _p(dz), _p(dlogdet), B, N,
                                         mel.shape[2], _table(grads), _p(dmel), _p(dx), _p(ws), ws.numel(), _stream()), "wg_wf_backward")
         return grads, dmel, dx
+
+
+# ---- log-mel conditioner (include/wgflow.h: wg_melspec) -------------------------------------------------------------------------
+def melspec(x, sr, n_fft, hop, f_min, f_max, n_mels):
+    """audio [B, N] -> log-mel [B, n_mels, N // hop + 1]  (MelSpec.forward, model/condition.py:18-19)."""
+    require_device(x)
+    if x.dim() != 2:
+        raise WgError("MelSpec expects audio [B, N]")
+    x = x.contiguous()
+    B, N = x.shape
+    frames = _lib.lib().wg_melspec_frames(N, n_fft, hop)
+    out = torch.empty(B, n_mels, frames, dtype=torch.float32, device=x.device)
+    check(_lib.lib().wg_melspec(_p(x), B, N, int(sr), int(n_fft), int(hop), float(f_min), float(f_max if f_max is not None else 0.0),
+                                int(n_mels), _p(out), _stream()), "wg_melspec")
+    return out

@@ -208,6 +208,15 @@ int wg_wf_backward(const wg_wf_config *cfg, const void *const *params, const voi
                    const float *dz, const float *dlogdet, int B, int N, int F, void *const *grads, float *dmel, float *dx,
                    void *ws, size_t ws_bytes, void *stream);
 
+/* ---- log-mel conditioner ---------------------------------------------------------------------------
+ * Replaces MelSpec.forward (model/condition.py:7-19): reflection pad (n_fft/2 - hop/2, n_fft/2 + hop/2), torchaudio
+ * MelSpectrogram(sample_rate, n_fft, hop_length, center=False, f_min, f_max, n_mels) with torchaudio's defaults for the rest
+ * (periodic Hann, power 2, HTK mel scale, norm None), then log(x + 1e-7).  audio[B,N] -> mel[B,n_mels,N/hop + 1].
+ * f_max <= 0 means sr // 2.  n_fft must be a power of two <= 2048.  torchaudio is not part of the reference tree: its published
+ * algorithm is restated (parity unpinned against torchaudio itself). */
+int wg_melspec_frames(int N, int n_fft, int hop);
+int wg_melspec(const float *audio, int B, int N, int sr, int n_fft, int hop, double f_min, double f_max, int n_mels, float *mel, void *stream);
+
 /* ---- optimizer step (trainer parity) ---------------------------------------------------------------
  * torch.optim.Adam (amsgrad = false, maximize = false) on one contiguous fp32 range: what the reference's
  * configure_optimizers builds from `optimizer` in its configs (model/lightning.py:41-44; configs/waveglow_LJ_speech.json:

@@ -648,3 +648,23 @@ def test_waveflow_shipped_width_vs_oracle(dev, precision):
     with torch.no_grad():
         x, _ = m.reverse(z.detach(), ht.detach())
     assert np.abs(npy(x) - audio).max() < Z_ATOL
+
+
+# ---- log-mel conditioner -----------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("B,N", [(1, 4096), (3, 16000), (2, 22016)])
+def test_melspec_kernel_vs_oracle(dev, precision, B, N):
+    """wg_melspec against the numpy restatement of MelSpec (reflection pad, 1024-point periodic-Hann STFT power, HTK mel filters to
+    8 kHz, log(x + 1e-7)); the configuration is the one every WaveGlow / WaveFlow config ships (conditioner.args)."""
+    if precision != "f32":
+        pytest.skip("the conditioner does not depend on the contraction mode")
+    from oracle import mel_oracle as mo
+    x = fill.uniform("mel/x%d_%d" % (B, N), (B, N), -0.8, 0.8)
+    x[0, : N // 4] *= 1e-3                                       # a quiet stretch: log-mel near its floor
+    cond = cm.MelSpec(sr=22050, n_fft=1024, hop_length=256, f_max=8000, n_mels=80)
+    got = npy(cond(T(x, dev)))
+    want = mo.melspec(x, 22050, 1024, 256, 0.0, 8000.0, 80)
+    assert got.shape == want.shape == (B, 80, N // 256 + 1)
+    assert np.abs(got - want).max() < 1e-4                       # log domain, fp32 direct DFT vs float64 FFT
+    with pytest.raises(cm.WgError):
+        cm.MelSpec(sr=22050, n_fft=1024, hop_length=256, power=1.0)

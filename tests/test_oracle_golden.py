@@ -253,3 +253,22 @@ def test_waveflow_matches_reference(golden_dir, name, double):
     x, ld = wfo.inverse(oc, fill.table(specs, P), G["z"], mel, double=double)
     assert np.abs(x - G["x_inv"]).max() < 2e-6 and np.abs(x - audio).max() < 2e-6
     assert _logdet_close(ld, G["logdet_inv"], N)
+
+
+# ---- log-mel conditioner: the oracle's own sanity (parity vs torchaudio is unpinned, see oracle/mel_oracle.py) ----
+
+def test_mel_oracle_properties():
+    from oracle import mel_oracle as mo
+    sr, n_fft, hop, n_mels = 22050, 1024, 256, 80
+    fb = mo.mel_filterbank(sr, n_fft, n_mels, 0.0, 8000.0)
+    assert fb.shape == (513, 80) and fb.min() >= 0.0 and fb.max() <= 1.0
+    assert np.all(fb[0] == 0.0) and np.all(fb[int(8000 / (11025 / 512)) + 2:] == 0.0)        # nothing at DC, nothing above f_max
+    peaks = fb.argmax(0)
+    assert np.all(np.diff(peaks) > 0)                                                       # centres increase with the mel index
+    t = np.arange(16000) / sr
+    x = (0.5 * np.sin(2 * np.pi * 1000.0 * t)).astype(np.float32)[None]
+    m = mo.melspec(x, sr, n_fft, hop, 0.0, 8000.0, n_mels)
+    assert m.shape == (1, 80, 63)                                                           # 63 frames for 16000 samples
+    centre_hz = 700.0 * (10.0 ** (np.linspace(0, 2595 * np.log10(1 + 8000 / 700), 82)[1:-1] / 2595.0) - 1.0)
+    assert abs(centre_hz[m[0, :, 30].argmax()] - 1000.0) < 60.0                             # a 1 kHz tone lights the 1 kHz filter
+    assert np.allclose(mo.melspec(np.zeros((1, 4096), np.float32), sr, n_fft, hop, 0.0, 8000.0, n_mels), np.log(1e-7))
