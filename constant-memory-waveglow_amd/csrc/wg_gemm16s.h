@@ -62,7 +62,33 @@ __global__ void to_splane_kernel(PRef src, int nvalid, SRef dst, Geo g)
 // All auxiliary loads of a thread (residual input, skip accumulator, tanh/sigmoid) are issued first, into registers that
 // overwrite the accumulators they are combined with, and only then the stores: the epilogue is HBM/latency bound at two
 // waves per SIMD, so memory-level parallelism (64-128 loads in flight per lane) is what matters.
+// the auxiliary values of the STORE / RESSKIP epilogues (accumulate-into input, residual input, skip accumulator) as the INITIAL
+// value of the accumulators: the main loop then adds the products on top and the epilogue has nothing left to load
 template <int EPI>
+__device__ __forceinline__ void conv_acc_init(const ConvGemmArgs &a, f32x16 (&acc)[2][2], int t0, int m0, int b, int wr, int wc, int lane)
+{
+    const Geo g = a.g;
+    const int col = lane & 31;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int t = t0 + wc * 64 + ni * 32 + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * 64 + mi * 32 + acc_row(r, lane);
+                const float *px = nullptr;
+                if (EPI == EPI_STORE) px = a.aux0.p ? paddr(a.aux0, g, b, m, t) : nullptr;
+                else if (EPI == EPI_RESSKIP)
+                    px = m < a.nsplit ? paddr(a.aux0, g, b, m, t) : (a.accumulate ? paddr(a.out1, g, b, m - a.nsplit, t) : nullptr);
+                float x = 0.f;
+                if (t < g.T && m < a.M && px) x = *px;
+                acc[mi][ni][r] = x;
+            }
+        }
+}
+
+template <int EPI, bool PRE = false>
 __device__ __forceinline__ void conv_epilogue_s(const ConvGemmArgs &a, const SRef &s0, f32x16 (&acc)[2][2], int t0, int m0, int b,
                                                 int wr, int wc, int lane)
 {
@@ -107,7 +133,7 @@ __device__ __forceinline__ void conv_epilogue_s(const ConvGemmArgs &a, const SRe
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wr * 64 + mi * 32 + acc_row(r, lane);
                 float x = 0.f, y = 0.f;
-                if (t < g.T && m < a.M) {
+                if (!PRE && t < g.T && m < a.M) {
                     if (EPI == EPI_STORE) {
                         if (a.aux0.p) x = *paddr(a.aux0, g, b, m, t);
                     } else if (EPI == EPI_RESSKIP) {
@@ -378,9 +404,11 @@ __global__ __launch_bounds__(256) void convgemm16p_kernel(const ConvGemm16sArgs 
 //   loader waves alone                                                82 us
 //   both                                                             129 us; loads served from L1/L2 only: no change; compute
 //   waves skipping their LDS reads: no change; s_setprio on the compute waves: no change.
-// Register note: only the gate instantiation (124 VGPRs) runs two workgroups per CU.  The store / residual+skip / gate-backward
-// epilogues hold all their auxiliary loads at once (64-128 values per lane; 162 / 158 / 220 VGPRs), so those launches run one
-// workgroup per CU -- deliberately: splitting the epilogue per 32x32 block and capping the kernel at 128 VGPRs restores two
+// Register note: the store and residual+skip instantiations take their auxiliary values (accumulate-into input, residual input,
+// skip accumulator) as the INITIAL value of the accumulators (conv_acc_init): no epilogue loads, 128 VGPRs, two workgroups per CU
+// (store/dgrad conv 143 -> 135 us, residual+skip 95 -> 93.5 us; -DWG_OPT_NO_ACCINIT restores the epilogue loads).  The gate
+// backward multiplies by its two auxiliary tensors, holds all 128 values per lane at once (220 VGPRs) and runs one workgroup per
+// CU -- deliberately: splitting the epilogue per 32x32 block and capping the kernel at 128 VGPRs restores two
 // workgroups per CU but leaves 16-32 loads in flight per lane, and these launches are bound by their epilogue's HBM traffic
 // (residual+skip 92 -> 102 us, gate backward 87 -> 119 us).  A 4-stage (4 chunks in flight) loader for launches with fewer
 // tiles than CUs (single-utterance synthesis) was also measured: 2.85 -> 2.70 MHz, not kept.
@@ -518,12 +546,21 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
 #endif
     const int wr = wave >> 1, wc = wave & 1;
     f32x16 acc[2][2];
+    constexpr bool PRE = (EPI == EPI_STORE || EPI == EPI_RESSKIP)
+#if defined(WG_OPT_NO_ACCINIT)
+                         && false
+#endif
+        ;
+    if (PRE) {
+        conv_acc_init<EPI>(a, acc, t0, m0, b, wr, wc, lane);
+    } else {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+                for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    }
     const int r = lane & 31, h = lane >> 5;
     const int ao = (wr * 64 + r) * WG16_ROWB + h * 16, bo = (wc * 64 + r) * WG16_ROWB + h * 16;
     __syncthreads();                                         // buffer 0 ready
@@ -552,7 +589,7 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
         mfma12(f1, acc);
     }
 #endif
-    conv_epilogue_s<EPI>(a, aa.s0, acc, t0, m0, b, wr, wc, lane);
+    conv_epilogue_s<EPI, PRE>(a, aa.s0, acc, t0, m0, b, wr, wc, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
