@@ -432,6 +432,45 @@ __global__ void pack_kernel(const PackArgs a)
 //   dg[o] = <dw,v>/||v|| ; dv = g/||v|| (dw - v <dw,v>/||v||^2)      (g == NULL: dv = dw)
 // optionally adds extra[o*I*R + e] * extra_scale  (the W^-T * dlogdet * T term of efficient_modules.py:242)
 // ------------------------------------------------------------------------------------------------
+// slab[0][e] = sum_s slab[s][e]: pre-reduction of the split-K slabs with the whole GPU when the weight tensor has few rows (the
+// finalize kernel runs one block per row, which is 128 blocks for WaveFlow's 128-row weights reading 512 slabs each)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(float *__restrict__ slab, int nsplit, size_t n)
+{
+    // 64 float4 columns x 4 slab lanes per block; a lane walks slabs lane, lane + 4, ... with four loads in flight
+    __shared__ float4 part[4][64];
+    const int tid = threadIdx.x, c = tid & 63, lane = tid >> 6;
+    const size_t e = ((size_t)blockIdx.x * 64 + c) * 4;
+    float4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    if (e < n) {
+        int s = lane;
+        for (; s + 12 < nsplit; s += 16) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(slab + (size_t)s * n + e);
+            const float4 v1 = *reinterpret_cast<const float4 *>(slab + (size_t)(s + 4) * n + e);
+            const float4 v2 = *reinterpret_cast<const float4 *>(slab + (size_t)(s + 8) * n + e);
+            const float4 v3 = *reinterpret_cast<const float4 *>(slab + (size_t)(s + 12) * n + e);
+            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+            a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+            a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+            a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+        }
+        for (; s < nsplit; s += 4) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(slab + (size_t)s * n + e);
+            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        }
+    }
+    float4 t;
+    t.x = (a0.x + a1.x) + (a2.x + a3.x); t.y = (a0.y + a1.y) + (a2.y + a3.y);
+    t.z = (a0.z + a1.z) + (a2.z + a3.z); t.w = (a0.w + a1.w) + (a2.w + a3.w);
+    part[lane][c] = t;
+    __syncthreads();                              // every slab has been read before slab 0 is overwritten (by this block's columns only)
+    if (lane == 0 && e < n) {
+        const float4 p1 = part[1][c], p2 = part[2][c], p3 = part[3][c];
+        t.x = (t.x + p1.x) + (p2.x + p3.x); t.y = (t.y + p1.y) + (p2.y + p3.y);
+        t.z = (t.z + p1.z) + (p2.z + p3.z); t.w = (t.w + p1.w) + (p2.w + p3.w);
+        *reinterpret_cast<float4 *>(slab + e) = t;
+    }
+}
+
 struct FinJob {
     const float *slab;
     int nsplit;

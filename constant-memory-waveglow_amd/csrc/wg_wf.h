@@ -205,3 +205,31 @@ __global__ void wf_logdet_kernel(const float *__restrict__ rowsum, int nflow, in
     }
     logdet[b] = s;
 }
+
+// S-plane row sum over the height axis: out[b][c][t] = sum_h in[b*H + h][c][t] (hi + lo summed in fp32, re-split).  Used for the
+// conditioning gradient, which is broadcast over the height axis: V^T (sum_h dxy[h]) instead of sum_h V^T dxy[h].
+__global__ void wf_rowsum_s_kernel(SRef in, Geo g, SRef out, Geo gi)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, cg = blockIdx.y, b = blockIdx.z;
+    if (t >= g.T) return;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < g.rows; ++h) {
+        const size_t i = s_index(in, g, b * g.rows + h, cg * 8, t);
+        const u32x4 hi = *reinterpret_cast<const u32x4 *>(in.hi + i), lo = *reinterpret_cast<const u32x4 *>(in.hi + in.lo_off + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[2 * e] += __uint_as_float(hi[e] << 16) + __uint_as_float(lo[e] << 16);
+            acc[2 * e + 1] += __uint_as_float(hi[e] & 0xffff0000u) + __uint_as_float(lo[e] & 0xffff0000u);
+        }
+    }
+    u32x4 oh, ol;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        unsigned hh, ll;
+        split2(acc[2 * e], acc[2 * e + 1], hh, ll);
+        oh[e] = hh; ol[e] = ll;
+    }
+    const size_t o = s_index(out, gi, b, cg * 8, t);
+    *reinterpret_cast<u32x4 *>(out.hi + o) = oh;
+    *reinterpret_cast<u32x4 *>(out.hi + out.lo_off + o) = ol;
+}

@@ -628,6 +628,11 @@ WgradOut run_wgrad(Ctx &cx, const Geo &g, const WSegSpec *sa, int nsa, const WSe
         WG_LAUNCH(cx, wgrad16s_kernel, grid, block, 0, q);
     } else if (cx.prec) WG_LAUNCH(cx, wgrad16_kernel, grid, block, 0, a);
     else WG_LAUNCH(cx, wgrad_kernel, grid, block, 0, a);
+    if (o.nsplit >= 8 && a.Mp <= 256) {          // few rows = few finalize blocks: fold the slabs with the whole GPU first
+        const size_t n = (size_t)a.Mp * a.Np;    // a multiple of 128 * 128
+        WG_LAUNCH(cx, slab_reduce_kernel, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, slab, o.nsplit, n);
+        o.nsplit = 1;
+    }
     return o;
 }
 
@@ -670,6 +675,8 @@ struct WnRun {
     const float *Y;      // aux plane base (auxp rows per item)
     const float *YS;     // its S-plane (precision 2)
     int save;            // keep all layers (backward) or ping-pong
+    Geo gi;              // mode2d: the per-item geometry (conditioning, its gradient)
+    float *rs;           // mode2d: S-plane [items][2 Cd][P] for the height-axis sum of dxy
 };
 
 void wn_forward(Ctx &cx, const WnRun &r)
@@ -788,7 +795,15 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
                          grads[0] ? grads[0] + ro : nullptr, grads[1] ? grads[1] + ro * d.aux : nullptr);
         }
         // dy += V_i^T dxy
-        if (dY) {
+        if (dY && d.mode2d) {
+            // the conditioning is broadcast over the height axis: sum dxy over the rows of an item first (64x fewer columns for
+            // the product, no per-row gradient plane), then dy[item] += V_i^T rowsum
+            WG_LAUNCH(cx, wf_rowsum_s_kernel, dim3((g.T + 255) / 256, 2 * d.Cd / 8, r.gi.B), dim3(256), 0, sref(g, ws + r.w.dxyS, 2 * d.Cd), g,
+                      sref(r.gi, r.rs, 2 * d.Cd), r.gi);
+            SegSpec s = {nullptr, 2 * d.Cd, 0, 2 * d.Cd, 0, r.rs, 2 * d.Cd, 0};
+            run_convgemm(cx, r.gi, r.pk + r.L.VN[i], r.L.ld_VN, d.aux, &s, 1, EPI_STORE, pref(dY, d.auxp()), pnull(), pnull(),
+                         pref(dY, d.auxp()), pnull(), 0, 0);
+        } else if (dY) {
             SegSpec s = {dxy, 2 * d.Cd, 0, 2 * d.Cd, 0, ws + r.w.dxyS, 2 * d.Cd, 0};
             run_convgemm(cx, g, r.pk + r.L.VN[i], r.L.ld_VN, d.aux, &s, 1, EPI_STORE, pref(dY, d.auxp()), pnull(), pnull(),
                          pref(dY, d.auxp()), pnull(), 0, 0);
@@ -875,7 +890,7 @@ WfPack wf_pack_layout(const wg_wf_config *cf)
 struct WfWs {
     Geo g, gi;              // one plane row per (item, height row) / one per item
     int auxp;
-    size_t Y, YS, X[2], rowsum, dX[2], dYrow, gp, dwup, total;
+    size_t Y, YS, X[2], rowsum, dX[2], dYrow, rs, gp, dwup, total;
     WnWs wn;
 };
 WfWs wf_ws_layout(const wg_wf_config *cf, int B, int Wd, int mode)
@@ -894,10 +909,11 @@ WfWs wf_ws_layout(const wg_wf_config *cf, int B, int Wd, int mode)
     w.YS = bp.take((size_t)B * w.auxp * w.gi.P);
     w.X[0] = bp.take(xplane); w.X[1] = bp.take(xplane);
     w.rowsum = bp.take((size_t)cf->flows * w.g.B);
-    w.dX[0] = w.dX[1] = w.dYrow = w.gp = w.dwup = 0;
+    w.dX[0] = w.dX[1] = w.dYrow = w.rs = w.gp = w.dwup = 0;
     if (mode) {
         w.dX[0] = bp.take(xplane); w.dX[1] = bp.take(xplane);
-        w.dYrow = bp.take((size_t)w.g.B * w.auxp * w.g.P);
+        w.dYrow = bp.take((size_t)B * w.auxp * w.gi.P);                 // conditioning gradient, per item
+        w.rs = bp.take((size_t)B * 2 * d.Cd * w.gi.P);
         w.gp = bp.take((size_t)B * cf->n_mels * Wd);
         w.dwup = bp.take((size_t)cf->n_mels * cf->n_mels * (2 * s + 1));
     }
@@ -1450,9 +1466,10 @@ int wg_wf_backward(const wg_wf_config *cf, const void *const *params, const void
     float *dXn = ws + W.dX[0], *dXc = ws + W.dX[1];
     WG_LAUNCH(cx, wf_squeeze_kernel, rgrid, dim3(256), 0, dz, pref(dXn, 1), g, N);
     wf_upsample(cx, cf, p, pk, L, mel, F, W, ws);
-    if (cx.err == 0 && hipMemsetAsync(ws + W.dYrow, 0, (size_t)g.B * W.auxp * g.P * sizeof(float), cx.st) != hipSuccess) cx.err = WG_ELAUNCH;
+    if (cx.err == 0 && hipMemsetAsync(ws + W.dYrow, 0, (size_t)B * W.auxp * W.gi.P * sizeof(float), cx.st) != hipSuccess) cx.err = WG_ELAUNCH;
     WnRun r;
     r.d = wf_wn(cf); r.L = wn_pack_layout(r.d); r.g = g; r.ws = ws; r.w = W.wn; r.Y = ws + W.Y; r.YS = ws + W.YS; r.save = 1;
+    r.gi = W.gi; r.rs = ws + W.rs;
     for (int k = cf->flows - 1; k >= 0; --k) {
         const float *Xk = (const float *)tape + (size_t)k * xplane;
         r.pk = pk + L.wn[k]; r.X = pref((float *)Xk, 1);
@@ -1463,7 +1480,9 @@ int wg_wf_backward(const wg_wf_config *cf, const void *const *params, const void
     }
     if (dx) WG_LAUNCH(cx, wf_unsqueeze_kernel, rgrid, dim3(256), 0, pref(dXn, 1), g, N, dx);
     // upsampler backward: sum the per-row conditioning gradient over the height axis, LeakyReLU', transposed conv, weight norm
-    WG_LAUNCH(cx, wf_rowsum_leaky_kernel, dim3((g.T + 255) / 256, M, B), dim3(256), 0, pref(ws + W.dYrow, W.auxp), g, pref(ws + W.Y, W.auxp),
+    Geo g1 = W.gi;
+    g1.rows = 1;                                            // the conditioning gradient is already summed over the height axis
+    WG_LAUNCH(cx, wf_rowsum_leaky_kernel, dim3((g.T + 255) / 256, M, B), dim3(256), 0, pref(ws + W.dYrow, W.auxp), g1, pref(ws + W.Y, W.auxp),
               W.gi, M, ws + W.gp);
     WfUpBwdArgs a;
     a.mel = mel; a.v = p[2]; a.scale = pk + L.up_scale; a.gp = ws + W.gp;
