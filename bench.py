@@ -83,6 +83,68 @@ def cpu_baseline():
             "sample": "1 segment of 16000 samples (B=1), WaveGlow-256ch 12 flows, fwd+NLL+bwd, one run = %.1f s" % dt}
 
 
+def other_models(dev):
+    """Secondary figures for the SURVEY.md 8f rows that are built (not the headline metric): one training step of WSRGlow 2x
+    (configs/wsrglow_vctk_2x.json: batch 12 x 8192) and of WaveFlow (configs/waveflow_LJ_speech.json: batch 12 x 16000), forward +
+    NLL + backward through autograd, 1 warm-up + 3 timed steps each.  A failure here never touches the headline line."""
+    import constant_memory_waveglow_amd as cm
+    res = {}
+
+    def timed(step):
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 3
+
+    try:
+        torch.manual_seed(0)
+        m = cm.WaveFlow(flows=8, n_group=64, n_mels=80, use_conv1x1=False, memory_efficient=False, dilation_channels=64,
+                        residual_channels=64, skip_channels=64, bias=False)
+        with torch.no_grad():
+            for wn in m.WNs:
+                wn.end.weight.normal_(0.0, 0.02)
+        m = m.to(dev)
+        crit = cm.WaveGlowLoss(1.0)
+        x = torch.rand(12, 16000, device=dev) * 2 - 1
+        h = torch.randn(12, 80, 63, device=dev)
+
+        def step():
+            m.zero_grad(set_to_none=True)
+            z, ld = m(x, h)
+            crit(z, ld).backward()
+        dt = timed(step)
+        res["waveflow"] = {"workload": "WaveFlow 64ch 8 flows n_group 64, batch 12 x 16000, fwd+NLL+bwd", "ms_per_step": dt * 1e3,
+                           "samples_per_s": 12 * 16000 / dt}
+        del m
+    except Exception as e:                                    # noqa: BLE001
+        res["waveflow"] = {"error": repr(e)}
+    try:
+        torch.manual_seed(0)
+        m = cm.WSRGlow(upsample_rate=2, memory_efficient=True, bias=False)
+        with torch.no_grad():
+            for blk in m.WNs:
+                blk.F.end.weight.normal_(0.0, 0.02)
+        m = m.to(dev)
+        crit = cm.WaveGlowLoss(1.0)
+        x = torch.rand(12, 8192, device=dev) * 2 - 1
+        c = (torch.rand(12, 4096, device=dev) * 2 - 1) * 0.9
+
+        def step():
+            m.zero_grad(set_to_none=True)
+            z, ld = m(x, c.clone())
+            crit(z, ld).backward()
+        dt = timed(step)
+        res["wsrglow"] = {"workload": "WSRGlow 2x, batch 12 x 8192, fwd+NLL+bwd", "ms_per_step": dt * 1e3, "samples_per_s": 12 * 8192 / dt}
+        del m
+    except Exception as e:                                    # noqa: BLE001
+        res["wsrglow"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,6 +153,7 @@ def main():
     ap.add_argument("--batch", type=int, default=24, help="per-GPU batch (configs[1]: 24)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-inverse", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the WSRGlow / WaveFlow step timings (SURVEY.md 8f rows)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -203,6 +266,8 @@ def main():
                 opt.step()
             torch.cuda.synchronize()
             out["adam_step_ms"] = (time.perf_counter() - t1) / 5 * 1e3
+        if world == 1 and not args.no_extra:
+            out["other_models"] = other_models(dev)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()
     if use_dist:
