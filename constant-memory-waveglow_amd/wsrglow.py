@@ -50,23 +50,37 @@ class _WsrCondFn(Function):
         return None, dmu, dang
 
 
+# front-end constants of the reference model (wsrglow.py:23-35); they are compiled into wg_wsr_cond as well
+MU_LEVELS, MU_DIM = 256, 400            # mu-law quantiser levels, embedding width per low-rate sample
+STFT_SIZE, STFT_HOP = 16, 8             # frame = 8 low-rate samples = one time step of the flow
+PHASE_LEVELS, PHASE_DIM = 120, 50
+N_BINS = STFT_SIZE // 2 + 1
+COND_CHANNELS = STFT_HOP * MU_DIM + N_BINS * (1 + PHASE_DIM)     # 3659
+assert COND_CHANNELS == engine.WSR_COND_CHANNELS
+
+
 class WSRGlow(WaveGlow):
+    """WaveGlow(12 flows, group = hop = 8 * rate, 2 early channels every 4 flows) conditioned on `_get_cond(low_rate_audio)`."""
+
     def __init__(self, upsample_rate: int = 2, memory_efficient: bool = False, **kwargs) -> None:
-        super().__init__(12, 8 * upsample_rate, 4, 2, 8 * upsample_rate, 8 * 400 + 51 * 9,
+        group = STFT_HOP * upsample_rate
+        super().__init__(flows=12, n_group=group, n_early_every=4, n_early_size=2, hop_size=group, n_mels=COND_CHANNELS,
                          memory_efficient=memory_efficient, **kwargs)
-        self.mu_enc = nn.Sequential(MuLawEncoding(256), nn.Embedding(256, 400))
-        self.angle_embed = AngleEmbedding(embed_num=120, hidden_dim=50)
-        self.n_fft = 16
-        self.hop_length = 8
-        self.register_buffer('window', torch.hann_window(self.n_fft))
+        self.mu_enc = nn.Sequential(MuLawEncoding(MU_LEVELS), nn.Embedding(MU_LEVELS, MU_DIM))
+        self.angle_embed = AngleEmbedding(embed_num=PHASE_LEVELS, hidden_dim=PHASE_DIM)
+        self.n_fft, self.hop_length = STFT_SIZE, STFT_HOP
+        self.register_buffer("window", torch.hann_window(STFT_SIZE))       # kept for state-dict parity; the kernel builds its own
 
     def _get_cond(self, c):
+        """low-rate audio [B, L] -> conditioning [B, 3659, L / 8]; clips `c` in place like the reference (wsrglow.py:38)."""
         engine.require_device(c)
-        c = c.clip_(-1, 1)                       # in place, as the reference (wsrglow.py:38)
+        c.clamp_(-1.0, 1.0)
         return _WsrCondFn.apply(c, self.mu_enc[1].weight, self.angle_embed.embed.weight)
 
     def forward_computation(self, x, h):
-        return super().forward_computation(x, self._get_cond(h))
+        cond = self._get_cond(h)
+        return WaveGlow.forward_computation(self, x, cond)
 
     def reverse_computation(self, z, h):
-        return super().reverse_computation(z, self._get_cond(h))
+        cond = self._get_cond(h)
+        return WaveGlow.reverse_computation(self, z, cond)
