@@ -668,3 +668,35 @@ def test_melspec_kernel_vs_oracle(dev, precision, B, N):
     assert np.abs(got - want).max() < 1e-4                       # log domain, fp32 direct DFT vs float64 FFT
     with pytest.raises(cm.WgError):
         cm.MelSpec(sr=22050, n_fft=1024, hop_length=256, power=1.0)
+
+
+# ---- race screen: the conv kernels' loader / compute protocol (hand-counted waits, one barrier per chunk) under repetition ---------
+
+def test_repeated_steps_are_bitwise_identical(dev, precision):
+    """Every kernel on the WaveGlow training path reduces in a fixed order, so the same inputs must give bit-identical outputs on
+    every run; a race between the loader and compute waves (a staged register read before its wait, an LDS buffer overwritten too
+    early) would show up as run-to-run differences long before it breaks a tolerance.  40 steps of C1 and 4 of the full-size model."""
+    from constant_memory_waveglow_amd.parallel import FlowTrainer
+    m, cfg, specs, P = build("c1", dev)
+    B, N, F = fill.SHAPES["c1"]
+    audio, h = fill.inputs("c1", B, N, F, cfg["n_mels"])
+    tr = FlowTrainer(m, fill.SIGMA)
+    x, ht = T(audio, dev), T(h, dev)
+    loss0, z0, ld0 = tr.step(x, ht)
+    g0 = tr.fg.flat.clone()
+    z0, ld0 = z0.clone(), ld0.clone()
+    for _ in range(40):
+        loss, z, ld = tr.step(x, ht)
+        assert torch.equal(z, z0) and torch.equal(ld, ld0) and torch.equal(tr.fg.flat, g0)
+    if precision != "bf16x3p":
+        return
+    import bench
+    big = FlowTrainer(bench.build_model(dev), bench.SIGMA)
+    g = torch.Generator(device=dev).manual_seed(7)
+    xb = torch.rand(24, bench.SEG, device=dev, generator=g) * 2 - 1
+    hb = torch.randn(24, 80, bench.FRAMES, device=dev, generator=g)
+    _, zb0, _ = big.step(xb, hb)
+    zb0, gb0 = zb0.clone(), big.fg.flat.clone()
+    for _ in range(4):
+        _, zb, _ = big.step(xb, hb)
+        assert torch.equal(zb, zb0) and torch.equal(big.fg.flat, gb0)
