@@ -422,8 +422,9 @@ __global__ __launch_bounds__(256) void convgemm16p_kernel(const ConvGemm16sArgs 
 // the next tile's first chunks land during the epilogue) was measured too: no gain for the gate conv (the second workgroup of the
 // CU already covers a tile's prologue and epilogue) and the tile loop around the epilogue costs registers (177-239 VGPRs for
 // three of the four epilogues -> one workgroup per CU): 99.9 ms per step against 89.9.  Not kept.
-// The barrier of chunk c moved between its two k-steps (-DWG_OPT_W_MIDBAR: fragments of chunk c+1 fetched under the MFMAs of
-// k-step 1) needs 132 VGPRs, i.e. one workgroup per CU: 148 us.
+// The barrier of chunk c moved between its two k-steps (fragments of chunk c+1 fetched under the MFMAs of k-step 1) needs
+// 132 VGPRs, i.e. one workgroup per CU: 148 us.  That variant and the ablation switches behind the numbers above are in this
+// file's history (round 1).
 // ------------------------------------------------------------------------------------------------
 struct Stage8 {
     u32x4 ah[2], al[2], bh[2], bl[2];
@@ -448,14 +449,8 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
 
     if (wave >= 4) {
         // ------------------------------- loader waves -------------------------------
-#if defined(WG_OPT_W_PRIO)
-        __builtin_amdgcn_s_setprio(0);
-#endif
         const int lt = tid - 256, bt = lt & 127, cg0 = lt >> 7;
         int cur_seg = 0, cur_c = 0, chunk = 0;
-#if defined(WG_ABL_W_SAMECHUNK)
-        int fake = 0;
-#endif
         const unsigned voff_a = (unsigned)lt * 16u;
         const unsigned voff_b = (unsigned)((cg0 * g.P + bt) * 16);
 #define WG_LD(dst, base, voff) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
@@ -493,11 +488,7 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
             WG_LD(st.bh[1], pb1, vb1);  WG_LD(st.bl[1], pb1l, vb1);
             if (live) {
                 ++chunk;
-#if defined(WG_ABL_W_SAMECHUNK)
-                --chunk; if (++fake >= nchunks) chunk = nchunks;
-#else
                 cur_c += WG16_BK;
-#endif
                 if (cur_c >= nch) { cur_c = 0; ++cur_seg; }
             }
         };
@@ -524,11 +515,9 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
         __syncthreads();                                     // buffer 0 ready
         // iteration c: compute waves multiply buffer c&1; we write chunk c+1 (landed) into the other buffer and issue chunk c+3
         auto iter = [&](Stage8 &st, int c) {
-#if !defined(WG_ABL_W_NOLOAD)
             asm_wait_keep8(st);
             write(st, (c & 1) ^ 1);
             issue(st);
-#endif
             __syncthreads();
         };
         // always in pairs (an even chunk count ends with one spare write of zero-halo data into the idle buffer, and the compute
@@ -541,9 +530,6 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
         return;
     }
     // ------------------------------- compute waves -------------------------------
-#if defined(WG_OPT_W_PRIO)
-    __builtin_amdgcn_s_setprio(3);
-#endif
     const int wr = wave >> 1, wc = wave & 1;
     f32x16 acc[2][2];
     constexpr bool PRE = (EPI == EPI_STORE || EPI == EPI_RESSKIP)
@@ -564,7 +550,6 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
     const int r = lane & 31, h = lane >> 5;
     const int ao = (wr * 64 + r) * WG16_ROWB + h * 16, bo = (wc * 64 + r) * WG16_ROWB + h * 16;
     __syncthreads();                                         // buffer 0 ready
-#if !defined(WG_OPT_W_MIDBAR)
     for (int c = 0; c < nchunks; ++c) {
         const char *sb = smem + (c & 1) * BUF;
         Frags16 f0, f1;
@@ -574,21 +559,6 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
         mfma12(f1, acc);
         if (c + 1 < nchunks || !(nchunks & 1)) __syncthreads();   // matches the loaders' barrier of iteration c (pairs: see there)
     }
-#else
-    // The barrier of chunk c ("chunk c+1 is written, buffer c&1 may be overwritten") sits in the MIDDLE of the chunk: both k-steps
-    // of chunk c are in registers by then, and the first k-step of chunk c+1 is fetched right behind it, under the twelve MFMAs
-    // of k-step 1.  A wave never starts a chunk by waiting for LDS.
-    Frags16 f0, f1;
-    read_frags16(f0, smem, smem + AIMG, smem + 2 * AIMG, smem + 3 * AIMG, ao, bo);
-    for (int c = 0; c < nchunks; ++c) {
-        const char *sb = smem + (c & 1) * BUF, *sn = smem + ((c & 1) ^ 1) * BUF;
-        read_frags16(f1, sb, sb + AIMG, sb + 2 * AIMG, sb + 3 * AIMG, ao + 32, bo + 32);
-        mfma12(f0, acc);
-        if (c + 1 < nchunks || !(nchunks & 1)) __syncthreads();   // matches the loaders' barrier of iteration c (pairs: see there)
-        if (c + 1 < nchunks) read_frags16(f0, sn, sn + AIMG, sn + 2 * AIMG, sn + 3 * AIMG, ao, bo);
-        mfma12(f1, acc);
-    }
-#endif
     conv_epilogue_s<EPI, PRE>(a, aa.s0, acc, t0, m0, b, wr, wc, lane);
 }
 
