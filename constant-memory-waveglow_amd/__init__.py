@@ -11,8 +11,8 @@ from .utils import add_weight_norms, get_instance, remove_weight_norms
 from .waveglow import WN, NonCausalLayer, WaveGlow, fused_gate
 from .wsrglow import WSRGlow
 from .waveflow import WaveFlow, WN2D
-from .condition import MelSpec
+from .condition import LowPass, MelSpec, STFTDecimate
 from ._lib import WgError
 
-__all__ = ["WaveGlow", "WSRGlow", "WaveFlow", "WN2D", "MelSpec", "WN", "NonCausalLayer", "fused_gate", "FlowBase", "Reversible", "InvertibleConv1x1",
+__all__ = ["WaveGlow", "WSRGlow", "WaveFlow", "WN2D", "MelSpec", "LowPass", "STFTDecimate", "WN", "NonCausalLayer", "fused_gate", "FlowBase", "Reversible", "InvertibleConv1x1",
            "AffineCouplingBlock", "WaveGlowLoss", "get_instance", "add_weight_norms", "remove_weight_norms", "WgError"]

@@ -24,3 +24,31 @@ class MelSpec(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         return engine.melspec(x, self.sr, self.n_fft, self.hop_length, self.f_min, self.f_max, self.n_mels)
+
+
+class LowPass(nn.Module):
+    """STFT brick-wall low-pass (condition.py:22-57): `forward(x, i)` keeps the lowest `int((nfft//2+1) * ratio[i])` bins."""
+
+    def __init__(self, nfft=1024, hop=256, ratio=(1 / 6, 1 / 3, 1 / 2, 2 / 3, 3 / 4, 4 / 5, 5 / 6, 1 / 1)):
+        super().__init__()
+        self.nfft, self.hop = nfft, hop
+        self.cuts = [int((nfft // 2 + 1) * r) for r in ratio]
+
+    def _run(self, x: Tensor, i: int, step: int) -> Tensor:
+        shape = x.shape
+        y = engine.lowpass(x.reshape(-1, shape[-1]), self.nfft, self.hop, self.cuts[int(i)], step)
+        return y.view(*shape[:-1], y.size(-1))
+
+    def forward(self, x: Tensor, r) -> Tensor:
+        return self._run(x, r, 1)
+
+
+class STFTDecimate(LowPass):
+    """Low-pass to 1/r of the band, then keep every r-th sample (condition.py:60-66): the conditioner of configs/wsrglow_vctk_*.json."""
+
+    def __init__(self, r, *args, **kwargs):
+        super().__init__(*args, ratio=[1 / r], **kwargs)
+        self.r = r
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self._run(x, 0, self.r)

@@ -1516,6 +1516,28 @@ int wg_melspec(const float *audio, int B, int N, int sr, int n_fft, int hop, dou
     return cx.err;
 }
 
+// ---- LowPass / STFTDecimate -----------------------------------------------------------------------
+size_t wg_lowpass_workspace_bytes(int B, int T, int n_fft, int hop)
+{
+    if (B < 1 || T < 1 || n_fft < 2 || hop < 1) return 0;
+    return (size_t)B * ((size_t)(T + n_fft) / hop + 1) * n_fft * sizeof(float);
+}
+int wg_lowpass(const float *x, int B, int T, int n_fft, int hop, int cut_bins, int step, float *out, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!x || !out || !ws || B < 1 || T < 1 || step < 1 || cut_bins < 1) return WG_EINVAL;
+    if (n_fft < 2 || n_fft > WG_MEL_MAXFFT || (n_fft & (n_fft - 1)) || hop < 1 || hop > n_fft || cut_bins > n_fft / 2 + 1) return WG_EUNSUPPORTED;
+    if (n_fft / 2 >= T + n_fft) return WG_ESHAPE;
+    if (ws_bytes < wg_lowpass_workspace_bytes(B, T, n_fft, hop)) return WG_EWORKSPACE;
+    Ctx cx = {(hipStream_t)stream, 0, 0};
+    LowPassArgs a;
+    a.x = x; a.frames = (float *)ws; a.out = out; a.T = T; a.n_fft = n_fft; a.hop = hop;
+    a.nframes = (T + n_fft) / hop + 1;                                  // stft of T + n_fft samples with center=True
+    a.cut = cut_bins; a.step = step; a.nout = (T + step - 1) / step;
+    WG_LAUNCH(cx, lowpass_frame_kernel, dim3(a.nframes, B), dim3(256), 0, a);
+    WG_LAUNCH(cx, lowpass_ola_kernel, dim3((a.nout + 255) / 256, B), dim3(256), 0, a);
+    return cx.err;
+}
+
 // ---- WSRGlow conditioning front-end ---------------------------------------------------------------
 int wg_wsr_cond(const float *c, int B, int L, const float *mu_table, const float *ang_table, float *cond, void *stream)
 {

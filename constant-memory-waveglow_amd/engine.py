@@ -433,3 +433,17 @@ def melspec(x, sr, n_fft, hop, f_min, f_max, n_mels):
     check(_lib.lib().wg_melspec(_p(x), B, N, int(sr), int(n_fft), int(hop), float(f_min), float(f_max if f_max is not None else 0.0),
                                 int(n_mels), _p(out), _stream()), "wg_melspec")
     return out
+
+
+def lowpass(x, n_fft, hop, cut_bins, step):
+    """x [B, T] -> STFT low-pass (bins >= cut_bins zeroed), every step-th sample: [B, ceil(T / step)]  (condition.py:22-66)."""
+    require_device(x)
+    if x.dim() != 2:
+        raise WgError("LowPass expects audio [B, T]")
+    x = x.contiguous()
+    B, T = x.shape
+    nbytes = _lib.lib().wg_lowpass_workspace_bytes(B, T, int(n_fft), int(hop))
+    ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=x.device)
+    out = torch.empty(B, (T + step - 1) // step, dtype=torch.float32, device=x.device)
+    check(_lib.lib().wg_lowpass(_p(x), B, T, int(n_fft), int(hop), int(cut_bins), int(step), _p(out), _p(ws), ws.numel(), _stream()), "wg_lowpass")
+    return out

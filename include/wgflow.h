@@ -217,6 +217,13 @@ int wg_wf_backward(const wg_wf_config *cfg, const void *const *params, const voi
 int wg_melspec_frames(int N, int n_fft, int hop);
 int wg_melspec(const float *audio, int B, int N, int sr, int n_fft, int hop, double f_min, double f_max, int n_mels, float *mel, void *stream);
 
+/* LowPass.forward / STFTDecimate.forward (model/condition.py:22-66), the conditioner of the WSRGlow configs: right zero-pad by
+ * n_fft, STFT (center, reflect, periodic Hann), zero the bins >= cut_bins, ISTFT, crop to T, keep every `step`-th sample.
+ * STFTDecimate(r) = cut_bins int((n_fft/2+1) / r), step r; LowPass(x, i) = cut_bins int((n_fft/2+1) * ratio[i]), step 1.
+ * x[B,T] -> out[B, ceil(T/step)].  ws: wg_lowpass_workspace_bytes. */
+size_t wg_lowpass_workspace_bytes(int B, int T, int n_fft, int hop);
+int wg_lowpass(const float *x, int B, int T, int n_fft, int hop, int cut_bins, int step, float *out, void *ws, size_t ws_bytes, void *stream);
+
 /* ---- optimizer step (trainer parity) ---------------------------------------------------------------
  * torch.optim.Adam (amsgrad = false, maximize = false) on one contiguous fp32 range: what the reference's
  * configure_optimizers builds from `optimizer` in its configs (model/lightning.py:41-44; configs/waveglow_LJ_speech.json:

@@ -42,3 +42,31 @@ def melspec(x, sr, n_fft, hop, f_min=0.0, f_max=None, n_mels=128):
     spec = np.abs(np.fft.rfft(xp[:, idx] * win, axis=-1)) ** 2          # [B, frames, n_freqs]
     mel = spec @ mel_filterbank(sr, n_fft, n_mels, f_min, f_max)        # [B, frames, n_mels]
     return np.log(mel.transpose(0, 2, 1) + 1e-7)
+
+
+# ---- STFTDecimate / LowPass (model/condition.py:22-66): the data-side conditioner of WSRGlow ------------------------------------
+def stft_decimate(x, r, nfft=1024, hop=256):
+    """x [B, T] float32 -> low-passed, decimated [B, ceil(T / r)] (float64 arithmetic).  Restates, with torch's documented stft / istft
+    semantics (center=True, reflect padding, periodic Hann, onesided, no normalisation; istft = overlap-add of windowed inverse
+    frames divided by the overlap-added squared window):
+        x = pad(x, (0, nfft)) ; S = stft(x) ; S[int((nfft//2+1) / r):] = 0 ; y = istft(S)[:, :T] ; return y[:, ::r]
+    Pinned to the reference itself: tests/golden/cond_stftdecimate.npz (make_golden.conditioner_fixture runs condition.py's
+    STFTDecimate under ref_shim's legacy-stft wrapper)."""
+    x = np.asarray(x, np.float32).astype(np.float64)
+    B, T = x.shape
+    half = nfft // 2
+    xp = np.pad(np.pad(x, ((0, 0), (0, nfft))), ((0, 0), (half, half)), mode="reflect")
+    frames = (xp.shape[1] - nfft) // hop + 1
+    win = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(nfft) / nfft)
+    idx = hop * np.arange(frames)[:, None] + np.arange(nfft)[None, :]
+    S = np.fft.rfft(xp[:, idx] * win, axis=-1)                      # [B, frames, nfft/2+1]
+    S[:, :, int((half + 1) * (1.0 / r)):] = 0.0
+    fr = np.fft.irfft(S, n=nfft, axis=-1) * win
+    L = nfft + hop * (frames - 1)
+    y = np.zeros((B, L))
+    env = np.zeros(L)
+    for f in range(frames):
+        y[:, f * hop:f * hop + nfft] += fr[:, f]
+        env[f * hop:f * hop + nfft] += win * win
+    y = y[:, half:L - half] / env[half:L - half]
+    return y[:, :T][:, ::r]

@@ -204,3 +204,7 @@ WF_SHAPES = {"wf8": (2, 8 * 96, 3), "wf64": (2, 64 * 24, 6)}       # (batch, sam
 
 def waveflow_inputs(tag, B, N, F, n_mels):
     return uniform(tag + "/audio", (B, N), -1.0, 1.0), normal(tag + "/mel", (B, n_mels, F))
+
+
+# STFTDecimate cases: (batch, samples, ratio) -- the shipped 2x / 3x models at their training segment, and a short ragged length
+DECIMATE_CASES = {"r2_8192": (2, 8192, 2), "r3_8193": (1, 8193, 3), "r2_1500": (3, 1500, 2)}

@@ -75,3 +75,57 @@ def load_wsrglow():
     ws = importlib.import_module("model.wsrglow")
     ns.WSRGlow = ws.WSRGlow
     return ns
+
+
+def load_conditioners():
+    """Returns the reference's LowPass / STFTDecimate classes (model/condition.py:22-66).
+
+    Two things stand between that file and this image:
+      * condition.py:4 imports torchaudio's MelSpectrogram (absent here; only MelSpec uses it) -- a placeholder class is registered
+        that raises if it is ever instantiated;
+      * LowPass.forward (condition.py:45-55) calls `torch.stft(x, nfft, hop, window=w)` / `torch.istft(real_view, ...)` with the
+        pre-1.8 API: a real [..., 2] view in and out.  Current torch requires `return_complex=` and a complex istft input.  While the
+        reference's forward runs, torch.stft / torch.istft are wrapped to supply exactly that legacy convention
+        (return_complex=False; view_as_complex on the way into istft).  The arithmetic is torch's own stft / istft.
+    """
+    load()
+    import contextlib
+    import importlib
+    import torch
+    if "torchaudio" not in sys.modules:
+        ta = types.ModuleType("torchaudio")
+        tr = types.ModuleType("torchaudio.transforms")
+        ta.transforms = tr
+        ta.__wg_standin__ = True
+        sys.modules["torchaudio"] = ta
+        sys.modules["torchaudio.transforms"] = tr
+    tr = sys.modules["torchaudio.transforms"]
+    if not hasattr(tr, "MelSpectrogram"):
+        class MelSpectrogram(torch.nn.Module):                      # placeholder: never used by the fixtures
+            def __init__(self, *a, **k):
+                raise RuntimeError("torchaudio is not installed: MelSpectrogram is a placeholder")
+        tr.MelSpectrogram = MelSpectrogram
+    cond = importlib.import_module("model.condition")
+
+    @contextlib.contextmanager
+    def legacy_stft_api():
+        stft, istft = torch.stft, torch.istft
+
+        def stft_legacy(x, n_fft, hop_length=None, **kw):
+            kw.setdefault("return_complex", False)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                return stft(x, n_fft, hop_length, **kw)
+
+        def istft_legacy(x, n_fft, hop_length=None, **kw):
+            if not torch.is_complex(x):
+                x = torch.view_as_complex(x.contiguous())
+            return istft(x, n_fft, hop_length, **kw)
+
+        torch.stft, torch.istft = stft_legacy, istft_legacy
+        try:
+            yield
+        finally:
+            torch.stft, torch.istft = stft, istft
+
+    return types.SimpleNamespace(LowPass=cond.LowPass, STFTDecimate=cond.STFTDecimate, legacy_stft_api=legacy_stft_api)

@@ -700,3 +700,19 @@ def test_repeated_steps_are_bitwise_identical(dev, precision):
     for _ in range(4):
         _, zb, _ = big.step(xb, hb)
         assert torch.equal(zb, zb0) and torch.equal(big.fg.flat, gb0)
+
+
+@pytest.mark.parametrize("tag", list(fill.DECIMATE_CASES))
+def test_stft_decimate_vs_reference_golden(dev, golden_dir, precision, tag):
+    """wg_lowpass behind STFTDecimate against the reference's own output (cond_stftdecimate.npz) and the oracle."""
+    if precision != "f32":
+        pytest.skip("the conditioner does not depend on the contraction mode")
+    from oracle import mel_oracle as mo
+    B, Tn, r = fill.DECIMATE_CASES[tag]
+    x = fill.uniform("decimate/" + tag, (B, Tn), -0.9, 0.9)
+    gold = np.load(os.path.join(golden_dir, "cond_stftdecimate.npz"))[tag]
+    got = npy(cm.STFTDecimate(r)(T(x, dev)))
+    assert got.shape == gold.shape
+    assert np.abs(got - gold).max() < 2e-5 and np.abs(got - mo.stft_decimate(x, r)).max() < 2e-5
+    full = npy(cm.LowPass()(T(x, dev), 7))                      # ratio 1/1 keeps every bin incl. Nyquist: the identity up to rounding
+    assert np.abs(full - x).max() < 2e-5

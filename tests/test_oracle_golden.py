@@ -272,3 +272,15 @@ def test_mel_oracle_properties():
     centre_hz = 700.0 * (10.0 ** (np.linspace(0, 2595 * np.log10(1 + 8000 / 700), 82)[1:-1] / 2595.0) - 1.0)
     assert abs(centre_hz[m[0, :, 30].argmax()] - 1000.0) < 60.0                             # a 1 kHz tone lights the 1 kHz filter
     assert np.allclose(mo.melspec(np.zeros((1, 4096), np.float32), sr, n_fft, hop, 0.0, 8000.0, n_mels), np.log(1e-7))
+
+
+def test_stft_decimate_oracle_matches_reference(golden_dir):
+    """oracle/mel_oracle.stft_decimate against the reference's STFTDecimate (model/condition.py:60-66) run under the legacy-stft
+    wrapper of tests/golden/ref_shim: the WSRGlow configs' conditioner, ratios 2 and 3, a ragged length."""
+    from oracle import mel_oracle as mo
+    G = np.load(os.path.join(golden_dir, "cond_stftdecimate.npz"))
+    for tag, (B, T, r) in fill.DECIMATE_CASES.items():
+        x = fill.uniform("decimate/" + tag, (B, T), -0.9, 0.9)
+        y = mo.stft_decimate(x, r)
+        assert y.shape == G[tag].shape == (B, (T + r - 1) // r)
+        assert np.abs(y - G[tag]).max() < 2e-6
