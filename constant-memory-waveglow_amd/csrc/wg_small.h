@@ -155,36 +155,62 @@ struct AffineArgs {
     int mode;
 };
 
+#define WG_AFF_T 64          // time steps per workgroup
 __global__ __launch_bounds__(256) void end_affine_kernel(const AffineArgs a)
 {
-    __shared__ float tile[4][32][33];
+    // out[m][t] = sum_k W_end[m][k] S[k][t] for the 2*ic <= 32 rows of the end conv: far too few rows for a matrix tile to pay, and
+    // the kernel is bound by reading S once.  A workgroup takes 64 time steps; its 4 waves split the skip channels, every lane
+    // streams its quarter of S[:, t] (coalesced along t, 16 loads in flight) into 2*ic accumulators, LDS adds the four quarters.
+    __shared__ float tile[32][WG_AFF_T + 1];
+    __shared__ float part[3][32][WG_AFF_T + 1];
     __shared__ float red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y, t0 = blockIdx.x * 128 + wave * 32;
+    const int b = blockIdx.y, t = blockIdx.x * WG_AFF_T + lane;
     const Geo g = a.g;
-    f32x16 acc;
+    const int rows = 2 * a.ic;
+    float acc[32];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int kh = lane >> 5, r31 = lane & 31;
-    const float *ap = a.endT + kh * 32 + r31;
-    const float *bp = paddr(a.S, g, b, kh, t0 + r31);
-#pragma unroll 8
-    for (int k = 0; k < a.Cs; k += 2) {
-        const float av = ap[(size_t)k * 32];
-        const float bv = bp[(size_t)k * g.P];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    for (int m = 0; m < 32; ++m) acc[m] = 0.f;
+    {
+        const int kq = (a.Cs + 3) / 4, k0 = wave * kq, k1 = min(a.Cs, k0 + kq);
+        const float *sp = paddr(a.S, g, b, 0, min(t, g.Tt - 1));        // columns in [T, Tt) read the zero padding; beyond Tt is clamped
+        for (int k = k0; k < k1; k += 16) {
+            float sv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) sv[u] = (k + u < k1) ? sp[(size_t)(k + u) * g.P] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const float *w = a.endT + (size_t)min(k + u, a.Cs - 1) * 32;      // wave-uniform address: scalar / broadcast loads
+                if (rows <= 8) {
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) acc[m] = fmaf(w[m], sv[u], acc[m]);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 32; ++m) acc[m] = fmaf(w[m], sv[u], acc[m]);
+                }
+            }
+        }
     }
+    if (wave > 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) tile[wave][acc_row(r, lane)][lane & 31] = acc[r];
+        for (int m = 0; m < 32; ++m)
+            if (m < rows) part[wave - 1][m][lane] = acc[m];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int m = 0; m < 32; ++m)
+            if (m < rows) tile[m][lane] = (acc[m] + part[0][m][lane]) + (part[1][m][lane] + part[2][m][lane]);
+    }
     __syncthreads();
 
     const int ic = a.ic;
     float lsum = 0.f;
-    for (int e = tid; e < ic * 128; e += 256) {
-        const int j = e >> 7, tl = e & 127, w = tl >> 5, cl = tl & 31;
-        const int t = blockIdx.x * 128 + tl;
+    for (int e = tid; e < ic * WG_AFF_T; e += 256) {
+        const int j = e / WG_AFF_T, tl = e - j * WG_AFF_T;
+        const int t = blockIdx.x * WG_AFF_T + tl;
         if (t >= g.T) continue;
-        const float ls = tile[w][j][cl], tt = tile[w][ic + j][cl];
+        const float ls = tile[j][tl], tt = tile[ic + j][tl];
         if (a.mode == AFF_RAW) {
             const size_t q = ((size_t)b * ic + j) * g.T + t;
             a.log_s_out[q] = ls;

@@ -432,7 +432,7 @@ ModelWs model_ws_layout(const wg_config *cf, int B, int T, int mode)
     w.g = make_geo(B, T, d0.maxdil() * (d0.radix - 1) / 2);
     w.Gp = rup(cf->n_group, WG_BK) + WG_BK;
     w.auxp = d0.auxp();
-    w.ntile = w.g.Tt / 128;
+    w.ntile = w.g.Tt / WG_AFF_T;          // partial log_s sums: one per end_affine workgroup
     Bump bp;
     w.X = bp.take((size_t)B * w.Gp * w.g.P);
     w.Y = bp.take((size_t)B * w.auxp * w.g.P);
@@ -727,7 +727,7 @@ void run_end_affine(Ctx &cx, const WnRun &r, int mode, PRef dX, float *log_s_out
     a.Gp = pref(r.ws + r.w.G, r.L.kp_end);
     a.log_s_out = log_s_out; a.dls_plain = dls_plain; a.dld = dld; a.partial = partial;
     a.g = r.g; a.mode = mode;
-    WG_LAUNCH(cx, end_affine_kernel, dim3(r.g.Tt / 128, r.g.B), dim3(256), 0, a);
+    WG_LAUNCH(cx, end_affine_kernel, dim3(r.g.Tt / WG_AFF_T, r.g.B), dim3(256), 0, a);
 }
 
 // backward through WN given the G plane (what autograd.grad at efficient_modules.py:143 evaluates).
@@ -1724,7 +1724,7 @@ int wg_wn_apply(const wg_wn_dims *dd, const void *packed, const float *x, const 
     memset(&a, 0, sizeof(a));
     a.endT = r.pk + r.L.endT; a.S = pref(ws + W.wn.skip, d.Cs); a.Cs = d.Cs; a.ic = d.ic; a.X = X;
     a.log_s_out = log_s; a.t_out = t; a.g = g; a.mode = AFF_RAW;
-    WG_LAUNCH(cx, end_affine_kernel, dim3(g.Tt / 128, g.B), dim3(256), 0, a);
+    WG_LAUNCH(cx, end_affine_kernel, dim3(g.Tt / WG_AFF_T, g.B), dim3(256), 0, a);
     return cx.err;
 }
 
