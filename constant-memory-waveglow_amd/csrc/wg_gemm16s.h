@@ -412,6 +412,11 @@ __global__ __launch_bounds__(256) void convgemm16p_kernel(const ConvGemm16sArgs 
 // workgroups per CU but leaves 16-32 loads in flight per lane, and these launches are bound by their epilogue's HBM traffic
 // (residual+skip 92 -> 102 us, gate backward 87 -> 119 us).  A 4-stage (4 chunks in flight) loader for launches with fewer
 // tiles than CUs (single-utterance synthesis) was also measured: 2.85 -> 2.70 MHz, not kept.
+// Where the residual+skip launch (K = 256, 8 chunks) spends its 89-97 us: main loop alone 39 us, + the accumulator-init loads 29 us,
+// + the stores 29 us -- additive.  The HBM pattern is not the issue (a copy kernel with the same lane -> element mapping moves
+// the planes at 6.6 TB/s, the same as a float4 row-contiguous one; tools/experiments/plane_copy_probe.hip), and the phases do not
+// add up because identical workgroups run in lockstep either: delaying every second workgroup of a CU by a quarter to a full tile
+// time only adds the delay.  Every phase is bound by the memory system (HBM for the planes, L2 -> CU for the operands).
 // A 256(M) x 128(T) workgroup tile at ONE workgroup per CU (4 compute waves with 128x64 tiles = 0.75x the LDS and L1 bytes per
 // MFMA, fragments double-buffered in the 256-register budget, barrier between the two k-steps, same asm loaders with 12 loads per
 // lane) was built and is bit-identical in results: 145 us for the gate conv against 128 us (compute waves alone 124 us, loaders
