@@ -140,6 +140,7 @@ class WaveGlow(FlowBase):
                                                 in_channels=c // 2, aux_channels=n_mels, **kwargs))
         self.z_split_sizes.append(c)
 
+        self._half_table, self._half_key = None, None          # fp32 copies of half parameters (inference --half)
         wn0 = self.WNs[0].F
         self._engine = engine.ModelEngine(engine.make_config(
             flows, n_group, n_early_every, n_early_size, hop_size, n_mels,
@@ -172,6 +173,14 @@ class WaveGlow(FlowBase):
         if torch.is_grad_enabled() and (z.requires_grad or h.requires_grad):
             warnings.warn("WaveGlow.reverse runs without autograd in the HIP engine", stacklevel=3)
         table = [None if t is None else t.detach() for t in self.param_table()]
+        if z.dtype == torch.float16 or h.dtype == torch.float16 or any(t is not None and t.dtype == torch.float16 for t in table):
+            # `inference.py --half` (model.half(), cond.half(), inference.py:33-36): the engine computes in fp32, so half tensors are
+            # widened on the way in and the result is narrowed on the way out -- the half-precision storage contract, fp32 arithmetic
+            if self._half_table is None or self._half_key != tuple((t.data_ptr(), t._version) for t in table if t is not None):
+                self._half_key = tuple((t.data_ptr(), t._version) for t in table if t is not None)
+                self._half_table = [None if t is None else t.float() for t in table]
+            x, logdet = self._engine.run(self._half_table, z.detach().float(), h.detach().float(), True)
+            return x.to(z.dtype), logdet.to(z.dtype)
         return self._engine.run(table, z.detach(), h.detach(), True)
 
     def forward_computation(self, x: Tensor, h: Tensor) -> Tuple[Tensor, Tensor]:

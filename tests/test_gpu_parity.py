@@ -716,3 +716,25 @@ def test_stft_decimate_vs_reference_golden(dev, golden_dir, precision, tag):
     assert np.abs(got - gold).max() < 2e-5 and np.abs(got - mo.stft_decimate(x, r)).max() < 2e-5
     full = npy(cm.LowPass()(T(x, dev), 7))                      # ratio 1/1 keeps every bin incl. Nyquist: the identity up to rounding
     assert np.abs(full - x).max() < 2e-5
+
+
+def test_half_inference_matches_fp32_engine(dev, precision):
+    """`inference.py --half` (model.half(), cond.half(), inference.py:33-36): half storage in and out, fp32 arithmetic inside.
+    The result equals the fp32 run on the half-rounded weights / inputs, rounded to half."""
+    if precision != "bf16x3p":
+        pytest.skip("one arithmetic mode is enough for the dtype plumbing")
+    m, cfg, specs, P = build("micro", dev)
+    B, N, F = fill.SHAPES["micro"]
+    _, h = fill.inputs("micro", B, N, F, cfg["n_mels"])
+    zlat = fill.normal("micro/latent", (B, N), 0.6)
+    mh = cm.WaveGlow(memory_efficient=True, bias=False, **cfg)
+    mh.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    mh = mh.to(dev).half()
+    with torch.no_grad():
+        xh, _ = mh.reverse(T(zlat, dev).half(), T(h, dev).half())
+        m32 = cm.WaveGlow(memory_efficient=True, bias=False, **cfg)
+        m32.load_state_dict({k: v.float() for k, v in mh.state_dict().items()})
+        x32, _ = m32.to(dev).reverse(T(zlat, dev).half().float(), T(h, dev).half().float())
+        y = mh.infer(T(h, dev).half()[0], sigma=0.6)
+    assert xh.dtype == torch.float16 and y.dtype == torch.float16 and y.shape == (F * cfg["hop_size"],)
+    assert torch.equal(xh, x32.half())
