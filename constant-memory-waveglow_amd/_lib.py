@@ -17,7 +17,7 @@ ABI_SYMBOLS = [
     "wg_nll_loss", "wg_nll_loss_backward", "wg_invconv_apply", "wg_invconv_backward", "wg_coupling_apply",
     "wg_coupling_backward", "wg_upsample", "wg_wn_apply", "wg_wsr_cond", "wg_wsr_cond_backward", "wg_adam_step",
     "wg_wf_param_count", "wg_wf_packed_bytes", "wg_wf_workspace_bytes", "wg_wf_tape_bytes", "wg_wf_pack_weights", "wg_wf_forward",
-    "wg_wf_inverse", "wg_wf_backward", "wg_melspec_frames", "wg_melspec", "wg_lowpass_workspace_bytes", "wg_lowpass",
+    "wg_wf_inverse", "wg_wf_backward", "wg_melspec_frames", "wg_melspec", "wg_lowpass_workspace_bytes", "wg_lowpass", "wg_train_step",
     "wg_timer_create", "wg_timer_attach", "wg_timer_count", "wg_timer_read", "wg_timer_destroy",
 ]
 K_CONV_STORE, K_CONV_GATE, K_CONV_RESSKIP, K_CONV_DGATE, K_WGRAD = range(5)
@@ -115,6 +115,7 @@ def lib():
     L.wg_lowpass_workspace_bytes.restype = sz
     L.wg_lowpass_workspace_bytes.argtypes = [i, i, i, i]
     L.wg_lowpass.argtypes = [vp, i, i, i, i, i, i, vp, vp, sz, vp]
+    L.wg_train_step.argtypes = [cfgp, vp, vp, vp, vp, i, i, i, f, i, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp]
     L.wg_timer_create.restype = vp
     L.wg_timer_create.argtypes = [i, i]
     L.wg_timer_attach.argtypes = [vp]

@@ -1095,8 +1095,12 @@ int wg_pack_weights(const wg_config *cf, const void *const *params, void *packed
 
 // ---- model level -------------------------------------------------------------------------------
 
+// ws_mode 1 + save_last: the training step's forward.  It runs in the BACKWARD workspace and keeps every layer of the flow it
+// processes last, so that wg_train_step can start the backward without recomputing that flow (its activations are the only ones
+// that fit the O(1)-in-depth budget; every other flow is recomputed from its rebuilt input as usual).
 static int model_run_fwd_or_inv(const wg_config *cf, const void *packed, const float *in, const float *h,
-                                int B, int N, int F, int inverse, float *out, float *logdet, void *wsv, size_t ws_bytes, void *stream)
+                                int B, int N, int F, int inverse, float *out, float *logdet, void *wsv, size_t ws_bytes, void *stream,
+                                int ws_mode = 0, int save_last = 0)
 {
     int rc = cfg_check(cf);
     if (rc) return rc;
@@ -1104,7 +1108,7 @@ static int model_run_fwd_or_inv(const wg_config *cf, const void *packed, const f
     rc = shape_check(cf, B, N, F, &T);
     if (rc) return rc;
     if (!packed || !in || !h || !out || !logdet || !wsv) return WG_EINVAL;
-    const ModelWs W = model_ws_layout(cf, B, T, 0);
+    const ModelWs W = model_ws_layout(cf, B, T, ws_mode);
     if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
     Ctx cx = {(hipStream_t)stream, 0, cf->precision};
     const float *pk = (const float *)packed;
@@ -1112,6 +1116,7 @@ static int model_run_fwd_or_inv(const wg_config *cf, const void *packed, const f
     float *ws = (float *)wsv;
     const Geo g = W.g;
     const int G = cf->n_group;
+    const int last_k = (cf->reverse_mode != 0) == (inverse != 0) ? cf->n_flows - 1 : 0;     // the flow this direction processes last
     PRef X = pref(ws + W.X, W.Gp);
     WG_LAUNCH(cx, squeeze_kernel, dim3((T + 255) / 256, B), dim3(256), 0, in, X, g, G, N);           // waveglow.py:153 / :184
     run_upsample(cx, cf, pk + M.up_w, pk + M.up_bias, h, F, g, pref(ws + W.Y, W.auxp), nullptr);                // :151,157
@@ -1122,6 +1127,7 @@ static int model_run_fwd_or_inv(const wg_config *cf, const void *packed, const f
     // one coupling (WN + affine, forward or inverse formulas) and one 1x1 mix on the channels [base, base + c_k)
     auto coupling = [&](int k, int base, int aff_mode) {
         r.d = flow_wn(cf, k); r.L = wn_pack_layout(r.d); r.pk = pk + M.wn[k]; r.X = pref(ws + W.X, W.Gp, base);
+        r.save = save_last && k == last_k;
         wn_forward(cx, r);
         run_end_affine(cx, r, aff_mode, pnull(), nullptr, nullptr, nullptr, partial + (size_t)k * B * W.ntile);
     };
@@ -1183,16 +1189,18 @@ int wg_inverse(const wg_config *cf, const void *packed, const float *z, const fl
 }
 
 
-int wg_backward(const wg_config *cf, const void *const *params, const void *packed, const float *z, const float *h,
-                const float *dz, const float *dlogdet, int B, int N, int F, void *const *grads, float *dh, float *dx,
-                float *x_rebuilt, void *wsv, size_t ws_bytes, void *stream, void *const *flow_events)
+// resume: called by wg_train_step right after the training forward ran in this workspace -- X, Y (and YS) are in place and the
+// flow the backward visits first still has all its layers, so neither the squeeze / upsample nor that flow's recompute is repeated.
+static int model_backward(const wg_config *cf, const void *const *params, const void *packed, const float *z, const float *h,
+                          const float *dz, const float *dlogdet, int B, int N, int F, void *const *grads, float *dh, float *dx,
+                          float *x_rebuilt, void *wsv, size_t ws_bytes, void *stream, void *const *flow_events, int resume)
 {
     int rc = cfg_check(cf);
     if (rc) return rc;
     int T;
     rc = shape_check(cf, B, N, F, &T);
     if (rc) return rc;
-    if (!params || !packed || !z || !h || !dz || !dlogdet || !grads || !wsv) return WG_EINVAL;
+    if (!params || !packed || (!z && !resume) || !h || !dz || !dlogdet || !grads || !wsv) return WG_EINVAL;
     const ModelWs W = model_ws_layout(cf, B, T, 1);
     if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
     Ctx cx = {(hipStream_t)stream, 0, cf->precision};
@@ -1204,10 +1212,13 @@ int wg_backward(const wg_config *cf, const void *const *params, const void *pack
     const Geo g = W.g;
     const int G = cf->n_group;
     PRef X = pref(ws + W.X, W.Gp), dX = pref(ws + W.dX, W.Gp);
-    WG_LAUNCH(cx, squeeze_kernel, dim3((T + 255) / 256, B), dim3(256), 0, z, X, g, G, N);
+    if (!resume) WG_LAUNCH(cx, squeeze_kernel, dim3((T + 255) / 256, B), dim3(256), 0, z, X, g, G, N);
     WG_LAUNCH(cx, squeeze_kernel, dim3((T + 255) / 256, B), dim3(256), 0, dz, dX, g, G, N);
-    run_upsample(cx, cf, pk + M.up_w, pk + M.up_bias, h, F, g, pref(ws + W.Y, W.auxp), nullptr);
-    if (cx.prec == 2) run_to_splane(cx, g, pref(ws + W.Y, W.auxp), cf->n_mels, ws + W.YS, W.auxp);
+    if (!resume) {
+        run_upsample(cx, cf, pk + M.up_w, pk + M.up_bias, h, F, g, pref(ws + W.Y, W.auxp), nullptr);
+        if (cx.prec == 2) run_to_splane(cx, g, pref(ws + W.Y, W.auxp), cf->n_mels, ws + W.YS, W.auxp);
+    }
+    bool have_first = resume != 0;                        // the first flow visited still holds its activations
     if (cx.err == 0 && hipMemsetAsync(ws + W.dY, 0, (size_t)B * W.auxp * g.P * sizeof(float), cx.st) != hipSuccess) cx.err = WG_ELAUNCH;
     WnRun r;
     r.g = g; r.ws = ws; r.w = W.wn; r.Y = ws + W.Y; r.YS = ws + W.YS; r.save = 1;
@@ -1215,7 +1226,8 @@ int wg_backward(const wg_config *cf, const void *const *params, const void *pack
     auto coupling_bwd = [&](int k, int base) {
         PRef Xk = pref(ws + W.X, W.Gp, base), dXk = pref(ws + W.dX, W.Gp, base);
         r.d = flow_wn(cf, k); r.L = wn_pack_layout(r.d); r.pk = pk + M.wn[k]; r.X = Xk;
-        wn_forward(cx, r);                                                                   // recompute :127-130
+        if (!have_first) wn_forward(cx, r);                                                  // recompute :127-130
+        have_first = false;
         run_end_affine(cx, r, AFF_BWD, dXk, nullptr, nullptr, dlogdet, nullptr);              // :132-148 (log_s.sum feeds logdet[b], waveglow.py:175)
         wn_backward(cx, r, p + wn_table_off(cf, k), gr + wn_table_off(cf, k), dXk, ws + W.dY);
     };
@@ -1258,6 +1270,35 @@ int wg_backward(const wg_config *cf, const void *const *params, const void *pack
               pref(ws + W.dY, W.auxp), g, cf->n_mels, F, cf->up_kernel, cf->up_stride, cf->up_pad, p[1], p[2], gr[0], gr[1], gr[2], dh);
     if (flow_events && flow_events[cf->n_flows] && !cx.err) (void)hipEventRecord((hipEvent_t)flow_events[cf->n_flows], cx.st);
     return cx.err;
+}
+
+int wg_backward(const wg_config *cf, const void *const *params, const void *packed, const float *z, const float *h,
+                const float *dz, const float *dlogdet, int B, int N, int F, void *const *grads, float *dh, float *dx,
+                float *x_rebuilt, void *wsv, size_t ws_bytes, void *stream, void *const *flow_events)
+{
+    return model_backward(cf, params, packed, z, h, dz, dlogdet, B, N, F, grads, dh, dx, x_rebuilt, wsv, ws_bytes, stream, flow_events, 0);
+}
+
+// The whole training step of model/lightning.py:52-56 in one call: z, logdet = model(x, h); loss = WaveGlowLoss(sigma)(z, logdet);
+// loss.backward().  Same kernels as wg_forward + wg_nll_loss + wg_nll_loss_backward + wg_backward, but the forward runs in the
+// backward's workspace and keeps the last flow's layers, so the backward starts without recomputing that flow and without a second
+// squeeze / upsample.  scratch: B*N + B floats (d loss / d z, d loss / d logdet).
+int wg_train_step(const wg_config *cf, const void *const *params, const void *packed, const float *audio, const float *h,
+                  int B, int N, int F, float sigma, int elementwise_mean, float *z, float *logdet, float *loss,
+                  void *const *grads, float *dh, float *scratch, void *ws, size_t ws_bytes, void *stream, void *const *flow_events)
+{
+    if (!z || !logdet || !loss || !scratch || !(sigma > 0.f)) return WG_EINVAL;
+    int rc = model_run_fwd_or_inv(cf, packed, audio, h, B, N, F, 0, z, logdet, ws, ws_bytes, stream, 1, 1);
+    if (rc) return rc;
+    Ctx cx = {(hipStream_t)stream, 0, 0};
+    const float inv_s2 = 1.0f / (sigma * sigma);
+    float *dz = scratch, *dld = scratch + (size_t)B * N;
+    WG_LAUNCH(cx, nll_loss_kernel, dim3(1), dim3(1024), 0, z, logdet, B, N, inv_s2, elementwise_mean, loss);
+    const size_t n = (size_t)B * N;
+    WG_LAUNCH(cx, nll_loss_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, z, B, N, inv_s2, elementwise_mean,
+              (const float *)nullptr, dz, dld);
+    if (cx.err) return cx.err;
+    return model_backward(cf, params, packed, nullptr, h, dz, dld, B, N, F, grads, dh, nullptr, nullptr, ws, ws_bytes, stream, flow_events, 1);
 }
 
 int wg_nll_loss(const float *z, const float *logdet, int B, int N, float sigma, int elementwise_mean, float *loss, void *stream)

@@ -184,6 +184,28 @@ class ModelEngine:
                                      self._events(flow_events)), "wg_backward")
         return grads, dh, dx, xr
 
+    def train_step(self, params, x, h, sigma, elementwise_mean, need, grads_out=None, need_dh=False, flow_events=None):
+        """wg_train_step: forward + NLL + backward in one call (the forward keeps the last flow's layers for the backward).
+        Returns (loss, z, logdet, grads, dh)."""
+        require_device(x, h, *params)
+        x, h = x.contiguous(), h.contiguous()
+        B, N = x.shape
+        pk = self._pack(params, x.device)
+        ws = self._ws(B, N, 1, x.device)
+        scratch = self.buffers.get((x.device, "step", B, N), 4 * (B * N + B), x.device)
+        if grads_out is not None:
+            grads = [g if nd else None for g, nd in zip(grads_out, need)]
+        else:
+            grads = [torch.empty_like(p) if (p is not None and nd) else None for p, nd in zip(params, need)]
+        z = torch.empty_like(x)
+        logdet = torch.empty(B, dtype=torch.float32, device=x.device)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        dh = torch.empty_like(h) if need_dh else None
+        check(_lib.lib().wg_train_step(C.byref(self.cfg), _table(params), _p(pk), _p(x), _p(h), B, N, h.shape[2], float(sigma),
+                                       int(elementwise_mean), _p(z), _p(logdet), _p(loss), _table(grads), _p(dh), _p(scratch),
+                                       _p(ws), ws.numel(), _stream(), self._events(flow_events)), "wg_train_step")
+        return loss, z, logdet, grads, dh
+
     @staticmethod
     def _events(events):
         """torch.cuda.Event list -> array of raw hipEvent_t (NULL when not given)"""

@@ -165,14 +165,11 @@ class FlowTrainer:
 
     @torch.no_grad()
     def step(self, x: torch.Tensor, h: torch.Tensor):
-        eng, E = self.model._engine, self._engine_mod
+        eng = self.model._engine
         table = [None if t is None else t.detach() for t in self.table]
-        z, logdet = eng.run(table, x, h, False)
-        loss = E.nll_loss(z, logdet, self.sigma, self.mean)
-        one = torch.ones((), dtype=torch.float32, device=z.device)
-        dz, dlogdet = E.nll_loss_backward(z, self.sigma, self.mean, one)
         need = [t is not None and t.requires_grad for t in self.table]
-        eng.backward(table, z, h, dz, dlogdet, need, False, False, grads_out=self.grad_views, flow_events=self.events)
+        loss, z, logdet, _, _ = eng.train_step(table, x, h, self.sigma, self.mean, need, grads_out=self.grad_views,
+                                               flow_events=self.events)        # one C call: wg_train_step
         # buckets become final in the order backward retires the flows: last flow first (first flow first in reverse_mode), upsampler last
         flows = range(self.n_flows) if self.model._reverse_mode else range(self.n_flows - 1, -1, -1)
         opt = self.optimizer

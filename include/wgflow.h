@@ -179,6 +179,14 @@ int wg_wsr_cond(const float *c, int B, int L, const float *mu_table, const float
  * through integer indices, :47 has no parameters).  Outputs are overwritten. */
 int wg_wsr_cond_backward(const float *c, int B, int L, const float *dcond, float *dmu_table, float *dang_table, void *stream);
 
+/* The training step of model/lightning.py:52-56 in ONE call: forward, WaveGlowLoss(sigma) (loss.py:10-15), backward to every
+ * parameter gradient (+ dh when not NULL).  Equivalent to wg_forward + wg_nll_loss + wg_nll_loss_backward + wg_backward; the
+ * forward runs in the backward's workspace (wg_workspace_bytes(.., mode 1)) and keeps the layers of the flow it processes last,
+ * which the backward then does not recompute.  scratch: (B*N + B) floats.  flow_events as in wg_backward. */
+int wg_train_step(const wg_config *cfg, const void *const *params, const void *packed, const float *audio, const float *h,
+                  int B, int N, int F, float sigma, int elementwise_mean, float *z, float *logdet, float *loss,
+                  void *const *grads, float *dh, float *scratch, void *ws, size_t ws_bytes, void *stream, void *const *flow_events);
+
 /* ---- WaveFlow (model/waveflow.py) -------------------------------------------------------------------
  * WaveFlow(flows, n_group, n_mels, use_conv1x1=False, ..., dilation/residual/skip_channels, bias=False): audio [B,N] viewed as
  * [B, n_group (height), N/n_group (time)], 8-layer WN2D with 3x3 dilated convs causal along the height axis, autoregressive
