@@ -691,6 +691,8 @@ __global__ __launch_bounds__(384, 3) void convgemm16d_kernel(const ConvGemm16sAr
 // LDS images are [t (32 rows)][c (128 channels)] bf16 with 320-byte rows, filled by 16-byte unit copies; an MFMA fragment
 // (8 consecutive time steps of one channel) is two ds_read_b64_tr_b16 (4x16 hardware transposes), conflict free.
 // ------------------------------------------------------------------------------------------------
+// The loader / compute split of convgemm16w was tried here too (wgrad16w: 8 waves, asm loads with counted waits, 101 VGPRs, parity
+// identical): 157 us against 149 us for this symmetric kernel on the same box -- not kept.
 #define WG16_ROWT 320
 struct WgSSeg {
     const unsigned short *hi;
