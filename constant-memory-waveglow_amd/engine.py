@@ -434,7 +434,7 @@ class WaveFlowEngine:
         B, N = dz.shape
         pk = self._pack(params, dz.device)
         ws = self._ws(B, N, 1, dz.device)
-        grads = [torch.empty_like(p) for p in params]
+        grads = [None if p is None else torch.empty_like(p) for p in params]
         dmel = torch.empty_like(mel) if need_dmel else None
         dx = torch.empty_like(dz) if need_dx else None
         check(_lib.lib().wg_wf_backward(C.byref(self.cfg), _table(params), _p(pk), _p(tape), _p(mel), _p(dz), _p(dlogdet), B, N,

@@ -81,7 +81,7 @@ class _WaveFlowFn(Function):
 
     @staticmethod
     def forward(ctx, model, x, h, *params):
-        table = [t.detach() for t in model.param_table()]
+        table = [None if t is None else t.detach() for t in model.param_table()]
         z, logdet, tape = model._engine.forward(table, x.detach(), h.detach(), keep_tape=True)
         ctx.model, ctx.tape = model, tape
         ctx.save_for_backward(h)
@@ -92,9 +92,9 @@ class _WaveFlowFn(Function):
         (h,) = ctx.saved_tensors
         model = ctx.model
         table = model.param_table()
-        grads, dmel, dx = model._engine.backward([t.detach() for t in table], ctx.tape, h, dz, dlogdet,
+        grads, dmel, dx = model._engine.backward([None if t is None else t.detach() for t in table], ctx.tape, h, dz, dlogdet,
                                                  ctx.needs_input_grad[2], ctx.needs_input_grad[1])
-        by_id = {id(t): g for t, g in zip(table, grads)}
+        by_id = {id(t): g for t, g in zip(table, grads) if t is not None}
         return (None, dx, dmel) + tuple(by_id.get(id(p)) for p in model.parameters())
 
 
@@ -119,15 +119,10 @@ class WaveFlow(FlowBase):
     def param_table(self):
         """C-ABI parameter table (include/wgflow.h): upsampler.1 bias, g, v; per flow the WN2D table."""
         up = self.upsampler[1]
-        g, v = conv_gv(up)
-        if g is None:
-            raise WgError("the WaveFlow engine needs the weight-normed parameterisation (do not call remove_weight_norms on it)")
+        g, v = conv_gv(up)                       # (None, weight) after remove_weight_norms (inference.py:19-22): plain weights
         tab = [up.bias, g, v]
         for wn in self.WNs:
-            t = wn.param_table()
-            if any(p is None for p in t):
-                raise WgError("the WaveFlow engine needs the weight-normed parameterisation (do not call remove_weight_norms on it)")
-            tab += t
+            tab += wn.param_table()
         return tab
 
     def _check(self, x: Tensor, h: Tensor):
@@ -144,4 +139,4 @@ class WaveFlow(FlowBase):
         self._check(z, h)
         if torch.is_grad_enabled() and (z.requires_grad or h.requires_grad):
             warnings.warn("WaveFlow.reverse runs without autograd in the HIP engine", stacklevel=3)
-        return self._engine.inverse([t.detach() for t in self.param_table()], z.detach(), h.detach())
+        return self._engine.inverse([None if t is None else t.detach() for t in self.param_table()], z.detach(), h.detach())

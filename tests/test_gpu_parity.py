@@ -738,3 +738,31 @@ def test_half_inference_matches_fp32_engine(dev, precision):
         y = mh.infer(T(h, dev).half()[0], sigma=0.6)
     assert xh.dtype == torch.float16 and y.dtype == torch.float16 and y.shape == (F * cfg["hop_size"],)
     assert torch.equal(xh, x32.half())
+
+
+def test_waveflow_after_remove_weight_norms(dev, precision):
+    """inference.py:19-22 folds the weight norm away before synthesis (model.apply(remove_weight_norms)); the engine then receives
+    plain weights (NULL weight_g entries) and must give the same forward / inverse, and still train."""
+    if precision != "bf16x3p":
+        pytest.skip("WaveFlow's 2-D taps are built for the S-plane kernels only")
+    name = "wf8"
+    cfg = fill.WF_CONFIGS[name]
+    B, N, F = fill.WF_SHAPES[name]
+    specs = fill.waveflow_param_specs(cfg)
+    P = fill.fill_params(specs, name + "/")
+    audio, mel = fill.waveflow_inputs(name, B, N, F, cfg["n_mels"])
+    m = cm.WaveFlow(use_conv1x1=False, memory_efficient=False, bias=False, **cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    m = m.to(dev)
+    with torch.no_grad():
+        z0, ld0 = m(T(audio, dev), T(mel, dev))
+    m.apply(cm.remove_weight_norms)
+    assert not any(n.endswith("weight_g") for n, _ in m.named_parameters())
+    with torch.no_grad():
+        z1, ld1 = m(T(audio, dev), T(mel, dev))
+        x1, _ = m.reverse(z1, T(mel, dev))
+    assert float((z1 - z0).abs().max()) < 1e-5 and float((ld1 - ld0).abs().max()) < 1e-3
+    assert float((x1 - T(audio, dev)).abs().max()) < Z_ATOL
+    z2, ld2 = m(T(audio, dev), T(mel, dev))
+    cm.WaveGlowLoss(fill.SIGMA)(z2, ld2).backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
