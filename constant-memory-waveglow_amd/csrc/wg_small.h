@@ -318,15 +318,31 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float *__restri
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
     if (tid == 0 && dbias) dbias[c] = red[0];
     __syncthreads();
-    // dw[kk] = sum_{b,i} h[b,c,i] * dY[b,c,S*i+kk-Pd]
-    for (int kk = tid; kk < K; kk += 256) {
-        float s = 0.f;
-        for (int b = 0; b < g.B; ++b)
-            for (int i = 0; i < F; ++i) {
-                const int j = S * i + kk - Pd;
+    // dw[kk] = sum_{b,i} h[b,c,i] * dY[b,c,S*i+kk-Pd].  Two shapes occur: many taps over few frames (WaveGlow: K = 65, F = 63)
+    // -> one thread per tap; few taps over many frames (WSRGlow: K = 3, F = 512 per item) -> the block reduces each tap.
+    if (K >= 32) {
+        for (int kk = tid; kk < K; kk += 256) {
+            float s = 0.f;
+            for (int b = 0; b < g.B; ++b)
+                for (int i = 0; i < F; ++i) {
+                    const int j = S * i + kk - Pd;
+                    if (j >= 0 && j < g.T) s += h[((size_t)b * C + c) * F + i] * *paddr(dY, g, b, c, j);
+                }
+            dw[kk] = s;
+        }
+    } else {
+        for (int kk = 0; kk < K; ++kk) {
+            float s = 0.f;
+            for (int e = tid; e < g.B * F; e += 256) {
+                const int b = e / F, i = e - b * F, j = S * i + kk - Pd;
                 if (j >= 0 && j < g.T) s += h[((size_t)b * C + c) * F + i] * *paddr(dY, g, b, c, j);
             }
-        dw[kk] = s;
+            red[tid] = s;
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+            if (tid == 0) dw[kk] = red[0];
+            __syncthreads();
+        }
     }
     __syncthreads();
     if (dh)
