@@ -232,9 +232,9 @@ def main():
             "config": {"workload": "WaveGlow 256ch, 12 flows, seg=16000, batch=%d per GPU (waveglow_LJ_speech.json), "
                                    "forward + NLL + constant-memory backward%s" % (B, " + RCCL grad all-reduce" if world > 1 else ""),
                        "global_batch": B * world, "segment": SEG, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "%s<EPI_GATE> (dilated k=3 conv + mel conditioning + gate)" % kname,
+            "roofline": {"bound": "mfma", "kernel": "%s<EPI_GATE%s> (dilated k=3 conv + mel conditioning + gate)" % (kname, ", 2" if kname == "convgemm16w_kernel" else ""),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": _traffic(kname + ("<1, 4>" if kname == "convgemm16_kernel" else "<1>")),
+                         "traffic": _traffic(kname + ("<1, 4>" if kname == "convgemm16_kernel" else "<1, 2>" if kname == "convgemm16w_kernel" else "<1>")) or _traffic(kname + "<1>"),
                          "launch_ms": gate_ms, "launches_timed": n, "flop_per_launch": gate_flop,
                          "mfma_tflops_issued": achieved * (3 if split else 1),
                          "x_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS},

@@ -64,16 +64,16 @@ __global__ void to_splane_kernel(PRef src, int nvalid, SRef dst, Geo g)
 // waves per SIMD, so memory-level parallelism (64-128 loads in flight per lane) is what matters.
 // the auxiliary values of the STORE / RESSKIP epilogues (accumulate-into input, residual input, skip accumulator) as the INITIAL
 // value of the accumulators: the main loop then adds the products on top and the epilogue has nothing left to load
-template <int EPI>
-__device__ __forceinline__ void conv_acc_init(const ConvGemmArgs &a, f32x16 (&acc)[2][2], int t0, int m0, int b, int wr, int wc, int lane)
+template <int EPI, int NI = 2>
+__device__ __forceinline__ void conv_acc_init(const ConvGemmArgs &a, f32x16 (&acc)[2][NI], int t0, int m0, int b, int wr, int wc, int lane)
 {
     const Geo g = a.g;
     const int col = lane & 31;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int t = t0 + wc * 64 + ni * 32 + col;
+        for (int ni = 0; ni < NI; ++ni) {
+            const int t = t0 + wc * (32 * NI) + ni * 32 + col;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wr * 64 + mi * 32 + acc_row(r, lane);
@@ -88,8 +88,9 @@ __device__ __forceinline__ void conv_acc_init(const ConvGemmArgs &a, f32x16 (&ac
         }
 }
 
-template <int EPI, bool PRE = false>
-__device__ __forceinline__ void conv_epilogue_s(const ConvGemmArgs &a, const SRef &s0, f32x16 (&acc)[2][2], int t0, int m0, int b,
+// NI = 32-column accumulator blocks per wave (2: the 128-column tile; 1: the 64-column tile of the small-grid launches)
+template <int EPI, bool PRE = false, int NI = 2>
+__device__ __forceinline__ void conv_epilogue_s(const ConvGemmArgs &a, const SRef &s0, f32x16 (&acc)[2][NI], int t0, int m0, int b,
                                                 int wr, int wc, int lane)
 {
     const Geo g = a.g;
@@ -97,8 +98,8 @@ __device__ __forceinline__ void conv_epilogue_s(const ConvGemmArgs &a, const SRe
     if (EPI == EPI_GATE) {
         const int chb = (m0 >> 1) + wr * 32;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int t = t0 + wc * 64 + ni * 32 + col;
+        for (int ni = 0; ni < NI; ++ni) {
+            const int t = t0 + wc * (32 * NI) + ni * 32 + col;
             if (t >= g.T) continue;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -122,13 +123,13 @@ __device__ __forceinline__ void conv_epilogue_s(const ConvGemmArgs &a, const SRe
         return;
     }
     // ---- phase 1: loads ----
-    f32x16 ax[2][2];                 // aux0 / skip accumulator
-    f32x16 ay[2][2];                 // aux1 (DGATE only)
+    f32x16 ax[2][NI];                // aux0 / skip accumulator
+    f32x16 ay[2][NI];                // aux1 (DGATE only)
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int t = t0 + wc * 64 + ni * 32 + col;
+        for (int ni = 0; ni < NI; ++ni) {
+            const int t = t0 + wc * (32 * NI) + ni * 32 + col;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wr * 64 + mi * 32 + acc_row(r, lane);
@@ -152,8 +153,8 @@ __device__ __forceinline__ void conv_epilogue_s(const ConvGemmArgs &a, const SRe
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int t = t0 + wc * 64 + ni * 32 + col;
+        for (int ni = 0; ni < NI; ++ni) {
+            const int t = t0 + wc * (32 * NI) + ni * 32 + col;
             if (t >= g.T) continue;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -434,37 +435,83 @@ __global__ __launch_bounds__(256) void convgemm16p_kernel(const ConvGemm16sArgs 
 struct Stage8 {
     u32x4 ah[2], al[2], bh[2], bl[2];
 };
+struct Stage6 {                      // the 64-column tile: one B unit per lane and image
+    u32x4 ah[2], al[2], bh[1], bl[1];
+};
+template <int NI> struct StageOf { typedef Stage8 type; };
+template <> struct StageOf<1> { typedef Stage6 type; };
 #define WG_STAGE_REGS(s) "+v"(s.ah[0]), "+v"(s.ah[1]), "+v"(s.al[0]), "+v"(s.al[1]), "+v"(s.bh[0]), "+v"(s.bh[1]), "+v"(s.bl[0]), "+v"(s.bl[1])
 __device__ __forceinline__ void asm_wait_keep8(Stage8 &s) { asm volatile("s_waitcnt vmcnt(8)" : WG_STAGE_REGS(s)::"memory"); }
+__device__ __forceinline__ void asm_wait_stage(Stage8 &s) { asm_wait_keep8(s); }
+__device__ __forceinline__ void asm_wait_stage(Stage6 &s)
+{
+    asm volatile("s_waitcnt vmcnt(6)" : "+v"(s.ah[0]), "+v"(s.ah[1]), "+v"(s.al[0]), "+v"(s.al[1]), "+v"(s.bh[0]), "+v"(s.bl[0])::"memory");
+}
+template <int NI> struct FragsW {
+    bf16x8 ah[2], al[2], bh[NI], bl[NI];
+};
+template <int NI>
+__device__ __forceinline__ void read_frags_w(FragsW<NI> &f, const char *Ahi, const char *Alo, const char *Bhi, const char *Blo, int ao, int bo)
+{
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        f.ah[i] = *reinterpret_cast<const bf16x8 *>(Ahi + ao + i * 32 * WG16_ROWB);
+        f.al[i] = *reinterpret_cast<const bf16x8 *>(Alo + ao + i * 32 * WG16_ROWB);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        f.bh[i] = *reinterpret_cast<const bf16x8 *>(Bhi + bo + i * 32 * WG16_ROWB);
+        f.bl[i] = *reinterpret_cast<const bf16x8 *>(Blo + bo + i * 32 * WG16_ROWB);
+    }
+}
+template <int NI>
+__device__ __forceinline__ void mfma_w(const FragsW<NI> &f, f32x16 (&acc)[2][NI])
+{
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[mi], f.bh[ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mi], f.bl[ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mi], f.bh[ni], acc[mi][ni], 0, 0, 0);
+        }
+}
 
-template <int EPI>
+// NI = 2: 128 x 128 tile (the training shapes).  NI = 1: 128 x 64 tile for launches that would otherwise leave most of the chip idle
+// (single-utterance synthesis, WSRGlow's 512-step segments, WaveFlow's row-by-row inverse): twice the workgroups, half the MFMAs
+// per chunk and wave, one B unit per loader lane and image (6 loads per chunk).
+template <int EPI, int NI>
 __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs aa)
 {
-    constexpr int AIMG = WG16_IMG;
-    constexpr int BUF = 4 * WG16_IMG;
+    typedef typename StageOf<NI>::type Stage;
+    constexpr int AIMG = WG16_IMG;                            // 128 rows x 80 B
+    constexpr int BIMG = 64 * NI * WG16_ROWB;
+    constexpr int BUF = 2 * AIMG + 2 * BIMG;
+    constexpr int TT = 64 * NI;                               // columns per tile
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
     const ConvGemmArgs &a = aa.c;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const Geo g = a.g;
-    const int t0 = blockIdx.x * WG_TILE, m0 = blockIdx.y * WG_TILE;
+    const int t0 = blockIdx.x * TT, m0 = blockIdx.y * WG_TILE;
     const int b = a.row_sel1 ? (int)blockIdx.z * g.rows + a.row_sel1 - 1 : (int)blockIdx.z;
     int nchunks = 0;
     for (int s = 0; s < a.nseg; ++s) nchunks += (a.seg[s].nch + WG16_BK - 1) / WG16_BK;
 
     if (wave >= 4) {
         // ------------------------------- loader waves -------------------------------
-        const int lt = tid - 256, bt = lt & 127, cg0 = lt >> 7;
+        const int lt = tid - 256;
+        const int bt = NI == 2 ? (lt & 127) : (lt & 63), cg0 = NI == 2 ? (lt >> 7) : (lt >> 6);     // B unit: position, k-group
         int cur_seg = 0, cur_c = 0, chunk = 0;
         const unsigned voff_a = (unsigned)lt * 16u;
         const unsigned voff_b = (unsigned)((cg0 * g.P + bt) * 16);
 #define WG_LD(dst, base, voff) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
         const unsigned short *zsrc = aa.sseg[0].hi;           // plane position 0 of the first operand: always-zero halo
-        // Every call issues exactly 8 loads in straight-line code: past the last chunk, and for the missing half of a 16-channel
-        // chunk, base and offset are SELECTED to the zero halo.  No branch may sit between an asm load and its counted wait --
-        // the compiler treats an asm output as valid at once and is free to copy it on a branch arm before the data has landed
-        // (tools/check_asm_loads.py walks the ISA for exactly that).
-        auto issue = [&](Stage8 &st) {
+        // Every call issues exactly 4 + 2 NI loads in straight-line code: past the last chunk, and for the missing half of a
+        // 16-channel chunk, base and offset are SELECTED to the zero halo.  No branch may sit between an asm load and its counted
+        // wait -- the compiler treats an asm output as valid at once and is free to copy it on a branch arm before the data has
+        // landed (tools/check_asm_loads.py walks the ISA for exactly that).
+        auto issue = [&](Stage &st) {
             const bool live = chunk < nchunks;
             const int sg = min(cur_seg, a.nseg - 1);
             const int nch = a.seg[sg].nch, shift = a.seg[sg].shift;
@@ -480,17 +527,27 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
             const bool blive = live && rowok, full = blive && (nch - cur_c > 16);
             const unsigned short *ih = aa.img + ((size_t)chunk * a.lda + m0) * WG16_BK, *il = ih + aa.img_stride;
             const unsigned short *row0 = ss.hi + ((size_t)bsrc * (ss.Cp >> 3) + ((ss.ch0 + cur_c) >> 3)) * g.P * 8;   // p = 0: zero halo
-            const unsigned short *b0 = row0 + (size_t)(g.H + t0 + shift) * 8, *b0l = b0 + ss.lo_off;
-            const unsigned short *b1 = b0 + (size_t)2 * g.P * 8, *b1l = b1 + ss.lo_off;
             const unsigned short *pa0 = live ? ih : zsrc, *pa1 = live ? ih + 2048 : zsrc;
             const unsigned short *pl0 = live ? il : zsrc, *pl1 = live ? il + 2048 : zsrc;
-            const unsigned short *pb0 = blive ? b0 : zsrc, *pb0l = blive ? b0l : zsrc;
-            const unsigned short *pb1 = full ? b1 : zsrc, *pb1l = full ? b1l : zsrc;
-            const unsigned va = live ? voff_a : 0u, vb = blive ? voff_b : 0u, vb1 = full ? voff_b : 0u;
+            const unsigned va = live ? voff_a : 0u;
             WG_LD(st.ah[0], pa0, va);   WG_LD(st.ah[1], pa1, va);
             WG_LD(st.al[0], pl0, va);   WG_LD(st.al[1], pl1, va);
-            WG_LD(st.bh[0], pb0, vb);   WG_LD(st.bl[0], pb0l, vb);
-            WG_LD(st.bh[1], pb1, vb1);  WG_LD(st.bl[1], pb1l, vb1);
+            if constexpr (NI == 2) {
+                const unsigned short *b0 = row0 + (size_t)(g.H + t0 + shift) * 8, *b0l = b0 + ss.lo_off;
+                const unsigned short *b1 = b0 + (size_t)2 * g.P * 8, *b1l = b1 + ss.lo_off;
+                const unsigned short *pb0 = blive ? b0 : zsrc, *pb0l = blive ? b0l : zsrc;
+                const unsigned short *pb1 = full ? b1 : zsrc, *pb1l = full ? b1l : zsrc;
+                const unsigned vb = blive ? voff_b : 0u, vb1 = full ? voff_b : 0u;
+                WG_LD(st.bh[0], pb0, vb);   WG_LD(st.bl[0], pb0l, vb);
+                WG_LD(st.bh[1], pb1, vb1);  WG_LD(st.bl[1], pb1l, vb1);
+            } else {
+                // one unit per lane: k-groups 2 and 3 of a 16-channel chunk do not exist -> those LANES read the zero halo
+                // (offset 0 from the plane row's position 0), the base stays uniform
+                const unsigned short *pb = blive ? row0 : zsrc, *pbl = blive ? row0 + ss.lo_off : zsrc;
+                const bool lane_ok = blive && (cg0 < 2 || full);
+                const unsigned vb = lane_ok ? voff_b + (unsigned)((g.H + t0 + shift) * 16) : 0u;
+                WG_LD(st.bh[0], pb, vb);    WG_LD(st.bl[0], pbl, vb);
+            }
             if (live) {
                 ++chunk;
                 cur_c += WG16_BK;
@@ -498,7 +555,7 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
             }
         };
 #undef WG_LD
-        auto write = [&](const Stage8 &st, int buf) {
+        auto write = [&](const Stage &st, int buf) {
             char *sb = smem + buf * BUF;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -506,21 +563,24 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
                 const int off = (p >> 2) * WG16_ROWB + (p & 3) * 16;
                 *reinterpret_cast<u32x4 *>(sb + off) = st.ah[j];
                 *reinterpret_cast<u32x4 *>(sb + AIMG + off) = st.al[j];
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
                 char *q = sb + 2 * AIMG + bt * WG16_ROWB + (cg0 + 2 * j) * 16;
                 *reinterpret_cast<u32x4 *>(q) = st.bh[j];
-                *reinterpret_cast<u32x4 *>(q + WG16_IMG) = st.bl[j];
+                *reinterpret_cast<u32x4 *>(q + BIMG) = st.bl[j];
             }
         };
-        Stage8 s0, s1;
+        Stage s0, s1;
         issue(s0);                                           // chunk 0
         issue(s1);                                           // chunk 1
-        asm_wait_keep8(s0);
+        asm_wait_stage(s0);
         write(s0, 0);
         issue(s0);                                           // chunk 2
         __syncthreads();                                     // buffer 0 ready
         // iteration c: compute waves multiply buffer c&1; we write chunk c+1 (landed) into the other buffer and issue chunk c+3
-        auto iter = [&](Stage8 &st, int c) {
-            asm_wait_keep8(st);
+        auto iter = [&](Stage &st, int c) {
+            asm_wait_stage(st);
             write(st, (c & 1) ^ 1);
             issue(st);
             __syncthreads();
@@ -536,35 +596,35 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
     }
     // ------------------------------- compute waves -------------------------------
     const int wr = wave >> 1, wc = wave & 1;
-    f32x16 acc[2][2];
+    f32x16 acc[2][NI];
     constexpr bool PRE = (EPI == EPI_STORE || EPI == EPI_RESSKIP)
 #if defined(WG_OPT_NO_ACCINIT)
                          && false
 #endif
         ;
     if (PRE) {
-        conv_acc_init<EPI>(a, acc, t0, m0, b, wr, wc, lane);
+        conv_acc_init<EPI, NI>(a, acc, t0, m0, b, wr, wc, lane);
     } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
     }
     const int r = lane & 31, h = lane >> 5;
-    const int ao = (wr * 64 + r) * WG16_ROWB + h * 16, bo = (wc * 64 + r) * WG16_ROWB + h * 16;
+    const int ao = (wr * 64 + r) * WG16_ROWB + h * 16, bo = (wc * 32 * NI + r) * WG16_ROWB + h * 16;
     __syncthreads();                                         // buffer 0 ready
     for (int c = 0; c < nchunks; ++c) {
         const char *sb = smem + (c & 1) * BUF;
-        Frags16 f0, f1;
-        read_frags16(f0, sb, sb + AIMG, sb + 2 * AIMG, sb + 3 * AIMG, ao, bo);
-        read_frags16(f1, sb, sb + AIMG, sb + 2 * AIMG, sb + 3 * AIMG, ao + 32, bo + 32);
-        mfma12(f0, acc);
-        mfma12(f1, acc);
+        FragsW<NI> f0, f1;
+        read_frags_w<NI>(f0, sb, sb + AIMG, sb + 2 * AIMG, sb + 2 * AIMG + BIMG, ao, bo);
+        read_frags_w<NI>(f1, sb, sb + AIMG, sb + 2 * AIMG, sb + 2 * AIMG + BIMG, ao + 32, bo + 32);
+        mfma_w<NI>(f0, acc);
+        mfma_w<NI>(f1, acc);
         if (c + 1 < nchunks || !(nchunks & 1)) __syncthreads();   // matches the loaders' barrier of iteration c (pairs: see there)
     }
-    conv_epilogue_s<EPI, PRE>(a, aa.s0, acc, t0, m0, b, wr, wc, lane);
+    conv_epilogue_s<EPI, PRE, NI>(a, aa.s0, acc, t0, m0, b, wr, wc, lane);
 }
 
 // ------------------------------------------------------------------------------------------------

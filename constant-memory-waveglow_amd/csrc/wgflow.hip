@@ -520,11 +520,21 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
             }
             return;
 #elif !defined(WG_OPT_NO_WSPEC)                   // default: loader waves + compute waves (8 waves per workgroup)
+            if (grid.x * grid.y * grid.z < 384) {                // fewer 128x128 tiles than 3/4 of the workgroup slots: 128x64 tiles
+                const dim3 g1(grid.x * 2, grid.y, grid.z);
+                switch (epi) {
+                case EPI_STORE: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_STORE, 1>), g1, dim3(512), 0, as); break;
+                case EPI_GATE: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_GATE, 1>), g1, dim3(512), 0, as); break;
+                case EPI_RESSKIP: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_RESSKIP, 1>), g1, dim3(512), 0, as); break;
+                case EPI_DGATE: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_DGATE, 1>), g1, dim3(512), 0, as); break;
+                }
+                return;
+            }
             switch (epi) {
-            case EPI_STORE: WG_LAUNCH(cx, convgemm16w_kernel<EPI_STORE>, grid, dim3(512), 0, as); break;
-            case EPI_GATE: WG_LAUNCH(cx, convgemm16w_kernel<EPI_GATE>, grid, dim3(512), 0, as); break;
-            case EPI_RESSKIP: WG_LAUNCH(cx, convgemm16w_kernel<EPI_RESSKIP>, grid, dim3(512), 0, as); break;
-            case EPI_DGATE: WG_LAUNCH(cx, convgemm16w_kernel<EPI_DGATE>, grid, dim3(512), 0, as); break;
+            case EPI_STORE: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_STORE, 2>), grid, dim3(512), 0, as); break;
+            case EPI_GATE: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_GATE, 2>), grid, dim3(512), 0, as); break;
+            case EPI_RESSKIP: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_RESSKIP, 2>), grid, dim3(512), 0, as); break;
+            case EPI_DGATE: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_DGATE, 2>), grid, dim3(512), 0, as); break;
             }
             return;
 #else                                             // A/B build: the symmetric software-pipelined kernel
