@@ -113,6 +113,7 @@ def other_models(dev):
 
         def step():
             m.zero_grad(set_to_none=True)
+            m._engine.packed.key = None            # as in training, where the weights change: re-pack every step
             z, ld = m(x, h)
             crit(z, ld).backward()
         dt = timed(step)
@@ -134,6 +135,7 @@ def other_models(dev):
 
         def step():
             m.zero_grad(set_to_none=True)
+            m._engine.packed.key = None            # as in training, where the weights change: re-pack every step
             z, ld = m(x, c.clone())
             crit(z, ld).backward()
         dt = timed(step)

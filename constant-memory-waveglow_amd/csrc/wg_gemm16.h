@@ -302,16 +302,29 @@ struct ImgJob {
     int nch[WG_MAX_SEG];
 };
 #define WG_IMG_JOBS 48
+#define WG_IMG_COLS 512     // columns of a chunk one block converts
 struct ImgArgs {
     int n;
+    int start[WG_IMG_JOBS + 1];     // prefix sums of the jobs' block counts (nchunks * column groups): the grid is exactly their total --
+                                    // a (max columns, max chunks, jobs) grid spent most of a launch dispatching blocks that return at once
     ImgJob job[WG_IMG_JOBS];
 };
 __global__ __launch_bounds__(256) void img_kernel(const ImgArgs a)
 {
     __shared__ float tile[32][65];
-    const ImgJob j = a.job[blockIdx.z];
-    const int ci = blockIdx.y, mb = blockIdx.x * 64;
-    if (ci >= j.nchunks || mb >= j.lda) return;
+    int ji = 0;
+    for (int q = 1; q < a.n; ++q)
+        if ((int)blockIdx.x >= a.start[q]) ji = q;
+    const ImgJob j = a.job[ji];
+    const int cgroups = (j.lda + WG_IMG_COLS - 1) / WG_IMG_COLS, local = (int)blockIdx.x - a.start[ji];
+    const int ci = local / cgroups, cbx = local - ci * cgroups;
+    if (ci >= j.nchunks) return;
+    // a block walks WG_IMG_COLS / 64 column groups of its chunk: 8 KB per group is too little work per block for the 230 M
+    // parameters of WSRGlow (the launch was dispatch bound)
+  for (int cbk = 0; cbk < WG_IMG_COLS / 64; ++cbk) {
+    const int mb = (cbx * (WG_IMG_COLS / 64) + cbk) * 64;
+    if (mb >= j.lda) return;
+    __syncthreads();
     // locate chunk ci
     int seg = 0, c0 = 0, row0 = 0, left = ci;
     for (seg = 0; seg < j.nseg; ++seg) {
@@ -339,4 +352,5 @@ __global__ __launch_bounds__(256) void img_kernel(const ImgArgs a)
     const size_t o = ((size_t)ci * j.lda + mb + m) * 32 + k8;
     *reinterpret_cast<u32x4 *>(j.img + o) = vh;
     *reinterpret_cast<u32x4 *>(j.img + (size_t)j.nchunks * j.lda * 32 + o) = vl;
+  }
 }

@@ -185,7 +185,7 @@ struct JobBatch {
     void flush_pack()
     {
         if (!pa.n) return;
-        WG_LAUNCH(*ctx, pack_kernel, dim3(64, pa.n), dim3(256), 0, pa);
+        WG_LAUNCH(*ctx, pack_kernel, dim3(512, pa.n), dim3(256), 0, pa);     // grid-stride over each job: 64 blocks left 230 M-parameter models dispatch-starved
         pa.n = 0;
     }
 };
@@ -244,9 +244,13 @@ struct ImgBatch {
     void flush()
     {
         if (!ia.n) return;
-        int mx = 0, my = 0;
-        for (int i = 0; i < ia.n; ++i) { mx = std::max(mx, ia.job[i].lda / 64); my = std::max(my, ia.job[i].nchunks); }
-        WG_LAUNCH(*ctx, img_kernel, dim3(mx, my, ia.n), dim3(256), 0, ia);
+        int total = 0;
+        for (int i = 0; i < ia.n; ++i) {
+            ia.start[i] = total;
+            total += ia.job[i].nchunks * ((ia.job[i].lda + WG_IMG_COLS - 1) / WG_IMG_COLS);
+        }
+        ia.start[ia.n] = total;
+        WG_LAUNCH(*ctx, img_kernel, dim3(total), dim3(256), 0, ia);
         ia.n = 0;
     }
 };

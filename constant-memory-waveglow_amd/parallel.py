@@ -141,8 +141,12 @@ class FlowTrainer:
         z, logdet = model(x, h); loss = NLL(z, logdet); backward to every parameter gradient; all-reduce(mean).
     Runs the HIP engine directly (no autograd graph) and leaves the gradients in p.grad (views of one flat buffer)."""
 
-    def __init__(self, model, sigma: float, elementwise_mean: bool = True, process_group=None):
+    def __init__(self, model, sigma: float, elementwise_mean: bool = True, process_group=None, repack_every_step: bool = True):
+        """repack_every_step: the reference recomputes w = g v / ||v|| in a forward-pre-hook on every call (utils.py:14-16), and in
+        training the parameters change between steps anyway.  The engine caches its packed weights by parameter version; a step
+        timed on frozen parameters would silently skip that work, so the trainer re-packs on every step unless told otherwise."""
         from . import engine
+        self.repack_every_step = repack_every_step
         self._engine_mod = engine
         self.model = model
         self.sigma, self.mean = sigma, elementwise_mean
@@ -166,6 +170,8 @@ class FlowTrainer:
     @torch.no_grad()
     def step(self, x: torch.Tensor, h: torch.Tensor):
         eng = self.model._engine
+        if self.repack_every_step:
+            eng.packed.key = None             # a training step always re-materialises the weight-normed weights (see __init__)
         table = [None if t is None else t.detach() for t in self.table]
         need = [t is not None and t.requires_grad for t in self.table]
         loss, z, logdet, _, _ = eng.train_step(table, x, h, self.sigma, self.mean, need, grads_out=self.grad_views,

@@ -42,6 +42,7 @@ def main():
 
     def step():
         m.zero_grad(set_to_none=True)
+        m._engine.packed.key = None                # as in training, where the weights change: re-pack every step
         z, logdet = m(x, h)
         loss = crit(z, logdet)
         loss.backward()

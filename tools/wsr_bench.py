@@ -39,6 +39,7 @@ def main():
 
     def step():
         m.zero_grad(set_to_none=True)
+        m._engine.packed.key = None                # as in training, where the weights change: re-pack every step
         z, logdet = m(x, c.clone())
         loss = crit(z, logdet)
         loss.backward()
