@@ -143,6 +143,24 @@ def other_models(dev):
         del m
     except Exception as e:                                    # noqa: BLE001
         res["wsrglow"] = {"error": repr(e)}
+    try:
+        # configs/waveglow_LJ_speech_fast.json: the headline network with memory_efficient=False.  Timed at the headline's batch
+        # (24 x 16000) so the two lines compare directly; the stored WN activations take ~1.9 GB per flow at that size.
+        from constant_memory_waveglow_amd.parallel import FlowTrainer
+        torch.manual_seed(0)
+        m = build_model(dev)
+        m.mem_efficient = False
+        tr = FlowTrainer(m, SIGMA)
+        x = torch.rand(24, SEG, device=dev) * 2 - 1
+        h = torch.randn(24, C2["n_mels"], FRAMES, device=dev)
+        dt = timed(lambda: tr.step(x, h))
+        res["waveglow_memory_efficient_false"] = {
+            "workload": "WaveGlow 256ch 12 flows (waveglow_LJ_speech_fast.json), batch 24 x 16000, fwd+NLL+bwd from stored activations",
+            "ms_per_step": dt * 1e3, "samples_per_s": 24 * SEG / dt,
+            "workspace_gb": sum(b.numel() for b in m._engine.buffers._ws.values()) / 1e9}
+        del m, tr
+    except Exception as e:                                    # noqa: BLE001
+        res["waveglow_memory_efficient_false"] = {"error": repr(e)}
     torch.cuda.empty_cache()
     return res
 

@@ -26,7 +26,7 @@ K_CONV_STORE, K_CONV_GATE, K_CONV_RESSKIP, K_CONV_DGATE, K_WGRAD = range(5)
 class WgConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n_flows", "n_group", "n_early_every", "n_early_size", "n_mels",
-        "up_stride", "up_kernel", "up_pad", "res_ch", "dil_ch", "skip_ch", "depth", "radix", "precision", "reverse_mode")]
+        "up_stride", "up_kernel", "up_pad", "res_ch", "dil_ch", "skip_ch", "depth", "radix", "precision", "reverse_mode", "keep_activations")]
 
 
 class WgWfConfig(C.Structure):

@@ -423,11 +423,28 @@ void wn_ws_layout(Bump &bp, const WnD &d, int ic_max, const Geo &g, int mode, in
     }
 }
 
+// Stored-activation mode (wg_config.keep_activations; the reference's memory_efficient=False, efficient_modules.py:33-35,71-75):
+// the planes of one WN that its backward reads -- everything else (fp32 ping-pong at precision 2, gradients, slab) stays shared.
+void wn_ws_layout_kept(Bump &bp, const WnD &d, int ic_max, const Geo &g, int prec, WnWs &w)
+{
+    const size_t pC = (size_t)g.B * d.C * g.P, pD = (size_t)g.B * d.Cd * g.P, pS = (size_t)g.B * d.Cs * g.P;
+    if (prec == 2) {
+        for (int i = 0; i < d.depth; ++i) { w.HS[i] = bp.take(pC); w.gateS[i] = bp.take(pD); }
+        w.XaS = bp.take((size_t)g.B * rup(ic_max, WG_BK) * g.P);
+    } else {
+        for (int i = 0; i < d.depth; ++i) { w.H[i] = bp.take(pC); w.gate[i] = bp.take(pD); }
+    }
+    for (int i = 0; i < d.depth; ++i) { w.tw[i] = bp.take(pD); w.sf[i] = bp.take(pD); }
+    w.skip = bp.take(pS);
+}
+
 struct ModelWs {
     Geo g;
     int Gp, auxp, ntile;
     size_t X, dX, Y, dY, YS, partial, total;
     WnWs wn;
+    std::vector<WnWs> wnk;     // keep_activations: per-flow view (shared scratch + that flow's kept planes); empty otherwise
+    const WnWs &flow(int k) const { return wnk.empty() ? wn : wnk[k]; }
 };
 ModelWs model_ws_layout(const wg_config *cf, int B, int T, int mode)
 {
@@ -448,6 +465,10 @@ ModelWs model_ws_layout(const wg_config *cf, int B, int T, int mode)
     }
     w.YS = cf->precision == 2 ? bp.take((size_t)B * w.auxp * w.g.P) : 0;
     wn_ws_layout(bp, d0, cf->n_group / 2, w.g, mode, cf->precision, w.wn);
+    if (mode && cf->keep_activations) {
+        w.wnk.assign(cf->n_flows, w.wn);                       // flow 0 owns the planes laid out above
+        for (int k = 1; k < cf->n_flows; ++k) wn_ws_layout_kept(bp, d0, cf->n_group / 2, w.g, cf->precision, w.wnk[k]);
+    }
     w.total = bp.off + 4096;   // slack
     return w;
 }
@@ -1122,6 +1143,8 @@ static int model_run_fwd_or_inv(const wg_config *cf, const void *packed, const f
     rc = shape_check(cf, B, N, F, &T);
     if (rc) return rc;
     if (!packed || !in || !h || !out || !logdet || !wsv) return WG_EINVAL;
+    const bool keep = cf->keep_activations && !inverse;   // stored-activation forward: mode-1 workspace, every flow keeps its layers
+    if (keep) ws_mode = 1;
     const ModelWs W = model_ws_layout(cf, B, T, ws_mode);
     if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
     Ctx cx = {(hipStream_t)stream, 0, cf->precision};
@@ -1141,7 +1164,8 @@ static int model_run_fwd_or_inv(const wg_config *cf, const void *packed, const f
     // one coupling (WN + affine, forward or inverse formulas) and one 1x1 mix on the channels [base, base + c_k)
     auto coupling = [&](int k, int base, int aff_mode) {
         r.d = flow_wn(cf, k); r.L = wn_pack_layout(r.d); r.pk = pk + M.wn[k]; r.X = pref(ws + W.X, W.Gp, base);
-        r.save = save_last && k == last_k;
+        r.save = keep || (save_last && k == last_k);
+        if (keep) r.w = W.flow(k);
         wn_forward(cx, r);
         run_end_affine(cx, r, aff_mode, pnull(), nullptr, nullptr, nullptr, partial + (size_t)k * B * W.ntile);
     };
@@ -1233,6 +1257,7 @@ static int model_backward(const wg_config *cf, const void *const *params, const 
         if (cx.prec == 2) run_to_splane(cx, g, pref(ws + W.Y, W.auxp), cf->n_mels, ws + W.YS, W.auxp);
     }
     bool have_first = resume != 0;                        // the first flow visited still holds its activations
+    const bool keep = cf->keep_activations != 0;          // every flow does: the forward (wg_forward / wg_train_step) ran in this workspace
     if (cx.err == 0 && hipMemsetAsync(ws + W.dY, 0, (size_t)B * W.auxp * g.P * sizeof(float), cx.st) != hipSuccess) cx.err = WG_ELAUNCH;
     WnRun r;
     r.g = g; r.ws = ws; r.w = W.wn; r.Y = ws + W.Y; r.YS = ws + W.YS; r.save = 1;
@@ -1240,7 +1265,8 @@ static int model_backward(const wg_config *cf, const void *const *params, const 
     auto coupling_bwd = [&](int k, int base) {
         PRef Xk = pref(ws + W.X, W.Gp, base), dXk = pref(ws + W.dX, W.Gp, base);
         r.d = flow_wn(cf, k); r.L = wn_pack_layout(r.d); r.pk = pk + M.wn[k]; r.X = Xk;
-        if (!have_first) wn_forward(cx, r);                                                  // recompute :127-130
+        if (keep) r.w = W.flow(k);                                                           // stored by the forward (memory_efficient=False)
+        else if (!have_first) wn_forward(cx, r);                                             // recompute :127-130
         have_first = false;
         run_end_affine(cx, r, AFF_BWD, dXk, nullptr, nullptr, dlogdet, nullptr);              // :132-148 (log_s.sum feeds logdet[b], waveglow.py:175)
         wn_backward(cx, r, p + wn_table_off(cf, k), gr + wn_table_off(cf, k), dXk, ws + W.dY);

@@ -99,6 +99,9 @@ class ModelEngine:
 
     def __init__(self, cfg: WgConfig):
         self.cfg = cfg
+        self.cfg_keep = WgConfig.from_buffer_copy(cfg)      # the same model in stored-activation mode (memory_efficient=False)
+        self.cfg_keep.keep_activations = 1
+        self._kept_gen = 0                                  # bumped by every call that rewrites a stored-activation workspace
         self.buffers = _Buffers()
         self.packed = PackedWeights()
         self.n_params = None
@@ -124,14 +127,30 @@ class ModelEngine:
         nbytes = _lib.lib().wg_workspace_bytes(C.byref(self.cfg), B, N, mode)
         return self.buffers.get((device, mode, B, N), nbytes, device)
 
-    def _launch(self, pk, ws, x, h, inverse):
+    def _ws_keep(self, B, N, device):
+        nbytes = _lib.lib().wg_workspace_bytes(C.byref(self.cfg_keep), B, N, 1)
+        return self.buffers.get((device, "keep", B, N), nbytes, device)
+
+    def _launch(self, pk, ws, x, h, inverse, cfg=None):
         B, N = x.shape
         out = torch.empty_like(x)
         logdet = torch.empty(B, dtype=torch.float32, device=x.device)
         fn = _lib.lib().wg_inverse if inverse else _lib.lib().wg_forward
-        check(fn(C.byref(self.cfg), _p(pk), _p(x), _p(h), B, N, h.shape[2], _p(out), _p(logdet), _p(ws), ws.numel(), _stream()),
+        check(fn(C.byref(cfg or self.cfg), _p(pk), _p(x), _p(h), B, N, h.shape[2], _p(out), _p(logdet), _p(ws), ws.numel(), _stream()),
               "wg_inverse" if inverse else "wg_forward")
         return out, logdet
+
+    def run_keep(self, params, x, h):
+        """wg_forward in stored-activation mode.  Returns (z, logdet, kept): `kept` = (generation, workspace) names the
+        activations this call left behind; `backward(kept=...)` uses them if no later call overwrote them."""
+        require_device(x, h, *params)
+        x, h = x.contiguous(), h.contiguous()
+        B, N = x.shape
+        pk = self._pack(params, x.device)
+        ws = self._ws_keep(B, N, x.device)
+        self._kept_gen += 1
+        z, logdet = self._launch(pk, ws, x, h, False, self.cfg_keep)
+        return z, logdet, (self._kept_gen, ws)
 
     def run(self, params, x, h, inverse):
         require_device(x, h, *params)
@@ -164,14 +183,22 @@ class ModelEngine:
         graph.replay()
         return out.clone(), logdet.clone()
 
-    def backward(self, params, z, h, dz, dlogdet, need, need_dh, need_dx, want_x=False, grads_out=None, flow_events=None):
-        """need[i]: produce the gradient of params[i] (into grads_out[i] when given).  Returns (grads, dh, dx, x_rebuilt)."""
+    def backward(self, params, z, h, dz, dlogdet, need, need_dh, need_dx, want_x=False, grads_out=None, flow_events=None,
+                 kept=None):
+        """need[i]: produce the gradient of params[i] (into grads_out[i] when given).  Returns (grads, dh, dx, x_rebuilt).
+        kept: what run_keep returned for this z; still-valid stored activations are used, overwritten ones fall back to
+        the recomputing backward (same gradients, one extra WN forward per flow)."""
         require_device(z, h, dz, dlogdet)
         z, h, dz, dlogdet = z.contiguous(), h.contiguous(), dz.contiguous(), dlogdet.contiguous()
         B, N = z.shape
         F = h.shape[2]
         pk = self._pack(params, z.device)
-        ws = self._ws(B, N, 1, z.device)
+        cfg = self.cfg
+        if kept is not None and kept[0] == self._kept_gen:
+            cfg, ws = self.cfg_keep, kept[1]
+            self._kept_gen += 1                             # the backward rebuilds X in place: the stored state is spent
+        else:
+            ws = self._ws(B, N, 1, z.device)
         if grads_out is not None:
             grads = [g if nd else None for g, nd in zip(grads_out, need)]
         else:
@@ -179,19 +206,26 @@ class ModelEngine:
         dh = torch.empty_like(h) if need_dh else None
         dx = torch.empty_like(z) if need_dx else None
         xr = torch.empty_like(z) if want_x else None
-        check(_lib.lib().wg_backward(C.byref(self.cfg), _table(params), _p(pk), _p(z), _p(h), _p(dz), _p(dlogdet), B, N, F,
+        check(_lib.lib().wg_backward(C.byref(cfg), _table(params), _p(pk), _p(z), _p(h), _p(dz), _p(dlogdet), B, N, F,
                                      _table(grads), _p(dh), _p(dx), _p(xr), _p(ws), ws.numel(), _stream(),
                                      self._events(flow_events)), "wg_backward")
         return grads, dh, dx, xr
 
-    def train_step(self, params, x, h, sigma, elementwise_mean, need, grads_out=None, need_dh=False, flow_events=None):
-        """wg_train_step: forward + NLL + backward in one call (the forward keeps the last flow's layers for the backward).
+    def train_step(self, params, x, h, sigma, elementwise_mean, need, grads_out=None, need_dh=False, flow_events=None,
+                   keep=False):
+        """wg_train_step: forward + NLL + backward in one call (the forward keeps the last flow's layers for the backward;
+        keep=True -- memory_efficient=False -- keeps every flow's, so no WN is recomputed).
         Returns (loss, z, logdet, grads, dh)."""
         require_device(x, h, *params)
         x, h = x.contiguous(), h.contiguous()
         B, N = x.shape
         pk = self._pack(params, x.device)
-        ws = self._ws(B, N, 1, x.device)
+        cfg = self.cfg_keep if keep else self.cfg
+        if keep:
+            ws = self._ws_keep(B, N, x.device)
+            self._kept_gen += 1
+        else:
+            ws = self._ws(B, N, 1, x.device)
         scratch = self.buffers.get((x.device, "step", B, N), 4 * (B * N + B), x.device)
         if grads_out is not None:
             grads = [g if nd else None for g, nd in zip(grads_out, need)]
@@ -201,7 +235,7 @@ class ModelEngine:
         logdet = torch.empty(B, dtype=torch.float32, device=x.device)
         loss = torch.empty((), dtype=torch.float32, device=x.device)
         dh = torch.empty_like(h) if need_dh else None
-        check(_lib.lib().wg_train_step(C.byref(self.cfg), _table(params), _p(pk), _p(x), _p(h), B, N, h.shape[2], float(sigma),
+        check(_lib.lib().wg_train_step(C.byref(cfg), _table(params), _p(pk), _p(x), _p(h), B, N, h.shape[2], float(sigma),
                                        int(elementwise_mean), _p(z), _p(logdet), _p(loss), _table(grads), _p(dh), _p(scratch),
                                        _p(ws), ws.numel(), _stream(), self._events(flow_events)), "wg_train_step")
         return loss, z, logdet, grads, dh

@@ -175,7 +175,8 @@ class FlowTrainer:
         table = [None if t is None else t.detach() for t in self.table]
         need = [t is not None and t.requires_grad for t in self.table]
         loss, z, logdet, _, _ = eng.train_step(table, x, h, self.sigma, self.mean, need, grads_out=self.grad_views,
-                                               flow_events=self.events)        # one C call: wg_train_step
+                                               flow_events=self.events,        # one C call: wg_train_step
+                                               keep=not self.model.mem_efficient)
         # buckets become final in the order backward retires the flows: last flow first (first flow first in reverse_mode), upsampler last
         flows = range(self.n_flows) if self.model._reverse_mode else range(self.n_flows - 1, -1, -1)
         opt = self.optimizer

@@ -92,13 +92,20 @@ class WN(nn.Module):
 
 class _WaveGlowFn(Function):
     """Whole-model autograd node: forward = wg_forward; backward = wg_backward, which walks the flows last to first
-    and rebuilds every block input from its output (constant activation memory in the number of flows)."""
+    and rebuilds every block input from its output (constant activation memory in the number of flows).  With
+    memory_efficient=False the WN activations of all flows are kept between the two calls instead (more memory, no
+    recompute); the block inputs are still rebuilt from the outputs, which costs nothing extra."""
 
     @staticmethod
     def forward(ctx, model, x, h, *params):
-        table = model.param_table()
-        z, logdet = model._engine.run([None if t is None else t.detach() for t in table], x.detach(), h.detach(), False)
-        ctx.model = model
+        table = [None if t is None else t.detach() for t in model.param_table()]
+        ctx.model, ctx.kept = model, None
+        if model.mem_efficient:
+            z, logdet = model._engine.run(table, x.detach(), h.detach(), False)
+        else:
+            # memory_efficient=False: every flow's WN layers stay in the engine's workspace and the backward reads them
+            # instead of recomputing each WN (the reference's plain-autograd blocks, efficient_modules.py:33-35,71-75)
+            z, logdet, ctx.kept = model._engine.run_keep(table, x.detach(), h.detach())
         ctx.save_for_backward(z, h)
         return z, logdet
 
@@ -109,7 +116,8 @@ class _WaveGlowFn(Function):
         table = model.param_table()
         need = [t is not None and t.requires_grad for t in table]
         grads, dh, dx, _ = model._engine.backward([None if t is None else t.detach() for t in table], z, h, dz, dlogdet,
-                                                  need, ctx.needs_input_grad[2], ctx.needs_input_grad[1])
+                                                  need, ctx.needs_input_grad[2], ctx.needs_input_grad[1], kept=ctx.kept)
+        ctx.kept = None
         by_id = {id(t): g for t, g in zip(table, grads) if t is not None}
         return (None, dx, dh) + tuple(by_id.get(id(p)) for p in model.parameters())
 

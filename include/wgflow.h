@@ -59,6 +59,11 @@ typedef struct wg_config {
     int32_t precision;                               /* WG_PREC_* : arithmetic of the MFMA contractions (not upstream) */
     int32_t reverse_mode;                            /* WaveGlow(reverse_mode=...) (waveglow.py:116, base.py:20-28): wg_forward is what
                                                         model.forward computes in that architecture, wg_inverse what model.reverse does */
+    int32_t keep_activations;                        /* WaveGlow(memory_efficient=False) (waveglow.py:118, efficient_modules.py:33-35,71-75):
+                                                        wg_forward / wg_train_step run in the MODE-1 workspace and leave every flow's WN layers
+                                                        there; wg_backward with the same workspace reads them instead of recomputing each WN.
+                                                        The caller guarantees nothing else used that workspace in between.  0 = the
+                                                        constant-memory scheme (only one flow's layers exist at a time). */
 } wg_config;
 
 /* Dimensions of one WN as AffineCouplingBlock builds it (efficient_modules.py:58-65, waveglow.py:50-59). */

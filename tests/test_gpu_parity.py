@@ -359,6 +359,83 @@ def test_trainer_step_matches_autograd(dev):
         assert torch.equal(a, p.grad)
 
 
+# ---- memory_efficient=False: stored-activation mode (configs/waveglow_LJ_speech_fast.json) --------------------------------
+
+@pytest.mark.parametrize("name,rev", [("micro", False), ("c1", False), ("wsr_like", False), ("c1", True)])
+def test_stored_activation_mode_vs_oracle(dev, name, rev):
+    """WaveGlow(memory_efficient=False): the forward leaves every flow's WN layers in the workspace and the backward reads
+    them (wg_config.keep_activations).  Same oracle, same tolerances as the constant-memory path; z / logdet are the same
+    kernels on the same inputs, hence bit-identical to it."""
+    m, cfg, specs, P = build(name, dev, mem_eff=False, reverse_mode=rev)
+    m_ce = build(name, dev, mem_eff=True, reverse_mode=rev)[0]
+    B, N, F = fill.SHAPES[name]
+    audio, h = fill.inputs(name, B, N, F, cfg["n_mels"])
+    ref = orc.train_step(orc.make_config(**cfg), fill.table(specs, P), audio, h, fill.SIGMA, need_dh=True, reverse_mode=rev)
+    x, ht = T(audio, dev).requires_grad_(True), T(h, dev).requires_grad_(True)
+    z, logdet = m(x, ht)
+    loss = cm.WaveGlowLoss(fill.SIGMA)(z, logdet)
+    gen = m._engine._kept_gen
+    loss.backward()
+    assert m._engine._kept_gen == gen + 1                      # the stored activations were the ones used (and are spent now)
+    z_ce, ld_ce = m_ce(T(audio, dev), T(h, dev))
+    assert torch.equal(z, z_ce) and torch.equal(logdet, ld_ce)
+    assert np.abs(npy(z) - ref["z"]).max() < Z_ATOL
+    assert logdet_close(npy(logdet), ref["logdet"], N)
+    assert abs(float(loss) - float(ref["loss"])) < LOSS_ATOL
+    assert relmax(npy(ht.grad), ref["dh"]) < GRAD_RTOL
+    named = dict(m.named_parameters())
+    for i, (n, _, _) in enumerate(specs):
+        assert relmax(npy(named[n].grad), ref["grads"][i]) < GRAD_RTOL, n
+    # dx: compare with the constant-memory path (the oracle's train_step does not return it)
+    x2, h2 = T(audio, dev).requires_grad_(True), T(h, dev)
+    z2, ld2 = m_ce(x2, h2)
+    cm.WaveGlowLoss(fill.SIGMA)(z2, ld2).backward()
+    assert relmax(npy(x.grad), npy(x2.grad)) < GRAD_RTOL
+
+
+def test_stored_activations_overwritten_fall_back_to_recompute(dev):
+    """Two forwards, then backward through the FIRST: its stored activations are gone, so the backward must notice and
+    recompute (never read the second call's activations)."""
+    m, cfg, specs, P = build("c1", dev, mem_eff=False)
+    B, N, F = fill.SHAPES["c1"]
+    audio, h = fill.inputs("c1", B, N, F, cfg["n_mels"])
+    ref = orc.train_step(orc.make_config(**cfg), fill.table(specs, P), audio, h, fill.SIGMA)
+    x, ht = T(audio, dev), T(h, dev)
+    z, logdet = m(x, ht)
+    m(T(audio[::-1] * 0.5, dev), T(h[::-1] + 0.25, dev))      # overwrites the workspace
+    gen = m._engine._kept_gen
+    cm.WaveGlowLoss(fill.SIGMA)(z, logdet).backward()
+    assert m._engine._kept_gen == gen                          # recompute path taken
+    named = dict(m.named_parameters())
+    for i, (n, _, _) in enumerate(specs):
+        assert relmax(npy(named[n].grad), ref["grads"][i]) < GRAD_RTOL, n
+
+
+def test_trainer_step_stored_activation_mode(dev):
+    """FlowTrainer on a memory_efficient=False model (wg_train_step with keep_activations) == that model's autograd path,
+    and within tolerance of the constant-memory trainer."""
+    from constant_memory_waveglow_amd.parallel import FlowTrainer
+    m, cfg, specs, P = build("c1", dev, mem_eff=False)
+    m_ce = build("c1", dev, mem_eff=True)[0]
+    B, N, F = fill.SHAPES["c1"]
+    audio, h = fill.inputs("c1", B, N, F, cfg["n_mels"])
+    x, ht = T(audio, dev), T(h, dev)
+    z, logdet = m(x, ht)
+    cm.WaveGlowLoss(fill.SIGMA)(z, logdet).backward()
+    ga = [p.grad.clone() for p in m.parameters()]
+    m.zero_grad(set_to_none=True)
+    loss, z2, ld2 = FlowTrainer(m, fill.SIGMA).step(x, ht)
+    assert torch.equal(z, z2) and torch.equal(logdet, ld2)
+    for a, p in zip(ga, m.parameters()):
+        assert torch.equal(a, p.grad)
+    loss_ce, _, _ = FlowTrainer(m_ce, fill.SIGMA).step(x, ht)
+    assert abs(float(loss) - float(loss_ce)) < LOSS_ATOL
+    for (n, p), q in zip(m.named_parameters(), m_ce.parameters()):
+        if n.endswith("start.weight_v") and p.shape[1] == 1:
+            continue                                           # fan-in 1: the true gradient is zero, what is left is rounding noise
+        assert relmax(npy(p.grad), npy(q.grad)) < GRAD_RTOL, n
+
+
 # ---- WSRGlow (SURVEY.md 8f rank 1): conditioning front-end kernels and the model ----------------------------------------
 
 def _wsr_tables():
