@@ -11,7 +11,12 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libwgflow.so")
-SOURCES = ["wgflow.hip", "wg_gemm.h", "wg_small.h", os.path.join("..", "..", "include", "wgflow.h")]
+
+
+def _sources():
+    """everything the one translation unit includes: csrc/*.hip, csrc/*.h and the public ABI header"""
+    own = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    return own + [os.path.join("..", "..", "include", "wgflow.h")]
 
 
 def _hipcc():
@@ -25,7 +30,7 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in SOURCES)
+    return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in _sources())
 
 
 def build(force=False, verbose=False, defines=(), out=None):

@@ -80,6 +80,12 @@ struct ConvGemm16Args {
 
 // MT = 64-row wave rows per workgroup: 2 -> 128x128 tile, 4 waves;  4 -> 256x128 tile, 8 waves (the B tile is converted once
 // for twice the MFMA work).  LDS: 2 buffers x (MT*64 + MT*64 + 128 + 128) rows x 80 B.
+// LDS byte offset of 16-byte piece p of an A image (global order: [128-row block][k-group][row][8 k]; LDS: padded rows)
+__device__ __forceinline__ int wg16_a_off(int p)
+{
+    return ((p >> 9) * 128 + (p & 127)) * WG16_ROWB + ((p >> 7) & 3) * 16;
+}
+
 template <int EPI, int MT>
 __global__ __launch_bounds__(128 * MT) void convgemm16_kernel(const ConvGemm16Args aa)
 {
@@ -117,7 +123,7 @@ __global__ __launch_bounds__(128 * MT) void convgemm16_kernel(const ConvGemm16Ar
         const ConvSeg sg = a.seg[cur_seg];
         const int nvalid = min(WG16_BK, sg.nch - cur_c);
         nk_loaded = nvalid >> 4;
-        // A: MT*256 pieces of 16 B per image: piece p -> row p>>2, part p&3
+        // A: MT*256 pieces of 16 B per image: piece p -> 128-row block p>>9, k-group (p>>7)&3, row p&127 (see img_kernel)
         const unsigned short *ih = aa.img + ((size_t)chunk * a.lda + m0) * WG16_BK;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(128 * MT) void convgemm16_kernel(const ConvGemm16Ar
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int p = tid + NT * j;
-            const int off = (p >> 2) * WG16_ROWB + (p & 3) * 16;
+            const int off = wg16_a_off(p);
             *reinterpret_cast<u32x4 *>(sb + off) = ra_hi[j];
             *reinterpret_cast<u32x4 *>(sb + AIMG + off) = ra_lo[j];
         }
@@ -349,7 +355,11 @@ __global__ __launch_bounds__(256) void img_kernel(const ImgArgs a)
         split2(tile[k8 + 2 * e][m], tile[k8 + 2 * e + 1][m], hh, ll);
         vh[e] = hh; vl[e] = ll;
     }
-    const size_t o = ((size_t)ci * j.lda + mb + m) * 32 + k8;
+    // image layout: per chunk and 128-row block, [k-group 0..3][row 0..127][8 k] -- the conv kernels stage a block with
+    // lane-linear 16-byte loads and consecutive lanes must land on consecutive LDS rows (80-byte stride: conflict free), not on
+    // the four pieces of one row (2-way conflict, measured as 20 % of the LDS cycles of the row-major layout)
+    const int mr = mb + m;
+    const size_t o = ((size_t)ci * j.lda + (mr & ~127)) * 32 + (size_t)(k8 >> 3) * 1024 + (size_t)(mr & 127) * 8;
     *reinterpret_cast<u32x4 *>(j.img + o) = vh;
     *reinterpret_cast<u32x4 *>(j.img + (size_t)j.nchunks * j.lda * 32 + o) = vl;
   }

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void convgemm16p_kernel(const ConvGemm16sArgs 
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int p = tid + NT * j;
-            const int off = (p >> 2) * WG16_ROWB + (p & 3) * 16;
+            const int off = wg16_a_off(p);
             *reinterpret_cast<u32x4 *>(sb + off) = ra_hi[S][j];
             *reinterpret_cast<u32x4 *>(sb + AIMG + off) = ra_lo[S][j];
         }
@@ -504,6 +504,7 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
         const int bt = NI == 2 ? (lt & 127) : (lt & 63), cg0 = NI == 2 ? (lt >> 7) : (lt >> 6);     // B unit: position, k-group
         int cur_seg = 0, cur_c = 0, chunk = 0;
         const unsigned voff_a = (unsigned)lt * 16u;
+        const int a_off0 = wg16_a_off(lt);                    // consecutive lanes -> consecutive 80-byte LDS rows: conflict-free staging
         const unsigned voff_b = (unsigned)((cg0 * g.P + bt) * 16);
 #define WG_LD(dst, base, voff) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
         const unsigned short *zsrc = aa.sseg[0].hi;           // plane position 0 of the first operand: always-zero halo
@@ -559,8 +560,7 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
             char *sb = smem + buf * BUF;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int p = lt + 256 * j;
-                const int off = (p >> 2) * WG16_ROWB + (p & 3) * 16;
+                const int off = a_off0 + 32 * j;               // piece lt + 256 j -> row lt & 127, k-group (lt >> 7) + 2 j (wg16_a_off)
                 *reinterpret_cast<u32x4 *>(sb + off) = st.ah[j];
                 *reinterpret_cast<u32x4 *>(sb + AIMG + off) = st.al[j];
             }
@@ -683,12 +683,12 @@ __global__ __launch_bounds__(384, 3) void convgemm16d_kernel(const ConvGemm16sAr
         auto issue = [&](int buf) {
             char *dst = smem + buf * BUF;
             if (wave == 4) {
-                const char *src = reinterpret_cast<const char *>(aa.img + ((size_t)chunk * a.lda + m0) * WG16_BK) + rsub * 64 + kg * 16;
+                const char *src = reinterpret_cast<const char *>(aa.img + ((size_t)chunk * a.lda + m0) * WG16_BK) + kg * 2048 + rsub * 16;
                 const char *srcl = src + aa.img_stride * 2;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    dma16(src + j * 1024, dst + j * 1024);
-                    dma16(srcl + j * 1024, dst + IMG + j * 1024);
+                    dma16(src + j * 256, dst + j * 1024);           // 16 rows further: 256 B in the k-group-major image, 1 KB in LDS
+                    dma16(srcl + j * 256, dst + IMG + j * 1024);
                 }
             } else {
                 const int nch = a.seg[cur_seg].nch, shift = a.seg[cur_seg].shift;
