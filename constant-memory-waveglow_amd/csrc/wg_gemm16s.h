@@ -480,6 +480,11 @@ __device__ __forceinline__ void mfma_w(const FragsW<NI> &f, f32x16 (&acc)[2][NI]
 // NI = 2: 128 x 128 tile (the training shapes).  NI = 1: 128 x 64 tile for launches that would otherwise leave most of the chip idle
 // (single-utterance synthesis, WSRGlow's 512-step segments, WaveFlow's row-by-row inverse): twice the workgroups, half the MFMAs
 // per chunk and wave, one B unit per loader lane and image (6 loads per chunk).
+#if defined(WG_DBG_NOBAR)      // timing experiment only (results are garbage): how much of a launch is barrier skew?
+#define WG16W_BAR() do { } while (0)
+#else
+#define WG16W_BAR() __syncthreads()
+#endif
 template <int EPI, int NI>
 __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs aa)
 {
@@ -577,13 +582,13 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
         asm_wait_stage(s0);
         write(s0, 0);
         issue(s0);                                           // chunk 2
-        __syncthreads();                                     // buffer 0 ready
+        WG16W_BAR();                                     // buffer 0 ready
         // iteration c: compute waves multiply buffer c&1; we write chunk c+1 (landed) into the other buffer and issue chunk c+3
         auto iter = [&](Stage &st, int c) {
             asm_wait_stage(st);
             write(st, (c & 1) ^ 1);
             issue(st);
-            __syncthreads();
+            WG16W_BAR();
         };
         // always in pairs (an even chunk count ends with one spare write of zero-halo data into the idle buffer, and the compute
         // waves take one matching extra barrier): the loop body stays branch-free between loads and waits
@@ -614,7 +619,8 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
     }
     const int r = lane & 31, h = lane >> 5;
     const int ao = (wr * 64 + r) * WG16_ROWB + h * 16, bo = (wc * 32 * NI + r) * WG16_ROWB + h * 16;
-    __syncthreads();                                         // buffer 0 ready
+    WG16W_BAR();                                         // buffer 0 ready
+#if defined(WG_OPT_OLDLOOP)
     for (int c = 0; c < nchunks; ++c) {
         const char *sb = smem + (c & 1) * BUF;
         FragsW<NI> f0, f1;
@@ -622,8 +628,65 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
         read_frags_w<NI>(f1, sb, sb + AIMG, sb + 2 * AIMG, sb + 2 * AIMG + BIMG, ao + 32, bo + 32);
         mfma_w<NI>(f0, acc);
         mfma_w<NI>(f1, acc);
-        if (c + 1 < nchunks || !(nchunks & 1)) __syncthreads();   // matches the loaders' barrier of iteration c (pairs: see there)
+        if (c + 1 < nchunks || !(nchunks & 1)) WG16W_BAR();   // matches the loaders' barrier of iteration c (pairs: see there)
     }
+#else
+    // Register-pipelined k-steps.  A chunk is two k-steps of 16; a k-step is two groups of 3 NI MFMAs: G0 = rows 0-31 of the wave
+    // tile (fragments A0) and G1 = rows 32-63 (A1), both against the step's B fragments.  The fragments of step s+1 are fetched
+    // under the MFMAs of step s: B and A1 into a second register set at the start of the step, A0 into its own registers as soon
+    // as G0 is issued.  64 accumulators + 14 fragment quads = 120 VGPRs: two workgroups per CU keep fitting, and no MFMA group
+    // starts by waiting for an LDS round trip (the compiler's own schedule of the plain loop, short of registers, exposed about
+    // four per chunk).  The barrier of chunk c sits between its k-steps: by then every fragment of chunk c is in registers, so
+    // the loaders may refill that buffer, and chunk c+1 (written during the first k-step) may be read.
+#define WG16W_SB() __builtin_amdgcn_sched_barrier(0)
+    bf16x8 a0h, a0l, a1h0, a1l0, a1h1, a1l1, bh0[NI], bl0[NI], bh1[NI], bl1[NI];
+    auto rd = [&](const char *q) { return *reinterpret_cast<const bf16x8 *>(q); };
+    auto grp = [&](const bf16x8 &xh, const bf16x8 &xl, const bf16x8 (&yh)[NI], const bf16x8 (&yl)[NI], f32x16 (&d)[NI]) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            d[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh[ni], d[ni], 0, 0, 0);
+            d[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl[ni], d[ni], 0, 0, 0);
+            d[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh[ni], d[ni], 0, 0, 0);
+        }
+    };
+    {
+        const char *pa = smem + ao, *pb = smem + 2 * AIMG + bo;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) { bh0[i] = rd(pb + i * 32 * WG16_ROWB); bl0[i] = rd(pb + BIMG + i * 32 * WG16_ROWB); }
+        a1h0 = rd(pa + 32 * WG16_ROWB); a1l0 = rd(pa + AIMG + 32 * WG16_ROWB);
+        a0h = rd(pa); a0l = rd(pa + AIMG);
+    }
+    for (int c = 0; c < nchunks; ++c) {
+        const char *pa = smem + (c & 1) * BUF + ao, *pb = smem + (c & 1) * BUF + 2 * AIMG + bo;
+        const char *na = smem + ((c & 1) ^ 1) * BUF + ao, *nb = smem + ((c & 1) ^ 1) * BUF + 2 * AIMG + bo;
+        // ---- k-step 0 (fragments *0), fetching k-step 1 of this chunk (fragments *1) ----
+#pragma unroll
+        for (int i = 0; i < NI; ++i) { bh1[i] = rd(pb + 32 + i * 32 * WG16_ROWB); bl1[i] = rd(pb + 32 + BIMG + i * 32 * WG16_ROWB); }
+        a1h1 = rd(pa + 32 + 32 * WG16_ROWB); a1l1 = rd(pa + 32 + AIMG + 32 * WG16_ROWB);
+        WG16W_SB();
+        grp(a0h, a0l, bh0, bl0, acc[0]);
+        WG16W_SB();
+        a0h = rd(pa + 32); a0l = rd(pa + 32 + AIMG);
+        WG16W_SB();
+        grp(a1h0, a1l0, bh0, bl0, acc[1]);
+        WG16W_SB();
+        if (c + 1 < nchunks || !(nchunks & 1)) WG16W_BAR();  // matches the loaders' barrier of iteration c (pairs: see there)
+        // ---- k-step 1 (fragments *1), fetching k-step 0 of the next chunk (fragments *0) ----
+        // (unconditional: after the last chunk these read stale LDS that nothing uses -- a branch here would make the compiler
+        // drain every outstanding read at the join)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) { bh0[i] = rd(nb + i * 32 * WG16_ROWB); bl0[i] = rd(nb + BIMG + i * 32 * WG16_ROWB); }
+        a1h0 = rd(na + 32 * WG16_ROWB); a1l0 = rd(na + AIMG + 32 * WG16_ROWB);
+        WG16W_SB();
+        grp(a0h, a0l, bh1, bl1, acc[0]);
+        WG16W_SB();
+        a0h = rd(na); a0l = rd(na + AIMG);
+        WG16W_SB();
+        grp(a1h1, a1l1, bh1, bl1, acc[1]);
+        WG16W_SB();
+    }
+#undef WG16W_SB
+#endif
     conv_epilogue_s<EPI, PRE, NI>(a, aa.s0, acc, t0, m0, b, wr, wc, lane);
 }
 
