@@ -67,25 +67,31 @@ __global__ void to_splane_kernel(PRef src, int nvalid, SRef dst, Geo g)
 template <int EPI, int NI = 2>
 __device__ __forceinline__ void conv_acc_init(const ConvGemmArgs &a, f32x16 (&acc)[2][NI], int t0, int m0, int b, int wr, int wc, int lane)
 {
+    // address = wave-uniform base of the 32-row block (64-bit, scalar registers) + a 32-bit per-lane offset: one VGPR per load
+    // instead of a 64-bit pointer pair (the preload is the register peak of the store / residual+skip instantiations)
     const Geo g = a.g;
     const int col = lane & 31;
+    const unsigned rowoff = (unsigned)(4 * (lane >> 5)) * (unsigned)g.P;          // acc_row's lane part
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < 2; ++mi) {
+        const int mb = m0 + wr * 64 + mi * 32;                                    // first row of this 32-row block (wave uniform)
+        const float *base = nullptr;
+        if (EPI == EPI_STORE) base = a.aux0.p ? paddr(a.aux0, g, b, mb, t0) : nullptr;
+        else if (EPI == EPI_RESSKIP)                                              // nsplit is a multiple of 32: a block lies on one side
+            base = mb < a.nsplit ? paddr(a.aux0, g, b, mb, t0) : (a.accumulate ? paddr(a.out1, g, b, mb - a.nsplit, t0) : nullptr);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-            const int t = t0 + wc * (32 * NI) + ni * 32 + col;
+            const int tl = wc * (32 * NI) + ni * 32 + col;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wr * 64 + mi * 32 + acc_row(r, lane);
-                const float *px = nullptr;
-                if (EPI == EPI_STORE) px = a.aux0.p ? paddr(a.aux0, g, b, m, t) : nullptr;
-                else if (EPI == EPI_RESSKIP)
-                    px = m < a.nsplit ? paddr(a.aux0, g, b, m, t) : (a.accumulate ? paddr(a.out1, g, b, m - a.nsplit, t) : nullptr);
+                const int rl = (r & 3) + 8 * (r >> 2);                            // acc_row's register part
+                const unsigned off = rowoff + (unsigned)rl * (unsigned)g.P + (unsigned)tl;
                 float x = 0.f;
-                if (t < g.T && m < a.M && px) x = *px;
+                if (t0 + tl < g.T && mb + rl + 4 * (lane >> 5) < a.M && base) x = base[off];
                 acc[mi][ni][r] = x;
             }
         }
+    }
 }
 
 // NI = 32-column accumulator blocks per wave (2: the 128-column tile; 1: the 64-column tile of the small-grid launches)
@@ -141,8 +147,12 @@ __device__ __forceinline__ void conv_epilogue_s(const ConvGemmArgs &a, const SRe
                         if (m < a.nsplit) x = *paddr(a.aux0, g, b, m, t);
                         else if (a.accumulate) x = *paddr(a.out1, g, b, m - a.nsplit, t);
                     } else if (EPI == EPI_DGATE) {
-                        x = *paddr(a.aux0, g, b, m, t);
-                        y = *paddr(a.aux1, g, b, m, t);
+                        // wave-uniform 64-bit base of the 32-row block + one 32-bit per-lane offset shared by both planes: the 128
+                        // loads in flight cost one address VGPR each, not a pointer pair (the allocator spilled those)
+                        const int mb = m0 + wr * 64 + mi * 32;
+                        const unsigned off = (unsigned)(acc_row(r, lane)) * (unsigned)g.P + (unsigned)(wc * (32 * NI) + ni * 32 + col);
+                        x = paddr(a.aux0, g, b, mb, t0)[off];
+                        y = paddr(a.aux1, g, b, mb, t0)[off];
                     }
                 }
                 ax[mi][ni][r] = x;
@@ -215,6 +225,7 @@ struct ConvGemm16sArgs {
     ConvGemmArgs c;               // geometry, seg[].nch / shift, epilogue operands (seg[].src unused)
     SSeg sseg[WG_MAX_SEG];
     SRef s0;                      // S-plane output (hi == nullptr: none)
+    int ntx, nty, ntz;            // convgemm16w: the tile grid (time tiles, 128-row tiles, plane rows); workgroup w walks tiles w, w + G, ...
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -498,27 +509,53 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const Geo g = a.g;
-    const int t0 = blockIdx.x * TT, m0 = blockIdx.y * WG_TILE;
-    const int b = a.row_sel1 ? (int)blockIdx.z * g.rows + a.row_sel1 - 1 : (int)blockIdx.z;
     int nchunks = 0;
     for (int s = 0; s < a.nseg; ++s) nchunks += (a.seg[s].nch + WG16_BK - 1) / WG16_BK;
+    // Persistent over tiles: workgroup w of G takes tiles w, w + G, ... in the order a 3-D grid would have dispatched them (time
+    // tile fastest, so the row tiles of one (plane row, time tile) stay 16 ids apart = on one XCD and share their B operand in its
+    // L2).  The loaders treat the chunks of all their tiles as ONE stream: while the compute waves are in the epilogue of tile
+    // i, the first chunks of tile i+1 are already being staged, and the epilogue's stores drain under the next main loop instead of
+    // in a chip-wide burst at the end of every workgroup (measured before: 48 of 133 us of the gate launch were that burst).
+    // (the gate backward keeps one workgroup per tile on a 3-D grid: its epilogue holds 128 auxiliary loads in flight next to the
+    // accumulators, a tile loop around that costs registers it does not have, and its launches are bound by those loads)
+    constexpr bool PERSIST = EPI != EPI_DGATE;
+    const int ntiles = aa.ntx * aa.nty * aa.ntz, G = (int)gridDim.x;
+    const int mine = PERSIST ? (ntiles - 1 - (int)blockIdx.x) / G + 1 : 1;   // host guarantees G <= ntiles
+    const int total = mine * nchunks;                                  // this workgroup's chunk stream
+    auto tile_at = [&](int k, int &t0, int &m0, int &b) {
+        if constexpr (PERSIST) {
+            const int id = (int)blockIdx.x + k * G;
+            const int tx = id % aa.ntx, q = id / aa.ntx, ty = q % aa.nty, tz = q / aa.nty;
+            t0 = tx * TT; m0 = ty * WG_TILE;
+            b = a.row_sel1 ? tz * g.rows + a.row_sel1 - 1 : tz;
+        } else {
+            t0 = blockIdx.x * TT; m0 = blockIdx.y * WG_TILE;
+            b = a.row_sel1 ? (int)blockIdx.z * g.rows + a.row_sel1 - 1 : (int)blockIdx.z;
+        }
+    };
 
     if (wave >= 4) {
         // ------------------------------- loader waves -------------------------------
         const int lt = tid - 256;
         const int bt = NI == 2 ? (lt & 127) : (lt & 63), cg0 = NI == 2 ? (lt >> 7) : (lt >> 6);     // B unit: position, k-group
-        int cur_seg = 0, cur_c = 0, chunk = 0;
+        int cur_seg = 0, cur_c = 0, chunk = 0;                // position inside the current tile
+        int gchunk = 0, tk = 0, t0, m0, b;                    // position in the stream; tile being loaded
+        tile_at(0, t0, m0, b);
         const unsigned voff_a = (unsigned)lt * 16u;
         const int a_off0 = wg16_a_off(lt);                    // consecutive lanes -> consecutive 80-byte LDS rows: conflict-free staging
         const unsigned voff_b = (unsigned)((cg0 * g.P + bt) * 16);
+#if defined(WG_DBG_NOLOAD)     // timing experiment only: the loaders write whatever their staging registers hold
+#define WG_LD(dst, base, voff) asm volatile("" : "=v"(dst) : "v"(voff), "s"(base))
+#else
 #define WG_LD(dst, base, voff) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
+#endif
         const unsigned short *zsrc = aa.sseg[0].hi;           // plane position 0 of the first operand: always-zero halo
         // Every call issues exactly 4 + 2 NI loads in straight-line code: past the last chunk, and for the missing half of a
         // 16-channel chunk, base and offset are SELECTED to the zero halo.  No branch may sit between an asm load and its counted
         // wait -- the compiler treats an asm output as valid at once and is free to copy it on a branch arm before the data has
         // landed (tools/check_asm_loads.py walks the ISA for exactly that).
         auto issue = [&](Stage &st) {
-            const bool live = chunk < nchunks;
+            const bool live = gchunk < total;
             const int sg = min(cur_seg, a.nseg - 1);
             const int nch = a.seg[sg].nch, shift = a.seg[sg].shift;
             const SSeg ss = aa.sseg[sg];
@@ -555,9 +592,15 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
                 WG_LD(st.bh[0], pb, vb);    WG_LD(st.bl[0], pbl, vb);
             }
             if (live) {
+                ++gchunk;
                 ++chunk;
                 cur_c += WG16_BK;
                 if (cur_c >= nch) { cur_c = 0; ++cur_seg; }
+                if (chunk == nchunks) {                       // next tile of this workgroup (past the last one: never loaded from)
+                    chunk = 0; cur_seg = 0; cur_c = 0;
+                    tk = min(tk + 1, mine - 1);
+                    tile_at(tk, t0, m0, b);
+                }
             }
         };
 #undef WG_LD
@@ -592,7 +635,7 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
         };
         // always in pairs (an even chunk count ends with one spare write of zero-halo data into the idle buffer, and the compute
         // waves take one matching extra barrier): the loop body stays branch-free between loads and waits
-        for (int c = 0; c + 1 < nchunks; c += 2) {
+        for (int c = 0; c + 1 < total; c += 2) {
             iter(s1, c);
             iter(s0, c + 1);
         }
@@ -607,30 +650,8 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
                          && false
 #endif
         ;
-    if (PRE) {
-        conv_acc_init<EPI, NI>(a, acc, t0, m0, b, wr, wc, lane);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
-    }
     const int r = lane & 31, h = lane >> 5;
     const int ao = (wr * 64 + r) * WG16_ROWB + h * 16, bo = (wc * 32 * NI + r) * WG16_ROWB + h * 16;
-    WG16W_BAR();                                         // buffer 0 ready
-#if defined(WG_OPT_OLDLOOP)
-    for (int c = 0; c < nchunks; ++c) {
-        const char *sb = smem + (c & 1) * BUF;
-        FragsW<NI> f0, f1;
-        read_frags_w<NI>(f0, sb, sb + AIMG, sb + 2 * AIMG, sb + 2 * AIMG + BIMG, ao, bo);
-        read_frags_w<NI>(f1, sb, sb + AIMG, sb + 2 * AIMG, sb + 2 * AIMG + BIMG, ao + 32, bo + 32);
-        mfma_w<NI>(f0, acc);
-        mfma_w<NI>(f1, acc);
-        if (c + 1 < nchunks || !(nchunks & 1)) WG16W_BAR();   // matches the loaders' barrier of iteration c (pairs: see there)
-    }
-#else
     // Register-pipelined k-steps.  A chunk is two k-steps of 16; a k-step is two groups of 3 NI MFMAs: G0 = rows 0-31 of the wave
     // tile (fragments A0) and G1 = rows 32-63 (A1), both against the step's B fragments.  The fragments of step s+1 are fetched
     // under the MFMAs of step s: B and A1 into a second register set at the start of the step, A0 into its own registers as soon
@@ -649,45 +670,85 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
             d[ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh[ni], d[ni], 0, 0, 0);
         }
     };
-    {
-        const char *pa = smem + ao, *pb = smem + 2 * AIMG + bo;
+    int gc = 0;                                              // chunk index in this workgroup's stream; its buffer is gc & 1
+    auto do_tile = [&](int k) {
+        int t0, m0, b;
+        tile_at(k, t0, m0, b);
+        int ln = lane;
+        // opaque per tile + nothing scheduled across: the per-lane addressing of the accumulator preload and of the epilogue is
+        // recomputed per tile instead of living across the main loop, and the preload of tile k+1 is not hoisted above the
+        // epilogue of tile k (that doubled the accumulators and cost the second workgroup per CU)
+        if (PERSIST) {
+            asm volatile("" : "+v"(ln)::"memory");
+            WG16W_SB();
+        }
+        if (PRE) {
+            conv_acc_init<EPI, NI>(a, acc, t0, m0, b, wr, wc, ln);
+        } else {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) { bh0[i] = rd(pb + i * 32 * WG16_ROWB); bl0[i] = rd(pb + BIMG + i * 32 * WG16_ROWB); }
-        a1h0 = rd(pa + 32 * WG16_ROWB); a1l0 = rd(pa + AIMG + 32 * WG16_ROWB);
-        a0h = rd(pa); a0l = rd(pa + AIMG);
-    }
-    for (int c = 0; c < nchunks; ++c) {
-        const char *pa = smem + (c & 1) * BUF + ao, *pb = smem + (c & 1) * BUF + 2 * AIMG + bo;
-        const char *na = smem + ((c & 1) ^ 1) * BUF + ao, *nb = smem + ((c & 1) ^ 1) * BUF + 2 * AIMG + bo;
-        // ---- k-step 0 (fragments *0), fetching k-step 1 of this chunk (fragments *1) ----
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < NI; ++i) { bh1[i] = rd(pb + 32 + i * 32 * WG16_ROWB); bl1[i] = rd(pb + 32 + BIMG + i * 32 * WG16_ROWB); }
-        a1h1 = rd(pa + 32 + 32 * WG16_ROWB); a1l1 = rd(pa + 32 + AIMG + 32 * WG16_ROWB);
-        WG16W_SB();
-        grp(a0h, a0l, bh0, bl0, acc[0]);
-        WG16W_SB();
-        a0h = rd(pa + 32); a0l = rd(pa + 32 + AIMG);
-        WG16W_SB();
-        grp(a1h0, a1l0, bh0, bl0, acc[1]);
-        WG16W_SB();
-        if (c + 1 < nchunks || !(nchunks & 1)) WG16W_BAR();  // matches the loaders' barrier of iteration c (pairs: see there)
-        // ---- k-step 1 (fragments *1), fetching k-step 0 of the next chunk (fragments *0) ----
-        // (unconditional: after the last chunk these read stale LDS that nothing uses -- a branch here would make the compiler
-        // drain every outstanding read at the join)
+                for (int j = 0; j < NI; ++j)
 #pragma unroll
-        for (int i = 0; i < NI; ++i) { bh0[i] = rd(nb + i * 32 * WG16_ROWB); bl0[i] = rd(nb + BIMG + i * 32 * WG16_ROWB); }
-        a1h0 = rd(na + 32 * WG16_ROWB); a1l0 = rd(na + AIMG + 32 * WG16_ROWB);
-        WG16W_SB();
-        grp(a0h, a0l, bh1, bl1, acc[0]);
-        WG16W_SB();
-        a0h = rd(na); a0l = rd(na + AIMG);
-        WG16W_SB();
-        grp(a1h1, a1l1, bh1, bl1, acc[1]);
-        WG16W_SB();
+                    for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+        }
+        if (k == 0) WG16W_BAR();                             // buffer 0 ready (later tiles: published by the previous chunk's barrier)
+        {
+            const char *pa = smem + (gc & 1) * BUF + ao, *pb = smem + (gc & 1) * BUF + 2 * AIMG + bo;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) { bh0[i] = rd(pb + i * 32 * WG16_ROWB); bl0[i] = rd(pb + BIMG + i * 32 * WG16_ROWB); }
+            a1h0 = rd(pa + 32 * WG16_ROWB); a1l0 = rd(pa + AIMG + 32 * WG16_ROWB);
+            a0h = rd(pa); a0l = rd(pa + AIMG);
+        }
+#if defined(WG_DBG_NOMFMA)     // timing experiment only: the compute waves just keep the barrier protocol
+        for (int c = 0; c < nchunks; ++c, ++gc)
+            if (gc + 1 < total || !(total & 1)) WG16W_BAR();
+        if (false)
+#endif
+        for (int c = 0; c < nchunks; ++c, ++gc) {
+            const char *pa = smem + (gc & 1) * BUF + ao, *pb = smem + (gc & 1) * BUF + 2 * AIMG + bo;
+            const char *na = smem + ((gc & 1) ^ 1) * BUF + ao, *nb = smem + ((gc & 1) ^ 1) * BUF + 2 * AIMG + bo;
+            // ---- k-step 0 (fragments *0), fetching k-step 1 of this chunk (fragments *1) ----
+#pragma unroll
+            for (int i = 0; i < NI; ++i) { bh1[i] = rd(pb + 32 + i * 32 * WG16_ROWB); bl1[i] = rd(pb + 32 + BIMG + i * 32 * WG16_ROWB); }
+            a1h1 = rd(pa + 32 + 32 * WG16_ROWB); a1l1 = rd(pa + 32 + AIMG + 32 * WG16_ROWB);
+            WG16W_SB();
+            grp(a0h, a0l, bh0, bl0, acc[0]);
+            WG16W_SB();
+            a0h = rd(pa + 32); a0l = rd(pa + 32 + AIMG);
+            WG16W_SB();
+            grp(a1h0, a1l0, bh0, bl0, acc[1]);
+            WG16W_SB();
+            if (gc + 1 < total || !(total & 1)) WG16W_BAR();     // matches the loaders' barrier of iteration gc (pairs: see there)
+            // ---- k-step 1 (fragments *1), fetching k-step 0 of the next chunk (fragments *0) ----
+            // (unconditional: after a tile's last chunk these read LDS that nothing uses -- a branch here would make the compiler
+            // drain every outstanding read at the join; the next tile starts with its own fetch)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) { bh0[i] = rd(nb + i * 32 * WG16_ROWB); bl0[i] = rd(nb + BIMG + i * 32 * WG16_ROWB); }
+            a1h0 = rd(na + 32 * WG16_ROWB); a1l0 = rd(na + AIMG + 32 * WG16_ROWB);
+            WG16W_SB();
+            grp(a0h, a0l, bh1, bl1, acc[0]);
+            WG16W_SB();
+            a0h = rd(na); a0l = rd(na + AIMG);
+            WG16W_SB();
+            grp(a1h1, a1l1, bh1, bl1, acc[1]);
+            WG16W_SB();
+        }
+#if defined(WG_DBG_NOEPI)      // timing experiment only: one store per lane keeps the accumulators alive
+        if (acc[0][0][0] + acc[1][0][0] + acc[0][NI - 1][5] + acc[1][NI - 1][7] == 12345.f) a.out0.p[lane] = 1.f;
+#else
+        int le = lane;
+        if (PRE) asm volatile("" : "+v"(le)::"memory");       // (a second opaque copy: no address shared with the preload survives the main loop)
+        conv_epilogue_s<EPI, PRE, NI>(a, aa.s0, acc, t0, m0, b, wr, wc, le);
+#endif
+        if (PERSIST) WG16W_SB();
+    };
+    if constexpr (PERSIST) {
+        for (int k = 0; k < mine; ++k) do_tile(k);
+    } else {
+        do_tile(0);
     }
 #undef WG16W_SB
-#endif
-    conv_epilogue_s<EPI, PRE, NI>(a, aa.s0, acc, t0, m0, b, wr, wc, lane);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -498,6 +498,19 @@ void run_to_splane(Ctx &cx, const Geo &g, PRef src, int nvalid, const float *dst
     WG_LAUNCH(cx, to_splane_kernel, dim3((g.T + 255) / 256, Cp_dst / 8, g.B), dim3(256), 0, src, nvalid, sref(g, dst, Cp_dst), g);
 }
 
+// CUs of the current device (256 on MI355X), asked once per device
+int device_cus()
+{
+    static std::atomic<int> cache[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    int n = cache[dev].load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cache[dev].store(n, std::memory_order_relaxed);
+    return n;
+}
+
 void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const SegSpec *segs, int nseg, int epi,
                   PRef out0, PRef out1, PRef out2, PRef aux0, PRef aux1, int nsplit, int accumulate, SRef s0 = snull())
 {
@@ -545,21 +558,31 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
             }
             return;
 #elif !defined(WG_OPT_NO_WSPEC)                   // default: loader waves + compute waves (8 waves per workgroup)
-            if (grid.x * grid.y * grid.z < 384) {                // fewer 128x128 tiles than 3/4 of the workgroup slots: 128x64 tiles
-                const dim3 g1(grid.x * 2, grid.y, grid.z);
+            // persistent launch: one workgroup per resident slot (two per CU), each walking its share of the tile grid -- see the
+            // kernel; the gate backward stays at one workgroup per tile.  -DWG_OPT_NO_PERSIST: one workgroup per tile everywhere.
+            const int cus = device_cus();
+            const bool small = grid.x * grid.y * grid.z < 384;   // fewer 128x128 tiles than 3/4 of the workgroup slots: 128x64 tiles
+            as.ntx = small ? (int)grid.x * 2 : (int)grid.x; as.nty = (int)grid.y; as.ntz = (int)grid.z;
+            const int ntiles = as.ntx * as.nty * as.ntz;
+            int slots = epi == EPI_DGATE ? ntiles : 2 * cus;
+#if defined(WG_OPT_NO_PERSIST)
+            slots = ntiles;
+#endif
+            const dim3 gp = epi == EPI_DGATE ? dim3(as.ntx, as.nty, as.ntz) : dim3(std::min(ntiles, slots));
+            if (small) {
                 switch (epi) {
-                case EPI_STORE: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_STORE, 1>), g1, dim3(512), 0, as); break;
-                case EPI_GATE: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_GATE, 1>), g1, dim3(512), 0, as); break;
-                case EPI_RESSKIP: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_RESSKIP, 1>), g1, dim3(512), 0, as); break;
-                case EPI_DGATE: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_DGATE, 1>), g1, dim3(512), 0, as); break;
+                case EPI_STORE: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_STORE, 1>), gp, dim3(512), 0, as); break;
+                case EPI_GATE: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_GATE, 1>), gp, dim3(512), 0, as); break;
+                case EPI_RESSKIP: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_RESSKIP, 1>), gp, dim3(512), 0, as); break;
+                case EPI_DGATE: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_DGATE, 1>), gp, dim3(512), 0, as); break;
                 }
                 return;
             }
             switch (epi) {
-            case EPI_STORE: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_STORE, 2>), grid, dim3(512), 0, as); break;
-            case EPI_GATE: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_GATE, 2>), grid, dim3(512), 0, as); break;
-            case EPI_RESSKIP: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_RESSKIP, 2>), grid, dim3(512), 0, as); break;
-            case EPI_DGATE: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_DGATE, 2>), grid, dim3(512), 0, as); break;
+            case EPI_STORE: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_STORE, 2>), gp, dim3(512), 0, as); break;
+            case EPI_GATE: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_GATE, 2>), gp, dim3(512), 0, as); break;
+            case EPI_RESSKIP: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_RESSKIP, 2>), gp, dim3(512), 0, as); break;
+            case EPI_DGATE: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_DGATE, 2>), gp, dim3(512), 0, as); break;
             }
             return;
 #else                                             // A/B build: the symmetric software-pipelined kernel
