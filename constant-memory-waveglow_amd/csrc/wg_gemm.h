@@ -66,15 +66,18 @@ __device__ __forceinline__ void mma_chunk(const float *__restrict__ As, const fl
     }
 }
 
-// gate nonlinearities: hardware exp2/rcp based forms (|err| ~1e-7, well inside the 1e-4 parity budget); the libm
+// gate nonlinearities: hardware exp2/rcp based forms (|err| ~3e-7, well inside the 1e-4 parity budget); the libm
 // forms cost ~4x the VALU work, which is visible once the contraction runs on the bf16 pipe.  -DWG_EXACT_GATE restores them.
+// The reciprocal is the bare v_rcp_f32 (1 ulp): __frcp_rn expands to the ten-instruction IEEE division sequence, and with 64
+// reciprocals per lane and tile that sequence alone was a quarter of the gate conv's epilogue, which is VALU bound (measured:
+// 37 us of a 133 us launch were the epilogue's arithmetic, 12 us its stores).
 #if !defined(WG_EXACT_GATE)
 #define WG_OPT_FASTGATE 1
 #endif
 __device__ __forceinline__ float wg_sigmoid(float x)
 {
 #if defined(WG_OPT_FASTGATE)
-    return __frcp_rn(1.0f + __expf(-x));
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 #else
     return 1.0f / (1.0f + expf(-x));
 #endif
@@ -83,7 +86,7 @@ __device__ __forceinline__ float wg_tanh(float x)
 {
 #if defined(WG_OPT_FASTGATE)
     const float e = __expf(-2.0f * fabsf(x));            // in (0,1]: no overflow
-    const float t = (1.0f - e) * __frcp_rn(1.0f + e);
+    const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
     return copysignf(t, x);
 #else
     return tanhf(x);

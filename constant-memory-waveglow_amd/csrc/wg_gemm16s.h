@@ -102,7 +102,13 @@ __device__ __forceinline__ void conv_epilogue_s(const ConvGemmArgs &a, const SRe
     const Geo g = a.g;
     const int col = lane & 31, h = lane >> 5;
     if (EPI == EPI_GATE) {
+        // fp32 planes: wave-uniform 64-bit base of the wave's 32 channels at the tile's first column + a 32-bit per-lane offset
+        // (this epilogue is VALU bound; 64-bit pointer arithmetic per store was a third of its instructions)
         const int chb = (m0 >> 1) + wr * 32;
+        float *b0 = a.out0.p ? paddr(a.out0, g, b, chb, t0) : nullptr;
+        float *b1 = a.out1.p ? paddr(a.out1, g, b, chb, t0) : nullptr;
+        float *b2 = a.out1.p ? paddr(a.out2, g, b, chb, t0) : nullptr;
+        const unsigned lane_off = (unsigned)(4 * h) * (unsigned)g.P + (unsigned)(wc * (32 * NI) + col);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int t = t0 + wc * (32 * NI) + ni * 32 + col;
@@ -117,13 +123,15 @@ __device__ __forceinline__ void conv_epilogue_s(const ConvGemmArgs &a, const SRe
                     const float tw = wg_tanh(acc[0][ni][4 * q + e]);
                     const float sf = wg_sigmoid(acc[1][ni][4 * q + e]);
                     gv[e] = tw * sf;
-                    if (a.out0.p) *paddr(a.out0, g, b, ch + e, t) = gv[e];
-                    if (a.out1.p) {
-                        *paddr(a.out1, g, b, ch + e, t) = tw;
-                        *paddr(a.out2, g, b, ch + e, t) = sf;
+                    const unsigned off = lane_off + (unsigned)(8 * q + e) * (unsigned)g.P + (unsigned)(ni * 32);
+                    if (b0) b0[off] = gv[e];
+                    if (b1) {
+                        b1[off] = tw;
+                        b2[off] = sf;
                     }
                 }
                 s_store4(s0, g, b, ch, t, gv);
+                __builtin_amdgcn_sched_barrier(0);           // one group of four channels at a time: keeps the epilogue inside 128 VGPRs
             }
         }
         return;
@@ -738,7 +746,8 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
         if (acc[0][0][0] + acc[1][0][0] + acc[0][NI - 1][5] + acc[1][NI - 1][7] == 12345.f) a.out0.p[lane] = 1.f;
 #else
         int le = lane;
-        if (PRE) asm volatile("" : "+v"(le)::"memory");       // (a second opaque copy: no address shared with the preload survives the main loop)
+        if (PERSIST) asm volatile("" : "+v"(le)::"memory");   // (a second opaque copy: the epilogue's per-lane offsets are computed here, per
+                                                              // tile, neither shared with the preload nor hoisted out of the tile loop)
         conv_epilogue_s<EPI, PRE, NI>(a, aa.s0, acc, t0, m0, b, wr, wc, le);
 #endif
         if (PERSIST) WG16W_SB();
