@@ -102,36 +102,62 @@ __device__ __forceinline__ void conv_epilogue_s(const ConvGemmArgs &a, const SRe
     const Geo g = a.g;
     const int col = lane & 31, h = lane >> 5;
     if (EPI == EPI_GATE) {
-        // fp32 planes: wave-uniform 64-bit base of the wave's 32 channels at the tile's first column + a 32-bit per-lane offset
-        // (this epilogue is VALU bound; 64-bit pointer arithmetic per store was a third of its instructions)
-        const int chb = (m0 >> 1) + wr * 32;
+        // This epilogue is VALU bound (measured: its arithmetic, not its stores, was a third of the launch), so it is written for
+        // the VALU: every address is a wave-uniform 64-bit base + a 32-bit per-lane offset, the null checks of the optional planes
+        // are hoisted out of the element loops, and the tanh / sigmoid chains of EIGHT outputs are straight-line code the
+        // scheduler can interleave (one chain alone is a string of dependent quarter-rate v_exp / v_rcp).
+        const int chb = (m0 >> 1) + wr * 32;                 // first gate channel of this wave (multiple of 32)
         float *b0 = a.out0.p ? paddr(a.out0, g, b, chb, t0) : nullptr;
         float *b1 = a.out1.p ? paddr(a.out1, g, b, chb, t0) : nullptr;
         float *b2 = a.out1.p ? paddr(a.out2, g, b, chb, t0) : nullptr;
-        const unsigned lane_off = (unsigned)(4 * h) * (unsigned)g.P + (unsigned)(wc * (32 * NI) + col);
+        unsigned short *sh = s0.hi + s_index(s0, g, b, chb, t0);          // unit of (channel group of chb, column t0)
+        unsigned short *sl = sh + s0.lo_off;
+        const unsigned tl = (unsigned)(wc * (32 * NI) + col);
+        const unsigned lane_off = (unsigned)(4 * h) * (unsigned)g.P + tl;
+        const unsigned s_lane = tl * 8u + (unsigned)(4 * h);              // element offset inside the unit row
+        const unsigned s_grp = (unsigned)g.P * 8u;                        // next channel group
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int t = t0 + wc * (32 * NI) + ni * 32 + col;
             if (t >= g.T) continue;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int ch = chb + 8 * q + 4 * h;
-                if (2 * ch >= a.M) continue;
-                float gv[4];
+            for (int qq = 0; qq < 4; qq += 2) {
+                float tw[8], sf[8], gv[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float tw = wg_tanh(acc[0][ni][4 * q + e]);
-                    const float sf = wg_sigmoid(acc[1][ni][4 * q + e]);
-                    gv[e] = tw * sf;
-                    const unsigned off = lane_off + (unsigned)(8 * q + e) * (unsigned)g.P + (unsigned)(ni * 32);
-                    if (b0) b0[off] = gv[e];
-                    if (b1) {
-                        b1[off] = tw;
-                        b2[off] = sf;
-                    }
+                for (int i = 0; i < 8; ++i) {
+                    tw[i] = wg_tanh(acc[0][ni][4 * qq + i]);
+                    sf[i] = wg_sigmoid(acc[1][ni][4 * qq + i]);
+                    gv[i] = tw[i] * sf[i];
                 }
-                s_store4(s0, g, b, ch, t, gv);
-                __builtin_amdgcn_sched_barrier(0);           // one group of four channels at a time: keeps the epilogue inside 128 VGPRs
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int q = qq + u;
+                    if (2 * (chb + 8 * q + 4 * h) >= a.M) continue;
+                    const unsigned off = lane_off + (unsigned)(8 * q) * (unsigned)g.P + (unsigned)(ni * 32);
+#if !defined(WG_DBG_GATE_NOSTORE)
+                    if (b0) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) b0[off + (unsigned)e * (unsigned)g.P] = gv[4 * u + e];
+                    }
+                    if (b1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            b1[off + (unsigned)e * (unsigned)g.P] = tw[4 * u + e];
+                            b2[off + (unsigned)e * (unsigned)g.P] = sf[4 * u + e];
+                        }
+                    }
+                    u32x2 vh, vl;
+                    unsigned hh, ll;
+                    split2(gv[4 * u], gv[4 * u + 1], hh, ll); vh[0] = hh; vl[0] = ll;
+                    split2(gv[4 * u + 2], gv[4 * u + 3], hh, ll); vh[1] = hh; vl[1] = ll;
+                    const unsigned so = s_lane + (unsigned)q * s_grp + (unsigned)(ni * 32 * 8);
+                    *reinterpret_cast<u32x2 *>(sh + so) = vh;
+                    *reinterpret_cast<u32x2 *>(sl + so) = vl;
+#else
+                    if (a.M == 12345 + q && tw[4 * u] + sf[4 * u + 1] + gv[4 * u + 2] + gv[4 * u + 3] == 3.f) b2[off] = gv[4 * u];
+#endif
+                }
+                __builtin_amdgcn_sched_barrier(0);           // eight outputs at a time: keeps the epilogue inside 128 VGPRs
             }
         }
         return;
@@ -499,6 +525,14 @@ __device__ __forceinline__ void mfma_w(const FragsW<NI> &f, f32x16 (&acc)[2][NI]
 // NI = 2: 128 x 128 tile (the training shapes).  NI = 1: 128 x 64 tile for launches that would otherwise leave most of the chip idle
 // (single-utterance synthesis, WSRGlow's 512-step segments, WaveFlow's row-by-row inverse): twice the workgroups, half the MFMAs
 // per chunk and wave, one B unit per loader lane and image (6 loads per chunk).
+#if defined(WG_DBG_TRACE)      // phase timestamps of the gate conv (100 MHz wall clock): [workgroup][16] = start, first barrier, then per
+                               // tile: main loop done, epilogue done.  Read back by wg_dbg_trace_read (tools/experiments/conv_trace.py).
+__device__ unsigned long long wg_dbg_trace[512 * 16];
+#define WG_TRACE(slot) do { if (EPI == EPI_GATE && NI == 2 && lane == 0 && wave == 0 && (slot) < 16) \
+        wg_dbg_trace[blockIdx.x * 16 + (slot)] = wall_clock64(); } while (0)
+#else
+#define WG_TRACE(slot) do { } while (0)
+#endif
 #if defined(WG_DBG_NOBAR)      // timing experiment only (results are garbage): how much of a launch is barrier skew?
 #define WG16W_BAR() do { } while (0)
 #else
@@ -700,7 +734,7 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
 #pragma unroll
                     for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
         }
-        if (k == 0) WG16W_BAR();                             // buffer 0 ready (later tiles: published by the previous chunk's barrier)
+        if (k == 0) { WG_TRACE(0); WG16W_BAR(); WG_TRACE(1); } // buffer 0 ready (later tiles: published by the previous chunk's barrier)
         {
             const char *pa = smem + (gc & 1) * BUF + ao, *pb = smem + (gc & 1) * BUF + 2 * AIMG + bo;
 #pragma unroll
@@ -742,6 +776,7 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
             grp(a1h1, a1l1, bh1, bl1, acc[1]);
             WG16W_SB();
         }
+        WG_TRACE(2 + 2 * k);
 #if defined(WG_DBG_NOEPI)      // timing experiment only: one store per lane keeps the accumulators alive
         if (acc[0][0][0] + acc[1][0][0] + acc[0][NI - 1][5] + acc[1][NI - 1][7] == 12345.f) a.out0.p[lane] = 1.f;
 #else
@@ -750,6 +785,7 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
                                                               // tile, neither shared with the preload nor hoisted out of the tile loop)
         conv_epilogue_s<EPI, PRE, NI>(a, aa.s0, acc, t0, m0, b, wr, wc, le);
 #endif
+        WG_TRACE(3 + 2 * k);
         if (PERSIST) WG16W_SB();
     };
     if constexpr (PERSIST) {

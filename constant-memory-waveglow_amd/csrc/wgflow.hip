@@ -1032,6 +1032,12 @@ const char *wg_strerror(int code)
 }
 int wg_abi_version(void) { return 1; }
 
+#if defined(WG_DBG_TRACE)
+int wg_dbg_trace_read(unsigned long long *out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(wg_dbg_trace), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 void *wg_timer_create(int kernel_id, int capacity)
 {
     if (capacity < 1) return nullptr;

@@ -1,0 +1,43 @@
+"""Phase timeline of the gate conv (developer experiment): needs a -DWG_DBG_TRACE build of libwgflow.so.
+
+    WGFLOW_LIB=.../variants/trace.so python tools/experiments/conv_trace.py
+
+Runs one coupling forward at the C2 shape, then prints per workgroup slot: start, first barrier, and for each of its tiles the
+end of the main loop and the end of the epilogue (us, relative to the earliest workgroup start of the LAST gate-conv launch)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import constant_memory_waveglow_amd as cm          # noqa: E402
+from constant_memory_waveglow_amd import _lib      # noqa: E402
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+blk = cm.AffineCouplingBlock(cm.WN, False, in_channels=4, aux_channels=80, zero_init=False, dilation_channels=256,
+                             residual_channels=256, skip_channels=256, depth=8).to(dev)
+x = torch.rand(24, 8, 2000, device=dev) * 2 - 1
+y = torch.randn(24, 80, 2000, device=dev)
+with torch.no_grad():
+    for _ in range(3):
+        blk(x.clone(), y)
+torch.cuda.synchronize()
+L = _lib.lib()
+buf = (C.c_ulonglong * (512 * 16))()
+L.wg_dbg_trace_read.argtypes = [C.c_void_p, C.c_int]
+assert L.wg_dbg_trace_read(buf, 512 * 16) == 0
+t = np.frombuffer(buf, dtype=np.uint64).reshape(512, 16).astype(np.float64) / 100.0     # us
+t0 = t[:, 0].min()
+t = t - t0
+names = ["start", "bar0", "ml0", "ep0", "ml1", "ep1", "ml2", "ep2"]
+print("workgroup   " + " ".join("%7s" % n for n in names))
+for w in list(range(0, 16)) + [100, 255, 256, 400, 511]:
+    print("%9d   " % w + " ".join("%7.1f" % v for v in t[w, :8]))
+d = np.diff(t[:, :8], axis=1)
+print("mean phase durations (us): " + " ".join("%s %.1f" % (n, v) for n, v in zip(names[1:], d.mean(axis=0))))
+print("std                      : " + " ".join("%s %.1f" % (n, v) for n, v in zip(names[1:], d.std(axis=0))))
+print("last epilogue end: mean %.1f max %.1f" % (t[:, 7].mean(), t[:, 7].max()))
