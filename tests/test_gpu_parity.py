@@ -602,13 +602,16 @@ SWEEP = [
     dict(flows=2, n_group=32, n_early_every=4, n_early_size=2, hop_size=32, n_mels=40, ch=(96, 96, 64), depth=3, radix=3, B=1, F=300),
     dict(flows=4, n_group=8, n_early_every=3, n_early_size=2, hop_size=16, n_mels=80, ch=(32, 32, 32), depth=9, radix=3, B=5, F=70),
     dict(flows=2, n_group=8, n_early_every=4, n_early_size=2, hop_size=64, n_mels=20, ch=(64, 64, 64), depth=2, radix=1, B=2, F=4),
+    # 37 time tiles x 7 items: 518 tiles (128x128 gate conv, 128x64 elsewhere) for 512 persistent workgroups -> some walk two tiles
+    dict(flows=1, n_group=8, n_early_every=4, n_early_size=2, hop_size=64, n_mels=20, ch=(128, 128, 128), depth=2, radix=3, B=7, F=592),
 ]
 
 
 @pytest.mark.parametrize("case", range(len(SWEEP)))
 def test_shape_sweep_vs_oracle(dev, case):
     """Odd channel mixes (dilation != residual != skip), depth 1 and 9 (dilation 256 > T), n_group 4..32, early outputs every flow,
-    radix 1, a time axis shorter than one tile and one that is not a multiple of it, batch 1..5."""
+    radix 1, a time axis shorter than one tile and one that is not a multiple of it, batch 1..7, and a launch with a few more tiles
+    than persistent workgroups."""
     c = SWEEP[case]
     cfg = dict(flows=c["flows"], n_group=c["n_group"], n_early_every=c["n_early_every"], n_early_size=c["n_early_size"],
                hop_size=c["hop_size"], n_mels=c["n_mels"], dilation_channels=c["ch"][0], residual_channels=c["ch"][1],
@@ -631,7 +634,12 @@ def test_shape_sweep_vs_oracle(dev, case):
     loss.backward()
     assert np.abs(npy(z) - ref["z"]).max() < Z_ATOL
     assert logdet_close(npy(logdet), ref["logdet"], N)
-    assert abs(float(loss) - ref["loss"]) < LOSS_ATOL
+    # the loss is a sum over B*N terms: the oracle's own fp32 accumulation is off by ~1e-6 at 265 000 terms (case 6), so the loss is
+    # checked against the float64 evaluation of the formula on the oracle's z / logdet (model/loss.py:10-15)
+    z64, ld64 = ref["z"].astype(np.float64), ref["logdet"].astype(np.float64)
+    loss64 = float(np.mean(0.5 * (z64 * z64).sum(1) / fill.SIGMA ** 2 - ld64) / N)
+    assert abs(loss64 - ref["loss"]) < 3 * LOSS_ATOL
+    assert abs(float(loss) - loss64) < LOSS_ATOL
     assert relmax(npy(ht.grad), ref["dh"]) < GRAD_RTOL
     named = dict(m.named_parameters())
     for i, (n, _, _) in enumerate(specs):
