@@ -939,11 +939,13 @@ struct WgradSArgs {
     int Mp, Np;
 };
 typedef short s4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8 tr_frag(const char *img, int off)
+// rows r..r+3 (lo) and r+4..r+7 (hi) of the image, r a multiple of 8 plus the lane's row: the upper four rows are stored rotated
+// by 32 bytes inside the 256-byte row payload (see the staging map of wgrad16s_kernel)
+__device__ __forceinline__ bf16x8 tr_frag(const char *img, int rowoff, int col)
 {
     typedef __attribute__((address_space(3))) s4v *lds_s4p;
-    const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(img + off));
-    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(img + off + 4 * WG16_ROWT));
+    const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(img + rowoff + col));
+    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(img + rowoff + 4 * WG16_ROWT + ((col + 32) & 255)));
     bf16x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
@@ -978,15 +980,20 @@ __global__ __launch_bounds__(256) void wgrad16s_kernel(const WgradSArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // staging: unit u = tid + 256*j -> t = 2*(u>>5) + (u&1), channel group cg = (u>>1)&15
+    // staging: unit u = tid + 256*j -> t = (u & 7) + 8 * (u >> 7), channel group cg = (u >> 3) & 15: eight consecutive lanes
+    // fetch the eight time steps of one channel group = one whole 128-byte line (the earlier 2 x 2 quad mapping fetched 32-byte
+    // pieces, four address-processing passes per line: the operand stream alone took 127 of the launch's 147 us).  In LDS a row is
+    // a time step; rows t and t+4 of one channel group would share banks (320-byte pitch), so rows with (t >> 2) odd are rotated by
+    // two units (32 bytes) inside their 256-byte payload, and the transposing fragment read applies the same rotation to its
+    // upper four rows (tr_frag).
     const unsigned short *pa[2], *pb[2];
     size_t la[2], lb_[2], sba[2], sbb[2];
     int loff[2], roff[2], pitem[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int u = tid + 256 * j;
-        const int tl = 2 * (u >> 5) + (u & 1), cg = (u >> 1) & 15;
-        loff[j] = tl * WG16_ROWT + cg * 16;
+        const int tl = (u & 7) + 8 * (u >> 7), cg = (u >> 3) & 15;
+        loff[j] = tl * WG16_ROWT + ((cg + 2 * ((tl >> 2) & 1)) & 15) * 16;
         const int ma = m0 + 8 * cg;
         const WgSSeg &sa = find_sseg(a.sa, a.nseg_a, ma >> 5);
         const int ca = ma - sa.blk0 * 32;
@@ -1003,18 +1010,43 @@ __global__ __launch_bounds__(256) void wgrad16s_kernel(const WgradSArgs a)
     const int c_begin = (int)((long)zs * a.total_chunks / a.nsplit), c_end = (int)((long)(zs + 1) * a.total_chunks / a.nsplit);
     const int nchunks = c_end - c_begin;
 
-    u32x4 rah[2], ral[2], rbh[2], rbl[2];
-    int lb = c_begin / a.cpb, lt = (c_begin - lb * a.cpb) * WG16_BK;
-    auto load_chunk = [&]() {
+    // fragment addressing: lane supplies row q = (l&15)>>2 of its 4x16 block, columns 4*(l&3)..; block = rows 8h (+4), cols 16*((l>>4)&1)
+    const int fq = (lane & 15) >> 2, fp = lane & 3, fh = lane >> 5, fg = (lane >> 4) & 1;
+    const int frow = (8 * fh + fq) * WG16_ROWT;
+    const int fca = (wr * 64 + 16 * fg + 4 * fp) * 2, fcb = (wc * 64 + 16 * fg + 4 * fp) * 2;
+    auto read_step = [&](Frags16 &f, const char *sb, int s) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f.ah[i] = tr_frag(sb, frow + s * 16 * WG16_ROWT, fca + i * 64);
+            f.al[i] = tr_frag(sb + IMG, frow + s * 16 * WG16_ROWT, fca + i * 64);
+            f.bh[i] = tr_frag(sb + 2 * IMG, frow + s * 16 * WG16_ROWT, fcb + i * 64);
+            f.bl[i] = tr_frag(sb + 3 * IMG, frow + s * 16 * WG16_ROWT, fcb + i * 64);
+        }
+    };
+    auto store_stage = [&](const Stage8 &st, int buf) {
+        char *sb = smem + buf * BUF;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            u32x4 z = {0u, 0u, 0u, 0u};
-            rah[j] = z; ral[j] = z; rbh[j] = z; rbl[j] = z;
-            if (pa[j]) {
-                const unsigned short *q = pa[j] + lb * sba[j] + (size_t)lt * 8;
-                rah[j] = *reinterpret_cast<const u32x4 *>(q);
-                ral[j] = *reinterpret_cast<const u32x4 *>(q + la[j]);
-            }
+            *reinterpret_cast<u32x4 *>(sb + loff[j]) = st.ah[j];
+            *reinterpret_cast<u32x4 *>(sb + IMG + loff[j]) = st.al[j];
+            *reinterpret_cast<u32x4 *>(sb + 2 * IMG + loff[j]) = st.bh[j];
+            *reinterpret_cast<u32x4 *>(sb + 3 * IMG + loff[j]) = st.bl[j];
+        }
+    };
+    // Two chunks in flight per wave: the loads are issued from inline asm (hipcc's own bookkeeping drains every outstanding load at
+    // the loop back edge, which caps a compiler-managed prefetch at half a chunk) and retired by counted waits, as in convgemm16w:
+    // the stream alone took 127 of this launch's 147 us at one chunk in flight (64 KB per CU).  Every issue is exactly eight loads
+    // in straight-line code: lanes without a source row and chunks past the end read the zero halo (selected pointers, no branch
+    // between a load and its wait; tools/check_asm_loads.py covers this kernel too).
+    const unsigned short *zsrc = a.sa[0].hi;                 // plane position 0 of the first operand: always-zero halo
+    int lb = c_begin / a.cpb, lt = (c_begin - lb * a.cpb) * WG16_BK, issued = 0;
+#define WG_LDP(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+    auto issue = [&](Stage8 &st) {
+        const bool live = issued < nchunks;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned short *qa = (live && pa[j]) ? pa[j] + lb * sba[j] + (size_t)lt * 8 : zsrc;
+            const unsigned short *qal = (live && pa[j]) ? qa + la[j] : zsrc;
             // B operand row: the chunk's own plane row, another row of the same item (2-D taps, zero outside it) or the item's row
             int bsrc = lb;
             bool rowok = true;
@@ -1023,76 +1055,47 @@ __global__ __launch_bounds__(256) void wgrad16s_kernel(const WgradSArgs a)
                 rowok = r >= 0 && r < g.rows;
                 bsrc = pitem[j] ? item : lb + roff[j];
             }
-            if (pb[j] && rowok) {
-                const unsigned short *q = pb[j] + bsrc * sbb[j] + (size_t)lt * 8;
-                rbh[j] = *reinterpret_cast<const u32x4 *>(q);
-                rbl[j] = *reinterpret_cast<const u32x4 *>(q + lb_[j]);
-            }
+            const bool bok = live && pb[j] && rowok;
+            const unsigned short *qb = bok ? pb[j] + bsrc * sbb[j] + (size_t)lt * 8 : zsrc;
+            const unsigned short *qbl = bok ? qb + lb_[j] : zsrc;
+            WG_LDP(st.ah[j], qa);  WG_LDP(st.al[j], qal);
+            WG_LDP(st.bh[j], qb);  WG_LDP(st.bl[j], qbl);
         }
-        lt += WG16_BK;
-        if (lt >= g.Tt) { lt = 0; ++lb; }
-    };
-    auto store_chunk = [&](int buf) {
-        char *sb = smem + buf * BUF;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            *reinterpret_cast<u32x4 *>(sb + loff[j]) = rah[j];
-            *reinterpret_cast<u32x4 *>(sb + IMG + loff[j]) = ral[j];
-            *reinterpret_cast<u32x4 *>(sb + 2 * IMG + loff[j]) = rbh[j];
-            *reinterpret_cast<u32x4 *>(sb + 3 * IMG + loff[j]) = rbl[j];
+        if (live) {
+            ++issued;
+            lt += WG16_BK;
+            if (lt >= g.Tt) { lt = 0; ++lb; }
         }
     };
-    // fragment addressing: lane supplies row q = (l&15)>>2 of its 4x16 block, columns 4*(l&3)..; block = rows 8h (+4), cols 16*((l>>4)&1)
-    const int fq = (lane & 15) >> 2, fp = lane & 3, fh = lane >> 5, fg = (lane >> 4) & 1;
-    const int fa = (8 * fh + fq) * WG16_ROWT + (wr * 64 + 16 * fg + 4 * fp) * 2;
-    const int fb = (8 * fh + fq) * WG16_ROWT + (wc * 64 + 16 * fg + 4 * fp) * 2;
-    auto read_step = [&](Frags16 &f, const char *sb, int s) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            f.ah[i] = tr_frag(sb, fa + s * 16 * WG16_ROWT + i * 64);
-            f.al[i] = tr_frag(sb + IMG, fa + s * 16 * WG16_ROWT + i * 64);
-            f.bh[i] = tr_frag(sb + 2 * IMG, fb + s * 16 * WG16_ROWT + i * 64);
-            f.bl[i] = tr_frag(sb + 3 * IMG, fb + s * 16 * WG16_ROWT + i * 64);
-        }
-    };
-
+#undef WG_LDP
     if (nchunks > 0) {
-        load_chunk();
-        store_chunk(0);
+        Stage8 s0, s1;
+        issue(s0);                                           // chunk 0
+        issue(s1);                                           // chunk 1
+        asm_wait_keep8(s0);
+        store_stage(s0, 0);
+        issue(s0);                                           // chunk 2
         __syncthreads();
-        // steady state (same software pipeline as convgemm16p): step-1 fragments are read between the MFMAs of step 0, the next
-        // chunk's LDS writes between the MFMAs of step 1
-        for (int c = 0; c + 1 < nchunks; ++c) {
+        // iteration c: multiply chunk c from buffer c & 1; the stage holding chunk c+1 has landed -> write it to the other buffer
+        // between the two k-steps, then re-issue that stage for chunk c+3
+        auto iter = [&](Stage8 &st, int c) {
             const char *sb = smem + (c & 1) * BUF;
             Frags16 f0, f1;
-            load_chunk();
             read_step(f0, sb, 0);
             read_step(f1, sb, 1);
             mfma12(f0, acc);
-            store_chunk((c & 1) ^ 1);
+            asm_wait_keep8(st);
+            store_stage(st, (c & 1) ^ 1);
+            issue(st);
             mfma12(f1, acc);
-            __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-                __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
-            }
             __syncthreads();
+        };
+        // always in pairs (after the last chunk the spare iteration multiplies a buffer of zero-halo data: adds exact zeros)
+        for (int c = 0; c < nchunks; c += 2) {
+            iter(s1, c);
+            iter(s0, c + 1);
         }
-        {
-            const char *sb = smem + ((nchunks - 1) & 1) * BUF;
-            Frags16 f0, f1;
-            read_step(f0, sb, 0);
-            read_step(f1, sb, 1);
-            mfma12(f0, acc);
-            mfma12(f1, acc);
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the trailing zero-halo loads before the wave ends
     }
     float *out = a.slab + (size_t)zs * a.Mp * a.Np;
     const int col = lane & 31;
