@@ -941,11 +941,12 @@ struct WgradSArgs {
 typedef short s4v __attribute__((ext_vector_type(4)));
 // rows r..r+3 (lo) and r+4..r+7 (hi) of the image, r a multiple of 8 plus the lane's row: the upper four rows are stored rotated
 // by 32 bytes inside the 256-byte row payload (see the staging map of wgrad16s_kernel)
+template <int PITCH>                      // row pitch in bytes; the row payload is PITCH - 64 bytes
 __device__ __forceinline__ bf16x8 tr_frag(const char *img, int rowoff, int col)
 {
     typedef __attribute__((address_space(3))) s4v *lds_s4p;
     const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(img + rowoff + col));
-    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(img + rowoff + 4 * WG16_ROWT + ((col + 32) & 255)));
+    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(img + rowoff + 4 * PITCH + ((col + 32) & (PITCH - 65))));
     bf16x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
@@ -960,16 +961,24 @@ __device__ __forceinline__ const WgSSeg &find_sseg(const WgSSeg *s, int n, int b
     return s[i];
 }
 
-__global__ __launch_bounds__(256) void wgrad16s_kernel(const WgradSArgs a)
+// MT = 1 (default): 128 x 128 tile, 4 waves, two workgroups per CU.  MT = 2 (-DWG_OPT_WGRAD_TALL): 256 x 128 tile, 8 waves, one
+// workgroup per CU; streams 48 KB instead of 64 KB per chunk for the same MFMAs and is still slower (155 vs 137 us).
+template <int MT>
+__global__ __launch_bounds__(256 * MT) void wgrad16s_kernel(const WgradSArgs a)
 {
-    constexpr int IMG = 32 * WG16_ROWT;     // 10240
-    constexpr int BUF = 4 * IMG;
+    constexpr int NT = 256 * MT;                // threads
+    constexpr int AROW = 256 * MT + 64;         // A image row pitch (bytes): 128 MT channels + pad (pitch = 16 dwords mod 64: four
+                                                // consecutive rows of a transposing read fall on disjoint banks)
+    constexpr int AIMG = 32 * AROW, BIMG = 32 * WG16_ROWT;
+    constexpr int BUF = 2 * AIMG + 2 * BIMG;
+    constexpr int NB = 2 / MT;                  // B units per thread and image
+    typedef typename StageOf<NB>::type Stage;   // 4 A + 2 NB B loads per chunk
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     int bx, by, zs;
     xcd_remap(bx, by, zs);
-    const int n0 = bx * WG_TILE, m0 = by * WG_TILE;
+    const int n0 = bx * WG_TILE, m0 = by * (WG_TILE * MT);
     const Geo g = a.g;
 
     f32x16 acc[2][2];
@@ -986,19 +995,25 @@ __global__ __launch_bounds__(256) void wgrad16s_kernel(const WgradSArgs a)
     // a time step; rows t and t+4 of one channel group would share banks (320-byte pitch), so rows with (t >> 2) odd are rotated by
     // two units (32 bytes) inside their 256-byte payload, and the transposing fragment read applies the same rotation to its
     // upper four rows (tr_frag).
-    const unsigned short *pa[2], *pb[2];
-    size_t la[2], lb_[2], sba[2], sbb[2];
-    int loff[2], roff[2], pitem[2];
+    const unsigned short *pa[2], *pb[NB];
+    size_t la[2], lb_[NB], sba[2], sbb[NB];
+    int loffa[2], loffb[NB], roff[NB], pitem[NB];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int u = tid + 256 * j;
-        const int tl = (u & 7) + 8 * (u >> 7), cg = (u >> 3) & 15;
-        loff[j] = tl * WG16_ROWT + ((cg + 2 * ((tl >> 2) & 1)) & 15) * 16;
+    for (int j = 0; j < 2; ++j) {                            // A: 32 time steps x 16 MT channel groups = 2 NT units
+        const int u = tid + NT * j;
+        const int tl = (u & 7) + 8 * (u / (128 * MT)), cg = (u >> 3) & (16 * MT - 1);
+        loffa[j] = tl * AROW + ((cg + 2 * ((tl >> 2) & 1)) & (16 * MT - 1)) * 16;
         const int ma = m0 + 8 * cg;
         const WgSSeg &sa = find_sseg(a.sa, a.nseg_a, ma >> 5);
         const int ca = ma - sa.blk0 * 32;
         pa[j] = (ma < a.Mp && ca < sa.nch) ? sa.hi + (((size_t)((sa.ch0 + ca) >> 3)) * g.P + g.H + tl) * 8 : nullptr;
         la[j] = sa.lo_off; sba[j] = (size_t)(sa.Cp >> 3) * g.P * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {                           // B: 32 x 16 = 512 units
+        const int u = tid + NT * j;
+        const int tl = (u & 7) + 8 * (u >> 7), cg = (u >> 3) & 15;
+        loffb[j] = tl * WG16_ROWT + ((cg + 2 * ((tl >> 2) & 1)) & 15) * 16;
         const int nb = n0 + 8 * cg;
         const WgSSeg &sb = find_sseg(a.sb, a.nseg_b, nb >> 5);
         const int cb = nb - sb.blk0 * 32;
@@ -1012,41 +1027,48 @@ __global__ __launch_bounds__(256) void wgrad16s_kernel(const WgradSArgs a)
 
     // fragment addressing: lane supplies row q = (l&15)>>2 of its 4x16 block, columns 4*(l&3)..; block = rows 8h (+4), cols 16*((l>>4)&1)
     const int fq = (lane & 15) >> 2, fp = lane & 3, fh = lane >> 5, fg = (lane >> 4) & 1;
-    const int frow = (8 * fh + fq) * WG16_ROWT;
+    const int frowa = (8 * fh + fq) * AROW, frowb = (8 * fh + fq) * WG16_ROWT;
     const int fca = (wr * 64 + 16 * fg + 4 * fp) * 2, fcb = (wc * 64 + 16 * fg + 4 * fp) * 2;
     auto read_step = [&](Frags16 &f, const char *sb, int s) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            f.ah[i] = tr_frag(sb, frow + s * 16 * WG16_ROWT, fca + i * 64);
-            f.al[i] = tr_frag(sb + IMG, frow + s * 16 * WG16_ROWT, fca + i * 64);
-            f.bh[i] = tr_frag(sb + 2 * IMG, frow + s * 16 * WG16_ROWT, fcb + i * 64);
-            f.bl[i] = tr_frag(sb + 3 * IMG, frow + s * 16 * WG16_ROWT, fcb + i * 64);
+            f.ah[i] = tr_frag<AROW>(sb, frowa + s * 16 * AROW, fca + i * 64);
+            f.al[i] = tr_frag<AROW>(sb + AIMG, frowa + s * 16 * AROW, fca + i * 64);
+            f.bh[i] = tr_frag<WG16_ROWT>(sb + 2 * AIMG, frowb + s * 16 * WG16_ROWT, fcb + i * 64);
+            f.bl[i] = tr_frag<WG16_ROWT>(sb + 2 * AIMG + BIMG, frowb + s * 16 * WG16_ROWT, fcb + i * 64);
         }
     };
-    auto store_stage = [&](const Stage8 &st, int buf) {
+    auto store_stage = [&](const Stage &st, int buf) {
         char *sb = smem + buf * BUF;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            *reinterpret_cast<u32x4 *>(sb + loff[j]) = st.ah[j];
-            *reinterpret_cast<u32x4 *>(sb + IMG + loff[j]) = st.al[j];
-            *reinterpret_cast<u32x4 *>(sb + 2 * IMG + loff[j]) = st.bh[j];
-            *reinterpret_cast<u32x4 *>(sb + 3 * IMG + loff[j]) = st.bl[j];
+            *reinterpret_cast<u32x4 *>(sb + loffa[j]) = st.ah[j];
+            *reinterpret_cast<u32x4 *>(sb + AIMG + loffa[j]) = st.al[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            *reinterpret_cast<u32x4 *>(sb + 2 * AIMG + loffb[j]) = st.bh[j];
+            *reinterpret_cast<u32x4 *>(sb + 2 * AIMG + BIMG + loffb[j]) = st.bl[j];
         }
     };
     // Two chunks in flight per wave: the loads are issued from inline asm (hipcc's own bookkeeping drains every outstanding load at
     // the loop back edge, which caps a compiler-managed prefetch at half a chunk) and retired by counted waits, as in convgemm16w:
     // the stream alone took 127 of this launch's 147 us at one chunk in flight (64 KB per CU).  Every issue is exactly eight loads
     // in straight-line code: lanes without a source row and chunks past the end read the zero halo (selected pointers, no branch
-    // between a load and its wait; tools/check_asm_loads.py covers this kernel too).
+    // between a load and its wait; tools/check_asm_loads.py covers this kernel too).  (4 + 2 NB loads per issue.)
     const unsigned short *zsrc = a.sa[0].hi;                 // plane position 0 of the first operand: always-zero halo
     int lb = c_begin / a.cpb, lt = (c_begin - lb * a.cpb) * WG16_BK, issued = 0;
 #define WG_LDP(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
-    auto issue = [&](Stage8 &st) {
+    auto issue = [&](Stage &st) {
         const bool live = issued < nchunks;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const unsigned short *qa = (live && pa[j]) ? pa[j] + lb * sba[j] + (size_t)lt * 8 : zsrc;
             const unsigned short *qal = (live && pa[j]) ? qa + la[j] : zsrc;
+            WG_LDP(st.ah[j], qa);  WG_LDP(st.al[j], qal);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
             // B operand row: the chunk's own plane row, another row of the same item (2-D taps, zero outside it) or the item's row
             int bsrc = lb;
             bool rowok = true;
@@ -1058,7 +1080,6 @@ __global__ __launch_bounds__(256) void wgrad16s_kernel(const WgradSArgs a)
             const bool bok = live && pb[j] && rowok;
             const unsigned short *qb = bok ? pb[j] + bsrc * sbb[j] + (size_t)lt * 8 : zsrc;
             const unsigned short *qbl = bok ? qb + lb_[j] : zsrc;
-            WG_LDP(st.ah[j], qa);  WG_LDP(st.al[j], qal);
             WG_LDP(st.bh[j], qb);  WG_LDP(st.bl[j], qbl);
         }
         if (live) {
@@ -1069,22 +1090,22 @@ __global__ __launch_bounds__(256) void wgrad16s_kernel(const WgradSArgs a)
     };
 #undef WG_LDP
     if (nchunks > 0) {
-        Stage8 s0, s1;
+        Stage s0, s1;
         issue(s0);                                           // chunk 0
         issue(s1);                                           // chunk 1
-        asm_wait_keep8(s0);
+        asm_wait_stage(s0);
         store_stage(s0, 0);
         issue(s0);                                           // chunk 2
         __syncthreads();
         // iteration c: multiply chunk c from buffer c & 1; the stage holding chunk c+1 has landed -> write it to the other buffer
         // between the two k-steps, then re-issue that stage for chunk c+3
-        auto iter = [&](Stage8 &st, int c) {
+        auto iter = [&](Stage &st, int c) {
             const char *sb = smem + (c & 1) * BUF;
             Frags16 f0, f1;
             read_step(f0, sb, 0);
             read_step(f1, sb, 1);
             mfma12(f0, acc);
-            asm_wait_keep8(st);
+            asm_wait_stage(st);
             store_stage(st, (c & 1) ^ 1);
             issue(st);
             mfma12(f1, acc);

@@ -669,7 +669,15 @@ WgradOut run_wgrad(Ctx &cx, const Geo &g, const WSegSpec *sa, int nsa, const WSe
         memset(&q, 0, sizeof(q));
         q.nseg_a = nsa; q.nseg_b = nsb; q.g = g;
         q.cpb = g.Tt / WG16_BK; q.total_chunks = g.B * q.cpb;
-        q.nsplit = plan_wgrad_flat(g, (a.Mp / WG_TILE) * (a.Np / WG_TILE));
+        // 256-row tiles (8 waves, one workgroup per CU): 25 % less operand stream for the same MFMAs, but MEASURED SLOWER (155 us
+        // against 137 us per launch at the headline shape, parity identical): one 8-wave workgroup in barrier lockstep hides less
+        // latency than two independent 4-wave ones.  Opt-in A/B build only.
+        const bool tall = a.Mp % 256 == 0
+#if !defined(WG_OPT_WGRAD_TALL)
+                          && false
+#endif
+            ;
+        q.nsplit = plan_wgrad_flat(g, (a.Mp / WG_TILE) * (a.Np / WG_TILE));   // tall: half the tiles for half the slots -- the same split
         o.nsplit = q.nsplit;
         if ((size_t)q.nsplit * a.Mp * a.Np > slab_cap) { if (!cx.err) cx.err = WG_EWORKSPACE; return o; }
         grid.z = q.nsplit;
@@ -683,7 +691,12 @@ WgradOut run_wgrad(Ctx &cx, const Geo &g, const WSegSpec *sa, int nsa, const WSe
             q.sb[s].Cp = sb[s].sCp; q.sb[s].ch0 = sb[s].sch0; q.sb[s].nch = sb[s].nch; q.sb[s].shift = sb[s].shift; q.sb[s].blk0 = a.sb[s].blk0;
             q.sb[s].row_off = sb[s].row_off; q.sb[s].per_item = sb[s].per_item;
         }
-        WG_LAUNCH(cx, wgrad16s_kernel, grid, block, 0, q);
+        if (tall) {
+            grid.y = a.Mp / 256;
+            WG_LAUNCH(cx, wgrad16s_kernel<2>, grid, dim3(512), 0, q);
+        } else {
+            WG_LAUNCH(cx, wgrad16s_kernel<1>, grid, block, 0, q);
+        }
     } else if (cx.prec) WG_LAUNCH(cx, wgrad16_kernel, grid, block, 0, a);
     else WG_LAUNCH(cx, wgrad_kernel, grid, block, 0, a);
     if (o.nsplit >= 8 && a.Mp <= 256) {          // few rows = few finalize blocks: fold the slabs with the whole GPU first

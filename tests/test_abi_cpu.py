@@ -125,7 +125,7 @@ def test_hand_issued_loads_are_never_touched_before_their_wait():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_loads.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if "asm loads" in l]
-    assert len(lines) == 9 and all(l.rstrip().endswith(" 0 violations") for l in lines), r.stdout   # conv: 4 epilogues x 2 tile widths; wgrad16s
+    assert len(lines) == 10 and all(l.rstrip().endswith(" 0 violations") for l in lines), r.stdout   # conv: 4 epilogues x 2 tile widths; wgrad16s: 2 tile heights
 
 
 def test_wsrglow_state_dict_layout_matches_reference(golden_dir):
