@@ -442,14 +442,26 @@ __global__ __launch_bounds__(256) void convgemm16p_kernel(const ConvGemm16sArgs 
 // waits).  The two roles meet at one barrier per chunk.  The per-CU vector-memory -> VGPR -> LDS path and the matrix pipe are
 // both busy for about the same time per chunk; in the symmetric kernels every wave alternates between the two and the
 // phases overlap poorly, here the overlap is structural.
-// Where the time of this kernel goes (gate conv, 27 chunks, 1536 tiles; rocprofv3 PMC: clock 2.06 GHz, matrix pipe 47 % busy):
-//   compute waves alone (loaders only take the barriers)            101 us = 2560 cycles per chunk and CU
-//     = 1536 cycles of MFMA (2 workgroups x 24 MFMA x 32 cycles per SIMD) + 1024 cycles of LDS reads (128 KB at 128 B/clk):
-//     the two do not overlap -- and LDS writes (64 KB, 512 cycles) + reads already fill the LDS pipe for as long as the MFMAs run,
-//     so at this tile shape (64x64 per wave, separate hi and lo images) the LDS port is co-critical with the matrix pipe;
-//   loader waves alone                                                82 us
-//   both                                                             129 us; loads served from L1/L2 only: no change; compute
-//   waves skipping their LDS reads: no change; s_setprio on the compute waves: no change.
+// Where the time of this kernel goes (gate conv, 27 chunks, 1536 tiles; rocprofv3 PMC: clock 2.06 GHz, matrix pipe 45-53 % busy).
+// Timing builds -DWG_DBG_NOLOAD / NOMFMA / NOEPI / GATE_NOSTORE; LDS and MFMA issue rates from tools/experiments/lds_probe.hip and
+// mfma_probe.hip; phase stamps per workgroup from -DWG_DBG_TRACE + tools/experiments/conv_trace.py:
+//   main loops only (no epilogue)                                     85 us   (loaders alone 70 us, compute waves alone 75 us,
+//                                                                              MFMA time 58 us)
+//   + the epilogue                                                   125-133 us
+//   * the loaders' 70 us is the L2 -> CU path itself: 1.36 GB of operands per launch at the 66-76 GB/s per CU that path delivers;
+//     with the matrix pipe active a CU sustains ~46 GB/s;
+//   * ds_read_b128 costs 4 cycles (256 B/clk), ds_write_b128 8; the LDS pipe is ~35 % busy -- an earlier note here called the LDS
+//     port co-critical with the matrix pipe; the counters do not support that.  What the counters did show: 20 % of the LDS
+//     cycles were bank conflicts of the four-lanes-per-row staging write of the weight images (fixed: wg16_a_off);
+//   * chained MFMAs issue at the full rate (32 cycles each, any number of accumulators in rotation);
+//   * the compute waves lost ~4 LDS round trips per chunk to the compiler's schedule of the plain loop at 128 VGPRs (fixed: the
+//     register pipeline in the kernel body); removing every main-loop barrier saves 4 %;
+//   * the epilogue of the gate conv is VALU bound (its arithmetic ~35 us, its stores ~10 us per launch): __frcp_rn was the IEEE
+//     division sequence, every store carried 64-bit pointer arithmetic (both fixed); while a workgroup is in its epilogue its
+//     operand stream pauses (both LDS buffers full), and the stream is what bounds the main loop;
+//   * the 256 workgroups dispatched first win issue arbitration against their CU mates: 26-29 us per tile against 55 us, the late
+//     half finishes alone at 24 us per tile.  s_setprio on the late half equalises the tiles (38 us) but is neutral to slower
+//     in a training step; a start-up stagger, a 4:2 tile split between the halves and dynamic variants are all neutral or slower.
 // Register note: the store and residual+skip instantiations take their auxiliary values (accumulate-into input, residual input,
 // skip accumulator) as the INITIAL value of the accumulators (conv_acc_init): no epilogue loads, 128 VGPRs, two workgroups per CU
 // (store/dgrad conv 143 -> 135 us, residual+skip 95 -> 93.5 us; -DWG_OPT_NO_ACCINIT restores the epilogue loads).  The gate
@@ -469,13 +481,13 @@ __global__ __launch_bounds__(256) void convgemm16p_kernel(const ConvGemm16sArgs 
 // alone 101 us).  With a single workgroup on the CU nothing runs under a tile's epilogue (tanh/sigmoid + 64-192 KB of stores) or
 // its first loads; two co-resident workgroups hide exactly that, and two workgroups cap a wave at 128 registers, i.e. at the
 // 64x64 wave tile used here.
-// A persistent form (2 workgroups per CU walking tiles w, w+512, ...; the loaders treat all their tiles as one chunk stream, so
-// the next tile's first chunks land during the epilogue) was measured too: no gain for the gate conv (the second workgroup of the
-// CU already covers a tile's prologue and epilogue) and the tile loop around the epilogue costs registers (177-239 VGPRs for
-// three of the four epilogues -> one workgroup per CU): 99.9 ms per step against 89.9.  Not kept.
-// The barrier of chunk c moved between its two k-steps (fragments of chunk c+1 fetched under the MFMAs of k-step 1) needs
-// 132 VGPRs, i.e. one workgroup per CU: 148 us.  That variant and the ablation switches behind the numbers above are in this
-// file's history (round 1).
+// The persistent form (workgroups walking tiles w, w + G, ...; the loaders treat all their tiles as one chunk stream) first lost
+// (the tile loop around the epilogue cost registers: 177-239 VGPRs -> one workgroup per CU) and is now the default for the store,
+// gate and residual+skip instantiations: with the accumulator preload on 32-bit offsets, opaque per-tile lane copies against
+// hoisting and the epilogue kept out of the loop-carried state they stay at 126 VGPRs (store/dgrad -9 %, residual+skip -10 %).
+// The barrier of chunk c between its two k-steps (fragments of chunk c+1 fetched under the MFMAs of k-step 1) first needed 132
+// VGPRs (one workgroup per CU: 148 us); with A0 reloaded in place and only A1 / B double-buffered it fits 125 and is what the
+// kernel body does now.
 // ------------------------------------------------------------------------------------------------
 struct Stage8 {
     u32x4 ah[2], al[2], bh[2], bl[2];
