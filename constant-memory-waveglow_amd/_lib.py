@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WGFLOW_LIB") or os.path.join(_HERE, "csrc", "libwgflow.so")   # WGFLOW_LIB: developer A/B builds
 _LIB = None
 
+ABI_VERSION = 2          # include/wgflow.h WG_ABI_VERSION (2: wg_config.keep_activations)
 ABI_SYMBOLS = [
     "wg_strerror", "wg_abi_version", "wg_param_count", "wg_packed_bytes", "wg_workspace_bytes",
     "wg_wn_param_count", "wg_wn_packed_bytes", "wg_coupling_workspace_bytes", "wg_invconv_workspace_bytes",
@@ -69,6 +70,9 @@ def lib():
     L.wg_strerror.restype = C.c_char_p
     L.wg_strerror.argtypes = [i]
     L.wg_abi_version.restype = i
+    if L.wg_abi_version() != ABI_VERSION:
+        raise WgError("%s implements ABI revision %d, this package binds revision %d (include/wgflow.h WG_ABI_VERSION): rebuild it"
+                      % (LIB_PATH, L.wg_abi_version(), ABI_VERSION))
     L.wg_param_count.argtypes = [cfgp]
     L.wg_packed_bytes.restype = sz
     L.wg_packed_bytes.argtypes = [cfgp]

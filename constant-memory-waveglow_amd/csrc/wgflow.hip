@@ -1043,7 +1043,7 @@ const char *wg_strerror(int code)
     }
     return "unknown error";
 }
-int wg_abi_version(void) { return 1; }
+int wg_abi_version(void) { return WG_ABI_VERSION; }
 
 #if defined(WG_DBG_TRACE)
 int wg_dbg_trace_read(unsigned long long *out, int n)

@@ -73,6 +73,9 @@ typedef struct wg_wn_dims {
 } wg_wn_dims;
 
 const char *wg_strerror(int code);
+/* ABI revision of this header (2: wg_config gained keep_activations).  A binding built against another revision must not pass its
+ * structs: the Python loader compares this with its own ABI_VERSION and refuses the library otherwise. */
+#define WG_ABI_VERSION 2
 int wg_abi_version(void);
 
 /* Diagnostics (no counterpart upstream; the reference times with wall-clock time(), inference.py:39-53): while a

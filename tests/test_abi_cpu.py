@@ -28,7 +28,14 @@ def test_library_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(L, s), "libwgflow.so lacks %s" % s
     assert sorted(_lib.ABI_SYMBOLS) == declared
-    assert L.wg_abi_version() == 1
+    assert L.wg_abi_version() == _lib.ABI_VERSION == 2
+    header = open(os.path.join(ROOT, "include", "wgflow.h")).read()
+    assert "#define WG_ABI_VERSION %d" % _lib.ABI_VERSION in header
+    # the ctypes mirror of wg_config has exactly the fields the header declares, in order
+    body = re.search(r"typedef struct wg_config \{(.*?)\} wg_config;", header, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = [n.strip() for decl in re.findall(r"int32_t([^;]*);", body) for n in decl.split(",")]
+    assert names == [n for n, _ in _lib.WgConfig._fields_]
     assert L.wg_strerror(0) == b"ok"
 
 
