@@ -32,10 +32,11 @@ def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "wgflow.h")).read()
     assert "#define WG_ABI_VERSION %d" % _lib.ABI_VERSION in header
     # the ctypes mirror of wg_config has exactly the fields the header declares, in order
-    body = re.search(r"typedef struct wg_config \{(.*?)\} wg_config;", header, re.S).group(1)
-    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-    names = [n.strip() for decl in re.findall(r"int32_t([^;]*);", body) for n in decl.split(",")]
-    assert names == [n for n, _ in _lib.WgConfig._fields_]
+    for cname, mirror in (("wg_config", _lib.WgConfig), ("wg_wn_dims", _lib.WgWnDims), ("wg_wf_config", _lib.WgWfConfig)):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), header, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = [n.strip() for decl in re.findall(r"int32_t([^;]*);", body) for n in decl.split(",")]
+        assert names == [n for n, _ in mirror._fields_], cname
     assert L.wg_strerror(0) == b"ok"
 
 
