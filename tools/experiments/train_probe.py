@@ -2,8 +2,12 @@
 headline network at the reference's learning rate must drive the loss down (0.018 -> -0.92 on an MI355X).  At lr 1e-3 the flow
 diverges within three steps -- and so does the upstream reference on CPU with torch.optim.Adam (0.018, -0.119, 5.2e5, ...), so that is
 the model, not the engine."""
-import sys, torch
-sys.path.insert(0, "/root/repo")
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from constant_memory_waveglow_amd.parallel import FlowTrainer, FlatAdam
 dev = torch.device("cuda:0")
