@@ -958,7 +958,11 @@ __device__ __forceinline__ bf16x8 tr_frag(const char *img, int rowoff, int col)
 {
     typedef __attribute__((address_space(3))) s4v *lds_s4p;
     const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(img + rowoff + col));
+#if defined(WG_OPT_WGRAD_OLDMAP)
+    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(img + rowoff + 4 * PITCH + col));
+#else
     const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4p)(img + rowoff + 4 * PITCH + ((col + 32) & (PITCH - 65))));
+#endif
     bf16x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
@@ -1004,17 +1008,26 @@ __global__ __launch_bounds__(256 * MT) void wgrad16s_kernel(const WgradSArgs a)
     // staging: unit u = tid + 256*j -> t = (u & 7) + 8 * (u >> 7), channel group cg = (u >> 3) & 15: eight consecutive lanes
     // fetch the eight time steps of one channel group = one whole 128-byte line (the earlier 2 x 2 quad mapping fetched 32-byte
     // pieces, four address-processing passes per line: the operand stream alone took 127 of the launch's 147 us).  In LDS a row is
-    // a time step; rows t and t+4 of one channel group would share banks (320-byte pitch), so rows with (t >> 2) odd are rotated by
-    // two units (32 bytes) inside their 256-byte payload, and the transposing fragment read applies the same rotation to its
-    // upper four rows (tr_frag).
+    // a time step; the eight rows one write pass touches fall on only two bank groups of the 32-bank write port (320-byte pitch =
+    // 16 dwords mod 32), a 4-way conflict; rows with (t >> 2) odd are therefore rotated by two units (32 bytes) inside their
+    // 256-byte payload -- the transposing fragment read applies the same rotation to its upper four rows (tr_frag) -- which leaves
+    // a 2-way write conflict (PMC: a third of this kernel's LDS cycles; profiles/r01m_pmc.json).  It cannot be rotated away: the
+    // fragment read needs the four rows of a group on disjoint 16-dword spans of the 64-bank read port, i.e. one rotation per
+    // group, and rows t and t+2 of a group are 32 dwords apart.  The conflict-free 2 x 2 quad map (-DWG_OPT_WGRAD_OLDMAP) is
+    // still 2 % slower end to end: the LDS pipe is half idle here, the global side is what counts.
     const unsigned short *pa[2], *pb[NB];
     size_t la[2], lb_[NB], sba[2], sbb[NB];
     int loffa[2], loffb[NB], roff[NB], pitem[NB];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {                            // A: 32 time steps x 16 MT channel groups = 2 NT units
         const int u = tid + NT * j;
+#if defined(WG_OPT_WGRAD_OLDMAP)    // experiment: the 2 x 2 quad map (32-byte global pieces, no LDS write conflicts, no rotation)
+        const int tl = 2 * (u >> 5) + (u & 1), cg = (u >> 1) & 15;
+        loffa[j] = tl * AROW + cg * 16;
+#else
         const int tl = (u & 7) + 8 * (u / (128 * MT)), cg = (u >> 3) & (16 * MT - 1);
         loffa[j] = tl * AROW + ((cg + 2 * ((tl >> 2) & 1)) & (16 * MT - 1)) * 16;
+#endif
         const int ma = m0 + 8 * cg;
         const WgSSeg &sa = find_sseg(a.sa, a.nseg_a, ma >> 5);
         const int ca = ma - sa.blk0 * 32;
@@ -1024,8 +1037,13 @@ __global__ __launch_bounds__(256 * MT) void wgrad16s_kernel(const WgradSArgs a)
 #pragma unroll
     for (int j = 0; j < NB; ++j) {                           // B: 32 x 16 = 512 units
         const int u = tid + NT * j;
+#if defined(WG_OPT_WGRAD_OLDMAP)
+        const int tl = 2 * (u >> 5) + (u & 1), cg = (u >> 1) & 15;
+        loffb[j] = tl * WG16_ROWT + cg * 16;
+#else
         const int tl = (u & 7) + 8 * (u >> 7), cg = (u >> 3) & 15;
         loffb[j] = tl * WG16_ROWT + ((cg + 2 * ((tl >> 2) & 1)) & 15) * 16;
+#endif
         const int nb = n0 + 8 * cg;
         const WgSSeg &sb = find_sseg(a.sb, a.nseg_b, nb >> 5);
         const int cb = nb - sb.blk0 * 32;
