@@ -109,8 +109,8 @@ int wn_check(const WnD &d)
 struct WnPack {
     size_t scale_V, scale_start, scale_W[16], scale_Wo[16];
     size_t startT, startN, endT, endN;
-    size_t Acat[16], WoT[16], WoN[16], WT[16], VN[16];
-    int ld_startT, ld_startN, ld_endN, ld_Acat, ld_WoT[16], ld_WoN, ld_WT, ld_VN;
+    size_t Acat[16], WoT[16], WoN[16], WT[16], VN[16], WskT;
+    int ld_startT, ld_startN, ld_endN, ld_Acat, ld_WoT[16], ld_WoN, ld_WT, ld_VN, ld_WskT;
     int kp_start, kp_end, kcat;
     size_t total;
 };
@@ -151,6 +151,9 @@ WnPack wn_pack_layout(const WnD &d)
         L.WT[i] = take_mat(d.radix * 2 * d.Cd, L.ld_WT);
         L.VN[i] = take_mat(2 * d.Cd, L.ld_VN);
     }
+    // the skip rows of every layer's W_o, stacked along K: skip = sum_i Wskip_i gate_i as ONE product over all the gates
+    L.ld_WskT = rup(d.Cs, WG_TILE);
+    L.WskT = take_mat(d.depth * d.Cd, L.ld_WskT);
     L.total = off;
     return L;
 }
@@ -220,6 +223,11 @@ void wn_pack_mats(JobBatch &jb, const WnD &d, const WnPack &L, const float *cons
         jb.pack(acat + (size_t)d.radix * d.C * L.ld_Acat, L.ld_Acat, d.auxp(), L.ld_Acat, 0, 2 * d.Cd, d.aux, d.Cd,
                 vV + (size_t)i * 2 * d.Cd * d.aux, pk + L.scale_V + (size_t)i * 2 * d.Cd, d.aux, 1, 0);
         jb.pack(pk + L.WoT[i], L.ld_WoT[i], d.Cd, L.ld_WoT[i], 0, rows, d.Cd, 0, vWo, pk + L.scale_Wo[i], d.Cd, 1, 0);
+        {   // rows i*Cd .. of WskT: A[i*Cd + j][m] = Wo_i[skip row m][j]  (the skip rows follow the C residual rows, except on the last layer)
+            const int r0 = rows - d.Cs;
+            jb.pack(pk + L.WskT + (size_t)i * d.Cd * L.ld_WskT, L.ld_WskT, d.Cd, L.ld_WskT, 0, d.Cs, d.Cd, 0, vWo + (size_t)r0 * d.Cd,
+                    pk + L.scale_Wo[i] + r0, d.Cd, 1, 0);
+        }
         jb.pack(pk + L.WoN[i], L.ld_WoN, rows, L.ld_WoN, 1, rows, d.Cd, 0, vWo, pk + L.scale_Wo[i], d.Cd, 1, 0);
         for (int kt = 0; kt < d.radix; ++kt)   // A[kt*2Cd + o][c] = W[o][c][kt]
             jb.pack(pk + L.WT[i] + (size_t)kt * 2 * d.Cd * L.ld_WT, L.ld_WT, 2 * d.Cd, L.ld_WT, 1, 2 * d.Cd, d.C, 0, vW,
@@ -276,6 +284,11 @@ void wn_pack_images(ImgBatch &ib, const WnD &d, const WnPack &L, float *pk)
         for (int kt = 0; kt < d.radix; ++kt) sg[ns++] = 2 * d.Cd;
         ib.add(pk + L.WT[i], L.ld_WT, sg, ns);
         one[0] = 2 * d.Cd; ib.add(pk + L.VN[i], L.ld_VN, one, 1);
+    }
+    if (d.depth <= WG_MAX_SEG) {                             // WskT: one K segment of Cd rows per layer (deeper WNs keep the per-layer skip)
+        int sgs[WG_MAX_SEG];
+        for (int i = 0; i < d.depth; ++i) sgs[i] = d.Cd;
+        ib.add(pk + L.WskT, L.ld_WskT, sgs, d.depth);
     }
 }
 
@@ -372,6 +385,20 @@ size_t slab_floats(const Geo &g, int Mp, int Np)
     return (size_t)std::max(p.nsplit, plan_wgrad_flat(g, tiles)) * Mp * Np;
 }
 
+// skip = sum_i Wskip_i gate_i as one product at the end of the WN (all gates kept) instead of a read-modify-write of the skip plane
+// per layer: the residual convs are bound by their HBM bytes, this takes a third of them away
+#if !defined(WG_FUSED_SKIP_MIN_COLS)
+#define WG_FUSED_SKIP_MIN_COLS 4096
+#endif
+inline bool fused_skip(const WnD &d)
+{
+#if defined(WG_OPT_NO_FUSED_SKIP)
+    (void)d; return false;
+#else
+    return d.depth <= WG_MAX_SEG;
+#endif
+}
+
 struct WnWs {               // plane bases (float offsets) of one WN's activations
     size_t H[16], tw[16], sf[16], gate[16], skip, G, dS, dH, dxy, slab;
     size_t HS[16], gateS[16], XaS, GS, dSS, dHS, dxyS;   // S-planes (precision 2), sized like the fp32 plane of the same tensor
@@ -388,7 +415,7 @@ void wn_ws_layout(Bump &bp, const WnD &d, int ic_max, const Geo &g, int mode, in
     if (prec == 2) {
         const int nHS = mode ? d.depth : 2;
         for (int i = 0; i < nHS; ++i) w.HS[i] = bp.take(pC);
-        for (int i = 0; i < d.depth; ++i) w.gateS[i] = (mode || i == 0) ? bp.take(pD) : w.gateS[0];
+        for (int i = 0; i < d.depth; ++i) w.gateS[i] = (mode || i == 0 || fused_skip(d)) ? bp.take(pD) : w.gateS[0];
         w.XaS = bp.take((size_t)g.B * rup(ic_max, WG_BK) * g.P);
         if (mode) {
             w.GS = bp.take((size_t)g.B * rup(2 * ic_max, WG_BK) * g.P);
@@ -400,7 +427,7 @@ void wn_ws_layout(Bump &bp, const WnD &d, int ic_max, const Geo &g, int mode, in
     w.nH = mode ? d.depth : 2;
     for (int i = 0; i < w.nH; ++i) w.H[i] = bp.take(pC);
     for (int i = 0; i < d.depth; ++i) {
-        w.gate[i] = (mode || i == 0) ? bp.take(pD) : w.gate[0];
+        w.gate[i] = (mode || i == 0 || (fused_skip(d) && prec != 2)) ? bp.take(pD) : w.gate[0];
         w.tw[i] = mode ? bp.take(pD) : 0;
         w.sf[i] = mode ? bp.take(pD) : 0;
     }
@@ -760,11 +787,15 @@ void wn_forward(Ctx &cx, const WnRun &r)
     SegSpec s0 = {r.X.p, r.X.Cp, r.X.ch0, r.L.kp_start, 0, ws + r.w.XaS, r.L.kp_start, 0};
     run_convgemm(cx, g, r.pk + r.L.startT, r.L.ld_startT, d.C, &s0, 1, EPI_STORE, pref(ws + r.w.H[0], d.C), pnull(), pnull(),
                  pnull(), pnull(), 0, 0, sp ? sref(g, ws + r.w.HS[0], d.C) : snull());             // waveglow.py:99
+    // one long product (depth x Cd / 32 chunks in a row) only pays where launches are bound by bytes, not by their chunk latency chain:
+    // single-utterance synthesis (2 048 columns) lost 9 % with it, the training shapes gain 2.5 % per step
+    const int cols = (cx.row_sel1 && g.rows > 0 ? g.B / g.rows : g.B) * g.Tt;
+    const bool fs = fused_skip(d) && cols >= WG_FUSED_SKIP_MIN_COLS;
     for (int i = 0; i < d.depth; ++i) {
         const int hin = r.save ? i : (i & 1), hout = r.save ? std::min(i + 1, d.depth - 1) : ((i + 1) & 1);
         float *Hin = ws + r.w.H[hin], *Hout = ws + r.w.H[hout];
-        float *gate = ws + r.w.gate[r.save ? i : 0];
-        const float *gateS = ws + r.w.gateS[r.save ? i : 0];
+        float *gate = ws + r.w.gate[(r.save || fs) ? i : 0];
+        const float *gateS = ws + r.w.gateS[(r.save || fs) ? i : 0];
         SegSpec sg[WG_MAX_SEG];
         int ns = 0;
         for (int kt = 0; kt < d.radix; ++kt) {
@@ -779,9 +810,22 @@ void wn_forward(Ctx &cx, const WnRun &r)
                      pnull(), pnull(), 0, 0, sp ? sref(g, gateS, d.Cd) : snull());                 // waveglow.py:42-44
         SegSpec so = {gate, d.Cd, 0, d.Cd, 0, gateS, d.Cd, 0};
         const int last = i == d.depth - 1;
+        if (fs) {
+            // residual rows only: h_{i+1} = h_i + Wres_i gate_i (the first C rows of W_o); the skip rows of all layers follow in one product
+            if (!last)
+                run_convgemm(cx, g, r.pk + r.L.WoT[i], r.L.ld_WoT[i], d.C, &so, 1, EPI_STORE, pref(Hout, d.C), pnull(), pnull(),
+                             pref(Hin, d.C), pnull(), 0, 0, sp ? sref(g, ws + r.w.HS[hout], d.C) : snull());   // :45-46
+            continue;
+        }
         run_convgemm(cx, g, r.pk + r.L.WoT[i], r.L.ld_WoT[i], d.wo_rows(i), &so, 1, EPI_RESSKIP, pref(Hout, d.C),
                      pref(ws + r.w.skip, d.Cs), pnull(), pref(Hin, d.C), pnull(), last ? 0 : d.C, i > 0,
                      (sp && !last) ? sref(g, ws + r.w.HS[hout], d.C) : snull());                   // :45-46,104
+    }
+    if (fs) {                                                 // cum_skip = sum_i skip_i (waveglow.py:104) = [Wskip_0 .. Wskip_{d-1}] [gate_0; ..; gate_{d-1}]
+        SegSpec sk[WG_MAX_SEG];
+        for (int i = 0; i < d.depth; ++i) sk[i] = {ws + r.w.gate[i], d.Cd, 0, d.Cd, 0, ws + r.w.gateS[i], d.Cd, 0};
+        run_convgemm(cx, g, r.pk + r.L.WskT, r.L.ld_WskT, d.Cs, sk, d.depth, EPI_STORE, pref(ws + r.w.skip, d.Cs), pnull(), pnull(),
+                     pnull(), pnull(), 0, 0);
     }
 }
 
