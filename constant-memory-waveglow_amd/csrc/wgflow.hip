@@ -109,7 +109,7 @@ int wn_check(const WnD &d)
 struct WnPack {
     size_t scale_V, scale_start, scale_W[16], scale_Wo[16];
     size_t startT, startN, endT, endN;
-    size_t Acat[16], WoT[16], WoN[16], WT[16], VN[16], WskT;
+    size_t Acat[16], WoT[16], WoN[16], WT[16], VN[16], WskT, VNall;
     int ld_startT, ld_startN, ld_endN, ld_Acat, ld_WoT[16], ld_WoN, ld_WT, ld_VN, ld_WskT;
     int kp_start, kp_end, kcat;
     size_t total;
@@ -154,6 +154,8 @@ WnPack wn_pack_layout(const WnD &d)
     // the skip rows of every layer's W_o, stacked along K: skip = sum_i Wskip_i gate_i as ONE product over all the gates
     L.ld_WskT = rup(d.Cs, WG_TILE);
     L.WskT = take_mat(d.depth * d.Cd, L.ld_WskT);
+    // V^T of every layer stacked along K: dy = sum_i V_i^T dxy_i as ONE product over all the layers' dxy (fused_dy)
+    L.VNall = take_mat(d.depth * 2 * d.Cd, L.ld_VN);
     L.total = off;
     return L;
 }
@@ -234,6 +236,8 @@ void wn_pack_mats(JobBatch &jb, const WnD &d, const WnPack &L, const float *cons
                     pk + L.scale_W[i], d.C * d.radix, d.radix, kt);
         jb.pack(pk + L.VN[i], L.ld_VN, 2 * d.Cd, L.ld_VN, 1, 2 * d.Cd, d.aux, 0, vV + (size_t)i * 2 * d.Cd * d.aux,
                 pk + L.scale_V + (size_t)i * 2 * d.Cd, d.aux, 1, 0);
+        jb.pack(pk + L.VNall + (size_t)i * 2 * d.Cd * L.ld_VN, L.ld_VN, 2 * d.Cd, L.ld_VN, 1, 2 * d.Cd, d.aux, 0,
+                vV + (size_t)i * 2 * d.Cd * d.aux, pk + L.scale_V + (size_t)i * 2 * d.Cd, d.aux, 1, 0);
     }
 }
 
@@ -289,6 +293,8 @@ void wn_pack_images(ImgBatch &ib, const WnD &d, const WnPack &L, float *pk)
         int sgs[WG_MAX_SEG];
         for (int i = 0; i < d.depth; ++i) sgs[i] = d.Cd;
         ib.add(pk + L.WskT, L.ld_WskT, sgs, d.depth);
+        for (int i = 0; i < d.depth; ++i) sgs[i] = 2 * d.Cd;
+        ib.add(pk + L.VNall, L.ld_VN, sgs, d.depth);
     }
 }
 
@@ -399,9 +405,21 @@ inline bool fused_skip(const WnD &d)
 #endif
 }
 
+// dy = sum_i V_i^T dxy_i as one product after the layer loop (every layer's dxy kept: +(depth - 1) x 2 Cd planes of workspace) instead of
+// an HBM-bound launch and a read-modify-write of dy per layer; 1-D WN only (WaveFlow sums dxy over the height axis first)
+inline bool fused_dy(const WnD &d)
+{
+#if defined(WG_OPT_NO_FUSED_DY)
+    (void)d; return false;
+#else
+    return d.depth <= WG_MAX_SEG && !d.mode2d;
+#endif
+}
+
 struct WnWs {               // plane bases (float offsets) of one WN's activations
     size_t H[16], tw[16], sf[16], gate[16], skip, G, dS, dH, dxy, slab;
     size_t HS[16], gateS[16], XaS, GS, dSS, dHS, dxyS;   // S-planes (precision 2), sized like the fp32 plane of the same tensor
+    size_t dxy_step = 0, dxyS_step = 0;                  // fused_dy: layer i's dxy at dxy + i * step (0: one buffer for all layers)
     int nH;                 // 2 (ping-pong) or depth
     size_t slab_floats;
 };
@@ -421,7 +439,9 @@ void wn_ws_layout(Bump &bp, const WnD &d, int ic_max, const Geo &g, int mode, in
             w.GS = bp.take((size_t)g.B * rup(2 * ic_max, WG_BK) * g.P);
             w.dSS = bp.take(pS);
             w.dHS = bp.take(pC);
+            w.dxyS_step = fused_dy(d) ? rupz(2 * pD, 64) : 0;
             w.dxyS = bp.take(2 * pD);
+            for (int i = 1; i < d.depth && w.dxyS_step; ++i) (void)bp.take(2 * pD);
         }
     }
     w.nH = mode ? d.depth : 2;
@@ -437,7 +457,9 @@ void wn_ws_layout(Bump &bp, const WnD &d, int ic_max, const Geo &g, int mode, in
         w.G = bp.take((size_t)g.B * rup(2 * ic_max, WG_BK) * g.P);
         w.dS = bp.take(pS);
         w.dH = bp.take(pC);
+        w.dxy_step = (fused_dy(d) && prec != 2) ? rupz(2 * pD, 64) : 0;
         w.dxy = bp.take(2 * pD);
+        for (int i = 1; i < d.depth && w.dxy_step; ++i) (void)bp.take(2 * pD);
         size_t s = 0;
         const int nW = rup(d.radix * rup(d.C, 32) + rup(d.aux, 32), WG_TILE);
         s = std::max(s, slab_floats(g, rup(2 * d.Cd, WG_TILE), nW));
@@ -855,7 +877,8 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
     const int nd = d.depth;
     float *slab = ws + r.w.slab;
     const size_t cap = r.w.slab_floats;
-    float *G = ws + r.w.G, *dS = ws + r.w.dS, *dH = ws + r.w.dH, *dxy = ws + r.w.dxy, *skip = ws + r.w.skip;
+    float *G = ws + r.w.G, *dS = ws + r.w.dS, *dH = ws + r.w.dH, *skip = ws + r.w.skip;
+    const bool fdy = dY && fused_dy(d);                       // every layer keeps its dxy; dy is one product after the loop
     const int Gc = r.L.kp_end;
     const bool sp = cx.prec == 2;
     // end: dW_end = sum G (x) S ; dS = W_end^T G
@@ -872,6 +895,8 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
     for (int i = nd - 1; i >= 0; --i) {
         const int rows = d.wo_rows(i), last = i == nd - 1;
         float *Hi = ws + r.w.H[i], *gate = ws + r.w.gate[i];
+        float *dxy = ws + r.w.dxy + (size_t)i * r.w.dxy_step;                    // (step 0: one buffer for all layers)
+        float *dxyS = ws + r.w.dxyS + (size_t)i * r.w.dxyS_step;
         // dW_o = sum do (x) gate,  do = last ? dS : cat(dh_{i+1}, dS)
         {
             WSegSpec sa[2];
@@ -889,11 +914,11 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
             if (!last) s[ns++] = {dH, d.C, 0, d.C, 0, ws + r.w.dHS, d.C, 0};
             s[ns++] = {dS, d.Cs, 0, d.Cs, 0, ws + r.w.dSS, d.Cs, 0};
             run_convgemm(cx, g, r.pk + r.L.WoN[i], r.L.ld_WoN, d.Cd, s, ns, EPI_DGATE, sp ? pnull() : pref(dxy, 2 * d.Cd), pnull(), pnull(),
-                         pref(ws + r.w.tw[i], d.Cd), pref(ws + r.w.sf[i], d.Cd), d.Cd, 0, sp ? sref(g, ws + r.w.dxyS, 2 * d.Cd) : snull());
+                         pref(ws + r.w.tw[i], d.Cd), pref(ws + r.w.sf[i], d.Cd), d.Cd, 0, sp ? sref(g, dxyS, 2 * d.Cd) : snull());
         }
         // dW (taps) and dV (conditioning) in one wgrad
         {
-            WSegSpec sa = {dxy, 2 * d.Cd, 0, 2 * d.Cd, 0, sp ? ws + r.w.dxyS : nullptr, 2 * d.Cd, 0};
+            WSegSpec sa = {dxy, 2 * d.Cd, 0, 2 * d.Cd, 0, sp ? dxyS : nullptr, 2 * d.Cd, 0};
             WSegSpec sb[WG_MAX_SEG];
             int nsb = 0;
             for (int kt = 0; kt < d.radix; ++kt) {
@@ -913,13 +938,13 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
         if (dY && d.mode2d) {
             // the conditioning is broadcast over the height axis: sum dxy over the rows of an item first (64x fewer columns for
             // the product, no per-row gradient plane), then dy[item] += V_i^T rowsum
-            WG_LAUNCH(cx, wf_rowsum_s_kernel, dim3((g.T + 255) / 256, 2 * d.Cd / 8, r.gi.B), dim3(256), 0, sref(g, ws + r.w.dxyS, 2 * d.Cd), g,
+            WG_LAUNCH(cx, wf_rowsum_s_kernel, dim3((g.T + 255) / 256, 2 * d.Cd / 8, r.gi.B), dim3(256), 0, sref(g, dxyS, 2 * d.Cd), g,
                       sref(r.gi, r.rs, 2 * d.Cd), r.gi);
             SegSpec s = {nullptr, 2 * d.Cd, 0, 2 * d.Cd, 0, r.rs, 2 * d.Cd, 0};
             run_convgemm(cx, r.gi, r.pk + r.L.VN[i], r.L.ld_VN, d.aux, &s, 1, EPI_STORE, pref(dY, d.auxp()), pnull(), pnull(),
                          pref(dY, d.auxp()), pnull(), 0, 0);
-        } else if (dY) {
-            SegSpec s = {dxy, 2 * d.Cd, 0, 2 * d.Cd, 0, ws + r.w.dxyS, 2 * d.Cd, 0};
+        } else if (dY && !fdy) {
+            SegSpec s = {dxy, 2 * d.Cd, 0, 2 * d.Cd, 0, dxyS, 2 * d.Cd, 0};
             run_convgemm(cx, g, r.pk + r.L.VN[i], r.L.ld_VN, d.aux, &s, 1, EPI_STORE, pref(dY, d.auxp()), pnull(), pnull(),
                          pref(dY, d.auxp()), pnull(), 0, 0);
         }
@@ -930,11 +955,18 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
             for (int kt = 0; kt < d.radix; ++kt) {
                 int ts, ro;
                 d.tap(i, kt, ts, ro);
-                s[ns++] = {dxy, 2 * d.Cd, 0, 2 * d.Cd, -ts, ws + r.w.dxyS, 2 * d.Cd, 0, -ro, 0};
+                s[ns++] = {dxy, 2 * d.Cd, 0, 2 * d.Cd, -ts, dxyS, 2 * d.Cd, 0, -ro, 0};
             }
             run_convgemm(cx, g, r.pk + r.L.WT[i], r.L.ld_WT, d.C, s, ns, EPI_STORE, pref(dH, d.C), pnull(), pnull(),
                          last ? pnull() : pref(dH, d.C), pnull(), 0, 0, sp ? sref(g, ws + r.w.dHS, d.C) : snull());
         }
+    }
+    if (fdy) {                                                // dy += [V_0^T .. V_{d-1}^T] [dxy_0; ..; dxy_{d-1}]
+        SegSpec sv[WG_MAX_SEG];
+        for (int i = 0; i < nd; ++i)
+            sv[i] = {ws + r.w.dxy + (size_t)i * r.w.dxy_step, 2 * d.Cd, 0, 2 * d.Cd, 0, ws + r.w.dxyS + (size_t)i * r.w.dxyS_step, 2 * d.Cd, 0};
+        run_convgemm(cx, g, r.pk + r.L.VNall, r.L.ld_VN, d.aux, sv, nd, EPI_STORE, pref(dY, d.auxp()), pnull(), pnull(),
+                     pref(dY, d.auxp()), pnull(), 0, 0);
     }
     // start: dW_start = sum dh_0 (x) xa ; dxa += W_start^T dh_0
     {
