@@ -81,6 +81,32 @@ struct WnD {
     int maxdil() const { return 1 << (depth - 1); }
 };
 
+// skip = sum_i Wskip_i gate_i as one product at the end of the WN (all gates kept) instead of a read-modify-write of the skip plane
+// per layer: the residual convs are bound by their HBM bytes, this takes a third of them away
+#if !defined(WG_FUSED_SKIP_MIN_COLS)
+#define WG_FUSED_SKIP_MIN_COLS 4096
+#endif
+inline bool fused_skip(const WnD &d)
+{
+#if defined(WG_OPT_NO_FUSED_SKIP)
+    (void)d; return false;
+#else
+    return d.depth <= WG_MAX_SEG;
+#endif
+}
+
+// dy = sum_i V_i^T dxy_i as one product after the layer loop (every layer's dxy kept: +(depth - 1) x 2 Cd planes of workspace) instead of
+// an HBM-bound launch and a read-modify-write of dy per layer; 1-D WN only (WaveFlow sums dxy over the height axis first)
+inline bool fused_dy(const WnD &d)
+{
+#if defined(WG_OPT_NO_FUSED_DY)
+    (void)d; return false;
+#else
+    return d.depth <= WG_MAX_SEG && !d.mode2d;
+#endif
+}
+
+
 Geo make_geo(int B, int T, int halo_need)
 {
     Geo g;
@@ -236,8 +262,9 @@ void wn_pack_mats(JobBatch &jb, const WnD &d, const WnPack &L, const float *cons
                     pk + L.scale_W[i], d.C * d.radix, d.radix, kt);
         jb.pack(pk + L.VN[i], L.ld_VN, 2 * d.Cd, L.ld_VN, 1, 2 * d.Cd, d.aux, 0, vV + (size_t)i * 2 * d.Cd * d.aux,
                 pk + L.scale_V + (size_t)i * 2 * d.Cd, d.aux, 1, 0);
-        jb.pack(pk + L.VNall + (size_t)i * 2 * d.Cd * L.ld_VN, L.ld_VN, 2 * d.Cd, L.ld_VN, 1, 2 * d.Cd, d.aux, 0,
-                vV + (size_t)i * 2 * d.Cd * d.aux, pk + L.scale_V + (size_t)i * 2 * d.Cd, d.aux, 1, 0);
+        if (fused_dy(d))
+            jb.pack(pk + L.VNall + (size_t)i * 2 * d.Cd * L.ld_VN, L.ld_VN, 2 * d.Cd, L.ld_VN, 1, 2 * d.Cd, d.aux, 0,
+                    vV + (size_t)i * 2 * d.Cd * d.aux, pk + L.scale_V + (size_t)i * 2 * d.Cd, d.aux, 1, 0);
     }
 }
 
@@ -294,7 +321,7 @@ void wn_pack_images(ImgBatch &ib, const WnD &d, const WnPack &L, float *pk)
         for (int i = 0; i < d.depth; ++i) sgs[i] = d.Cd;
         ib.add(pk + L.WskT, L.ld_WskT, sgs, d.depth);
         for (int i = 0; i < d.depth; ++i) sgs[i] = 2 * d.Cd;
-        ib.add(pk + L.VNall, L.ld_VN, sgs, d.depth);
+        if (fused_dy(d)) ib.add(pk + L.VNall, L.ld_VN, sgs, d.depth);
     }
 }
 
@@ -389,31 +416,6 @@ size_t slab_floats(const Geo &g, int Mp, int Np)
     const int tiles = (Mp / WG_TILE) * (Np / WG_TILE);
     const WgradPlan p = plan_wgrad(g, tiles);
     return (size_t)std::max(p.nsplit, plan_wgrad_flat(g, tiles)) * Mp * Np;
-}
-
-// skip = sum_i Wskip_i gate_i as one product at the end of the WN (all gates kept) instead of a read-modify-write of the skip plane
-// per layer: the residual convs are bound by their HBM bytes, this takes a third of them away
-#if !defined(WG_FUSED_SKIP_MIN_COLS)
-#define WG_FUSED_SKIP_MIN_COLS 4096
-#endif
-inline bool fused_skip(const WnD &d)
-{
-#if defined(WG_OPT_NO_FUSED_SKIP)
-    (void)d; return false;
-#else
-    return d.depth <= WG_MAX_SEG;
-#endif
-}
-
-// dy = sum_i V_i^T dxy_i as one product after the layer loop (every layer's dxy kept: +(depth - 1) x 2 Cd planes of workspace) instead of
-// an HBM-bound launch and a read-modify-write of dy per layer; 1-D WN only (WaveFlow sums dxy over the height axis first)
-inline bool fused_dy(const WnD &d)
-{
-#if defined(WG_OPT_NO_FUSED_DY)
-    (void)d; return false;
-#else
-    return d.depth <= WG_MAX_SEG && !d.mode2d;
-#endif
 }
 
 struct WnWs {               // plane bases (float offsets) of one WN's activations
