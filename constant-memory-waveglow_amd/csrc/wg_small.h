@@ -529,11 +529,9 @@ struct FinJob {
     float extra_mul;
 };
 #define WG_FIN_MAXCOLS 8192
-__global__ __launch_bounds__(256) void finalize_kernel(const FinJob j)
+__device__ __forceinline__ void finalize_row(const FinJob &j, int o, float *dw, float (*red)[256])
 {
-    __shared__ float dw[WG_FIN_MAXCOLS];
-    __shared__ float red[2][256];
-    const int o = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int cols = j.I * j.R;
     float esc = 0.f;
     if (j.extra) {
@@ -579,6 +577,29 @@ __global__ __launch_bounds__(256) void finalize_kernel(const FinJob j)
     if (tid == 0 && j.dg) j.dg[o] = dot / nrm;
     const float aa = j.g[o] / nrm, bq = dot / ss;
     for (int e = tid; e < cols; e += 256) j.dv[(size_t)o * cols + e] = aa * (dw[e] - j.v[(size_t)o * cols + e] * bq);
+}
+__global__ __launch_bounds__(256) void finalize_kernel(const FinJob j)
+{
+    __shared__ float dw[WG_FIN_MAXCOLS];
+    __shared__ float red[2][256];
+    finalize_row(j, blockIdx.x, dw, red);
+}
+// Several tensors in one launch (one block per weight row of every job): a WN layer's backward ends in three of these small
+// launches, each too short to fill the GPU; the weight gradients of a whole WN are finalised together instead (FinQueue).
+#define WG_FIN_JOBS 24
+struct FinBatch {
+    int n;
+    int start[WG_FIN_JOBS + 1];     // prefix sums of the jobs' row counts: the grid is exactly their total
+    FinJob job[WG_FIN_JOBS];
+};
+__global__ __launch_bounds__(256) void finalize_batch_kernel(const FinBatch b)
+{
+    __shared__ float dw[WG_FIN_MAXCOLS];
+    __shared__ float red[2][256];
+    int ji = 0;
+    for (int q = 1; q < b.n; ++q)
+        if ((int)blockIdx.x >= b.start[q]) ji = q;
+    finalize_row(b.job[ji], (int)blockIdx.x - b.start[ji], dw, red);
 }
 
 // InvConv1x1Func.backward tail (efficient_modules.py:276-277): dW = -W^-T dw W^-T - W^-T * dlogdet * T,

@@ -29,6 +29,7 @@ struct Ctx {
     int err;
     int prec;   // 0: exact fp32 MFMA; 1: bf16x3, operands split on the fly (wg_gemm16.h); 2: bf16x3 from pre-split S-planes (wg_gemm16s.h)
     int row_sel1;   // Geo::rows > 0 only: 0 = every plane row; r + 1 = the conv launches cover height row r of every item (WaveFlow's inverse)
+    struct FinQueue *fq = nullptr;   // set inside wn_backward: weight-gradient slabs come from its arena, finalisations are batched
 };
 #define WG_LAUNCH(ctx, kern, grid, block, shmem, ...)                         \
     do {                                                                      \
@@ -469,6 +470,8 @@ void wn_ws_layout(Bump &bp, const WnD &d, int ic_max, const Geo &g, int mode, in
         s = std::max(s, slab_floats(g, WG_TILE, rup(d.Cs, WG_TILE)));
         s = std::max(s, slab_floats(g, rup(d.C, WG_TILE), WG_TILE));
         s = std::max(s, slab_floats(g, WG_TILE, WG_TILE));
+        // room for several products' slabs (FinQueue batches the finalisations of a WN): up to 8 of the largest, at most 384 MB
+        s = std::max(s, std::min((size_t)8 * s, (size_t)96 << 20));
         w.slab_floats = s;
         w.slab = bp.take(s);
     }
@@ -683,7 +686,44 @@ struct WSegSpec {
 // returns the plan used (finalize needs nsplit / strides)
 struct WgradOut {
     int nsplit, Mp, Np;
+    float *slab = nullptr;      // where run_wgrad put the slabs (nullptr: the pointer the caller passes to run_finalize)
 };
+// Weight gradients of one WN backward, finalised together: every run_wgrad takes its split-K slab from the arena, every run_finalize
+// only queues its job; the queue is launched as ONE finalize_batch_kernel when the arena or the job table is full and when the WN
+// is done.  (Three 4-13 us finalize launches per layer, none of them filling the GPU, were 3 % of the step.)
+struct FinQueue {
+    Ctx &cx;
+    float *arena;
+    size_t cap, off = 0;
+    FinBatch b;
+    FinQueue(Ctx &c, float *a, size_t n) : cx(c), arena(a), cap(n) { b.n = 0; b.start[0] = 0; cx.fq = this; }
+    ~FinQueue() { flush(); cx.fq = nullptr; }
+    float *reserve(size_t n)
+    {
+        n = rupz(n, 64);
+        if (off + n > cap) {                                  // arena full: finalise what is queued, then start over -- in stream order the
+            flush();                                          // batch reads those slabs before any later product rewrites them
+            off = 0;
+        }
+        if (n > cap) { if (!cx.err) cx.err = WG_EWORKSPACE; return arena; }
+        float *p = arena + off;
+        off += n;
+        return p;
+    }
+    void add(const FinJob &j)
+    {
+        if (b.n == WG_FIN_JOBS) flush();                      // (the arena keeps growing: the job being added still owns its slab)
+        b.job[b.n] = j;
+        b.start[b.n + 1] = b.start[b.n] + j.rows;
+        ++b.n;
+    }
+    void flush()
+    {
+        if (b.n) WG_LAUNCH(cx, finalize_batch_kernel, dim3(b.start[b.n]), dim3(256), 0, b);
+        b.n = 0;
+    }
+};
+size_t slab_floats(const Geo &g, int Mp, int Np);
 WgradOut run_wgrad(Ctx &cx, const Geo &g, const WSegSpec *sa, int nsa, const WSegSpec *sb, int nsb, float *slab, size_t slab_cap)
 {
     WgradArgs a;
@@ -704,11 +744,15 @@ WgradOut run_wgrad(Ctx &cx, const Geo &g, const WSegSpec *sa, int nsa, const WSe
     }
     a.Np = rup(blk * 32, WG_TILE);
     a.g = g;
+    if (cx.fq) {                                             // batched finalisation: this product's slab comes from the queue's arena
+        slab_cap = slab_floats(g, a.Mp, a.Np);
+        slab = cx.fq->reserve(slab_cap);
+    }
     const WgradPlan p = plan_wgrad(g, (a.Mp / WG_TILE) * (a.Np / WG_TILE));
     a.t_per_split = p.t_per_split; a.nts = p.nts; a.b_per_split = p.b_per_split;
     a.slab = slab;
     WgradOut o;
-    o.nsplit = p.nsplit; o.Mp = a.Mp; o.Np = a.Np;
+    o.nsplit = p.nsplit; o.Mp = a.Mp; o.Np = a.Np; o.slab = slab;
     if ((size_t)p.nsplit * a.Mp * a.Np > slab_cap) { if (!cx.err) cx.err = WG_EWORKSPACE; return o; }
     dim3 grid(a.Np / WG_TILE, a.Mp / WG_TILE, p.nsplit), block(256);
     TimerScope ts(WG_K_WGRAD, cx.st);
@@ -764,10 +808,11 @@ void run_finalize(Ctx &cx, const float *slab, const WgradOut &wo, int row0, int 
 {
     if (!dv) return;
     FinJob j;
-    j.slab = slab; j.nsplit = wo.nsplit; j.sstride = (size_t)wo.Mp * wo.Np; j.ldn = wo.Np; j.row0 = row0;
+    j.slab = wo.slab ? wo.slab : slab; j.nsplit = wo.nsplit; j.sstride = (size_t)wo.Mp * wo.Np; j.ldn = wo.Np; j.row0 = row0;
     j.rows = rows; j.I = I; j.R = R; j.col0 = col0; j.ci = ci; j.cr = cr;
     j.g = gp; j.v = vp; j.dg = dg; j.dv = dv;
     j.extra = extra; j.extra_scale_src = esrc; j.n_extra = n_extra; j.extra_mul = emul;
+    if (cx.fq) { cx.fq->add(j); return; }
     WG_LAUNCH(cx, finalize_kernel, dim3(rows), dim3(256), 0, j);
 }
 
@@ -883,6 +928,9 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
     const bool fdy = dY && fused_dy(d);                       // every layer keeps its dxy; dy is one product after the loop
     const int Gc = r.L.kp_end;
     const bool sp = cx.prec == 2;
+#if !defined(WG_OPT_NO_FIN_BATCH)
+    FinQueue fq(cx, slab, cap);                               // flushed when it goes out of scope: before the caller's next launch
+#endif
     // end: dW_end = sum G (x) S ; dS = W_end^T G
     {
         // skip (fp32 only: it feeds the fp32 end conv) has no S-plane -> this small product runs on the on-the-fly kernel
