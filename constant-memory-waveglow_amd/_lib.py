@@ -10,15 +10,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WGFLOW_LIB") or os.path.join(_HERE, "csrc", "libwgflow.so")   # WGFLOW_LIB: developer A/B builds
 _LIB = None
 
-ABI_VERSION = 2          # include/wgflow.h WG_ABI_VERSION (2: wg_config.keep_activations)
+ABI_VERSION = 3          # include/wgflow.h WG_ABI_VERSION (3: logged training scalars out of wg_nll_loss / wg_train_step)
 ABI_SYMBOLS = [
     "wg_strerror", "wg_abi_version", "wg_param_count", "wg_packed_bytes", "wg_workspace_bytes",
     "wg_wn_param_count", "wg_wn_packed_bytes", "wg_coupling_workspace_bytes", "wg_invconv_workspace_bytes",
     "wg_workspace_init", "wg_pack_weights", "wg_wn_pack_weights", "wg_forward", "wg_inverse", "wg_backward",
     "wg_nll_loss", "wg_nll_loss_backward", "wg_invconv_apply", "wg_invconv_backward", "wg_coupling_apply",
     "wg_coupling_backward", "wg_upsample", "wg_wn_apply", "wg_wsr_cond", "wg_wsr_cond_backward", "wg_adam_step",
-    "wg_wf_param_count", "wg_wf_packed_bytes", "wg_wf_workspace_bytes", "wg_wf_tape_bytes", "wg_wf_pack_weights", "wg_wf_forward",
+    "wg_wf_param_count", "wg_wf_packed_bytes", "wg_wf_workspace_bytes", "wg_wf_tape_bytes", "wg_wf_pack_weights", "wg_wf_upsample", "wg_wf_forward",
     "wg_wf_inverse", "wg_wf_backward", "wg_melspec_frames", "wg_melspec", "wg_lowpass_workspace_bytes", "wg_lowpass", "wg_train_step",
+    "wg_nll_scratch_floats", "wg_train_scratch_floats",
     "wg_timer_create", "wg_timer_attach", "wg_timer_count", "wg_timer_read", "wg_timer_destroy",
 ]
 K_CONV_STORE, K_CONV_GATE, K_CONV_RESSKIP, K_CONV_DGATE, K_WGRAD = range(5)
@@ -91,7 +92,11 @@ def lib():
     L.wg_forward.argtypes = [cfgp, vp, vp, vp, i, i, i, vp, vp, vp, sz, vp]
     L.wg_inverse.argtypes = [cfgp, vp, vp, vp, i, i, i, vp, vp, vp, sz, vp]
     L.wg_backward.argtypes = [cfgp, vp, vp, vp, vp, vp, vp, i, i, i, vp, vp, vp, vp, vp, sz, vp, vp]
-    L.wg_nll_loss.argtypes = [vp, vp, i, i, f, i, vp, vp]
+    L.wg_nll_scratch_floats.restype = sz
+    L.wg_nll_scratch_floats.argtypes = [i]
+    L.wg_train_scratch_floats.restype = sz
+    L.wg_train_scratch_floats.argtypes = [i, i]
+    L.wg_nll_loss.argtypes = [vp, vp, i, i, f, i, vp, vp, vp, vp]
     L.wg_nll_loss_backward.argtypes = [vp, i, i, f, i, vp, vp, vp, vp]
     L.wg_invconv_apply.argtypes = [vp, i, vp, i, i, i, vp, vp, vp, sz, vp]
     L.wg_invconv_backward.argtypes = [vp, i, vp, vp, vp, i, i, i, vp, vp, vp, vp, sz, vp]
@@ -111,15 +116,16 @@ def lib():
     L.wg_wf_tape_bytes.restype = sz
     L.wg_wf_tape_bytes.argtypes = [wfp, i, i]
     L.wg_wf_pack_weights.argtypes = [wfp, vp, vp, vp]
+    L.wg_wf_upsample.argtypes = [wfp, vp, vp, vp, i, i, i, vp, vp]
     L.wg_wf_forward.argtypes = [wfp, vp, vp, vp, vp, i, i, i, vp, vp, vp, vp, sz, vp]
     L.wg_wf_inverse.argtypes = [wfp, vp, vp, vp, vp, i, i, i, vp, vp, vp, sz, vp]
     L.wg_wf_backward.argtypes = [wfp, vp, vp, vp, vp, vp, vp, i, i, i, vp, vp, vp, vp, sz, vp]
     L.wg_melspec_frames.argtypes = [i, i, i]
-    L.wg_melspec.argtypes = [vp, i, i, i, i, i, C.c_double, C.c_double, i, vp, vp]
+    L.wg_melspec.argtypes = [vp, i, i, i, i, i, C.c_double, C.c_double, i, vp, vp, vp]
     L.wg_lowpass_workspace_bytes.restype = sz
     L.wg_lowpass_workspace_bytes.argtypes = [i, i, i, i]
     L.wg_lowpass.argtypes = [vp, i, i, i, i, i, i, vp, vp, sz, vp]
-    L.wg_train_step.argtypes = [cfgp, vp, vp, vp, vp, i, i, i, f, i, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp]
+    L.wg_train_step.argtypes = [cfgp, vp, vp, vp, vp, i, i, i, f, i, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp]
     L.wg_timer_create.restype = vp
     L.wg_timer_create.argtypes = [i, i]
     L.wg_timer_attach.argtypes = [vp]

@@ -14,6 +14,7 @@
 struct MelArgs {
     const float *audio;     // [B][N]
     float *mel;             // [B][n_mels][frames]
+    float *power;           // optional [B][n_fft/2+1][frames]: |STFT|^2 before the mel filterbank (what torch.stft(...).abs()**2 gives)
     int N, n_fft, hop, n_mels, frames, pad_left, sr_half;
     float m_min, m_max;     // HTK mel of f_min / f_max
 };
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(256) void melspec_kernel(const MelArgs a)
             idx = (idx + k) & (nf - 1);
         }
         pw[k] = re * re + im * im;
+        if (a.power) a.power[((size_t)b * nb + k) * a.frames + f] = pw[k];
     }
     __syncthreads();
     if (tid < a.n_mels) {

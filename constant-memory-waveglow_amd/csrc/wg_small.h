@@ -356,15 +356,16 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float *__restri
             dh[((size_t)b * C + c) * F + i] = s;
         }
     // weight-norm backward of row c (utils.py:14-16): serial over K (K ~ 65)
-    if (tid == 0 && dv) {
+    if (tid == 0 && (dv || dg)) {
         if (gparam) {
             float ss = 0.f, dot = 0.f;
             for (int kk = 0; kk < K; ++kk) { const float vv = v[c * K + kk]; ss += vv * vv; dot += dw[kk] * vv; }
             const float nrm = sqrtf(ss);
             if (dg) dg[c] = dot / nrm;
             const float aa = gparam[c] / nrm, bq = dot / ss;
-            for (int kk = 0; kk < K; ++kk) dv[c * K + kk] = aa * (dw[kk] - v[c * K + kk] * bq);
-        } else {
+            if (dv)
+                for (int kk = 0; kk < K; ++kk) dv[c * K + kk] = aa * (dw[kk] - v[c * K + kk] * bq);
+        } else if (dv) {
             for (int kk = 0; kk < K; ++kk) dv[c * K + kk] = dw[kk];
         }
     }
@@ -373,25 +374,64 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float *__restri
 // ------------------------------------------------------------------------------------------------
 // NLL loss (model/loss.py:10-15)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void nll_loss_kernel(const float *__restrict__ z, const float *__restrict__ logdet, int B, int N,
-                                                        float inv_sigma2, int elementwise_mean, float *__restrict__ loss)
+// Two launches: WG_NLL_BLK blocks per batch item reduce (sum z, sum z^2) of their slice into `part`, one block combines the
+// partials in double.  Besides the loss the second kernel produces the four scalars the reference logs every step
+// (model/lightning.py:58-64): logdet.sum() / z.numel(), z.mean(), z.std() (unbiased, torch's default) and the loss.
+#define WG_NLL_BLK 8
+__global__ __launch_bounds__(256) void nll_partial_kernel(const float *__restrict__ z, int N, float *__restrict__ part)
 {
-    __shared__ float red[1024];
+    __shared__ float red[2][4];
+    const int b = blockIdx.y, k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (N + WG_NLL_BLK - 1) / WG_NLL_BLK, n0 = k * per, n1 = min(N, n0 + per);
+    const float *zb = z + (size_t)b * N;
+    float s1 = 0.f, s2 = 0.f;
+    for (int n = n0 + tid; n < n1; n += 256) { const float v = zb[n]; s1 += v; s2 = fmaf(v, v, s2); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o, 64); s2 += __shfl_down(s2, o, 64); }
+    if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        float *o = part + ((size_t)b * WG_NLL_BLK + k) * 2;
+        o[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        o[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+// metrics (nullable) = [ sum_b logdet_b / (B N), mean(z), std(z), loss ]
+__global__ __launch_bounds__(256) void nll_finish_kernel(const float *__restrict__ part, const float *__restrict__ logdet, int B, int N,
+                                                         float inv_sigma2, int elementwise_mean, float *__restrict__ loss,
+                                                         float *__restrict__ metrics)
+{
+    __shared__ double red[4][256];
     const int tid = threadIdx.x;
-    float total = 0.f;
-    for (int b = 0; b < B; ++b) {
-        float s = 0.f;
-        for (int n = tid; n < N; n += 1024) { const float v = z[(size_t)b * N + n]; s += v * v; }
-        red[tid] = s;
-        __syncthreads();
-        for (int o = 512; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-        if (tid == 0) total += 0.5f * red[0] * inv_sigma2 - logdet[b];
+    double s1 = 0.0, s2 = 0.0, ld = 0.0, item = 0.0;
+    for (int b = tid; b < B; b += 256) {
+        double q1 = 0.0, q2 = 0.0;
+        for (int k = 0; k < WG_NLL_BLK; ++k) { q1 += part[((size_t)b * WG_NLL_BLK + k) * 2]; q2 += part[((size_t)b * WG_NLL_BLK + k) * 2 + 1]; }
+        s1 += q1; s2 += q2; ld += logdet[b];
+        item += 0.5 * q2 * (double)inv_sigma2 - (double)logdet[b];                 // loss.py:11
+    }
+    red[0][tid] = s1; red[1][tid] = s2; red[2][tid] = ld; red[3][tid] = item;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[q][tid] += red[q][tid + o];
+        }
         __syncthreads();
     }
     if (tid == 0) {
-        float l = total / (float)B;
-        if (elementwise_mean) l /= (float)N;
-        loss[0] = l;
+        const double n = (double)B * (double)N;
+        double l = red[3][0] / (double)B;                                          // :12
+        if (elementwise_mean) l /= (double)N;                                      // :13-14
+        loss[0] = (float)l;
+        if (metrics) {
+            const double mean = red[0][0] / n;
+            const double var = n > 1.0 ? fmax(red[1][0] - red[0][0] * mean, 0.0) / (n - 1.0) : __builtin_nan("");
+            metrics[0] = (float)(red[2][0] / n);
+            metrics[1] = (float)mean;
+            metrics[2] = (float)sqrt(var);
+            metrics[3] = (float)l;
+        }
     }
 }
 __global__ void nll_loss_bwd_kernel(const float *__restrict__ z, int B, int N, float inv_sigma2, int elementwise_mean,
@@ -563,7 +603,8 @@ __device__ __forceinline__ void finalize_row(const FinJob &j, int o, float *dw, 
         if (j.g) { const float vv = j.v[(size_t)o * cols + e]; dot += s * vv; ss += vv * vv; }
     }
     if (!j.g) {
-        for (int e = tid; e < cols; e += 256) j.dv[(size_t)o * cols + e] = dw[e];
+        if (j.dv)
+            for (int e = tid; e < cols; e += 256) j.dv[(size_t)o * cols + e] = dw[e];
         return;
     }
     red[0][tid] = dot; red[1][tid] = ss;
@@ -575,6 +616,7 @@ __device__ __forceinline__ void finalize_row(const FinJob &j, int o, float *dw, 
     dot = red[0][0]; ss = red[1][0];
     const float nrm = sqrtf(ss);
     if (tid == 0 && j.dg) j.dg[o] = dot / nrm;
+    if (!j.dv) return;                                   // weight_v frozen, weight_g trainable: only dg is wanted
     const float aa = j.g[o] / nrm, bq = dot / ss;
     for (int e = tid; e < cols; e += 256) j.dv[(size_t)o * cols + e] = aa * (dw[e] - j.v[(size_t)o * cols + e] * bq);
 }

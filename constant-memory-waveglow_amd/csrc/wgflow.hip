@@ -806,7 +806,7 @@ void run_finalize(Ctx &cx, const float *slab, const WgradOut &wo, int row0, int 
                   const float *gp, const float *vp, float *dg, float *dv,
                   const float *extra = nullptr, const float *esrc = nullptr, int n_extra = 0, float emul = 0.f)
 {
-    if (!dv) return;
+    if (!dv && !dg) return;
     FinJob j;
     j.slab = wo.slab ? wo.slab : slab; j.nsplit = wo.nsplit; j.sstride = (size_t)wo.Mp * wo.Np; j.ldn = wo.Np; j.row0 = row0;
     j.rows = rows; j.I = I; j.R = R; j.col0 = col0; j.ci = ci; j.cr = cr;
@@ -822,7 +822,8 @@ void run_mix(Ctx &cx, const Geo &g, PRef X, int c, const float *Mx, int transpos
     switch (c) {
 #define WG_MIX_CASE(CC) case CC: WG_LAUNCH(cx, mix_kernel<CC>, grid, block, 0, X, Mx, transpose, g); break;
         WG_MIX_CASE(2) WG_MIX_CASE(4) WG_MIX_CASE(6) WG_MIX_CASE(8) WG_MIX_CASE(10) WG_MIX_CASE(12)
-        WG_MIX_CASE(14) WG_MIX_CASE(16) WG_MIX_CASE(20) WG_MIX_CASE(24) WG_MIX_CASE(28) WG_MIX_CASE(32)
+        WG_MIX_CASE(14) WG_MIX_CASE(16) WG_MIX_CASE(18) WG_MIX_CASE(20) WG_MIX_CASE(22) WG_MIX_CASE(24) WG_MIX_CASE(26) WG_MIX_CASE(28)
+        WG_MIX_CASE(30) WG_MIX_CASE(32)
 #undef WG_MIX_CASE
     default: if (!cx.err) cx.err = WG_EUNSUPPORTED;
     }
@@ -1067,6 +1068,7 @@ int wf_check(const wg_wf_config *cf)
     const int H = cf->n_group;
     if (H != 8 && H != 16 && H != 32 && H != 64 && H != 128) return WG_EUNSUPPORTED;     // the keys of dilation_dict (waveflow.py:81-87)
     if (cf->precision != WG_PREC_BF16X3_PLANES) return WG_EUNSUPPORTED;                      // only the S-plane kernels know 2-D taps
+    if (cf->n_mels * (2 * (256 / H) + 1) > WG_FIN_MAXCOLS) return WG_EUNSUPPORTED;           // upsampler weight row [n_mels x (2s+1)] in finalize's LDS
     return wn_check(wf_wn(cf));
 }
 struct WfPack {
@@ -1395,6 +1397,14 @@ int wg_inverse(const wg_config *cf, const void *packed, const float *z, const fl
 }
 
 
+// A gradient bucket's event gates its all-reduce on the caller's communication stream: a failed record would leave that stream
+// waiting on a stale record and reducing half-written gradients, so it is an error of the call.
+static void record_event(Ctx &cx, void *const *flow_events, int k)
+{
+    if (!flow_events || !flow_events[k] || cx.err) return;
+    if (hipEventRecord((hipEvent_t)flow_events[k], cx.st) != hipSuccess) cx.err = WG_ELAUNCH;
+}
+
 // resume: called by wg_train_step right after the training forward ran in this workspace -- X, Y (and YS) are in place and the
 // flow the backward visits first still has all its layers, so neither the squeeze / upsample nor that flow's recompute is repeated.
 static int model_backward(const wg_config *cf, const void *const *params, const void *packed, const float *z, const float *h,
@@ -1459,7 +1469,7 @@ static int model_backward(const wg_config *cf, const void *const *params, const 
         for (int k = cf->n_flows - 1; k >= 0; --k) {
             coupling_bwd(k, base);
             invconv_bwd(k, base);
-            if (flow_events && flow_events[k] && !cx.err) (void)hipEventRecord((hipEvent_t)flow_events[k], cx.st);   // flow k's grads final
+            record_event(cx, flow_events, k);                                                        // flow k's grads final
             if (k % cf->n_early_every == 0 && k) base -= cf->n_early_size;
         }
     } else {                                              // reverse_mode architecture: per flow the 1x1 came last, flows ran n-1..0
@@ -1468,7 +1478,7 @@ static int model_backward(const wg_config *cf, const void *const *params, const 
             if (k % cf->n_early_every == 0 && k) base += cf->n_early_size;
             invconv_bwd(k, base);
             coupling_bwd(k, base);
-            if (flow_events && flow_events[k] && !cx.err) (void)hipEventRecord((hipEvent_t)flow_events[k], cx.st);
+            record_event(cx, flow_events, k);
         }
     }
     if (x_rebuilt) WG_LAUNCH(cx, unsqueeze_kernel, dim3((T + 255) / 256, B), dim3(256), 0, X, x_rebuilt, g, G, N);
@@ -1476,7 +1486,7 @@ static int model_backward(const wg_config *cf, const void *const *params, const 
     // upsampler backward (+ its weight norm)
     WG_LAUNCH(cx, upsample_bwd_kernel, dim3(cf->n_mels), dim3(256), (size_t)(cf->up_kernel + 256) * sizeof(float), h, pk + M.up_w,
               pref(ws + W.dY, W.auxp), g, cf->n_mels, F, cf->up_kernel, cf->up_stride, cf->up_pad, p[1], p[2], gr[0], gr[1], gr[2], dh);
-    if (flow_events && flow_events[cf->n_flows] && !cx.err) (void)hipEventRecord((hipEvent_t)flow_events[cf->n_flows], cx.st);
+    record_event(cx, flow_events, cf->n_flows);
     return cx.err;
 }
 
@@ -1491,8 +1501,17 @@ int wg_backward(const wg_config *cf, const void *const *params, const void *pack
 // loss.backward().  Same kernels as wg_forward + wg_nll_loss + wg_nll_loss_backward + wg_backward, but the forward runs in the
 // backward's workspace and keeps the last flow's layers, so the backward starts without recomputing that flow and without a second
 // squeeze / upsample.  scratch: B*N + B floats (d loss / d z, d loss / d logdet).
+static void run_nll(Ctx &cx, const float *z, const float *logdet, int B, int N, float inv_s2, int elementwise_mean, float *loss,
+                    float *metrics, float *part)
+{
+    WG_LAUNCH(cx, nll_partial_kernel, dim3(WG_NLL_BLK, B), dim3(256), 0, z, N, part);
+    WG_LAUNCH(cx, nll_finish_kernel, dim3(1), dim3(256), 0, (const float *)part, logdet, B, N, inv_s2, elementwise_mean, loss, metrics);
+}
+size_t wg_nll_scratch_floats(int B) { return B < 1 ? 0 : (size_t)2 * WG_NLL_BLK * B; }
+size_t wg_train_scratch_floats(int B, int N) { return (B < 1 || N < 1) ? 0 : (size_t)B * N + B + wg_nll_scratch_floats(B); }
+
 int wg_train_step(const wg_config *cf, const void *const *params, const void *packed, const float *audio, const float *h,
-                  int B, int N, int F, float sigma, int elementwise_mean, float *z, float *logdet, float *loss,
+                  int B, int N, int F, float sigma, int elementwise_mean, float *z, float *logdet, float *loss, float *metrics,
                   void *const *grads, float *dh, float *scratch, void *ws, size_t ws_bytes, void *stream, void *const *flow_events)
 {
     if (!z || !logdet || !loss || !scratch || !(sigma > 0.f)) return WG_EINVAL;
@@ -1500,8 +1519,8 @@ int wg_train_step(const wg_config *cf, const void *const *params, const void *pa
     if (rc) return rc;
     Ctx cx = {(hipStream_t)stream, 0, 0};
     const float inv_s2 = 1.0f / (sigma * sigma);
-    float *dz = scratch, *dld = scratch + (size_t)B * N;
-    WG_LAUNCH(cx, nll_loss_kernel, dim3(1), dim3(1024), 0, z, logdet, B, N, inv_s2, elementwise_mean, loss);
+    float *dz = scratch, *dld = scratch + (size_t)B * N, *part = dld + B;
+    run_nll(cx, z, logdet, B, N, inv_s2, elementwise_mean, loss, metrics, part);
     const size_t n = (size_t)B * N;
     WG_LAUNCH(cx, nll_loss_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, z, B, N, inv_s2, elementwise_mean,
               (const float *)nullptr, dz, dld);
@@ -1509,11 +1528,12 @@ int wg_train_step(const wg_config *cf, const void *const *params, const void *pa
     return model_backward(cf, params, packed, nullptr, h, dz, dld, B, N, F, grads, dh, nullptr, nullptr, ws, ws_bytes, stream, flow_events, 1);
 }
 
-int wg_nll_loss(const float *z, const float *logdet, int B, int N, float sigma, int elementwise_mean, float *loss, void *stream)
+int wg_nll_loss(const float *z, const float *logdet, int B, int N, float sigma, int elementwise_mean, float *loss, float *metrics,
+                float *scratch, void *stream)
 {
-    if (!z || !logdet || !loss || B < 1 || N < 1 || !(sigma > 0.f)) return WG_EINVAL;
+    if (!z || !logdet || !loss || !scratch || B < 1 || N < 1 || !(sigma > 0.f)) return WG_EINVAL;
     Ctx cx = {(hipStream_t)stream, 0, 0};
-    WG_LAUNCH(cx, nll_loss_kernel, dim3(1), dim3(1024), 0, z, logdet, B, N, 1.0f / (sigma * sigma), elementwise_mean, loss);
+    run_nll(cx, z, logdet, B, N, 1.0f / (sigma * sigma), elementwise_mean, loss, metrics, scratch);
     return cx.err;
 }
 int wg_nll_loss_backward(const float *z, int B, int N, float sigma, int elementwise_mean, const float *dloss, float *dz,
@@ -1603,6 +1623,26 @@ int wg_wf_pack_weights(const wg_wf_config *cf, const void *const *params, void *
     ImgBatch ib(&cx);
     for (int k = 0; k < cf->flows; ++k) wn_pack_images(ib, d, WL, pk + L.wn[k]);
     ib.flush();
+    return cx.err;
+}
+
+// WaveFlow._upsample_h (waveflow.py:255-257) alone: mel[B,n_mels,F] -> y[B,n_mels,T], T <= F s - 2 (s // 2) + 2 s + 1 (plain layout).
+int wg_wf_upsample(const wg_wf_config *cf, const void *const *params, const void *packed, const float *mel, int B, int F, int T,
+                   float *y, void *stream)
+{
+    int rc = wf_check(cf);
+    if (rc) return rc;
+    if (!params || !packed || !mel || !y || B < 1 || F < 1 || T < 1) return WG_EINVAL;
+    const int s = 256 / cf->n_group;
+    if (T > F * s - 2 * (s / 2) + 2 * s + 1) return WG_ESHAPE;
+    Ctx cx = {(hipStream_t)stream, 0, 0};
+    const float *const *p = (const float *const *)params;
+    const WfPack L = wf_pack_layout(cf);
+    WfUpArgs a;
+    a.mel = mel; a.v = p[2]; a.scale = (const float *)packed + L.up_scale; a.bias = p[0];
+    a.M = cf->n_mels; a.F = F; a.K = 2 * s + 1; a.s = s; a.pad = s / 2;
+    a.Y = pref(y, cf->n_mels); a.gi = Geo{B, T, T, 0, T, 0};          // a "plane" with no halo and pitch T = the plain [B][M][T] layout
+    WG_LAUNCH(cx, wf_upsample_fwd_kernel, dim3((T + 255) / 256, cf->n_mels, B), dim3(256), 0, a);
     return cx.err;
 }
 
@@ -1746,7 +1786,8 @@ int wg_wf_backward(const wg_wf_config *cf, const void *const *params, const void
 
 // ---- log-mel conditioner --------------------------------------------------------------------------
 int wg_melspec_frames(int N, int n_fft, int hop) { return (N < 1 || hop < 1) ? WG_EINVAL : N / hop + 1; }
-int wg_melspec(const float *audio, int B, int N, int sr, int n_fft, int hop, double f_min, double f_max, int n_mels, float *mel, void *stream)
+int wg_melspec(const float *audio, int B, int N, int sr, int n_fft, int hop, double f_min, double f_max, int n_mels, float *mel,
+               float *power, void *stream)
 {
     if (!audio || !mel || B < 1 || N < 2 || sr < 2 || hop < 1 || n_mels < 1) return WG_EINVAL;
     if (n_fft < 2 || n_fft > WG_MEL_MAXFFT || (n_fft & (n_fft - 1)) || n_mels > 256 || hop > n_fft) return WG_EUNSUPPORTED;
@@ -1755,7 +1796,7 @@ int wg_melspec(const float *audio, int B, int N, int sr, int n_fft, int hop, dou
     if (!(f_min >= 0.0) || !(f_max > f_min)) return WG_EINVAL;
     Ctx cx = {(hipStream_t)stream, 0, 0};
     MelArgs a;
-    a.audio = audio; a.mel = mel; a.N = N; a.n_fft = n_fft; a.hop = hop; a.n_mels = n_mels;
+    a.audio = audio; a.mel = mel; a.power = power; a.N = N; a.n_fft = n_fft; a.hop = hop; a.n_mels = n_mels;
     a.frames = N / hop + 1;                                               // (N + n_fft - n_fft) / hop + 1 with center=False
     a.pad_left = n_fft / 2 - hop / 2;
     a.sr_half = sr / 2;

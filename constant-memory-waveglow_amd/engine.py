@@ -19,11 +19,41 @@ def _use_graphs():
     return os.environ.get("WG_GRAPHS", "0") == "1"
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    """the stream the kernels are enqueued on: torch's current stream OF THE TENSORS' DEVICE (not of the current device)"""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def on_device(fn):
+    """Runs an engine entry point with the device of its first tensor argument current: the library sizes its launches with
+    hipGetDevice and torch's allocations / streams follow the current device, so a model on cuda:1 must not be driven from
+    cuda:0's context."""
+    import functools
+
+    def first_tensor(xs):
+        for a in xs:
+            if torch.is_tensor(a):
+                return a
+            if isinstance(a, (list, tuple)):
+                t = first_tensor(a)
+                if t is not None:
+                    return t
+        return None
+
+    @functools.wraps(fn)
+    def run(*args, **kwargs):
+        t = first_tensor(args) if args else None
+        if t is None:
+            t = first_tensor(list(kwargs.values()))
+        if t is None or not t.is_cuda:
+            return fn(*args, **kwargs)                  # require_device raises the proper error
+        with torch.cuda.device(t.device):
+            return fn(*args, **kwargs)
+    return run
 
 
 def require_device(*tensors):
+    dev = None
     for t in tensors:
         if t is None:
             continue
@@ -32,6 +62,10 @@ def require_device(*tensors):
                           "There is no CPU fallback." % t.device)
         if t.dtype != torch.float32:
             raise WgError("the HIP engine computes in float32 (got %s)" % t.dtype)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise WgError("tensors of one call sit on different devices (%s and %s)" % (dev, t.device))
 
 
 def _p(t):
@@ -140,6 +174,7 @@ class ModelEngine:
               "wg_inverse" if inverse else "wg_forward")
         return out, logdet
 
+    @on_device
     def run_keep(self, params, x, h):
         """wg_forward in stored-activation mode.  Returns (z, logdet, kept): `kept` = (generation, workspace) names the
         activations this call left behind; `backward(kept=...)` uses them if no later call overwrote them."""
@@ -152,6 +187,7 @@ class ModelEngine:
         z, logdet = self._launch(pk, ws, x, h, False, self.cfg_keep)
         return z, logdet, (self._kept_gen, ws)
 
+    @on_device
     def run(self, params, x, h, inverse):
         require_device(x, h, *params)
         x, h = x.contiguous(), h.contiguous()
@@ -183,6 +219,7 @@ class ModelEngine:
         graph.replay()
         return out.clone(), logdet.clone()
 
+    @on_device
     def backward(self, params, z, h, dz, dlogdet, need, need_dh, need_dx, want_x=False, grads_out=None, flow_events=None,
                  kept=None):
         """need[i]: produce the gradient of params[i] (into grads_out[i] when given).  Returns (grads, dh, dx, x_rebuilt).
@@ -211,10 +248,12 @@ class ModelEngine:
                                      self._events(flow_events)), "wg_backward")
         return grads, dh, dx, xr
 
+    @on_device
     def train_step(self, params, x, h, sigma, elementwise_mean, need, grads_out=None, need_dh=False, flow_events=None,
-                   keep=False):
+                   keep=False, metrics=None):
         """wg_train_step: forward + NLL + backward in one call (the forward keeps the last flow's layers for the backward;
         keep=True -- memory_efficient=False -- keeps every flow's, so no WN is recomputed).
+        metrics (optional, 4 device floats): receives the logged scalars [logdet/numel, z.mean, z.std, loss] (lightning.py:58-64).
         Returns (loss, z, logdet, grads, dh)."""
         require_device(x, h, *params)
         x, h = x.contiguous(), h.contiguous()
@@ -226,7 +265,7 @@ class ModelEngine:
             self._kept_gen += 1
         else:
             ws = self._ws(B, N, 1, x.device)
-        scratch = self.buffers.get((x.device, "step", B, N), 4 * (B * N + B), x.device)
+        scratch = self.buffers.get((x.device, "step", B, N), 4 * _lib.lib().wg_train_scratch_floats(B, N), x.device)
         if grads_out is not None:
             grads = [g if nd else None for g, nd in zip(grads_out, need)]
         else:
@@ -236,7 +275,7 @@ class ModelEngine:
         loss = torch.empty((), dtype=torch.float32, device=x.device)
         dh = torch.empty_like(h) if need_dh else None
         check(_lib.lib().wg_train_step(C.byref(cfg), _table(params), _p(pk), _p(x), _p(h), B, N, h.shape[2], float(sigma),
-                                       int(elementwise_mean), _p(z), _p(logdet), _p(loss), _table(grads), _p(dh), _p(scratch),
+                                       int(elementwise_mean), _p(z), _p(logdet), _p(loss), _p(metrics), _table(grads), _p(dh), _p(scratch),
                                        _p(ws), ws.numel(), _stream(), self._events(flow_events)), "wg_train_step")
         return loss, z, logdet, grads, dh
 
@@ -250,6 +289,7 @@ class ModelEngine:
             arr[i] = e.cuda_event
         return arr
 
+    @on_device
     def upsample(self, params, h, T):
         require_device(h)
         h = h.contiguous()
@@ -284,6 +324,7 @@ class CouplingEngine:
         nbytes = _lib.lib().wg_coupling_workspace_bytes(C.byref(self.dims), B, T, mode)
         return self.buffers.get((device, mode, B, T), nbytes, device)
 
+    @on_device
     def apply(self, params, x, y, reverse):
         require_device(x, y, *params)
         x, y = x.contiguous(), y.contiguous()
@@ -298,6 +339,7 @@ class CouplingEngine:
                                            _p(ws), ws.numel(), _stream()), "wg_coupling_apply")
         return z, log_s
 
+    @on_device
     def wn(self, params, x, y):
         require_device(x, y, *params)
         x, y = x.contiguous(), y.contiguous()
@@ -309,6 +351,7 @@ class CouplingEngine:
                                      _stream()), "wg_wn_apply")
         return log_s, t
 
+    @on_device
     def backward(self, params, z, y, dz, dlog_s, reverse, need, need_dy, x_out):
         require_device(z, y, dz, dlog_s)
         z, y, dz, dlog_s = z.contiguous(), y.contiguous(), dz.contiguous(), dlog_s.contiguous()
@@ -327,6 +370,7 @@ class CouplingEngine:
 _INV_BUFFERS = _Buffers()
 
 
+@on_device
 def invconv_apply(W, x, reverse):
     require_device(W, x)
     x = x.contiguous()
@@ -341,6 +385,7 @@ def invconv_apply(W, x, reverse):
     return z, logdet
 
 
+@on_device
 def invconv_backward(W, z, dz, dlogdet, reverse, x_out):
     require_device(W, z, dz, dlogdet)
     z, dz = z.contiguous(), dz.contiguous()
@@ -355,15 +400,28 @@ def invconv_backward(W, z, dz, dlogdet, reverse, x_out):
     return dx, dW
 
 
-def nll_loss(z, logdet, sigma, elementwise_mean):
-    require_device(z, logdet)
+@on_device
+def nll_loss(z, logdet, sigma, elementwise_mean, metrics=None):
+    """loss (device scalar); metrics (optional, 4 device floats) receives [logdet.sum()/z.numel(), z.mean(), z.std(), loss]."""
+    require_device(z, logdet, metrics)
     z, logdet = z.contiguous(), logdet.contiguous()
     B, N = z.shape
     loss = torch.empty((), dtype=torch.float32, device=z.device)
-    check(_lib.lib().wg_nll_loss(_p(z), _p(logdet), B, N, float(sigma), int(elementwise_mean), _p(loss), _stream()), "wg_nll_loss")
+    scratch = torch.empty(_lib.lib().wg_nll_scratch_floats(B), dtype=torch.float32, device=z.device)
+    check(_lib.lib().wg_nll_loss(_p(z), _p(logdet), B, N, float(sigma), int(elementwise_mean), _p(loss), _p(metrics), _p(scratch),
+                                 _stream()), "wg_nll_loss")
     return loss
 
 
+def training_metrics(z, logdet, sigma=1.0, elementwise_mean=True):
+    """The scalars LightModel.training_step logs (model/lightning.py:58-64) as ONE device vector
+    [logdet.sum() / z.numel(), z.mean(), z.std(), loss]; a data-parallel caller mean-reduces it (sync_dist=True)."""
+    m = torch.empty(4, dtype=torch.float32, device=z.device)
+    nll_loss(z, logdet, sigma, elementwise_mean, metrics=m)
+    return m
+
+
+@on_device
 def nll_loss_backward(z, sigma, elementwise_mean, dloss):
     require_device(z, dloss)
     z = z.contiguous()
@@ -379,6 +437,7 @@ def nll_loss_backward(z, sigma, elementwise_mean, dloss):
 WSR_COND_CHANNELS = 8 * 400 + 9 * 51
 
 
+@on_device
 def wsr_cond(c, mu_table, ang_table):
     """c[B,L] -> cond[B,3659,L/8]  (WSRGlow._get_cond, model/wsrglow.py:37-50; c is read clipped, not modified)."""
     require_device(c, mu_table, ang_table)
@@ -393,15 +452,22 @@ def wsr_cond(c, mu_table, ang_table):
     return cond
 
 
-def wsr_cond_backward(c, dcond):
-    """-> (d mu_table [256,400], d ang_table [120,50]) from dcond[B,3659,L/8]."""
+@on_device
+def wsr_cond_backward(c, dcond, out=None):
+    """-> (d mu_table [256,400], d ang_table [120,50]) from dcond[B,3659,L/8]; out: optional pair of contiguous tensors to fill."""
     require_device(c, dcond)
     c, dcond = c.contiguous(), dcond.contiguous()
     B, L = c.shape
     if tuple(dcond.shape) != (B, WSR_COND_CHANNELS, L // 8):
         raise WgError("dcond must be [B, 3659, L/8]")
-    dmu = torch.empty(256, 400, dtype=torch.float32, device=c.device)
-    dang = torch.empty(120, 50, dtype=torch.float32, device=c.device)
+    if out is not None:
+        dmu, dang = out
+        require_device(dmu, dang)
+        if tuple(dmu.shape) != (256, 400) or tuple(dang.shape) != (120, 50) or not (dmu.is_contiguous() and dang.is_contiguous()):
+            raise WgError("wsr_cond_backward: out must be contiguous [256,400] and [120,50] tensors")
+    else:
+        dmu = torch.empty(256, 400, dtype=torch.float32, device=c.device)
+        dang = torch.empty(120, 50, dtype=torch.float32, device=c.device)
     check(_lib.lib().wg_wsr_cond_backward(_p(c), B, L, _p(dcond), _p(dmu), _p(dang), _stream()), "wg_wsr_cond_backward")
     return dmu, dang
 
@@ -434,6 +500,7 @@ class WaveFlowEngine:
         nbytes = _lib.lib().wg_wf_workspace_bytes(C.byref(self.cfg), B, N, mode)
         return self.buffers.get((device, mode, B, N), nbytes, device)
 
+    @on_device
     def forward(self, params, x, mel, keep_tape):
         require_device(x, mel, *params)
         x, mel = x.contiguous(), mel.contiguous()
@@ -442,14 +509,31 @@ class WaveFlowEngine:
         ws = self._ws(B, N, 0, x.device)
         tape = None
         if keep_tape:
+            # one tape PER forward call, owned by that call's autograd node: a second forward of the same shape before the first
+            # backward (two losses, gradient accumulation, a grad-enabled evaluation pass) must not overwrite the flow inputs the
+            # first backward recomputes from.  (zero-filled: the kernels keep the halo of every plane zero, they do not write it)
             nbytes = _lib.lib().wg_wf_tape_bytes(C.byref(self.cfg), B, N)
-            tape = self.buffers.get((x.device, "tape", B, N), nbytes, x.device)
+            tape = torch.zeros(nbytes, dtype=torch.uint8, device=x.device)
         z = torch.empty_like(x)
         logdet = torch.empty(B, dtype=torch.float32, device=x.device)
         check(_lib.lib().wg_wf_forward(C.byref(self.cfg), _table(params), _p(pk), _p(x), _p(mel), B, N, mel.shape[2], _p(z), _p(logdet),
                                        _p(tape), _p(ws), ws.numel(), _stream()), "wg_wf_forward")
         return z, logdet, tape
 
+    @on_device
+    def upsample(self, params, mel):
+        """WaveFlow._upsample_h: mel [B, n_mels, F] -> [B, n_mels, F s - 2 (s // 2) + 2 s + 1]"""
+        require_device(mel, *params)
+        mel = mel.contiguous()
+        B, M, F = mel.shape
+        s = 256 // self.cfg.n_group
+        T = F * s - 2 * (s // 2) + 2 * s + 1
+        pk = self._pack(params, mel.device)
+        y = torch.empty(B, M, T, dtype=torch.float32, device=mel.device)
+        check(_lib.lib().wg_wf_upsample(C.byref(self.cfg), _table(params), _p(pk), _p(mel), B, F, T, _p(y), _stream()), "wg_wf_upsample")
+        return y
+
+    @on_device
     def inverse(self, params, z, mel):
         require_device(z, mel, *params)
         z, mel = z.contiguous(), mel.contiguous()
@@ -462,6 +546,7 @@ class WaveFlowEngine:
                                        _p(ws), ws.numel(), _stream()), "wg_wf_inverse")
         return x, logdet
 
+    @on_device
     def backward(self, params, tape, mel, dz, dlogdet, need_dmel, need_dx):
         require_device(mel, dz, dlogdet)
         mel, dz, dlogdet = mel.contiguous(), dz.contiguous(), dlogdet.contiguous()
@@ -477,8 +562,10 @@ class WaveFlowEngine:
 
 
 # ---- log-mel conditioner (include/wgflow.h: wg_melspec) -------------------------------------------------------------------------
-def melspec(x, sr, n_fft, hop, f_min, f_max, n_mels):
-    """audio [B, N] -> log-mel [B, n_mels, N // hop + 1]  (MelSpec.forward, model/condition.py:18-19)."""
+@on_device
+def melspec(x, sr, n_fft, hop, f_min, f_max, n_mels, return_power=False):
+    """audio [B, N] -> log-mel [B, n_mels, N // hop + 1]  (MelSpec.forward, model/condition.py:18-19).
+    return_power: also the power spectrogram [B, n_fft // 2 + 1, frames] the mel filters are applied to."""
     require_device(x)
     if x.dim() != 2:
         raise WgError("MelSpec expects audio [B, N]")
@@ -486,11 +573,13 @@ def melspec(x, sr, n_fft, hop, f_min, f_max, n_mels):
     B, N = x.shape
     frames = _lib.lib().wg_melspec_frames(N, n_fft, hop)
     out = torch.empty(B, n_mels, frames, dtype=torch.float32, device=x.device)
+    power = torch.empty(B, n_fft // 2 + 1, frames, dtype=torch.float32, device=x.device) if return_power else None
     check(_lib.lib().wg_melspec(_p(x), B, N, int(sr), int(n_fft), int(hop), float(f_min), float(f_max if f_max is not None else 0.0),
-                                int(n_mels), _p(out), _stream()), "wg_melspec")
-    return out
+                                int(n_mels), _p(out), _p(power), _stream()), "wg_melspec")
+    return (out, power) if return_power else out
 
 
+@on_device
 def lowpass(x, n_fft, hop, cut_bins, step):
     """x [B, T] -> STFT low-pass (bins >= cut_bins zeroed), every step-th sample: [B, ceil(T / step)]  (condition.py:22-66)."""
     require_device(x)

@@ -15,9 +15,10 @@ import torch.distributed as dist
 
 
 class FlatGrads:
-    """A flat gradient buffer with per-parameter views and per-bucket slices."""
+    """A flat gradient buffer with per-parameter views and per-bucket slices.  `tail` extra floats follow the last bucket: they
+    travel in that bucket's collective (the four logged training scalars ride there) but are not part of any parameter range."""
 
-    def __init__(self, params: Sequence[torch.Tensor], bucket_of: Sequence[int]):
+    def __init__(self, params: Sequence[torch.Tensor], bucket_of: Sequence[int], tail: int = 0):
         assert len(params) == len(bucket_of)
         self.sizes = [p.numel() for p in params]
         order = sorted(range(len(params)), key=lambda i: (bucket_of[i], i))
@@ -35,33 +36,49 @@ class FlatGrads:
         if cur is not None:
             self.bucket_ranges.append((start, off))
         self.total = off
-        self.flat = torch.zeros(self.total, dtype=params[0].dtype, device=params[0].device)
+        self.tail_off = (off + 3) // 4 * 4                     # 16-byte aligned
+        self.tail_len = int(tail)
+        self.flat = torch.zeros(self.tail_off + self.tail_len, dtype=params[0].dtype, device=params[0].device)
         self.views = [self.flat[o:o + n].view_as(p) for o, n, p in zip(self.offsets, self.sizes, params)]
+        self.tail = self.flat[self.tail_off:self.tail_off + self.tail_len]
 
     def bucket(self, b: int) -> torch.Tensor:
+        """the parameter gradients of bucket b"""
         s, e = self.bucket_ranges[b]
         return self.flat[s:e]
 
+    def comm_slice(self, b: int) -> torch.Tensor:
+        """what bucket b's collective moves: its gradients, plus the tail for the last bucket"""
+        s, e = self.bucket_ranges[b]
+        if b == len(self.bucket_ranges) - 1 and self.tail_len:
+            e = self.tail_off + self.tail_len
+        return self.flat[s:e]
 
-def waveglow_buckets(n_flows: int, depth: int) -> List[int]:
-    """bucket id per parameter-table entry: flow k (its WN and its 1x1 weight) -> bucket k; upsampler -> bucket n_flows."""
+
+def waveglow_buckets(n_flows: int, depth: int, extra: int = 0) -> List[int]:
+    """bucket id per parameter-table entry: flow k (its WN and its 1x1 weight) -> bucket k; upsampler -> bucket n_flows;
+    `extra` trailing entries (WSRGlow's two embedding tables) -> bucket n_flows + 1."""
     ids = [n_flows] * 3 + list(range(n_flows))
     for k in range(n_flows):
         ids += [k] * (4 + 4 * depth + 1)
-    return ids
+    return ids + [n_flows + 1] * extra
 
 
 class GradSync:
     """Mean all-reduce of a FlatGrads over the process group, bucket by bucket in backward order."""
 
-    def __init__(self, process_group=None):
+    def __init__(self, process_group=None, force_collectives=None):
+        """force_collectives: run the collectives (side stream, events, RCCL calls) even in a group of ONE rank -- how the
+        path is exercised on a single GPU (tests, WG_BENCH_FORCE_DIST=1); default: the environment variable decides."""
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         backend = dist.get_backend(process_group) if dist.is_initialized() else None
         self._avg = backend == "nccl"          # RCCL has a native AVG; gloo does not
         self._comm = None
         import os
-        self._force = dist.is_initialized() and os.environ.get("WG_BENCH_FORCE_DIST") == "1"   # 1-rank smoke of the collective path
+        if force_collectives is None:
+            force_collectives = os.environ.get("WG_BENCH_FORCE_DIST") == "1"
+        self._force = dist.is_initialized() and bool(force_collectives)
 
     def all_reduce(self, fg: FlatGrads, order: Sequence[int] = None, events=None, after_bucket=None):
         """events[b] (torch.cuda.Event, optional): bucket b's gradients are final once the event has fired; its all-reduce is
@@ -81,7 +98,7 @@ class GradSync:
                 self._comm = torch.cuda.Stream(device=fg.flat.device)
             with torch.cuda.stream(self._comm):
                 for b in order:
-                    t = fg.bucket(b)
+                    t = fg.comm_slice(b)
                     if t.numel() == 0:
                         continue
                     self._comm.wait_event(events[b])
@@ -98,7 +115,7 @@ class GradSync:
                 return
         else:
             for b in order:
-                t = fg.bucket(b)
+                t = fg.comm_slice(b)
                 if t.numel() == 0:
                     continue
                 works.append((dist.all_reduce(t, op=op, group=self.pg, async_op=True), t))
@@ -136,51 +153,80 @@ class GradSync:
             dist.broadcast(p.data, src=src, group=self.pg)
 
 
-class FlowTrainer:
-    """The training step of model/lightning.py:52-56 without Lightning:
-        z, logdet = model(x, h); loss = NLL(z, logdet); backward to every parameter gradient; all-reduce(mean).
-    Runs the HIP engine directly (no autograd graph) and leaves the gradients in p.grad (views of one flat buffer)."""
+METRIC_NAMES = ("logdet", "z_mean", "z_std", "loss")      # the keys LightModel.training_step logs (model/lightning.py:58-64)
 
-    def __init__(self, model, sigma: float, elementwise_mean: bool = True, process_group=None, repack_every_step: bool = True):
+
+class FlowTrainer:
+    """The training step of model/lightning.py:52-65 without Lightning:
+        z, logdet = model(x, h); loss = NLL(z, logdet); backward to every parameter gradient; all-reduce(mean);
+        the logged scalars logdet.sum()/z.numel(), z.mean(), z.std(), loss, mean-reduced over the ranks (sync_dist=True).
+    Runs the HIP engine directly (no autograd graph) and leaves the gradients in p.grad (views of one flat buffer).
+    `model` is a WaveGlow or a WSRGlow (a WaveGlow whose conditioning is built from the low-rate signal by `_get_cond`:
+    step(x, c) then takes that signal, and the two embedding tables get their own gradient bucket behind the upsampler's)."""
+
+    def __init__(self, model, sigma: float, elementwise_mean: bool = True, process_group=None, repack_every_step: bool = True,
+                 force_collectives=None):
         """repack_every_step: the reference recomputes w = g v / ||v|| in a forward-pre-hook on every call (utils.py:14-16), and in
         training the parameters change between steps anyway.  The engine caches its packed weights by parameter version; a step
-        timed on frozen parameters would silently skip that work, so the trainer re-packs on every step unless told otherwise."""
+        timed on frozen parameters would silently skip that work, so the trainer re-packs on every step unless told otherwise.
+        force_collectives: see GradSync."""
         from . import engine
         self.repack_every_step = repack_every_step
         self._engine_mod = engine
         self.model = model
         self.sigma, self.mean = sigma, elementwise_mean
-        self.sync = GradSync(process_group)
-        self.table = [t for t in model.param_table()]
+        self.sync = GradSync(process_group, force_collectives)
+        self.frontend = [model.mu_enc[1].weight, model.angle_embed.embed.weight] if hasattr(model, "_get_cond") else []
+        self.flow_table = [t for t in model.param_table()]              # the C-ABI table of the flow (wg_train_step)
+        self.table = self.flow_table + self.frontend
         wn0 = model.WNs[0].F
-        ids = waveglow_buckets(len(model.WNs), len(wn0.layers))
+        ids = waveglow_buckets(len(model.WNs), len(wn0.layers), extra=len(self.frontend))
         live = [(t, b) for t, b in zip(self.table, ids) if t is not None]
-        self.fg = FlatGrads([t for t, _ in live], [b for _, b in live])
+        self.fg = FlatGrads([t for t, _ in live], [b for _, b in live], tail=len(METRIC_NAMES))
         it = iter(self.fg.views)
         self.grad_views = [next(it) if t is not None else None for t in self.table]
         self.sync.broadcast_params([t for t in self.table if t is not None])
         self.n_flows = len(model.WNs)
+        self.n_buckets = len(self.fg.bucket_ranges)
+        self.metrics = self.fg.tail       # [logdet.sum()/z.numel(), z.mean(), z.std(), loss] of the last step, reduced over the ranks
         self.optimizer = None             # a FlatAdam attaches itself here; step() then updates the weights as well
         self.events = None
         if self.table[0].is_cuda and (self.sync.world > 1 or self.sync._force):
-            self.events = [torch.cuda.Event() for _ in range(self.n_flows + 1)]
-            for e in self.events:
-                e.record()                # materialise the underlying hipEvent_t so its handle can cross the C ABI
+            with torch.cuda.device(self.table[0].device):
+                self.events = [torch.cuda.Event() for _ in range(self.n_buckets)]
+                for e in self.events:
+                    e.record()            # materialise the underlying hipEvent_t so its handle can cross the C ABI
 
     @torch.no_grad()
     def step(self, x: torch.Tensor, h: torch.Tensor):
-        eng = self.model._engine
+        """x [B, N] audio; h: the conditioning [B, n_mels, frames] (WaveGlow) or the low-rate signal [B, N / rate] (WSRGlow, which
+        clips it in place like the reference, wsrglow.py:38).  Returns this rank's (loss, z, logdet)."""
+        eng, E = self.model._engine, self._engine_mod
         if self.repack_every_step:
             eng.packed.key = None             # a training step always re-materialises the weight-normed weights (see __init__)
-        table = [None if t is None else t.detach() for t in self.table]
-        need = [t is not None and t.requires_grad for t in self.table]
-        loss, z, logdet, _, _ = eng.train_step(table, x, h, self.sigma, self.mean, need, grads_out=self.grad_views,
-                                               flow_events=self.events,        # one C call: wg_train_step
-                                               keep=not self.model.mem_efficient)
-        # buckets become final in the order backward retires the flows: last flow first (first flow first in reverse_mode), upsampler last
+        nflow = len(self.flow_table)
+        table = [None if t is None else t.detach() for t in self.flow_table]
+        need = [t is not None and t.requires_grad for t in self.flow_table]
+        c = None
+        if self.frontend:
+            c = h.clamp_(-1.0, 1.0)
+            h = E.wsr_cond(c, self.frontend[0].detach(), self.frontend[1].detach())
+        loss, z, logdet, _, dh = eng.train_step(table, x, h, self.sigma, self.mean, need, grads_out=self.grad_views[:nflow],
+                                                need_dh=bool(self.frontend),
+                                                flow_events=self.events[:self.n_flows + 1] if self.events else None,
+                                                keep=not self.model.mem_efficient, metrics=self.metrics)   # one C call: wg_train_step
+        # buckets become final in the order backward retires the flows: last flow first (first flow first in reverse_mode), then the
+        # upsampler, then (WSRGlow) the embedding tables, whose gradients come out of the conditioning gradient
         flows = range(self.n_flows) if self.model._reverse_mode else range(self.n_flows - 1, -1, -1)
+        order = list(flows) + [self.n_flows]
+        if self.frontend:
+            E.wsr_cond_backward(c, dh, out=(self.grad_views[nflow], self.grad_views[nflow + 1]))
+            del dh
+            if self.events:
+                self.events[self.n_flows + 1].record(torch.cuda.current_stream(x.device))
+            order.append(self.n_flows + 1)
         opt = self.optimizer
-        self.sync.all_reduce(self.fg, order=list(flows) + [self.n_flows], events=self.events,
+        self.sync.all_reduce(self.fg, order=order, events=self.events,
                              after_bucket=opt.step_bucket if opt is not None else None)
         if opt is not None:
             opt.finish_step()
@@ -188,6 +234,10 @@ class FlowTrainer:
             if t is not None:
                 t.grad = g
         return loss, z, logdet
+
+    def metrics_dict(self):
+        """{'logdet', 'z_mean', 'z_std', 'loss'} of the last step as Python floats (one device->host copy)."""
+        return dict(zip(METRIC_NAMES, self.metrics.tolist()))
 
 
 class FlatAdam:

@@ -82,7 +82,8 @@ class _WaveFlowFn(Function):
     @staticmethod
     def forward(ctx, model, x, h, *params):
         table = [None if t is None else t.detach() for t in model.param_table()]
-        z, logdet, tape = model._engine.forward(table, x.detach(), h.detach(), keep_tape=True)
+        # (Function.forward runs with grad mode off; whether a backward can follow is what needs_input_grad says)
+        z, logdet, tape = model._engine.forward(table, x.detach(), h.detach(), keep_tape=any(ctx.needs_input_grad))
         ctx.model, ctx.tape = model, tape
         ctx.save_for_backward(h)
         return z, logdet
@@ -130,6 +131,10 @@ class WaveFlow(FlowBase):
             raise WgError("expected audio [B, N] and conditioning [B, n_mels, frames]")
         s = self.sub_sr
         assert x.size(1) // self.n_group <= h.size(2) * s - 2 * (s // 2) + 2 * s + 1
+
+    def _upsample_h(self, h):
+        """the conditioning at the flow's time resolution (waveflow.py:255-257); no autograd here (it is part of wg_wf_forward)"""
+        return self._engine.upsample([None if t is None else t.detach() for t in self.param_table()], h.detach().float())
 
     def forward_computation(self, x: Tensor, h: Tensor) -> Tuple[Tensor, Tensor]:
         self._check(x, h)

@@ -73,9 +73,10 @@ typedef struct wg_wn_dims {
 } wg_wn_dims;
 
 const char *wg_strerror(int code);
-/* ABI revision of this header (2: wg_config gained keep_activations).  A binding built against another revision must not pass its
+/* ABI revision of this header (2: wg_config gained keep_activations; 3: wg_nll_loss / wg_train_step produce the logged
+ * training scalars and take their scratch from the caller).  A binding built against another revision must not pass its
  * structs: the Python loader compares this with its own ABI_VERSION and refuses the library otherwise. */
-#define WG_ABI_VERSION 2
+#define WG_ABI_VERSION 3
 int wg_abi_version(void);
 
 /* Diagnostics (no counterpart upstream; the reference times with wall-clock time(), inference.py:39-53): while a
@@ -139,10 +140,14 @@ int wg_backward(const wg_config *cfg, const void *const *params, const void *pac
                 void *ws, size_t ws_bytes, void *stream, void *const *flow_events);
 
 /* WaveGlowLoss.forward (model/loss.py:10-15): loss = mean_b(0.5*sum z^2/sigma^2 - logdet_b) [/N].
- * loss is a device scalar.  The backward writes dz[B,N], dlogdet[B] for an upstream gradient dloss (device scalar,
- * NULL = 1). */
+ * loss is a device scalar.  metrics (nullable, 4 device floats) receives the scalars the reference's training step logs
+ * next to the loss (model/lightning.py:58-64): [0] logdet.sum() / z.numel(), [1] z.mean(), [2] z.std() (unbiased),
+ * [3] the loss -- per process; a data-parallel caller mean-reduces the vector (Lightning's sync_dist=True).
+ * scratch: wg_nll_scratch_floats(B) floats.  The backward writes dz[B,N], dlogdet[B] for an upstream gradient dloss
+ * (device scalar, NULL = 1). */
+size_t wg_nll_scratch_floats(int B);
 int wg_nll_loss(const float *z, const float *logdet, int B, int N, float sigma, int elementwise_mean,
-                float *loss, void *stream);
+                float *loss, float *metrics, float *scratch, void *stream);
 int wg_nll_loss_backward(const float *z, int B, int N, float sigma, int elementwise_mean,
                          const float *dloss, float *dz, float *dlogdet, void *stream);
 
@@ -187,12 +192,14 @@ int wg_wsr_cond(const float *c, int B, int L, const float *mu_table, const float
  * through integer indices, :47 has no parameters).  Outputs are overwritten. */
 int wg_wsr_cond_backward(const float *c, int B, int L, const float *dcond, float *dmu_table, float *dang_table, void *stream);
 
-/* The training step of model/lightning.py:52-56 in ONE call: forward, WaveGlowLoss(sigma) (loss.py:10-15), backward to every
- * parameter gradient (+ dh when not NULL).  Equivalent to wg_forward + wg_nll_loss + wg_nll_loss_backward + wg_backward; the
- * forward runs in the backward's workspace (wg_workspace_bytes(.., mode 1)) and keeps the layers of the flow it processes last,
- * which the backward then does not recompute.  scratch: (B*N + B) floats.  flow_events as in wg_backward. */
+/* The training step of model/lightning.py:52-65 in ONE call: forward, WaveGlowLoss(sigma) (loss.py:10-15), backward to every
+ * parameter gradient (+ dh when not NULL), and the four logged scalars (metrics, nullable: see wg_nll_loss).  Equivalent to
+ * wg_forward + wg_nll_loss + wg_nll_loss_backward + wg_backward; the forward runs in the backward's workspace
+ * (wg_workspace_bytes(.., mode 1)) and keeps the layers of the flow it processes last, which the backward then does not
+ * recompute.  scratch: wg_train_scratch_floats(B, N) floats.  flow_events as in wg_backward. */
+size_t wg_train_scratch_floats(int B, int N);
 int wg_train_step(const wg_config *cfg, const void *const *params, const void *packed, const float *audio, const float *h,
-                  int B, int N, int F, float sigma, int elementwise_mean, float *z, float *logdet, float *loss,
+                  int B, int N, int F, float sigma, int elementwise_mean, float *z, float *logdet, float *loss, float *metrics,
                   void *const *grads, float *dh, float *scratch, void *ws, size_t ws_bytes, void *stream, void *const *flow_events);
 
 /* ---- WaveFlow (model/waveflow.py) -------------------------------------------------------------------
@@ -211,6 +218,9 @@ size_t wg_wf_packed_bytes(const wg_wf_config *cfg);
 size_t wg_wf_workspace_bytes(const wg_wf_config *cfg, int B, int N, int mode);      /* 0: forward; 1: backward / inverse */
 size_t wg_wf_tape_bytes(const wg_wf_config *cfg, int B, int N);
 int wg_wf_pack_weights(const wg_wf_config *cfg, const void *const *params, void *packed, void *stream);
+/* WaveFlow._upsample_h (waveflow.py:163-169,255-257): mel[B,n_mels,F] -> y[B,n_mels,T] for T <= F*s - 2*(s/2) + 2*s + 1, s = 256/n_group. */
+int wg_wf_upsample(const wg_wf_config *cfg, const void *const *params, const void *packed, const float *mel, int B, int F, int T,
+                   float *y, void *stream);
 /* WaveFlow.forward_computation (waveflow.py:182-208): z[B,N], logdet[B].  `tape` (nullable; zero-initialised once) receives every
  * flow's input for wg_wf_backward. */
 int wg_wf_forward(const wg_wf_config *cfg, const void *const *params, const void *packed, const float *audio, const float *mel,
@@ -228,10 +238,14 @@ int wg_wf_backward(const wg_wf_config *cfg, const void *const *params, const voi
  * Replaces MelSpec.forward (model/condition.py:7-19): reflection pad (n_fft/2 - hop/2, n_fft/2 + hop/2), torchaudio
  * MelSpectrogram(sample_rate, n_fft, hop_length, center=False, f_min, f_max, n_mels) with torchaudio's defaults for the rest
  * (periodic Hann, power 2, HTK mel scale, norm None), then log(x + 1e-7).  audio[B,N] -> mel[B,n_mels,N/hop + 1].
- * f_max <= 0 means sr // 2.  n_fft must be a power of two <= 2048.  torchaudio is not part of the reference tree: its published
+ * f_max <= 0 means sr // 2.  n_fft must be a power of two <= 2048.  power (nullable, [B, n_fft/2+1, frames]) additionally receives
+ * the power spectrogram before the mel filterbank -- the half of the conditioner that is plain torch upstream
+ * (nn.ReflectionPad1d + torch.stft(periodic Hann, center=False).abs()**2) and is pinned to torch's own output
+ * (tests/golden/cond_melspec_power.npz); the HTK filterbank on top restates torchaudio's published formula.  torchaudio is not part of the reference tree: its published
  * algorithm is restated (parity unpinned against torchaudio itself). */
 int wg_melspec_frames(int N, int n_fft, int hop);
-int wg_melspec(const float *audio, int B, int N, int sr, int n_fft, int hop, double f_min, double f_max, int n_mels, float *mel, void *stream);
+int wg_melspec(const float *audio, int B, int N, int sr, int n_fft, int hop, double f_min, double f_max, int n_mels, float *mel,
+               float *power, void *stream);
 
 /* LowPass.forward / STFTDecimate.forward (model/condition.py:22-66), the conditioner of the WSRGlow configs: right zero-pad by
  * n_fft, STFT (center, reflect, periodic Hann), zero the bins >= cut_bins, ISTFT, crop to T, keep every `step`-th sample.

@@ -147,6 +147,8 @@ CONFIGS["wsr_like"] = dict(flows=4, n_group=16, n_early_every=2, n_early_size=2,
 # WSRGlow(upsample_rate=2, **WSR_KW): the WaveGlow underneath is fixed by model/wsrglow.py:23-26
 WSR_KW = dict(dilation_channels=32, residual_channels=32, skip_channels=32, depth=2, radix=3)
 CONFIGS["wsr"] = dict(flows=12, n_group=16, n_early_every=4, n_early_size=2, hop_size=16, n_mels=8 * 400 + 51 * 9, **WSR_KW)
+# WSRGlow(upsample_rate=3, **WSR_KW) (configs/wsrglow_vctk_3x.json): 24 squeezed channels -> 1x1 convs of 24, 22 and 20 channels
+CONFIGS["wsr3"] = dict(flows=12, n_group=24, n_early_every=4, n_early_size=2, hop_size=24, n_mels=8 * 400 + 51 * 9, **WSR_KW)
 WSR_TABLES = [("mu_enc.1.weight", (256, 400)), ("angle_embed.embed.weight", (120, 50))]
 SHAPES = {  # (batch, samples, mel frames)
     "micro": (2, 512, 8),
@@ -154,7 +156,12 @@ SHAPES = {  # (batch, samples, mel frames)
     "c2": (1, 16000, 63),
     "wsr_like": (2, 16 * 300, 300),
     "wsr": (2, 1024, 64),        # conditioning signal: [2, 512] low-rate samples -> 64 frames
+    "wsr3": (2, 24 * 37, 37),    # rate 3: [2, 296] low-rate samples -> 37 frames (not a multiple of anything the kernels tile by)
 }
+WSR_RATE = {"wsr": 2, "wsr3": 3}
+# MelSpec cases (batch, samples): the conditioner every WaveGlow / WaveFlow config ships (sr 22050, n_fft 1024, hop 256, f_max 8000, 80 mels)
+MEL_CASES = {"short": (2, 4096), "segment": (1, 16000)}
+MEL_KW = dict(sr=22050, n_fft=1024, hop_length=256, f_max=8000, n_mels=80)
 SIGMA = 0.7   # configs/waveglow_LJ_speech.json:47
 
 
@@ -162,9 +169,16 @@ def inputs(tag, B, N, F, n_mels):
     return uniform(tag + "/audio", (B, N), -1.0, 1.0), normal(tag + "/mel", (B, n_mels, F))
 
 
-def wsr_inputs(tag, B, N):
-    """(audio [B,N], low-rate conditioning signal c [B,N/2] in (-1.15, 1.15): exercises the clip and every mu-law level)."""
-    return uniform(tag + "/audio", (B, N), -1.0, 1.0), uniform(tag + "/lowres", (B, N // 2), -1.15, 1.15)
+def wsr_inputs(tag, B, N, rate=2):
+    """(audio [B,N], low-rate conditioning signal c [B,N/rate] in (-1.15, 1.15): exercises the clip and every mu-law level)."""
+    return uniform(tag + "/audio", (B, N), -1.0, 1.0), uniform(tag + "/lowres", (B, N // rate), -1.15, 1.15)
+
+
+def mel_input(tag):
+    B, N = MEL_CASES[tag]
+    x = uniform("mel/" + tag, (B, N), -0.8, 0.8)
+    x[0, : N // 4] *= 1e-3                       # a quiet stretch: log-mel near its floor
+    return x
 
 
 def wsr_tables(tag):

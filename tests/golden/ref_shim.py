@@ -41,6 +41,18 @@ def load():
     return ns
 
 
+def _standin_transforms():
+    """the stand-in `torchaudio.transforms` module (created once; every loader adds the class it restates)"""
+    if "torchaudio" not in sys.modules:
+        ta = types.ModuleType("torchaudio")
+        tr = types.ModuleType("torchaudio.transforms")
+        ta.transforms = tr
+        ta.__wg_standin__ = True
+        sys.modules["torchaudio"] = ta
+        sys.modules["torchaudio.transforms"] = tr
+    return sys.modules["torchaudio.transforms"]
+
+
 def load_wsrglow():
     """Returns the reference's WSRGlow class (model/wsrglow.py).
 
@@ -54,7 +66,8 @@ def load_wsrglow():
     ns = load()
     import importlib
     import torch
-    if "torchaudio" not in sys.modules:
+    tr = _standin_transforms()
+    if not hasattr(tr, "MuLawEncoding"):
         class MuLawEncoding(torch.nn.Module):
             def __init__(self, quantization_channels: int = 256) -> None:
                 super().__init__()
@@ -65,13 +78,7 @@ def load_wsrglow():
                 x_mu = torch.sign(x) * torch.log1p(mu * torch.abs(x)) / torch.log1p(mu)
                 return ((x_mu + 1) / 2 * mu + 0.5).to(torch.int64)
 
-        ta = types.ModuleType("torchaudio")
-        tr = types.ModuleType("torchaudio.transforms")
         tr.MuLawEncoding = MuLawEncoding
-        ta.transforms = tr
-        ta.__wg_standin__ = True
-        sys.modules["torchaudio"] = ta
-        sys.modules["torchaudio.transforms"] = tr
     ws = importlib.import_module("model.wsrglow")
     ns.WSRGlow = ws.WSRGlow
     return ns
@@ -92,14 +99,7 @@ def load_conditioners():
     import contextlib
     import importlib
     import torch
-    if "torchaudio" not in sys.modules:
-        ta = types.ModuleType("torchaudio")
-        tr = types.ModuleType("torchaudio.transforms")
-        ta.transforms = tr
-        ta.__wg_standin__ = True
-        sys.modules["torchaudio"] = ta
-        sys.modules["torchaudio.transforms"] = tr
-    tr = sys.modules["torchaudio.transforms"]
+    tr = _standin_transforms()
     if not hasattr(tr, "MelSpectrogram"):
         class MelSpectrogram(torch.nn.Module):                      # placeholder: never used by the fixtures
             def __init__(self, *a, **k):
@@ -129,3 +129,68 @@ def load_conditioners():
             torch.stft, torch.istft = stft, istft
 
     return types.SimpleNamespace(LowPass=cond.LowPass, STFTDecimate=cond.STFTDecimate, legacy_stft_api=legacy_stft_api)
+
+
+def load_melspec():
+    """Returns the reference's MelSpec class (model/condition.py:7-19) with a stand-in for torchaudio's MelSpectrogram.
+
+    MelSpec = nn.ReflectionPad1d -> torchaudio.transforms.MelSpectrogram(center=False, ...) -> add_(1e-7).log_().  torchaudio is
+    neither in /root/reference nor in this image, so a stand-in `torchaudio.transforms.MelSpectrogram` is registered for the import.
+    It restates torchaudio's published algorithm with torch's own operators:
+        Spectrogram:   torch.stft(x, n_fft, hop, win_length, window_fn(win_length) [periodic Hann], center, pad_mode,
+                                  normalized=False, onesided=True, return_complex=True).abs().pow(power)
+        MelScale:      fb = melscale_fbanks(n_fft // 2 + 1, f_min, f_max or sr // 2, n_mels, sr, norm=None, mel_scale="htk");
+                       mel = (spec^T fb)^T
+        melscale_fbanks (htk):  all_freqs = linspace(0, sr // 2, n_freqs); m_pts = linspace(hz2mel(f_min), hz2mel(f_max), n_mels + 2),
+                       hz2mel(f) = 2595 log10(1 + f / 700); f_pts = 700 (10^(m / 2595) - 1);
+                       fb = max(0, min(-slopes[:, :-2] / f_diff[:-1], slopes[:, 2:] / f_diff[1:])), slopes = f_pts[None] - all_freqs[:, None]
+    So the fixtures pin the reflection pad and the log to the reference's own code, the STFT power to torch.stft, and the mel
+    filterbank to the published formula only.  The stand-in keeps the last power spectrogram in `.last_power` for the fixture.
+    """
+    load()
+    import importlib
+    import math
+    import torch
+    tr = _standin_transforms()
+
+    class MelSpectrogram(torch.nn.Module):
+        __wg_standin__ = True
+
+        def __init__(self, sample_rate=16000, n_fft=400, win_length=None, hop_length=None, f_min=0.0, f_max=None, pad=0, n_mels=128,
+                     window_fn=torch.hann_window, power=2.0, normalized=False, wkwargs=None, center=True, pad_mode="reflect",
+                     onesided=None, norm=None, mel_scale="htk"):
+            super().__init__()
+            assert pad == 0 and not normalized and norm is None and mel_scale == "htk"
+            self.n_fft = n_fft
+            self.win_length = win_length if win_length is not None else n_fft
+            self.hop_length = hop_length if hop_length is not None else self.win_length // 2
+            self.power, self.center, self.pad_mode = power, center, pad_mode
+            self.register_buffer("window", window_fn(self.win_length) if wkwargs is None else window_fn(self.win_length, **wkwargs))
+            f_max = float(sample_rate // 2) if f_max is None else float(f_max)
+            n_freqs = n_fft // 2 + 1
+            all_freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+            m_min = 2595.0 * math.log10(1.0 + f_min / 700.0)
+            m_max = 2595.0 * math.log10(1.0 + f_max / 700.0)
+            m_pts = torch.linspace(m_min, m_max, n_mels + 2)
+            f_pts = 700.0 * (10 ** (m_pts / 2595.0) - 1.0)
+            f_diff = f_pts[1:] - f_pts[:-1]
+            slopes = f_pts.unsqueeze(0) - all_freqs.unsqueeze(1)
+            down = (-1.0 * slopes[:, :-2]) / f_diff[:-1]
+            up = slopes[:, 2:] / f_diff[1:]
+            self.register_buffer("fb", torch.max(torch.zeros(1), torch.min(down, up)))
+            self.last_power = None
+
+        def forward(self, x):
+            shape = x.shape
+            spec = torch.stft(x.reshape(-1, shape[-1]), self.n_fft, self.hop_length, self.win_length, self.window, center=self.center,
+                              pad_mode=self.pad_mode, normalized=False, onesided=True, return_complex=True)
+            spec = spec.abs().pow(self.power)
+            spec = spec.reshape(shape[:-1] + spec.shape[-2:])
+            self.last_power = spec.detach().clone()
+            return torch.matmul(spec.transpose(-1, -2), self.fb).transpose(-1, -2)
+
+    if not getattr(getattr(tr, "MelSpectrogram", None), "__wg_standin__", False):
+        tr.MelSpectrogram = MelSpectrogram
+    sys.modules.pop("model.condition", None)                  # re-import so that condition.py binds the stand-in above
+    cond = importlib.import_module("model.condition")
+    return types.SimpleNamespace(MelSpec=cond.MelSpec)
