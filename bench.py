@@ -51,36 +51,71 @@ def build_model(dev, seed=0):
 
 
 def _traffic(kernel):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary (profiles/*_hbm_traffic.json, produced by
-    tools/profile_summary.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command); None if absent."""
+    """(HBM bytes per launch of the dominant kernel, the file it was read from).  NOT measured in this run: the bytes come from the
+    newest committed PMC summary (profiles/*_hbm_traffic.json, produced by tools/profile_summary.py from separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); (None, None) if absent."""
     import glob
-    best = None
+    best = (None, None)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
         try:
             k = json.load(open(f))["kernels"]
         except Exception:
             continue
         if kernel in k:
-            best = k[kernel]["hbm_bytes_per_launch"]
+            best = (k[kernel]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT))
     return best
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+# BASELINE.md section 2: on the SAME 8 cores the reference itself (torch-CPU / MKLDNN) runs the C2 B=1 step at ~7 980 samples/s and
+# the plain-C oracle timed here at ~2 300 (DESIGN.md section 6): multiply a "port" figure by this to estimate the reference's CPU path
+REF_OVER_PORT = 7980.0 / 2300.0
+
+
 def cpu_baseline():
-    """One training step of the C2 network on ONE segment with the CPU oracle (kind = "port")."""
+    """Training steps of the CPU oracle (kind = "port") on the host cores: BASELINE.md section 4's plan -- C1 (64ch, 6 flows, B=2,
+    seg 4000) and the C2 network at B=1 and B=2, 1 warm-up + 3 timed runs each, median reported.  `value` is the C2 B=1 figure."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import fill
     from oracle import wg_oracle as orc
-    specs = fill.model_param_specs(C2)
-    tab = fill.table(specs, fill.fill_params(specs, "c2/"))
-    audio, h = fill.inputs("c2", 1, SEG, FRAMES, C2["n_mels"])
     # the oracle's loops expose 64-128 independent row blocks: cap the OpenMP team there (measured: more threads are slower)
     cores = orc.set_threads(min(int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)), 64))
-    oc = orc.make_config(**C2)
-    t0 = time.time()
-    orc.train_step(oc, tab, audio, h, SIGMA)
-    dt = time.time() - t0
-    return {"value": SEG / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "1 segment of 16000 samples (B=1), WaveGlow-256ch 12 flows, fwd+NLL+bwd, one run = %.1f s" % dt}
+
+    def timed(cfg_name, cfg, B, N, F, runs=3):
+        specs = fill.model_param_specs(cfg)
+        tab = fill.table(specs, fill.fill_params(specs, cfg_name + "/"))
+        audio, h = fill.inputs(cfg_name + "/cpu%d" % B, B, N, F, cfg["n_mels"])
+        oc = orc.make_config(**cfg)
+        orc.train_step(oc, tab, audio, h, SIGMA)                       # warm-up (page-in, OpenMP team start)
+        ts = []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            orc.train_step(oc, tab, audio, h, SIGMA)
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        return {"samples_per_s": B * N / ts[len(ts) // 2], "median_s": ts[len(ts) // 2], "min_s": ts[0], "runs": runs, "batch": B}
+
+    c1 = fill.CONFIGS["c1"]
+    res = {"c1_b2": timed("c1", c1, 2, 4000, 16), "c2_b1": timed("c2", C2, 1, SEG, FRAMES), "c2_b2": timed("c2", C2, 2, SEG, FRAMES)}
+    total = sum(r["median_s"] * (r["runs"] + 1) for r in res.values())
+    return {"value": res["c2_b1"]["samples_per_s"], "unit": "samples/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
+            "sample": "WaveGlow-256ch 12 flows fwd+NLL+bwd on 1 segment of 16000 samples (B=1): median of 3 runs after 1 warm-up; "
+                      "also C2 at B=2 and C1 (64ch, 6 flows, B=2, seg 4000); %.0f s of CPU work in all" % total,
+            "configs": res,
+            "ref_calibration": {"reference_over_port": REF_OVER_PORT,
+                                "note": "BASELINE.md section 2: the reference's own torch-CPU/MKLDNN path ran the C2 B=1 step 3.5x faster than "
+                                        "this plain-C port on the same 8 cores of the build container (7980 vs 2300 samples/s); the reference's "
+                                        "Python cannot travel to the GPU box, so the estimate for it is value * reference_over_port",
+                                "estimated_reference_value": res["c2_b1"]["samples_per_s"] * REF_OVER_PORT}}
 
 
 def other_models(dev):
@@ -90,14 +125,23 @@ def other_models(dev):
     import constant_memory_waveglow_amd as cm
     res = {}
 
+    last = {}
+
     def timed(step):
-        step()
+        last["loss"] = step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(3):
-            step()
+            last["loss"] = step()
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / 3
+
+    def checked(loss):
+        """the secondary lines are only worth printing for a step that produced finite numbers"""
+        v = float(loss)
+        if not np.isfinite(v):
+            raise FloatingPointError("non-finite loss %r" % v)
+        return v
 
     try:
         torch.manual_seed(0)
@@ -115,10 +159,22 @@ def other_models(dev):
             m.zero_grad(set_to_none=True)
             m._engine.packed.key = None            # as in training, where the weights change: re-pack every step
             z, ld = m(x, h)
-            crit(z, ld).backward()
+            loss = crit(z, ld)
+            loss.backward()
+            return loss
         dt = timed(step)
+        gfin = all(bool(torch.isfinite(p.grad).all()) for p in m.parameters())
         res["waveflow"] = {"workload": "WaveFlow 64ch 8 flows n_group 64, batch 12 x 16000, fwd+NLL+bwd", "ms_per_step": dt * 1e3,
-                           "samples_per_s": 12 * 16000 / dt}
+                           "samples_per_s": 12 * 16000 / dt, "loss": checked(last["loss"]), "grads_finite": gfin}
+        with torch.no_grad():                      # synthesis (row-by-row inverse): ~0.7 s and ~10 s of audio, as inference.py:50-56
+            for frames in (63, 862):
+                hc = torch.randn(1, 80, frames, device=dev)
+                m.infer(hc, 0.6)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                xs = m.infer(hc, 0.6)
+                torch.cuda.synchronize()
+                res["waveflow"]["inverse_khz_%d" % xs.numel()] = xs.numel() / (time.perf_counter() - t1) / 1000.0
         del m
     except Exception as e:                                    # noqa: BLE001
         res["waveflow"] = {"error": repr(e)}
@@ -133,14 +189,14 @@ def other_models(dev):
         x = torch.rand(12, 8192, device=dev) * 2 - 1
         c = (torch.rand(12, 4096, device=dev) * 2 - 1) * 0.9
 
-        def step():
-            m.zero_grad(set_to_none=True)
-            m._engine.packed.key = None            # as in training, where the weights change: re-pack every step
-            z, ld = m(x, c.clone())
-            crit(z, ld).backward()
-        dt = timed(step)
-        res["wsrglow"] = {"workload": "WSRGlow 2x, batch 12 x 8192, fwd+NLL+bwd", "ms_per_step": dt * 1e3, "samples_per_s": 12 * 8192 / dt}
-        del m
+        from constant_memory_waveglow_amd.parallel import FlowTrainer
+        trw = FlowTrainer(m, 1.0)                  # the bucketed trainer (per-flow gradient buckets + the embedding-table bucket), re-packs every step
+        dt = timed(lambda: trw.step(x, c.clone())[0])
+        gfin = bool(torch.isfinite(trw.fg.flat).all())
+        res["wsrglow"] = {"workload": "WSRGlow 2x, batch 12 x 8192, fwd+NLL+bwd (FlowTrainer)", "ms_per_step": dt * 1e3,
+                          "samples_per_s": 12 * 8192 / dt, "loss": checked(last["loss"]), "grads_finite": gfin,
+                          "logged": trw.metrics_dict()}
+        del m, trw
     except Exception as e:                                    # noqa: BLE001
         res["wsrglow"] = {"error": repr(e)}
     try:
@@ -153,8 +209,9 @@ def other_models(dev):
         tr = FlowTrainer(m, SIGMA)
         x = torch.rand(24, SEG, device=dev) * 2 - 1
         h = torch.randn(24, C2["n_mels"], FRAMES, device=dev)
-        dt = timed(lambda: tr.step(x, h))
+        dt = timed(lambda: tr.step(x, h)[0])
         res["waveglow_memory_efficient_false"] = {
+            "loss": checked(last["loss"]),
             "workload": "WaveGlow 256ch 12 flows (waveglow_LJ_speech_fast.json), batch 24 x 16000, fwd+NLL+bwd from stored activations",
             "ms_per_step": dt * 1e3, "samples_per_s": 24 * SEG / dt,
             "workspace_gb": sum(b.numel() for b in m._engine.buffers._ws.values()) / 1e9}
@@ -163,6 +220,48 @@ def other_models(dev):
         res["waveglow_memory_efficient_false"] = {"error": repr(e)}
     torch.cuda.empty_cache()
     return res
+
+
+def f32_mode(dev, x, h):
+    """The same step with the contractions on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32; WG_PRECISION=f32): the number that needs no
+    argument about operand splitting, next to the bf16x3 headline.  1 warm-up + 2 timed steps; the gate kernel against the fp32 roof."""
+    from constant_memory_waveglow_amd import _lib
+    from constant_memory_waveglow_amd.parallel import FlowTrainer
+    old = os.environ.get("WG_PRECISION")
+    os.environ["WG_PRECISION"] = "f32"
+    try:
+        model = build_model(dev)
+        tr = FlowTrainer(model, SIGMA)
+        L = _lib.lib()
+        tr.step(x, h)
+        torch.cuda.synchronize()
+        steps = 2
+        timer = L.wg_timer_create(_lib.K_CONV_GATE, 2 * C2["flows"] * C2["depth"] * steps)
+        L.wg_timer_attach(timer)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss, _, _ = tr.step(x, h)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        L.wg_timer_attach(None)
+        n = L.wg_timer_count(timer)
+        buf = (C.c_float * n)()
+        L.wg_timer_read(timer, buf, n)
+        L.wg_timer_destroy(timer)
+        gate_ms = float(np.mean(np.frombuffer(buf, dtype=np.float32)))
+        B = x.shape[0]
+        gate_flop = 2.0 * (C2["radix"] * C2["residual_channels"] + C2["n_mels"]) * 2 * C2["dilation_channels"] * B * (SEG // C2["n_group"])
+        ach = gate_flop / (gate_ms * 1e-3) / 1e12
+        return {"dtype": "f32 (v_mfma_f32_32x32x2_f32, bit-exact fp32 fma chains)", "ms_per_step": dt * 1e3, "value": B * SEG / dt,
+                "loss": float(loss), "steps": steps,
+                "roofline": {"kernel": "convgemm_kernel<EPI_GATE>", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": ach / FP32_MFMA_PEAK_TFLOPS, "launch_ms": gate_ms}}
+    finally:
+        if old is None:
+            os.environ.pop("WG_PRECISION", None)
+        else:
+            os.environ["WG_PRECISION"] = old
+        torch.cuda.empty_cache()
 
 
 def main():
@@ -244,6 +343,11 @@ def main():
         # bf16x3: every fp32 product costs three bf16 MFMAs; the roofline is the bf16 matrix pipe and only the
         # algorithmic FLOPs are credited (the 3x is overhead, not work) -- SURVEY.md 8d
         peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+        traffic, traffic_src = _traffic(kname + ("<1, 4>" if kname == "convgemm16_kernel" else "<1, 2>" if kname == "convgemm16w_kernel" else "<1>"))
+        if traffic is None:
+            traffic, traffic_src = _traffic(kname + "<1>")
+        if traffic_src:
+            traffic_src += " (committed rocprofv3 --pmc summary of this command; not re-measured in this run)"
         out = {
             "metric": "audio samples/sec (fwd+bwd) WaveGlow-256ch seg=16000",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -254,13 +358,14 @@ def main():
                        "global_batch": B * world, "segment": SEG, "parallelism": "dp%d" % world},
             "roofline": {"bound": "mfma", "kernel": "%s<EPI_GATE%s> (dilated k=3 conv + mel conditioning + gate)" % (kname, ", 2" if kname == "convgemm16w_kernel" else ""),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": _traffic(kname + ("<1, 4>" if kname == "convgemm16_kernel" else "<1, 2>" if kname == "convgemm16w_kernel" else "<1>")) or _traffic(kname + "<1>"),
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": gate_ms, "launches_timed": n, "flop_per_launch": gate_flop,
                          "mfma_tflops_issued": achieved * (3 if split else 1),
                          "x_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS},
             "step_tflops_algorithmic": value * STEP_FLOP_PER_SAMPLE / 1e12 / world,
             "step_frac_of_fp32_mfma_peak": value * STEP_FLOP_PER_SAMPLE / 1e12 / world / FP32_MFMA_PEAK_TFLOPS,
             "loss": float(loss),
+            "logged": trainer.metrics_dict(),          # the scalars LightModel.training_step logs (lightning.py:58-64), rank-mean
         }
         if not args.no_inverse:
             with torch.no_grad():
@@ -287,6 +392,7 @@ def main():
             torch.cuda.synchronize()
             out["adam_step_ms"] = (time.perf_counter() - t1) / 5 * 1e3
         if world == 1 and not args.no_extra:
+            out["f32_mode"] = f32_mode(dev, x, h)
             out["other_models"] = other_models(dev)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()

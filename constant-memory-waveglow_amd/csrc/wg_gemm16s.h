@@ -36,6 +36,21 @@ __device__ __forceinline__ void s_store4(const SRef &r, const Geo &g, int b, int
     *reinterpret_cast<u32x2 *>(r.hi + r.lo_off + i) = l;
 }
 
+// Two 8-byte half units -> one 16-byte unit per lane.  In the MFMA accumulator layout lanes l and l + 32 own channels 4h .. 4h+3
+// (h = 0 / 1) of the same time step, i.e. the two halves of ONE S-plane unit, so a direct store is 8 bytes per lane.  Given the
+// packed halves of two channel groups q0 (v0) and q1 (v1), v_permlane32_swap exchanges the upper half-wave of one register with the
+// lower half-wave of the other: afterwards lanes < 32 hold the whole unit of group q0 and lanes >= 32 the whole unit of group q1,
+// and the wave stores 2 x 512 contiguous bytes with one dwordx4 per lane instead of two dwordx2 (half the store instructions).
+// Must be executed by ALL lanes (no divergence around it); predicate only the store.
+__device__ __forceinline__ u32x4 pair_units(const u32x2 &v0, const u32x2 &v1)
+{
+    const u32x2 a = __builtin_amdgcn_permlane32_swap(v0[0], v1[0], false, false);
+    const u32x2 b = __builtin_amdgcn_permlane32_swap(v0[1], v1[1], false, false);
+    u32x4 r;
+    r[0] = a[0]; r[1] = b[0]; r[2] = a[1]; r[3] = b[1];
+    return r;
+}
+
 // fp32 plane channels [ch0, ch0+nvalid) -> S-plane channels [0, Cp_dst) (zero filled beyond nvalid)
 __global__ void to_splane_kernel(PRef src, int nvalid, SRef dst, Geo g)
 {
@@ -116,6 +131,55 @@ __device__ __forceinline__ void conv_epilogue_s(const ConvGemmArgs &a, const SRe
         const unsigned lane_off = (unsigned)(4 * h) * (unsigned)g.P + tl;
         const unsigned s_lane = tl * 8u + (unsigned)(4 * h);              // element offset inside the unit row
         const unsigned s_grp = (unsigned)g.P * 8u;                        // next channel group
+#if defined(WG_OPT_SWAP_STORE)
+        if (2 * chb >= a.M) return;                          // (2 Cd is a multiple of 64: a wave's 32 gate channels are all valid or none)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int t = t0 + wc * (32 * NI) + ni * 32 + col;
+            const bool tok = t < g.T;
+#pragma unroll
+            for (int qq = 0; qq < 4; qq += 2) {
+                float tw[8], sf[8], gv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    tw[i] = wg_tanh(acc[0][ni][4 * qq + i]);
+                    sf[i] = wg_sigmoid(acc[1][ni][4 * qq + i]);
+                    gv[i] = tw[i] * sf[i];
+                }
+                if (tok) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const unsigned off = lane_off + (unsigned)(8 * (qq + u)) * (unsigned)g.P + (unsigned)(ni * 32);
+                        if (b0) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) b0[off + (unsigned)e * (unsigned)g.P] = gv[4 * u + e];
+                        }
+                        if (b1) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                b1[off + (unsigned)e * (unsigned)g.P] = tw[4 * u + e];
+                                b2[off + (unsigned)e * (unsigned)g.P] = sf[4 * u + e];
+                            }
+                        }
+                    }
+                }
+                // S-plane: the halves of groups qq and qq + 1 paired into whole 16-byte units (all lanes take part in the swap)
+                u32x2 h0, l0, h1, l1;
+                unsigned hh, ll;
+                split2(gv[0], gv[1], hh, ll); h0[0] = hh; l0[0] = ll;
+                split2(gv[2], gv[3], hh, ll); h0[1] = hh; l0[1] = ll;
+                split2(gv[4], gv[5], hh, ll); h1[0] = hh; l1[0] = ll;
+                split2(gv[6], gv[7], hh, ll); h1[1] = hh; l1[1] = ll;
+                const u32x4 uh = pair_units(h0, h1), ul = pair_units(l0, l1);
+                if (tok) {
+                    const unsigned so = tl * 8u + (unsigned)(qq + h) * s_grp + (unsigned)(ni * 32 * 8);
+                    *reinterpret_cast<u32x4 *>(sh + so) = uh;
+                    *reinterpret_cast<u32x4 *>(sl + so) = ul;
+                }
+                __builtin_amdgcn_sched_barrier(0);           // eight outputs at a time: keeps the epilogue inside 128 VGPRs
+            }
+        }
+#else
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int t = t0 + wc * (32 * NI) + ni * 32 + col;
@@ -160,6 +224,7 @@ __device__ __forceinline__ void conv_epilogue_s(const ConvGemmArgs &a, const SRe
                 __builtin_amdgcn_sched_barrier(0);           // eight outputs at a time: keeps the epilogue inside 128 VGPRs
             }
         }
+#endif
         return;
     }
     // ---- phase 1: loads ----
@@ -595,6 +660,17 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
         int cur_seg = 0, cur_c = 0, chunk = 0;                // position inside the current tile
         int gchunk = 0, tk = 0, t0, m0, b;                    // position in the stream; tile being loaded
         tile_at(0, t0, m0, b);
+#if defined(WG_OPT_ROT)
+        // Every tile's K loop starts at a workgroup-dependent chunk and wraps around: the 64 workgroups of an XCD would otherwise
+        // sweep the SAME weight-image lines in step (every workgroup reads chunk c of the A image at about the same time).
+        const int rot = (int)(((unsigned)blockIdx.x >> 3) * 5u % (unsigned)nchunks);
+        int rot_seg = 0, rot_c = 0, cnt = 0;
+        for (int i = 0; i < rot; ++i) {
+            rot_c += WG16_BK;
+            if (rot_c >= a.seg[rot_seg].nch) { rot_c = 0; ++rot_seg; }
+        }
+        cur_seg = rot_seg; cur_c = rot_c; chunk = rot;
+#endif
         const unsigned voff_a = (unsigned)lt * 16u;
         const int a_off0 = wg16_a_off(lt);                    // consecutive lanes -> consecutive 80-byte LDS rows: conflict-free staging
         const unsigned voff_b = (unsigned)((cg0 * g.P + bt) * 16);
@@ -621,11 +697,20 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
                 rowok = r >= 0 && r < g.rows;
                 bsrc = ss.per_item ? item : b + ss.row_off;
             }
+#if defined(WG_DBG_HALFB)      // timing experiment only (garbage results): the second half of every B chunk is not fetched (-25 % operand bytes)
+            const bool blive = live && rowok, full = false;
+#else
             const bool blive = live && rowok, full = blive && (nch - cur_c > 16);
+#endif
             const unsigned short *ih = aa.img + ((size_t)chunk * a.lda + m0) * WG16_BK, *il = ih + aa.img_stride;
             const unsigned short *row0 = ss.hi + ((size_t)bsrc * (ss.Cp >> 3) + ((ss.ch0 + cur_c) >> 3)) * g.P * 8;   // p = 0: zero halo
+#if defined(WG_DBG_HALFA)      // timing experiment only (garbage results): half of every A chunk is not fetched (-25 % operand bytes)
+            const unsigned short *pa0 = live ? ih : zsrc, *pa1 = zsrc;
+            const unsigned short *pl0 = live ? il : zsrc, *pl1 = zsrc;
+#else
             const unsigned short *pa0 = live ? ih : zsrc, *pa1 = live ? ih + 2048 : zsrc;
             const unsigned short *pl0 = live ? il : zsrc, *pl1 = live ? il + 2048 : zsrc;
+#endif
             const unsigned va = live ? voff_a : 0u;
             WG_LD(st.ah[0], pa0, va);   WG_LD(st.ah[1], pa1, va);
             WG_LD(st.al[0], pl0, va);   WG_LD(st.al[1], pl1, va);
@@ -650,11 +735,20 @@ __global__ __launch_bounds__(512) void convgemm16w_kernel(const ConvGemm16sArgs 
                 ++chunk;
                 cur_c += WG16_BK;
                 if (cur_c >= nch) { cur_c = 0; ++cur_seg; }
+#if defined(WG_OPT_ROT)
+                if (chunk == nchunks) { chunk = 0; cur_seg = 0; cur_c = 0; }     // wrap around inside the tile
+                if (++cnt == nchunks) {                       // next tile of this workgroup: back to the rotated start
+                    cnt = 0; chunk = rot; cur_seg = rot_seg; cur_c = rot_c;
+                    tk = min(tk + 1, mine - 1);
+                    tile_at(tk, t0, m0, b);
+                }
+#else
                 if (chunk == nchunks) {                       // next tile of this workgroup (past the last one: never loaded from)
                     chunk = 0; cur_seg = 0; cur_c = 0;
                     tk = min(tk + 1, mine - 1);
                     tile_at(tk, t0, m0, b);
                 }
+#endif
             }
         };
 #undef WG_LD

@@ -260,7 +260,7 @@ class FlatAdam:
         live = [t for t in trainer.table if t is not None]
         if not live[0].is_cuda:
             raise _lib.WgError("FlatAdam runs on the HIP device only (no CPU fallback)")
-        self.flat = torch.empty_like(fg.flat)
+        self.flat = torch.zeros_like(fg.flat)                # (zeros: the alignment padding and the metric tail are not parameters)
         for t, o, n in zip(live, fg.offsets, fg.sizes):
             view = self.flat[o:o + n].view_as(t)
             view.copy_(t.data)

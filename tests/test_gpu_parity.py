@@ -843,7 +843,10 @@ def test_wsrglow_full_size_properties(dev, precision):
     tr = FlowTrainer(m, 1.0)
     tr.step(x, c.clone())
     for n, p in m.named_parameters():
-        assert torch.equal(p.grad, g_full[n]), n
+        if n in ("mu_enc.1.weight", "angle_embed.embed.weight"):       # LDS float atomics: equal to rounding, not bit for bit
+            assert float((p.grad - g_full[n]).abs().max()) <= 1e-5 * float(g_full[n].abs().max()), n
+        else:
+            assert torch.equal(p.grad, g_full[n]), n
 
 
 def test_waveflow_shipped_width_vs_oracle(dev, precision):

@@ -180,15 +180,24 @@ def test_wsrglow_trainer_matches_autograd(dev, one_rank_rccl, name):
     loss, z2, ld2 = tr.step(x, ct)
     assert float(ct.abs().max()) <= 1.0                                  # clipped in place, as upstream (wsrglow.py:38)
     assert torch.equal(z, z2) and torch.equal(logdet, ld2)
+    tables = ("mu_enc.1.weight", "angle_embed.embed.weight")
     for n, p in m.named_parameters():
-        assert torch.equal(ga[n], p.grad), n
+        if n in tables:
+            # embedding-table gradients are scatter-adds through LDS float atomics: the summation order inside a slice is not fixed
+            # (like torch's own CUDA embedding backward), so they repeat to rounding, not bit for bit
+            assert float((ga[n] - p.grad).abs().max()) <= 1e-5 * float(ga[n].abs().max()), n
+        else:
+            assert torch.equal(ga[n], p.grad), n
     m1, _ = build_wsr(name, dev)
     coll = FlowTrainer(m1, 1.0, force_collectives=True)
     assert len(coll.events) == cfg["flows"] + 2
     for _ in range(2):
         l1, z1, _ = coll.step(x, T(c, dev))
         torch.cuda.synchronize()
-    assert torch.equal(z1, z) and torch.equal(coll.fg.flat, tr.fg.flat)
+    assert torch.equal(z1, z)
+    lo, hi = tr.fg.bucket_ranges[cfg["flows"] + 1]                       # the embedding-table bucket: equal to rounding (see above)
+    assert torch.equal(coll.fg.flat[:lo], tr.fg.flat[:lo]) and torch.equal(coll.fg.tail, tr.fg.tail)
+    assert float((coll.fg.flat[lo:hi] - tr.fg.flat[lo:hi]).abs().max()) <= 1e-5 * float(tr.fg.flat[lo:hi].abs().max())
 
 
 def test_frozen_weight_v_still_gets_weight_g_gradient(dev):

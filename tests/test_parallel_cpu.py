@@ -25,6 +25,13 @@ def test_flat_grads_layout():
     assert [v.shape for v in fg.views] == [p.shape for p in params]
     ids = waveglow_buckets(12, 8)
     assert len(ids) == 459 and ids[:3] == [12] * 3 and ids[3:15] == list(range(12)) and ids[15] == 0 and ids[-1] == 11
+    assert waveglow_buckets(12, 8, extra=2)[-2:] == [13, 13]                     # WSRGlow's embedding tables: their own bucket
+    # the metric tail rides in the LAST bucket's collective and in no parameter range
+    fg = FlatGrads(params, [1, 0, 1, 2], tail=4)
+    assert fg.bucket_ranges == [(0, 4), (4, 12), (12, 13)] and fg.tail_off == 16 and fg.flat.numel() == 20 and fg.tail.numel() == 4
+    assert fg.comm_slice(0).numel() == 4 and fg.comm_slice(2).numel() == 20 - 12 and fg.bucket(2).numel() == 1
+    fg.tail.fill_(3.0)
+    assert float(fg.comm_slice(2).sum()) == 12.0 and float(fg.bucket(2).sum()) == 0.0
 
 
 def _free_port():
@@ -49,9 +56,13 @@ def _worker(rank, world, port, q):
     mine = slice(2 * rank, 2 * rank + 2)
     r = orc.train_step(oc, tab, audio[mine], h[mine], fill.SIGMA)
     params = [torch.from_numpy(p) for p in tab]
-    fg = FlatGrads(params, waveglow_buckets(cfg["flows"], cfg["depth"]))
+    fg = FlatGrads(params, waveglow_buckets(cfg["flows"], cfg["depth"]), tail=4)
     for v, g in zip(fg.views, r["grads"]):
         v.copy_(torch.from_numpy(g))
+    # the four scalars the reference logs with sync_dist=True (model/lightning.py:58-64), this rank's values, in the tail
+    zt, ldt = torch.from_numpy(r["z"]), torch.from_numpy(r["logdet"])
+    mine_metrics = torch.tensor([float(ldt.sum() / zt.numel()), float(zt.mean()), float(zt.std()), r["loss"]])
+    fg.tail.copy_(mine_metrics)
     sync = GradSync()
     # after_bucket is where FlatAdam hangs the optimizer step: it must see each bucket already averaged, in the order given
     seen = []
@@ -60,6 +71,10 @@ def _worker(rank, world, port, q):
     sync.all_reduce(fg, order=order, after_bucket=lambda b: seen.append((b, float((fg.bucket(b) - half[b]).abs().max()))))
     assert [b for b, _ in seen] == order, seen
     assert any(d > 0 for _, d in seen)                                  # the buckets had been reduced when the callback ran
+    # the 4-float metric vector came out as the mean over the ranks (what Lightning's sync_dist does with each logged scalar)
+    both = [torch.zeros(4), torch.zeros(4)]
+    dist.all_gather(both, mine_metrics)
+    assert torch.allclose(fg.tail, (both[0] + both[1]) / 2, rtol=1e-6, atol=1e-7), (fg.tail, both)
     # autograd-trained models (WSRGlow, WaveFlow): one coalesced mean all-reduce of p.grad
     ps = [torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(2, 3)), torch.nn.Parameter(torch.zeros(1))]
     ps[0].grad = torch.full((5,), float(rank + 1))
@@ -73,6 +88,10 @@ def _worker(rank, world, port, q):
     if rank == 0:
         full = orc.train_step(oc, tab, audio, h, fill.SIGMA)
         worst = max(float(np.abs(v.numpy() - g).max() / max(np.abs(g).max(), 1e-30)) for v, g in zip(fg.views, full["grads"]))
+        # equal per-rank batches: the rank-mean of logdet/numel, z.mean and the loss IS the global-batch value
+        zf, lf = torch.from_numpy(full["z"]), torch.from_numpy(full["logdet"])
+        assert abs(float(fg.tail[0]) - float(lf.sum() / zf.numel())) < 1e-6 and abs(float(fg.tail[1]) - float(zf.mean())) < 1e-6
+        assert abs(float(fg.tail[3]) - full["loss"]) < 1e-6
         q.put((worst, float(probe[0][0])))
     else:
         q.put((None, float(probe[0][0])))

@@ -63,6 +63,9 @@ def main():
         L.wg_timer_read(t, buf, n)
         L.wg_timer_destroy(t)
         ms = np.frombuffer(buf, dtype=np.float32).copy()
+        if ms.size == 0:
+            print("%-13s no launches" % name)
+            continue
         big = ms[ms > 0.5 * ms.max()]
         print("%-13s launches/iter %3d  total %.3f ms/iter  big-instance avg %.4f ms (n=%d) -> %.1f TF" % (
             name, n // a.iters, ms.sum() / a.iters, big.mean(), big.size, flops[name] / (big.mean() * 1e-3) / 1e12))
