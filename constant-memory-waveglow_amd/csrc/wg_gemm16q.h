@@ -1,0 +1,409 @@
+// wg_gemm16q.h -- the wave-specialised conv kernel on v_mfma_f32_16x16x32_bf16 ("q": a lane owns a quad of 4 rows per 16x16 block).
+//
+// Why another MFMA shape.  The conv kernels do not run at the clock the roofline assumes: stamped with s_memtime / s_memrealtime
+// (-DWG_DBG_TRACE) the main loop of the gate conv holds 1.34-1.42 GHz on random data -- the chip's power management, not the issue
+// stream, sets the rate of the matrix pipe.  On this chip the 16x16x32 shape does the same FLOPs per cycle for less energy:
+// tools/experiments/shape_probe.hip (a compute wave's chunk loop alone: 64x64 tile per wave, all fragments re-read from LDS, three
+// products per fragment pair, random data, 8 waves per CU) measured 2052-2074 TFLOP/s at 2.04-2.09 GHz against 1850 TFLOP/s at
+// 1.85 GHz for 32x32x16 -- +11 % for the same cycles per FLOP (MI355X_MICROARCH.md, "DVFS give-back" item 7).
+//
+// What changes against convgemm16w (wg_gemm16s.h), whose workgroup structure, loader waves, barrier protocol and persistent tile
+// walk are kept:
+//   * LDS images are UNPADDED 64-byte rows [row][32 k]; the 16-byte unit of k-group q of row r sits at position q ^ F(r),
+//     F(r) = {0,2,3,1}[(r >> 1) & 3].  With that one swizzle both access patterns are bank-conflict free (searched exhaustively,
+//     tools/experiments/lds_layout_search.py): the 16x16x32 fragment read (lane l: row l & 15, k-group l >> 4) and the loaders'
+//     lane-linear staging write (consecutive lanes -> consecutive rows of one k-group).  64 KB of LDS per workgroup instead of 80.
+//   * a chunk (32 k) is ONE k-step of 12 NB MFMAs (NB = column blocks of 16 per wave), issued as NB groups: group nb multiplies the
+//     four row blocks by column block nb.  Registers: all four A fragments of the chunk (hi, lo: 32 VGPRs) stay resident, B is
+//     double-buffered one group ahead (16 VGPRs), 64 accumulators: 112.  The chunk's barrier sits in front of its LAST group: by then
+//     every fragment of the chunk is in registers (the loaders may refill the buffer) and the next chunk has been staged; the last
+//     group reloads each A fragment from the next buffer as soon as its MFMAs are issued and fetches the next chunk's first B.
+//   * accumulator layout: block (mb, nb) of a wave's 64 x 32 NI tile: rows mb*16 + 4*(lane >> 4) + e (e = register 0..3), column
+//     nb*16 + (lane & 15).  A lane still owns 4 consecutive channels of one time step, so S-plane stores are unchanged in kind
+//     (8 bytes per lane, 2 x 256 contiguous bytes per wave instruction).
+#pragma once
+#include "wg_gemm16s.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define WG16Q_ROWB 64                                     // bytes per LDS row: 32 bf16, no padding
+__device__ __forceinline__ int wg16q_swz(int row) { return (0x1320 >> (4 * ((row >> 1) & 3))) & 3; }     // F(row): nibbles 0,2,3,1
+// byte offset of the unit of k-group kg of image row `row`
+__device__ __forceinline__ int wg16q_off(int row, int kg) { return row * WG16Q_ROWB + ((kg ^ wg16q_swz(row)) << 4); }
+
+// ------------------------------------------------------------------------------------------------
+// epilogues in the 16x16 accumulator layout (same contracts as conv_acc_init / conv_epilogue_s)
+// ------------------------------------------------------------------------------------------------
+template <int EPI, int NI>
+__device__ __forceinline__ void conv_acc_init_q(const ConvGemmArgs &a, f32x4 (&acc)[4][2 * NI], int t0, int m0, int b, int wr, int wc, int lane)
+{
+    const Geo g = a.g;
+    const int col = lane & 15, rq = lane >> 4;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const int mbase = m0 + wr * 64 + mb * 16;                                 // first row of this 16-row block (wave uniform)
+        const float *base = nullptr;
+        if (EPI == EPI_STORE) base = a.aux0.p ? paddr(a.aux0, g, b, mbase, t0) : nullptr;
+        else if (EPI == EPI_RESSKIP)                                              // nsplit is a multiple of 32: a block lies on one side
+            base = mbase < a.nsplit ? paddr(a.aux0, g, b, mbase, t0) : (a.accumulate ? paddr(a.out1, g, b, mbase - a.nsplit, t0) : nullptr);
+#pragma unroll
+        for (int nb = 0; nb < 2 * NI; ++nb) {
+            const int tl = wc * (32 * NI) + nb * 16 + col;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned off = (unsigned)(4 * rq + e) * (unsigned)g.P + (unsigned)tl;
+                float x = 0.f;
+                if (t0 + tl < g.T && mbase + 4 * rq + e < a.M && base) x = base[off];
+                acc[mb][nb][e] = x;
+            }
+        }
+    }
+}
+
+template <int EPI, int NI>
+__device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRef &s0, f32x4 (&acc)[4][2 * NI], int t0, int m0, int b,
+                                                int wr, int wc, int lane)
+{
+    const Geo g = a.g;
+    const int col = lane & 15, rq = lane >> 4;
+    constexpr int NB = 2 * NI;
+    if (EPI == EPI_GATE) {
+        // rows 0-31 of the wave tile are the tanh halves, rows 32-63 the sigmoid halves of the same 32 gate channels (pack_kernel's
+        // 64-row interleave): channel chb + mbp*16 + 4 rq + e pairs acc[mbp] with acc[mbp + 2]
+        const int chb = (m0 >> 1) + wr * 32;
+        if (2 * chb >= a.M) return;                              // (2 Cd is a multiple of 64: a wave's 32 gate channels are all valid or none)
+        float *b0 = a.out0.p ? paddr(a.out0, g, b, chb, t0) : nullptr;
+        float *b1 = a.out1.p ? paddr(a.out1, g, b, chb, t0) : nullptr;
+        float *b2 = a.out1.p ? paddr(a.out2, g, b, chb, t0) : nullptr;
+        unsigned short *sh = s0.hi + s_index(s0, g, b, chb, t0);
+        unsigned short *sl = sh + s0.lo_off;
+        const unsigned s_grp = (unsigned)g.P * 8u;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const unsigned tl = (unsigned)(wc * (32 * NI) + nb * 16 + col);
+            if (t0 + (int)tl >= g.T) continue;
+            float tw[8], sf[8], gv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                tw[i] = wg_tanh(acc[i >> 2][nb][i & 3]);
+                sf[i] = wg_sigmoid(acc[2 + (i >> 2)][nb][i & 3]);
+                gv[i] = tw[i] * sf[i];
+            }
+#pragma unroll
+            for (int mbp = 0; mbp < 2; ++mbp) {
+                const unsigned off = (unsigned)(mbp * 16 + 4 * rq) * (unsigned)g.P + tl;
+                if (b0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b0[off + (unsigned)e * (unsigned)g.P] = gv[4 * mbp + e];
+                }
+                if (b1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        b1[off + (unsigned)e * (unsigned)g.P] = tw[4 * mbp + e];
+                        b2[off + (unsigned)e * (unsigned)g.P] = sf[4 * mbp + e];
+                    }
+                }
+                u32x2 vh, vl;
+                unsigned hh, ll;
+                split2(gv[4 * mbp], gv[4 * mbp + 1], hh, ll); vh[0] = hh; vl[0] = ll;
+                split2(gv[4 * mbp + 2], gv[4 * mbp + 3], hh, ll); vh[1] = hh; vl[1] = ll;
+                const unsigned so = (unsigned)(2 * mbp + (rq >> 1)) * s_grp + tl * 8u + (unsigned)(4 * (rq & 1));
+                *reinterpret_cast<u32x2 *>(sh + so) = vh;
+                *reinterpret_cast<u32x2 *>(sl + so) = vl;
+            }
+            __builtin_amdgcn_sched_barrier(0);                   // eight outputs at a time
+        }
+        return;
+    }
+    if (EPI == EPI_DGATE) {
+        // all auxiliary loads (tanh / sigmoid of the forward gate) first, then combine and store: the launch is bound by these bytes
+        f32x4 ax[4][NB], ay[4][NB];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const int mbase = m0 + wr * 64 + mb * 16;
+            const float *p0 = paddr(a.aux0, g, b, mbase, t0), *p1 = paddr(a.aux1, g, b, mbase, t0);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int tl = wc * (32 * NI) + nb * 16 + col;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned off = (unsigned)(4 * rq + e) * (unsigned)g.P + (unsigned)tl;
+                    float x = 0.f, y = 0.f;
+                    if (t0 + tl < g.T && mbase + 4 * rq + e < a.M) { x = p0[off]; y = p1[off]; }
+                    ax[mb][nb][e] = x; ay[mb][nb][e] = y;
+                }
+            }
+        }
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int t = t0 + wc * (32 * NI) + nb * 16 + col, m = m0 + wr * 64 + mb * 16 + 4 * rq;
+                if (t >= g.T || m >= a.M) continue;
+                float o[4], o2[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[mb][nb][e], tw = ax[mb][nb][e], sf = ay[mb][nb][e];
+                    o[e] = v * sf * (1.0f - tw * tw);
+                    o2[e] = v * tw * sf * (1.0f - sf);
+                    if (a.out0.p) {
+                        *paddr(a.out0, g, b, m + e, t) = o[e];
+                        *paddr(a.out0, g, b, a.nsplit + m + e, t) = o2[e];
+                    }
+                }
+                s_store4(s0, g, b, m, t, o);
+                s_store4(s0, g, b, a.nsplit + m, t, o2);
+            }
+        return;
+    }
+    // EPI_STORE / EPI_RESSKIP: the auxiliary values were the accumulators' initial value (conv_acc_init_q): stores only
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const int mbase = m0 + wr * 64 + mb * 16;
+        if (mbase >= a.M) continue;
+        const bool res = EPI == EPI_STORE || mbase < a.nsplit;                    // RESSKIP: rows below nsplit -> out0 (+ S), the rest -> out1
+        const PRef &dst = res ? a.out0 : a.out1;
+        float *base = dst.p ? paddr(dst, g, b, res ? mbase : mbase - a.nsplit, t0) : nullptr;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int tl = wc * (32 * NI) + nb * 16 + col, t = t0 + tl, m = mbase + 4 * rq;
+            if (t >= g.T || m >= a.M) continue;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = acc[mb][nb][e];
+                if (base && m + e < a.M) base[(unsigned)(4 * rq + e) * (unsigned)g.P + (unsigned)tl] = o[e];
+            }
+            if (res && s0.hi) s_store4(s0, g, b, m, t, o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the kernel: 8 waves, waves 0-3 multiply, waves 4-7 move operands (see convgemm16w_kernel for the protocol)
+// ------------------------------------------------------------------------------------------------
+#if defined(WG_DBG_TRACE)
+#define WGQ_TRACE(slot) do { if (EPI == EPI_GATE && NI == 2 && lane == 0 && wave == 0 && (slot) < 16) { \
+        wg_dbg_trace[blockIdx.x * 16 + (slot)] = wall_clock64(); wg_dbg_trace_cyc[blockIdx.x * 16 + (slot)] = clock64(); } } while (0)
+#else
+#define WGQ_TRACE(slot) do { } while (0)
+#endif
+template <int EPI, int NI>
+__global__ __launch_bounds__(512) void convgemm16q_kernel(const ConvGemm16sArgs aa)
+{
+    typedef typename StageOf<NI>::type Stage;
+    constexpr int AIMG = 128 * WG16Q_ROWB;                    // 128 rows x 64 B
+    constexpr int BIMG = 64 * NI * WG16Q_ROWB;
+    constexpr int BUF = 2 * AIMG + 2 * BIMG;
+    constexpr int TT = 64 * NI;                               // columns per tile
+    constexpr int NB = 2 * NI;                                // 16-column blocks per wave
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+    const ConvGemmArgs &a = aa.c;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const Geo g = a.g;
+    int nchunks = 0;
+    for (int s = 0; s < a.nseg; ++s) nchunks += (a.seg[s].nch + WG16_BK - 1) / WG16_BK;
+    constexpr bool PERSIST = EPI != EPI_DGATE;                // (the gate backward keeps one workgroup per tile: see convgemm16w_kernel)
+    const int ntiles = aa.ntx * aa.nty * aa.ntz, G = (int)gridDim.x;
+    const int mine = PERSIST ? (ntiles - 1 - (int)blockIdx.x) / G + 1 : 1;
+    const int total = mine * nchunks;
+    auto tile_at = [&](int k, int &t0, int &m0, int &b) {
+        if constexpr (PERSIST) {
+            const int id = (int)blockIdx.x + k * G;
+            const int tx = id % aa.ntx, q = id / aa.ntx, ty = q % aa.nty, tz = q / aa.nty;
+            t0 = tx * TT; m0 = ty * WG_TILE;
+            b = a.row_sel1 ? tz * g.rows + a.row_sel1 - 1 : tz;
+        } else {
+            t0 = blockIdx.x * TT; m0 = blockIdx.y * WG_TILE;
+            b = a.row_sel1 ? (int)blockIdx.z * g.rows + a.row_sel1 - 1 : (int)blockIdx.z;
+        }
+    };
+
+    if (wave >= 4) {
+        // ------------------------------- loader waves (as convgemm16w_kernel; only the LDS destination differs) -------------------------------
+        const int lt = tid - 256;
+        const int bt = NI == 2 ? (lt & 127) : (lt & 63), cg0 = NI == 2 ? (lt >> 7) : (lt >> 6);     // B unit: position, k-group
+        int cur_seg = 0, cur_c = 0, chunk = 0;
+        int gchunk = 0, tk = 0, t0, m0, b;
+        tile_at(0, t0, m0, b);
+        const unsigned voff_a = (unsigned)lt * 16u;
+        const int arow = lt & 127, akg = lt >> 7;             // A piece lt + 256 j: row lt & 127, k-group (lt >> 7) + 2 j
+        const int a_off[2] = {wg16q_off(arow, akg), wg16q_off(arow, akg + 2)};
+        const int b_off[2] = {wg16q_off(bt, cg0), wg16q_off(bt, (cg0 + 2) & 3)};
+        const unsigned voff_b = (unsigned)((cg0 * g.P + bt) * 16);
+#if defined(WG_DBG_NOLOAD)
+#define WG_LD(dst, base, voff) asm volatile("" : "=v"(dst) : "v"(voff), "s"(base))
+#else
+#define WG_LD(dst, base, voff) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
+#endif
+        const unsigned short *zsrc = aa.sseg[0].hi;           // plane position 0 of the first operand: always-zero halo
+        auto issue = [&](Stage &st) {                         // exactly 4 + 2 NI loads in straight-line code (tools/check_asm_loads.py)
+            const bool live = gchunk < total;
+            const int sg = min(cur_seg, a.nseg - 1);
+            const int nch = a.seg[sg].nch, shift = a.seg[sg].shift;
+            const SSeg ss = aa.sseg[sg];
+            int bsrc = b;
+            bool rowok = true;
+            if (g.rows > 0) {
+                const int item = b / g.rows, r = b - item * g.rows + ss.row_off;
+                rowok = r >= 0 && r < g.rows;
+                bsrc = ss.per_item ? item : b + ss.row_off;
+            }
+            const bool blive = live && rowok, full = blive && (nch - cur_c > 16);
+            const unsigned short *ih = aa.img + ((size_t)chunk * a.lda + m0) * WG16_BK, *il = ih + aa.img_stride;
+            const unsigned short *row0 = ss.hi + ((size_t)bsrc * (ss.Cp >> 3) + ((ss.ch0 + cur_c) >> 3)) * g.P * 8;
+            const unsigned short *pa0 = live ? ih : zsrc, *pa1 = live ? ih + 2048 : zsrc;
+            const unsigned short *pl0 = live ? il : zsrc, *pl1 = live ? il + 2048 : zsrc;
+            const unsigned va = live ? voff_a : 0u;
+            WG_LD(st.ah[0], pa0, va);   WG_LD(st.ah[1], pa1, va);
+            WG_LD(st.al[0], pl0, va);   WG_LD(st.al[1], pl1, va);
+            if constexpr (NI == 2) {
+                const unsigned short *b0 = row0 + (size_t)(g.H + t0 + shift) * 8, *b0l = b0 + ss.lo_off;
+                const unsigned short *b1 = b0 + (size_t)2 * g.P * 8, *b1l = b1 + ss.lo_off;
+                const unsigned short *pb0 = blive ? b0 : zsrc, *pb0l = blive ? b0l : zsrc;
+                const unsigned short *pb1 = full ? b1 : zsrc, *pb1l = full ? b1l : zsrc;
+                const unsigned vb = blive ? voff_b : 0u, vb1 = full ? voff_b : 0u;
+                WG_LD(st.bh[0], pb0, vb);   WG_LD(st.bl[0], pb0l, vb);
+                WG_LD(st.bh[1], pb1, vb1);  WG_LD(st.bl[1], pb1l, vb1);
+            } else {
+                const unsigned short *pb = blive ? row0 : zsrc, *pbl = blive ? row0 + ss.lo_off : zsrc;
+                const bool lane_ok = blive && (cg0 < 2 || full);
+                const unsigned vb = lane_ok ? voff_b + (unsigned)((g.H + t0 + shift) * 16) : 0u;
+                WG_LD(st.bh[0], pb, vb);    WG_LD(st.bl[0], pbl, vb);
+            }
+            if (live) {
+                ++gchunk;
+                ++chunk;
+                cur_c += WG16_BK;
+                if (cur_c >= nch) { cur_c = 0; ++cur_seg; }
+                if (chunk == nchunks) {
+                    chunk = 0; cur_seg = 0; cur_c = 0;
+                    tk = min(tk + 1, mine - 1);
+                    tile_at(tk, t0, m0, b);
+                }
+            }
+        };
+#undef WG_LD
+        auto write = [&](const Stage &st, int buf) {
+            char *sb = smem + buf * BUF;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                *reinterpret_cast<u32x4 *>(sb + a_off[j]) = st.ah[j];
+                *reinterpret_cast<u32x4 *>(sb + AIMG + a_off[j]) = st.al[j];
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                *reinterpret_cast<u32x4 *>(sb + 2 * AIMG + b_off[j]) = st.bh[j];
+                *reinterpret_cast<u32x4 *>(sb + 2 * AIMG + BIMG + b_off[j]) = st.bl[j];
+            }
+        };
+        Stage s0, s1;
+        issue(s0);
+        issue(s1);
+        asm_wait_stage(s0);
+        write(s0, 0);
+        issue(s0);
+        WG16W_BAR();                                          // buffer 0 ready
+        auto iter = [&](Stage &st, int c) {
+            asm_wait_stage(st);
+            write(st, (c & 1) ^ 1);
+            issue(st);
+            WG16W_BAR();
+        };
+        for (int c = 0; c + 1 < total; c += 2) {              // always in pairs: see convgemm16w_kernel
+            iter(s1, c);
+            iter(s0, c + 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    // ------------------------------- compute waves -------------------------------
+    const int wr = wave >> 1, wc = wave & 1;
+    f32x4 acc[4][NB];
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int ao = wg16q_off(wr * 64 + r16, kg), bo = wg16q_off(wc * 32 * NI + r16, kg);      // + 16-row block * 1024
+#define WGQ_SB() __builtin_amdgcn_sched_barrier(0)
+    bf16x8 ah[4], al[4], bh[2], bl[2];
+    auto rd = [&](const char *q) { return *reinterpret_cast<const bf16x8 *>(q); };
+    int gc = 0;                                              // chunk index in this workgroup's stream; its buffer is gc & 1
+    auto do_tile = [&](int k) {
+        int t0, m0, b;
+        tile_at(k, t0, m0, b);
+        int ln = lane;
+        if (PERSIST) {
+            asm volatile("" : "+v"(ln)::"memory");
+            WGQ_SB();
+        }
+        if (EPI == EPI_STORE || EPI == EPI_RESSKIP) {
+            conv_acc_init_q<EPI, NI>(a, acc, t0, m0, b, wr, wc, ln);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[i][j][q] = 0.f;
+        }
+        if (k == 0) { WGQ_TRACE(0); WG16W_BAR(); WGQ_TRACE(1); }     // buffer 0 ready (later tiles: published by the previous chunk's barrier)
+        {
+            const char *pa = smem + (gc & 1) * BUF + ao, *pb = smem + (gc & 1) * BUF + 2 * AIMG + bo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { ah[i] = rd(pa + i * 1024); al[i] = rd(pa + AIMG + i * 1024); }
+            bh[0] = rd(pb); bl[0] = rd(pb + BIMG);
+        }
+#if defined(WG_DBG_NOMFMA)
+        for (int c = 0; c < nchunks; ++c, ++gc)
+            if (gc + 1 < total || !(total & 1)) WG16W_BAR();
+        if (false)
+#endif
+        for (int c = 0; c < nchunks; ++c, ++gc) {
+            const char *pb = smem + (gc & 1) * BUF + 2 * AIMG + bo;
+            const char *na = smem + ((gc & 1) ^ 1) * BUF + ao, *nb_ = smem + ((gc & 1) ^ 1) * BUF + 2 * AIMG + bo;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int cur = nb & 1, nxt = cur ^ 1;
+                if (nb == NB - 1) {
+                    // every fragment of this chunk is in registers (the B of this last group was requested a group ago): release the
+                    // buffer / publish the next one, then fetch the next chunk's first B under this group's MFMAs
+                    WGQ_SB();
+                    if (gc + 1 < total || !(total & 1)) WG16W_BAR();
+                    bh[nxt] = rd(nb_); bl[nxt] = rd(nb_ + BIMG);
+                } else {
+                    bh[nxt] = rd(pb + (nb + 1) * 1024); bl[nxt] = rd(pb + BIMG + (nb + 1) * 1024);
+                }
+                WGQ_SB();
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mb], bh[cur], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mb], bl[cur], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mb], bh[cur], acc[mb][nb], 0, 0, 0);
+                    if (nb == NB - 1) {
+                        // (unconditional: after a tile's last chunk these read LDS that nothing uses -- a branch here would make the
+                        // compiler drain every outstanding read at the join; the next tile starts with its own fetch)
+                        WGQ_SB();
+                        ah[mb] = rd(na + mb * 1024); al[mb] = rd(na + AIMG + mb * 1024);
+                        WGQ_SB();
+                    }
+                }
+                WGQ_SB();
+            }
+        }
+        WGQ_TRACE(2 + 2 * k);
+#if defined(WG_DBG_NOEPI)
+        if (acc[0][0][0] + acc[1][0][0] + acc[2][NB - 1][1] + acc[3][NB - 1][3] == 12345.f) a.out0.p[lane] = 1.f;
+#else
+        int le = lane;
+        if (PERSIST) asm volatile("" : "+v"(le)::"memory");
+        conv_epilogue_q<EPI, NI>(a, aa.s0, acc, t0, m0, b, wr, wc, le);
+#endif
+        WGQ_TRACE(3 + 2 * k);
+        if (PERSIST) WGQ_SB();
+    };
+    if constexpr (PERSIST) {
+        for (int k = 0; k < mine; ++k) do_tile(k);
+    } else {
+        do_tile(0);
+    }
+#undef WGQ_SB
+}

@@ -604,9 +604,10 @@ __device__ __forceinline__ void mfma_w(const FragsW<NI> &f, f32x16 (&acc)[2][NI]
 // per chunk and wave, one B unit per loader lane and image (6 loads per chunk).
 #if defined(WG_DBG_TRACE)      // phase timestamps of the gate conv (100 MHz wall clock): [workgroup][16] = start, first barrier, then per
                                // tile: main loop done, epilogue done.  Read back by wg_dbg_trace_read (tools/experiments/conv_trace.py).
-__device__ unsigned long long wg_dbg_trace[512 * 16];
-#define WG_TRACE(slot) do { if (EPI == EPI_GATE && NI == 2 && lane == 0 && wave == 0 && (slot) < 16) \
-        wg_dbg_trace[blockIdx.x * 16 + (slot)] = wall_clock64(); } while (0)
+__device__ unsigned long long wg_dbg_trace[512 * 16];       // 100 MHz wall clock
+__device__ unsigned long long wg_dbg_trace_cyc[512 * 16];   // shader cycles (s_memtime): cycles / wall = the clock the chip holds in the phase
+#define WG_TRACE(slot) do { if (EPI == EPI_GATE && NI == 2 && lane == 0 && wave == 0 && (slot) < 16) { \
+        wg_dbg_trace[blockIdx.x * 16 + (slot)] = wall_clock64(); wg_dbg_trace_cyc[blockIdx.x * 16 + (slot)] = clock64(); } } while (0)
 #else
 #define WG_TRACE(slot) do { } while (0)
 #endif

@@ -5,6 +5,7 @@
 #include "wg_small.h"
 #include "wg_gemm16.h"
 #include "wg_gemm16s.h"
+#include "wg_gemm16q.h"
 #include "wg_wsr.h"
 #include "wg_wf.h"
 #include "wg_mel.h"
@@ -623,6 +624,24 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
             slots = ntiles;
 #endif
             const dim3 gp = epi == EPI_DGATE ? dim3(as.ntx, as.nty, as.ntz) : dim3(std::min(ntiles, slots));
+#if !defined(WG_OPT_MFMA32)                       // default: the 16x16x32 form of the same kernel (wg_gemm16q.h)
+            if (small) {
+                switch (epi) {
+                case EPI_STORE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE, 1>), gp, dim3(512), 0, as); break;
+                case EPI_GATE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE, 1>), gp, dim3(512), 0, as); break;
+                case EPI_RESSKIP: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_RESSKIP, 1>), gp, dim3(512), 0, as); break;
+                case EPI_DGATE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_DGATE, 1>), gp, dim3(512), 0, as); break;
+                }
+                return;
+            }
+            switch (epi) {
+            case EPI_STORE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE, 2>), gp, dim3(512), 0, as); break;
+            case EPI_GATE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE, 2>), gp, dim3(512), 0, as); break;
+            case EPI_RESSKIP: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_RESSKIP, 2>), gp, dim3(512), 0, as); break;
+            case EPI_DGATE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_DGATE, 2>), gp, dim3(512), 0, as); break;
+            }
+            return;
+#endif
             if (small) {
                 switch (epi) {
                 case EPI_STORE: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_STORE, 1>), gp, dim3(512), 0, as); break;
@@ -1177,6 +1196,10 @@ int wg_abi_version(void) { return WG_ABI_VERSION; }
 int wg_dbg_trace_read(unsigned long long *out, int n)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(wg_dbg_trace), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+int wg_dbg_trace_read_cycles(unsigned long long *out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(wg_dbg_trace_cyc), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif
 void *wg_timer_create(int kernel_id, int capacity)

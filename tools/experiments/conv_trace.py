@@ -41,3 +41,13 @@ d = np.diff(t[:, :8], axis=1)
 print("mean phase durations (us): " + " ".join("%s %.1f" % (n, v) for n, v in zip(names[1:], d.mean(axis=0))))
 print("std                      : " + " ".join("%s %.1f" % (n, v) for n, v in zip(names[1:], d.std(axis=0))))
 print("last epilogue end: mean %.1f max %.1f" % (t[:, 7].mean(), t[:, 7].max()))
+if hasattr(L, "wg_dbg_trace_read_cycles"):
+    cb = (C.c_ulonglong * (512 * 16))()
+    L.wg_dbg_trace_read_cycles.argtypes = [C.c_void_p, C.c_int]
+    assert L.wg_dbg_trace_read_cycles(cb, 512 * 16) == 0
+    cyc = np.frombuffer(cb, dtype=np.uint64).reshape(512, 16).astype(np.float64)
+    wall = np.frombuffer(buf, dtype=np.uint64).reshape(512, 16).astype(np.float64)       # 10 ns ticks
+    dc, dw = np.diff(cyc[:, :8], axis=1), np.diff(wall[:, :8], axis=1)
+    ghz = dc / np.maximum(dw, 1) / 10.0
+    print("clock held per phase (GHz, median over workgroups): " + " ".join("%s %.2f" % (n, v) for n, v in zip(names[1:], np.median(ghz, axis=0))))
+    print("whole kernel: %.2f GHz" % np.median((cyc[:, 7] - cyc[:, 0]) / (wall[:, 7] - wall[:, 0]) / 10.0))
