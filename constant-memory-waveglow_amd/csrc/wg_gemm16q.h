@@ -188,11 +188,16 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
 #else
 #define WGQ_TRACE(slot) do { } while (0)
 #endif
-template <int EPI, int NI>
-__global__ __launch_bounds__(512) void convgemm16q_kernel(const ConvGemm16sArgs aa)
+// MG = 128-row compute groups per workgroup.  MG = 1: 8 waves (4 compute + 4 loaders), 128 x 64 NI tile, two workgroups per CU.
+// MG = 2 (NI = 2 only): 16 waves, ONE workgroup per CU, 256 x 128 tile: the two compute groups share the B image of every chunk,
+// i.e. the L2 -> LDS stream carries 48 KB per chunk for two 128 x 128 tiles instead of 64 KB, and there is no second, slower
+// co-resident workgroup whose last tiles run alone.
+template <int EPI, int NI, int MG = 1>
+__global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16sArgs aa)
 {
-    typedef typename StageOf<NI>::type Stage;
-    constexpr int AIMG = 128 * WG16Q_ROWB;                    // 128 rows x 64 B
+    static_assert(MG == 1 || NI == 2, "the two-group workgroup is built for the 128-column tile");
+    typedef typename StageOf<MG == 2 ? 1 : NI>::type Stage;   // loads per loader lane and chunk: MG = 1: 4 A + 2 NI B; MG = 2: 4 A + 2 B
+    constexpr int AIMG = 128 * MG * WG16Q_ROWB;               // 128 MG rows x 64 B
     constexpr int BIMG = 64 * NI * WG16Q_ROWB;
     constexpr int BUF = 2 * AIMG + 2 * BIMG;
     constexpr int TT = 64 * NI;                               // columns per tile
@@ -212,24 +217,30 @@ __global__ __launch_bounds__(512) void convgemm16q_kernel(const ConvGemm16sArgs 
         if constexpr (PERSIST) {
             const int id = (int)blockIdx.x + k * G;
             const int tx = id % aa.ntx, q = id / aa.ntx, ty = q % aa.nty, tz = q / aa.nty;
-            t0 = tx * TT; m0 = ty * WG_TILE;
+            t0 = tx * TT; m0 = ty * (WG_TILE * MG);
             b = a.row_sel1 ? tz * g.rows + a.row_sel1 - 1 : tz;
         } else {
-            t0 = blockIdx.x * TT; m0 = blockIdx.y * WG_TILE;
+            t0 = blockIdx.x * TT; m0 = blockIdx.y * (WG_TILE * MG);
             b = a.row_sel1 ? (int)blockIdx.z * g.rows + a.row_sel1 - 1 : (int)blockIdx.z;
         }
     };
 
-    if (wave >= 4) {
+    if (wave >= 4 * MG) {
         // ------------------------------- loader waves (as convgemm16w_kernel; only the LDS destination differs) -------------------------------
-        const int lt = tid - 256;
+        const int lt = tid - 256 * MG;
+#if defined(WG_OPT_LOADER_PRIO)
+        __builtin_amdgcn_s_setprio(WG_OPT_LOADER_PRIO);      // experiment: the loaders' few instructions never queue behind the compute waves
+#endif
         const int bt = NI == 2 ? (lt & 127) : (lt & 63), cg0 = NI == 2 ? (lt >> 7) : (lt >> 6);     // B unit: position, k-group
         int cur_seg = 0, cur_c = 0, chunk = 0;
         int gchunk = 0, tk = 0, t0, m0, b;
         tile_at(0, t0, m0, b);
         const unsigned voff_a = (unsigned)lt * 16u;
-        const int arow = lt & 127, akg = lt >> 7;             // A piece lt + 256 j: row lt & 127, k-group (lt >> 7) + 2 j
-        const int a_off[2] = {wg16q_off(arow, akg), wg16q_off(arow, akg + 2)};
+        // A pieces of a lane.  MG = 1: pieces lt and lt + 256 of the 128-row block: row lt & 127, k-groups (lt >> 7) and (lt >> 7) + 2.
+        // MG = 2 (512 loader lanes): piece lt (row lt & 127, k-group lt >> 7) of BOTH 128-row blocks of the tile.
+        const int arow = lt & 127, akg = lt >> 7;
+        const int a_off[2] = {wg16q_off(arow, akg), MG == 2 ? wg16q_off(128 + arow, akg) : wg16q_off(arow, akg + 2)};
+        constexpr int A_NEXT = MG == 2 ? 4096 : 2048;         // elements from a lane's first A piece to its second
         const int b_off[2] = {wg16q_off(bt, cg0), wg16q_off(bt, (cg0 + 2) & 3)};
         const unsigned voff_b = (unsigned)((cg0 * g.P + bt) * 16);
 #if defined(WG_DBG_NOLOAD)
@@ -253,12 +264,12 @@ __global__ __launch_bounds__(512) void convgemm16q_kernel(const ConvGemm16sArgs 
             const bool blive = live && rowok, full = blive && (nch - cur_c > 16);
             const unsigned short *ih = aa.img + ((size_t)chunk * a.lda + m0) * WG16_BK, *il = ih + aa.img_stride;
             const unsigned short *row0 = ss.hi + ((size_t)bsrc * (ss.Cp >> 3) + ((ss.ch0 + cur_c) >> 3)) * g.P * 8;
-            const unsigned short *pa0 = live ? ih : zsrc, *pa1 = live ? ih + 2048 : zsrc;
-            const unsigned short *pl0 = live ? il : zsrc, *pl1 = live ? il + 2048 : zsrc;
+            const unsigned short *pa0 = live ? ih : zsrc, *pa1 = live ? ih + A_NEXT : zsrc;
+            const unsigned short *pl0 = live ? il : zsrc, *pl1 = live ? il + A_NEXT : zsrc;
             const unsigned va = live ? voff_a : 0u;
             WG_LD(st.ah[0], pa0, va);   WG_LD(st.ah[1], pa1, va);
             WG_LD(st.al[0], pl0, va);   WG_LD(st.al[1], pl1, va);
-            if constexpr (NI == 2) {
+            if constexpr (NI == 2 && MG == 1) {
                 const unsigned short *b0 = row0 + (size_t)(g.H + t0 + shift) * 8, *b0l = b0 + ss.lo_off;
                 const unsigned short *b1 = b0 + (size_t)2 * g.P * 8, *b1l = b1 + ss.lo_off;
                 const unsigned short *pb0 = blive ? b0 : zsrc, *pb0l = blive ? b0l : zsrc;
@@ -293,7 +304,7 @@ __global__ __launch_bounds__(512) void convgemm16q_kernel(const ConvGemm16sArgs 
                 *reinterpret_cast<u32x4 *>(sb + AIMG + a_off[j]) = st.al[j];
             }
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
+            for (int j = 0; j < (MG == 2 ? 1 : NI); ++j) {
                 *reinterpret_cast<u32x4 *>(sb + 2 * AIMG + b_off[j]) = st.bh[j];
                 *reinterpret_cast<u32x4 *>(sb + 2 * AIMG + BIMG + b_off[j]) = st.bl[j];
             }
@@ -319,10 +330,10 @@ __global__ __launch_bounds__(512) void convgemm16q_kernel(const ConvGemm16sArgs 
         return;
     }
     // ------------------------------- compute waves -------------------------------
-    const int wr = wave >> 1, wc = wave & 1;
+    const int grp = wave >> 2, wr = (wave >> 1) & 1, wc = wave & 1;       // grp: which 128-row half of the tile (MG = 2)
     f32x4 acc[4][NB];
     const int r16 = lane & 15, kg = lane >> 4;
-    const int ao = wg16q_off(wr * 64 + r16, kg), bo = wg16q_off(wc * 32 * NI + r16, kg);      // + 16-row block * 1024
+    const int ao = wg16q_off(grp * 128 + wr * 64 + r16, kg), bo = wg16q_off(wc * 32 * NI + r16, kg);      // + 16-row block * 1024
 #define WGQ_SB() __builtin_amdgcn_sched_barrier(0)
     bf16x8 ah[4], al[4], bh[2], bl[2];
     auto rd = [&](const char *q) { return *reinterpret_cast<const bf16x8 *>(q); };
@@ -330,6 +341,7 @@ __global__ __launch_bounds__(512) void convgemm16q_kernel(const ConvGemm16sArgs 
     auto do_tile = [&](int k) {
         int t0, m0, b;
         tile_at(k, t0, m0, b);
+        m0 += grp * 128;
         int ln = lane;
         if (PERSIST) {
             asm volatile("" : "+v"(ln)::"memory");
@@ -395,7 +407,13 @@ __global__ __launch_bounds__(512) void convgemm16q_kernel(const ConvGemm16sArgs 
 #else
         int le = lane;
         if (PERSIST) asm volatile("" : "+v"(le)::"memory");
+#if defined(WG_OPT_EPI_PRIO)
+        __builtin_amdgcn_s_setprio(WG_OPT_EPI_PRIO);         // experiment: the epilogue's VALU / store issue ahead of the co-resident workgroup's waves
+#endif
         conv_epilogue_q<EPI, NI>(a, aa.s0, acc, t0, m0, b, wr, wc, le);
+#if defined(WG_OPT_EPI_PRIO)
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #endif
         WGQ_TRACE(3 + 2 * k);
         if (PERSIST) WGQ_SB();

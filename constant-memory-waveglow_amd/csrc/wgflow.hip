@@ -634,6 +634,22 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                 }
                 return;
             }
+#if !defined(WG_OPT_NO_MG2)
+            // 256 x 128 tiles, one 16-wave workgroup per CU (the compute groups share every chunk's B image: 25 % less L2 -> LDS
+            // traffic, no slower co-resident workgroup left to finish alone): gate conv 125.7 -> 118.6 us.  Only where the tiles deal out
+            // evenly over the CUs: at 1.5 tiles per CU (the 256-row products of the training shape: 384 such tiles) the half-empty second
+            // round costs more than the sharing saves (measured: step 81.8 -> 83.0 ms with every eligible launch on this path).
+            if (epi != EPI_DGATE && rup(mrows, WG_TILE) % 256 == 0 && ((ntiles / 2) % cus == 0 || ntiles / 2 >= 8 * cus)) {
+                as.nty = (int)grid.y / 2;
+                const dim3 g2(std::min(ntiles / 2, cus));
+                switch (epi) {
+                case EPI_STORE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE, 2, 2>), g2, dim3(1024), 0, as); break;
+                case EPI_GATE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE, 2, 2>), g2, dim3(1024), 0, as); break;
+                case EPI_RESSKIP: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_RESSKIP, 2, 2>), g2, dim3(1024), 0, as); break;
+                }
+                return;
+            }
+#endif
             switch (epi) {
             case EPI_STORE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE, 2>), gp, dim3(512), 0, as); break;
             case EPI_GATE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE, 2>), gp, dim3(512), 0, as); break;
