@@ -35,10 +35,34 @@ __device__ __forceinline__ int wg16q_off(int row, int kg) { return row * WG16Q_R
 // epilogues in the 16x16 accumulator layout (same contracts as conv_acc_init / conv_epilogue_s)
 // ------------------------------------------------------------------------------------------------
 template <int EPI, int NI>
-__device__ __forceinline__ void conv_acc_init_q(const ConvGemmArgs &a, f32x4 (&acc)[4][2 * NI], int t0, int m0, int b, int wr, int wc, int lane)
+__device__ __forceinline__ void conv_acc_init_q(const ConvGemmArgs &a, const SRef &saux, f32x4 (&acc)[4][2 * NI], int t0, int m0, int b, int wr, int wc,
+                                                int lane)
 {
     const Geo g = a.g;
     const int col = lane & 15, rq = lane >> 4;
+    if (EPI == EPI_STORE && saux.hi) {
+        // the value to accumulate into comes as an S-plane: a lane's 4 rows of one column are exactly one half unit (8 bytes) of the hi
+        // array and one of the lo array; x = hi + lo (the fp32 plane of such a tensor is then never written nor read)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const int m = m0 + wr * 64 + mb * 16 + 4 * rq;
+#pragma unroll
+            for (int nb = 0; nb < 2 * NI; ++nb) {
+                const int t = t0 + wc * (32 * NI) + nb * 16 + col;
+                u32x2 vh = {0u, 0u}, vl = {0u, 0u};
+                if (t < g.T && m < a.M) {
+                    const size_t i = s_index(saux, g, b, m, t);
+                    vh = *reinterpret_cast<const u32x2 *>(saux.hi + i);
+                    vl = *reinterpret_cast<const u32x2 *>(saux.hi + saux.lo_off + i);
+                }
+                acc[mb][nb][0] = __uint_as_float(vh[0] << 16) + __uint_as_float(vl[0] << 16);
+                acc[mb][nb][1] = __uint_as_float(vh[0] & 0xffff0000u) + __uint_as_float(vl[0] & 0xffff0000u);
+                acc[mb][nb][2] = __uint_as_float(vh[1] << 16) + __uint_as_float(vl[1] << 16);
+                acc[mb][nb][3] = __uint_as_float(vh[1] & 0xffff0000u) + __uint_as_float(vl[1] & 0xffff0000u);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
         const int mbase = m0 + wr * 64 + mb * 16;                                 // first row of this 16-row block (wave uniform)
@@ -348,7 +372,7 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
             WGQ_SB();
         }
         if (EPI == EPI_STORE || EPI == EPI_RESSKIP) {
-            conv_acc_init_q<EPI, NI>(a, acc, t0, m0, b, wr, wc, ln);
+            conv_acc_init_q<EPI, NI>(a, aa.saux, acc, t0, m0, b, wr, wc, ln);
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)

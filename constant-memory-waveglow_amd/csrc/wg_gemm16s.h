@@ -324,6 +324,7 @@ struct ConvGemm16sArgs {
     ConvGemmArgs c;               // geometry, seg[].nch / shift, epilogue operands (seg[].src unused)
     SSeg sseg[WG_MAX_SEG];
     SRef s0;                      // S-plane output (hi == nullptr: none)
+    SRef saux;                    // EPI_STORE, convgemm16q only: the accumulate-into input as an S-plane (hi + lo) instead of the fp32 plane aux0
     int ntx, nty, ntz;            // convgemm16w: the tile grid (time tiles, 128-row tiles, plane rows); workgroup w walks tiles w, w + G, ...
 };
 

@@ -89,6 +89,30 @@ def test_model_step_vs_oracle_and_golden(dev, golden_dir, name):
     assert torch.equal(x, T(audio, dev))                       # the caller's audio survives (waveglow.py:153 copies)
 
 
+def test_wide_batch_step_vs_oracle(dev):
+    """C1 at batch 9 (4 608 columns per launch): from 4 096 columns on the engine computes the skip sum and the conditioning gradient
+    as ONE product per WN and carries the residual stream / its gradient as S-planes only (wgflow.hip: fused_skip, fused_dy,
+    s_only_chain) -- code the small fixtures never reach.  Against the float64 oracle on the same inputs."""
+    m, cfg, specs, P = build("c1", dev)
+    B, (_, N, F) = 9, fill.SHAPES["c1"]
+    audio, h = fill.inputs("c1x9", B, N, F, cfg["n_mels"])
+    ref = orc.train_step(orc.make_config(**cfg), fill.table(specs, P), audio, h, fill.SIGMA, need_dh=True, double=True)
+    x, ht = T(audio, dev), T(h, dev).requires_grad_(True)
+    z, logdet = m(x, ht)
+    loss = cm.WaveGlowLoss(fill.SIGMA)(z, logdet)
+    loss.backward()
+    assert np.abs(npy(z) - ref["z"]).max() < Z_ATOL
+    assert logdet_close(npy(logdet), ref["logdet"], N)
+    assert abs(float(loss) - ref["loss"]) < LOSS_ATOL
+    assert relmax(npy(ht.grad), ref["dh"]) < GRAD_RTOL
+    named = dict(m.named_parameters())
+    for i, (n, _, _) in enumerate(specs):
+        assert relmax(npy(named[n].grad), ref["grads"][i]) < GRAD_RTOL, n
+    with torch.no_grad():
+        xr, _ = m.reverse(z.detach(), ht.detach())
+    assert np.abs(npy(xr) - audio).max() < Z_ATOL
+
+
 @pytest.mark.parametrize("name", ["micro", "c1"])
 def test_model_inverse_and_infer(dev, golden_dir, name):
     m, cfg, specs, P = build(name, dev)
