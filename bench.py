@@ -95,7 +95,8 @@ def cpu_baseline():
         tab = fill.table(specs, fill.fill_params(specs, cfg_name + "/"))
         audio, h = fill.inputs(cfg_name + "/cpu%d" % B, B, N, F, cfg["n_mels"])
         oc = orc.make_config(**cfg)
-        orc.train_step(oc, tab, audio, h, SIGMA)                       # warm-up (page-in, OpenMP team start)
+        if runs > 1:
+            orc.train_step(oc, tab, audio, h, SIGMA)                   # warm-up (page-in, OpenMP team start)
         ts = []
         for _ in range(runs):
             t0 = time.perf_counter()
@@ -105,11 +106,12 @@ def cpu_baseline():
         return {"samples_per_s": B * N / ts[len(ts) // 2], "median_s": ts[len(ts) // 2], "min_s": ts[0], "runs": runs, "batch": B}
 
     c1 = fill.CONFIGS["c1"]
-    res = {"c1_b2": timed("c1", c1, 2, 4000, 16), "c2_b1": timed("c2", C2, 1, SEG, FRAMES), "c2_b2": timed("c2", C2, 2, SEG, FRAMES)}
-    total = sum(r["median_s"] * (r["runs"] + 1) for r in res.values())
+    # (B=2 runs are ~11 s each on 64 cores: one timed run behind the B=1 warm-up keeps the leg at about half a minute)
+    res = {"c1_b2": timed("c1", c1, 2, 4000, 16), "c2_b1": timed("c2", C2, 1, SEG, FRAMES), "c2_b2": timed("c2", C2, 2, SEG, FRAMES, runs=1)}
+    total = sum(r["median_s"] * (r["runs"] + (1 if r["runs"] > 1 else 0)) for r in res.values())
     return {"value": res["c2_b1"]["samples_per_s"], "unit": "samples/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
             "sample": "WaveGlow-256ch 12 flows fwd+NLL+bwd on 1 segment of 16000 samples (B=1): median of 3 runs after 1 warm-up; "
-                      "also C2 at B=2 and C1 (64ch, 6 flows, B=2, seg 4000); %.0f s of CPU work in all" % total,
+                      "also C2 at B=2 (one run) and C1 (64ch, 6 flows, B=2, seg 4000; 3 runs); %.0f s of CPU work in all" % total,
             "configs": res,
             "ref_calibration": {"reference_over_port": REF_OVER_PORT,
                                 "note": "BASELINE.md section 2: the reference's own torch-CPU/MKLDNN path ran the C2 B=1 step 3.5x faster than "
@@ -339,13 +341,18 @@ def main():
         gate_flop = 2.0 * kcat * 2 * C2["dilation_channels"] * B * T     # algorithmic FLOPs of one launch
         achieved = gate_flop / (gate_ms * 1e-3) / 1e12
         split = _lib.default_precision() != _lib.PREC_F32
-        kname = {0: 'convgemm_kernel', 1: 'convgemm16_kernel', 2: 'convgemm16w_kernel'}[_lib.default_precision()]
+        kname = {0: 'convgemm_kernel', 1: 'convgemm16_kernel', 2: 'convgemm16q_kernel'}[_lib.default_precision()]
         # bf16x3: every fp32 product costs three bf16 MFMAs; the roofline is the bf16 matrix pipe and only the
         # algorithmic FLOPs are credited (the 3x is overhead, not work) -- SURVEY.md 8d
         peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
-        traffic, traffic_src = _traffic(kname + ("<1, 4>" if kname == "convgemm16_kernel" else "<1, 2>" if kname == "convgemm16w_kernel" else "<1>"))
-        if traffic is None:
-            traffic, traffic_src = _traffic(kname + "<1>")
+        # template arguments as rocprofv3 prints them: <EPI_GATE = 1, NI = 2 (128 columns), MG = 2 (256-row tile, one workgroup per CU)>
+        targs = {"convgemm_kernel": ["<1>"], "convgemm16_kernel": ["<1, 4>", "<1, 2>"], "convgemm16q_kernel": ["<1, 2, 2>", "<1, 2, 1>"]}[kname]
+        traffic, traffic_src, tsel = None, None, targs[0]
+        for ta in targs:
+            traffic, traffic_src = _traffic(kname + ta)
+            if traffic is not None:
+                tsel = ta
+                break
         if traffic_src:
             traffic_src += " (committed rocprofv3 --pmc summary of this command; not re-measured in this run)"
         out = {
@@ -356,7 +363,7 @@ def main():
             "config": {"workload": "WaveGlow 256ch, 12 flows, seg=16000, batch=%d per GPU (waveglow_LJ_speech.json), "
                                    "forward + NLL + constant-memory backward%s" % (B, " + RCCL grad all-reduce" if world > 1 else ""),
                        "global_batch": B * world, "segment": SEG, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "%s<EPI_GATE%s> (dilated k=3 conv + mel conditioning + gate)" % (kname, ", 2" if kname == "convgemm16w_kernel" else ""),
+            "roofline": {"bound": "mfma", "kernel": "%s%s (EPI_GATE: dilated k=3 conv + mel conditioning + gate)" % (kname, tsel),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": gate_ms, "launches_timed": n, "flop_per_launch": gate_flop,

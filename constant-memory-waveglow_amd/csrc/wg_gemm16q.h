@@ -401,12 +401,9 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
                 const int cur = nb & 1, nxt = cur ^ 1;
                 if (nb == NB - 1) {
                     // every fragment of this chunk is in registers (the B of this last group was requested a group ago): release the
-                    // buffer / publish the next one, then fetch the next chunk's first B under this group's MFMAs
+                    // buffer / publish the next one
                     WGQ_SB();
                     if (gc + 1 < total || !(total & 1)) WG16W_BAR();
-                    bh[nxt] = rd(nb_); bl[nxt] = rd(nb_ + BIMG);
-                } else {
-                    bh[nxt] = rd(pb + (nb + 1) * 1024); bl[nxt] = rd(pb + BIMG + (nb + 1) * 1024);
                 }
                 WGQ_SB();
 #pragma unroll
@@ -414,6 +411,15 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mb], bh[cur], acc[mb][nb], 0, 0, 0);
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mb], bl[cur], acc[mb][nb], 0, 0, 0);
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mb], bh[cur], acc[mb][nb], 0, 0, 0);
+                    if (mb == 0) {
+                        // the next group's B is requested BEHIND this group's first MFMAs: everything those wait for was requested a
+                        // group ago, so the wait in front of them is short (requested in front of them, the compiler waits for the
+                        // fresh reads as well: one exposed LDS round trip per chunk in the first version of this loop)
+                        WGQ_SB();
+                        if (nb == NB - 1) { bh[nxt] = rd(nb_); bl[nxt] = rd(nb_ + BIMG); }
+                        else { bh[nxt] = rd(pb + (nb + 1) * 1024); bl[nxt] = rd(pb + BIMG + (nb + 1) * 1024); }
+                        WGQ_SB();
+                    }
                     if (nb == NB - 1) {
                         // (unconditional: after a tile's last chunk these read LDS that nothing uses -- a branch here would make the
                         // compiler drain every outstanding read at the join; the next tile starts with its own fetch)

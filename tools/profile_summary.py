@@ -26,7 +26,36 @@ def ours(name):
     return not ("at::native" in name or "rocclr" in name)
 
 
+def pmc_summary(tag, paths):
+    """python tools/profile_summary.py --pmc <tag> <counter_collection.csv>...: per-kernel averages of every counter in the given
+    rocprofv3 --pmc passes -> profiles/<tag>_pmc.json, plus the derived shares (matrix pipe busy = SQ_VALU_MFMA_BUSY_CYCLES /
+    (4 SIMDs x SQ_BUSY_CU_CYCLES); LDS conflict share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE)."""
+    sums, cnt = defaultdict(lambda: defaultdict(float)), defaultdict(lambda: defaultdict(int))
+    for path in paths:
+        for r in csv.DictReader(open(path)):
+            if ours(r["Kernel_Name"]):
+                k = short(r["Kernel_Name"])
+                sums[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                cnt[k][r["Counter_Name"]] += 1
+    res = {}
+    for k in sorted(sums):
+        e = {c: round(sums[k][c] / cnt[k][c], 1) for c in sorted(sums[k])}
+        e["launches"] = max(cnt[k].values())
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in e and e.get("SQ_BUSY_CU_CYCLES"):
+            e["mfma_busy_share"] = round(e["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * e["SQ_BUSY_CU_CYCLES"]), 4)
+        if "SQ_LDS_BANK_CONFLICT" in e and e.get("SQ_LDS_IDX_ACTIVE"):
+            e["lds_conflict_share"] = round(e["SQ_LDS_BANK_CONFLICT"] / e["SQ_LDS_IDX_ACTIVE"], 4)
+        res[k] = e
+    out = os.path.join(ROOT, "profiles", "%s_pmc.json" % tag)
+    json.dump({"source": "rocprofv3 --kernel-trace --pmc <counters> -- python3 tools/kbench.py --iters 1 (one coupling forward + backward at the C2 "
+                         "shape; separate passes per counter group); per-launch averages over the launches of each kernel",
+               "kernels": res}, open(out, "w"), indent=1)
+    print("wrote", out)
+
+
 def main():
+    if sys.argv[1] == "--pmc":
+        return pmc_summary(sys.argv[2], sys.argv[3:])
     tag, stats = sys.argv[1], sys.argv[2]
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     rows = list(csv.DictReader(open(stats)))
