@@ -5,7 +5,9 @@
  * product never links, imports or calls anything under oracle/.
  *
  * Restates, in plain C loops (citations: path:line under yoyololicon/constant-memory-waveglow):
- *   - WaveFlow.forward_computation / reverse_computation      model/waveflow.py:182-208, 210-253 (use_conv1x1 = False)
+ *   - WaveFlow.forward_computation / reverse_computation      model/waveflow.py:182-208, 210-253; with use_conv1x1 the flip
+ *     between flows is replaced by an InvertibleConv1x1(n_group) over the height axis (waveflow.py:179-181,203-206,219-226;
+ *     model/efficient_modules.py:37-54: z = W x, logdet += W_time * logdet W)
  *   - the upsampler: ReplicationPad1d((0,1)) -> ConvTranspose1d(n_mels, n_mels, 2s+1, s, padding s//2) -> LeakyReLU(0.4)
  *                                                              model/waveflow.py:163-169, 255-257
  *   - WN2D: start 1x1, V conditioning, 8 NonCausalLayer2D (3x3 dilated conv, causal along the height axis, gate, W_o,
@@ -35,6 +37,7 @@ typedef WGO_REAL real;
 typedef struct {
     int32_t flows, n_group, n_mels;
     int32_t res_ch, dil_ch, skip_ch;
+    int32_t use_conv1x1;        /* WaveFlow(use_conv1x1=True): parameters invconv1x1.{k}.weight [H,H,1] follow the WN2D tables */
 } wfo_config;
 
 static void *xmalloc(size_t n)
@@ -66,6 +69,74 @@ static int h_dilations(int n_group, int *hd)
     return 0;
 }
 
+/* ---- invertible 1x1 over the height axis (efficient_modules.py:17-54) ------------------------------------------------------ */
+/* LU with partial pivoting: log|det|, sign and (optionally) the inverse of a c x c matrix */
+static void lu_logdet_inverse(const real *W, int c, real *logabs, int *sign, real *Winv)
+{
+    real *a = ralloc((size_t)c * c), *yv = ralloc(c);
+    int *perm = (int *)xmalloc(sizeof(int) * c);
+    memcpy(a, W, sizeof(real) * c * c);
+    for (int i = 0; i < c; ++i) perm[i] = i;
+    int sg = 1;
+    real la = 0;
+    for (int k = 0; k < c; ++k) {
+        int p = k;
+        real best = (real)fabs((double)a[k * c + k]);
+        for (int r = k + 1; r < c; ++r) {
+            const real v = (real)fabs((double)a[r * c + k]);
+            if (v > best) { best = v; p = r; }
+        }
+        if (p != k) {
+            for (int j = 0; j < c; ++j) { real tmp = a[k * c + j]; a[k * c + j] = a[p * c + j]; a[p * c + j] = tmp; }
+            int ti = perm[k]; perm[k] = perm[p]; perm[p] = ti;
+            sg = -sg;
+        }
+        const real piv = a[k * c + k];
+        if (piv < 0) sg = -sg;
+        la += (real)log(fabs((double)piv));
+        for (int r = k + 1; r < c; ++r) {
+            const real f = a[r * c + k] / piv;
+            a[r * c + k] = f;
+            for (int j = k + 1; j < c; ++j) a[r * c + j] -= f * a[k * c + j];
+        }
+    }
+    *logabs = la;
+    *sign = sg;
+    if (Winv)
+        for (int col = 0; col < c; ++col) {
+            for (int r = 0; r < c; ++r) {
+                real s = (perm[r] == col) ? (real)1 : (real)0;
+                for (int j = 0; j < r; ++j) s -= a[r * c + j] * yv[j];
+                yv[r] = s;
+            }
+            for (int r = c - 1; r >= 0; --r) {
+                real s = yv[r];
+                for (int j = r + 1; j < c; ++j) s -= a[r * c + j] * Winv[j * c + col];
+                Winv[r * c + col] = s / a[r * c + r];
+            }
+        }
+    free(a); free(yv); free(perm);
+}
+typedef struct { real *W, *Wi, ld; } mix_w;           /* ld = logdet W (NaN if det < 0, as torch.logdet) */
+static void mix_w_build(const float *w, int H, mix_w *m)
+{
+    m->W = ralloc((size_t)H * H); m->Wi = ralloc((size_t)H * H);
+    for (int i = 0; i < H * H; ++i) m->W[i] = (real)w[i];
+    real la; int sg;
+    lu_logdet_inverse(m->W, H, &la, &sg, m->Wi);
+    m->ld = sg > 0 ? la : (real)NAN;
+}
+/* out[o][t] = sum_h M[o][h] x[h][t]   (transpose: M[h][o]) */
+static void hmix(const real *M, int H, int Wd, const real *x, real *out, int transpose)
+{
+    for (int o = 0; o < H; ++o)
+        for (int t = 0; t < Wd; ++t) {
+            real acc = 0;
+            for (int h = 0; h < H; ++h) acc += (transpose ? M[h * H + o] : M[o * H + h]) * x[(long)h * Wd + t];
+            out[(long)o * Wd + t] = acc;
+        }
+}
+
 /* weight norm, dim 0 (utils.py:14-16): w[o,:] = g[o] v[o,:] / ||v[o,:]|| */
 static void wn_fwd(const float *g, const float *v, int rows, int cols, real *w)
 {
@@ -94,7 +165,7 @@ static void wn_bwd(const float *g, const float *v, const real *dw, int rows, int
  *   0 upsampler.1.bias  1 upsampler.1.weight_g  2 upsampler.1.weight_v
  *   per flow (37 entries): V.g V.v start.g start.v {W.g W.v W_o.g W_o.v} x 8  end.weight */
 #define WF_PF (4 + 4 * WF_DEPTH + 1)
-WFO_API int wfo_param_count(const wfo_config *cf) { return 3 + cf->flows * WF_PF; }
+WFO_API int wfo_param_count(const wfo_config *cf) { return 3 + cf->flows * WF_PF + (cf->use_conv1x1 ? cf->flows : 0); }
 
 typedef struct {            /* effective (weight-normed) weights of one flow */
     real *V;                /* [16 Cd][n_mels] */
@@ -274,6 +345,9 @@ WFO_API int wfo_forward(const wfo_config *cf, const float *const *params, const 
     wn_fwd(params[1], params[2], cf->n_mels, cf->n_mels * (2 * s + 1), wup);
     flow_w *fw = (flow_w *)xmalloc(sizeof(flow_w) * cf->flows);
     for (int k = 0; k < cf->flows; ++k) flow_w_build(cf, params + 3 + k * WF_PF, &fw[k]);
+    const int conv = cf->use_conv1x1;
+    mix_w *mw = (mix_w *)xmalloc(sizeof(mix_w) * cf->flows);
+    if (conv) for (int k = 0; k < cf->flows; ++k) mix_w_build(params[3 + cf->flows * WF_PF + k], H, &mw[k]);
 #pragma omp parallel for schedule(dynamic)
     for (int b = 0; b < B; ++b) {
         real *x = ralloc((size_t)H * Wd), *xn = ralloc((size_t)H * Wd), *y = ralloc((size_t)cf->n_mels * Wd);
@@ -283,22 +357,27 @@ WFO_API int wfo_forward(const wfo_config *cf, const float *const *params, const 
         real ld = 0;
         for (int k = 0; k < cf->flows; ++k) {
             wn_forward(cf, &fw[k], hd, x, y, R, Wd, ls, tt, NULL);
-            /* xout[r] = x[r+1] exp(ls[r]) + t[r] ; x_next = cat(flip(xout), x0)   waveflow.py:198-206 */
+            /* xout[r] = x[r+1] exp(ls[r]) + t[r] ; x_next = cat(flip(xout), x0), or W cat(x0, xout) with the 1x1   waveflow.py:198-206 */
             for (int r = 0; r < R; ++r)
                 for (int t = 0; t < Wd; ++t) {
                     const long e = (long)r * Wd + t;
-                    xn[(long)(R - 1 - r) * Wd + t] = x[(long)(r + 1) * Wd + t] * (real)exp((double)ls[e]) + tt[e];
+                    xn[(long)(conv ? r + 1 : R - 1 - r) * Wd + t] = x[(long)(r + 1) * Wd + t] * (real)exp((double)ls[e]) + tt[e];
                     ld += ls[e];
                 }
-            memcpy(xn + (long)(H - 1) * Wd, x, sizeof(real) * Wd);
-            real *tmp = x; x = xn; xn = tmp;
+            memcpy(xn + (long)(conv ? 0 : H - 1) * Wd, x, sizeof(real) * Wd);
+            if (conv) {
+                hmix(mw[k].W, H, Wd, xn, x, 0);                      /* efficient_modules.py:40 */
+                ld += (real)Wd * mw[k].ld;                           /* :39, waveflow.py:206 */
+            } else {
+                real *tmp = x; x = xn; xn = tmp;
+            }
         }
         squeeze_out(x, H, Wd, z + (long)b * N);
         logdet[b] = (float)ld;
         free(x); free(xn); free(y); free(ls); free(tt);
     }
-    for (int k = 0; k < cf->flows; ++k) flow_w_free(&fw[k]);
-    free(fw); free(wup);
+    for (int k = 0; k < cf->flows; ++k) { flow_w_free(&fw[k]); if (conv) { free(mw[k].W); free(mw[k].Wi); } }
+    free(fw); free(wup); free(mw);
     return 0;
 }
 
@@ -314,6 +393,9 @@ WFO_API int wfo_inverse(const wfo_config *cf, const float *const *params, const 
     wn_fwd(params[1], params[2], cf->n_mels, cf->n_mels * (2 * s + 1), wup);
     flow_w *fw = (flow_w *)xmalloc(sizeof(flow_w) * cf->flows);
     for (int k = 0; k < cf->flows; ++k) flow_w_build(cf, params + 3 + k * WF_PF, &fw[k]);
+    const int conv = cf->use_conv1x1;
+    mix_w *mw = (mix_w *)xmalloc(sizeof(mix_w) * cf->flows);
+    if (conv) for (int k = 0; k < cf->flows; ++k) mix_w_build(params[3 + cf->flows * WF_PF + k], H, &mw[k]);
 #pragma omp parallel for schedule(dynamic)
     for (int b = 0; b < B; ++b) {
         real *zc = ralloc((size_t)H * Wd), *x = ralloc((size_t)H * Wd), *y = ralloc((size_t)cf->n_mels * Wd);
@@ -325,6 +407,11 @@ WFO_API int wfo_inverse(const wfo_config *cf, const float *const *params, const 
         real ld = 0;
         for (int k = cf->flows - 1; k >= 0; --k) {
             const flow_w *w = &fw[k];
+            if (conv) {                                             /* z = W^-1 z ; logdet -= W_time logdet W   (waveflow.py:224-229) */
+                hmix(mw[k].Wi, H, Wd, zc, x, 0);
+                memcpy(zc, x, sizeof(real) * H * Wd);
+                ld -= (real)Wd * mw[k].ld;
+            } else
             /* z = z.flip(2)  (waveflow.py:222) : rows [xout_flipped.., x0] -> [x0, xout..] */
             for (int h = 0; h < H / 2; ++h)
                 for (int t = 0; t < Wd; ++t) {
@@ -358,8 +445,8 @@ WFO_API int wfo_inverse(const wfo_config *cf, const float *const *params, const 
         wn_saved_free(&sv);
         free(zc); free(x); free(y); free(vy); free(spare);
     }
-    for (int k = 0; k < cf->flows; ++k) flow_w_free(&fw[k]);
-    free(fw); free(wup);
+    for (int k = 0; k < cf->flows; ++k) { flow_w_free(&fw[k]); if (conv) { free(mw[k].W); free(mw[k].Wi); } }
+    free(fw); free(wup); free(mw);
     return 0;
 }
 
@@ -502,6 +589,10 @@ WFO_API int wfo_train_step(const wfo_config *cf, const float *const *params, con
     flow_w *fw = (flow_w *)xmalloc(sizeof(flow_w) * nf);
     flow_g *fg = (flow_g *)xmalloc(sizeof(flow_g) * nf);
     for (int k = 0; k < nf; ++k) { flow_w_build(cf, params + 3 + k * WF_PF, &fw[k]); flow_g_alloc(cf, &fg[k]); }
+    const int conv = cf->use_conv1x1;
+    mix_w *mw = (mix_w *)xmalloc(sizeof(mix_w) * nf);
+    real **gmix = (real **)xmalloc(sizeof(real *) * nf);          /* d loss / d W of the 1x1 convs, summed over the batch */
+    for (int k = 0; k < nf; ++k) { gmix[k] = NULL; if (conv) { mix_w_build(params[3 + nf * WF_PF + k], H, &mw[k]); gmix[k] = rzalloc((size_t)H * H); } }
     real *gwup = rzalloc((size_t)M * M * K), *gbias = rzalloc(M);
     double loss_acc = 0;
     const real inv_s2 = (real)(1.0 / ((double)sigma * sigma)), scale = (real)(1.0 / ((double)B * N));
@@ -515,16 +606,20 @@ WFO_API int wfo_train_step(const wfo_config *cf, const float *const *params, con
         upsample_fwd(cf, wup, params[0], melb, F, Wd, y, pre);
         squeeze_in(audio + (long)b * N, H, Wd, xs[0]);
         real ld = 0;
+        real **pm = (real **)xmalloc(sizeof(real *) * nf);          /* use_conv1x1: cat(x0, xout), the input of flow k's 1x1 */
         for (int k = 0; k < nf; ++k) {
             lss[k] = ralloc((size_t)RW);
+            pm[k] = conv ? ralloc((size_t)HW) : NULL;
+            real *dst = conv ? pm[k] : xs[k + 1];
             wn_forward(cf, &fw[k], hd, xs[k], y, R, Wd, lss[k], tt, NULL);
             for (int r = 0; r < R; ++r)
                 for (int t = 0; t < Wd; ++t) {
                     const long e = (long)r * Wd + t;
-                    xs[k + 1][(long)(R - 1 - r) * Wd + t] = xs[k][(long)(r + 1) * Wd + t] * (real)exp((double)lss[k][e]) + tt[e];
+                    dst[(long)(conv ? r + 1 : R - 1 - r) * Wd + t] = xs[k][(long)(r + 1) * Wd + t] * (real)exp((double)lss[k][e]) + tt[e];
                     ld += lss[k][e];
                 }
-            memcpy(xs[k + 1] + (long)(H - 1) * Wd, xs[k], sizeof(real) * Wd);
+            memcpy(dst + (long)(conv ? 0 : H - 1) * Wd, xs[k], sizeof(real) * Wd);
+            if (conv) { hmix(mw[k].W, H, Wd, pm[k], xs[k + 1], 0); ld += (real)Wd * mw[k].ld; }
         }
         squeeze_out(xs[nf], H, Wd, z + (long)b * N);
         logdet[b] = (float)ld;
@@ -541,17 +636,33 @@ WFO_API int wfo_train_step(const wfo_config *cf, const float *const *params, con
         for (int k = nf - 1; k >= 0; --k) {
             flow_g_alloc(cf, &lg[k]);
             wn_forward(cf, &fw[k], hd, xs[k], y, R, Wd, lss[k], tt, &sv);       /* activations of this flow (plain autograd keeps them) */
+            real *lgm = NULL;
+            if (conv) {
+                /* z = W u, logdet += W_time logdet W:  dW = sum_t dz u^T + W^-T (d logdet) W_time,  du = W^T dz   (efficient_modules.py:239-242) */
+                lgm = rzalloc((size_t)H * H);
+                for (int o = 0; o < H; ++o)
+                    for (int h2 = 0; h2 < H; ++h2) {
+                        real acc = 0;
+                        for (int t = 0; t < Wd; ++t) acc += dxn[(long)o * Wd + t] * pm[k][(long)h2 * Wd + t];
+                        lgm[o * H + h2] = acc + mw[k].Wi[h2 * H + o] * (-scale) * (real)Wd;
+                    }
+                hmix(mw[k].W, H, Wd, dxn, dx, 1);
+                memcpy(dxn, dx, sizeof(real) * HW);
+#pragma omp critical
+                for (int j = 0; j < H * H; ++j) gmix[k][j] += lgm[j];
+                free(lgm);
+            }
             memset(dx, 0, sizeof(real) * HW);
             for (int r = 0; r < R; ++r)
                 for (int t = 0; t < Wd; ++t) {
                     const long e = (long)r * Wd + t;
-                    const real gout = dxn[(long)(R - 1 - r) * Wd + t], es = (real)exp((double)lss[k][e]);
+                    const real gout = dxn[(long)(conv ? r + 1 : R - 1 - r) * Wd + t], es = (real)exp((double)lss[k][e]);
                     const real xv = xs[k][(long)(r + 1) * Wd + t];
                     dx[(long)(r + 1) * Wd + t] += gout * es;
                     dls[e] = gout * xv * es - scale;                            /* + d loss / d logdet = -1/(B N) */
                     dtt[e] = gout;
                 }
-            for (int t = 0; t < Wd; ++t) dx[t] += dxn[(long)(H - 1) * Wd + t];
+            for (int t = 0; t < Wd; ++t) dx[t] += dxn[(long)(conv ? 0 : H - 1) * Wd + t];
             wn_backward(cf, &fw[k], hd, xs[k], y, R, Wd, &sv, dls, dtt, dx, dy, &lg[k]);
             real *tmp = dxn; dxn = dx; dx = tmp;
         }
@@ -582,7 +693,8 @@ WFO_API int wfo_train_step(const wfo_config *cf, const float *const *params, con
             for (long j = 0; j < (long)M * M * K; ++j) gwup[j] += lgw[j];
             for (int j = 0; j < M; ++j) gbias[j] += lgb[j];
         }
-        for (int k = 0; k < nf; ++k) { flow_g_free(&lg[k]); free(lss[k]); }
+        for (int k = 0; k < nf; ++k) { flow_g_free(&lg[k]); free(lss[k]); free(pm[k]); }
+        free(pm);
         for (int k = 0; k <= nf; ++k) free(xs[k]);
         free(lg); free(xs); free(lss); free(y); free(pre); free(tt); free(dxn); free(dx); free(dy); free(dls); free(dtt);
         free(dmelb); free(lgw); free(lgb);
@@ -602,8 +714,13 @@ WFO_API int wfo_train_step(const wfo_config *cf, const float *const *params, con
         }
         for (int j = 0; j < 2 * cf->skip_ch; ++j) g[4 + 4 * WF_DEPTH][j] = (float)fg[k].end[j];
         flow_w_free(&fw[k]); flow_g_free(&fg[k]);
+        if (conv) {
+            float *gw = grads[3 + nf * WF_PF + k];
+            if (gw) for (int j = 0; j < H * H; ++j) gw[j] = (float)gmix[k][j];
+            free(gmix[k]); free(mw[k].W); free(mw[k].Wi);
+        }
     }
-    free(fw); free(fg); free(wup); free(gwup); free(gbias);
+    free(fw); free(fg); free(wup); free(gwup); free(gbias); free(mw); free(gmix);
     return 0;
 }
 

@@ -1,8 +1,9 @@
 """ctypes/numpy front end of oracle/wf_oracle.c -- the WaveFlow oracle (TEST INFRASTRUCTURE, see the C file's header).
 
 Parameter table = list of float32 arrays in the order of the reference model's named_parameters() for
-WaveFlow(use_conv1x1=False, bias=False): upsampler.1.{bias, weight_g, weight_v}, then per flow
-WNs.k.{V.weight_g, V.weight_v, start.weight_g, start.weight_v, layers.i.{W.weight_g, W.weight_v, W_o.weight_g, W_o.weight_v} x 8, end.weight}.
+WaveFlow(bias=False): upsampler.1.{bias, weight_g, weight_v}, then per flow
+WNs.k.{V.weight_g, V.weight_v, start.weight_g, start.weight_v, layers.i.{W.weight_g, W.weight_v, W_o.weight_g, W_o.weight_v} x 8, end.weight},
+then (use_conv1x1=True) invconv1x1.k.weight [H, H, 1] per flow.
 """
 import ctypes as C
 import os
@@ -16,12 +17,12 @@ _LIBS = {}
 
 
 class Config(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("flows", "n_group", "n_mels", "res_ch", "dil_ch", "skip_ch")]
+    _fields_ = [(n, C.c_int32) for n in ("flows", "n_group", "n_mels", "res_ch", "dil_ch", "skip_ch", "use_conv1x1")]
 
 
-def make_config(flows, n_group, n_mels, dilation_channels=256, residual_channels=256, skip_channels=256, **_unused):
+def make_config(flows, n_group, n_mels, dilation_channels=256, residual_channels=256, skip_channels=256, use_conv1x1=False, **_unused):
     """keyword names of the reference's WaveFlow(**arch.args) (model/waveflow.py:156-162, configs/waveflow_LJ_speech.json)"""
-    return Config(flows, n_group, n_mels, residual_channels, dilation_channels, skip_channels)
+    return Config(flows, n_group, n_mels, residual_channels, dilation_channels, skip_channels, int(bool(use_conv1x1)))
 
 
 def _lib(double=False):

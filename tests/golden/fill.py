@@ -204,6 +204,8 @@ def waveflow_param_specs(cfg):
             specs += [(p + "layers.%d.W.weight_g" % i, (2 * Cd, 1, 1, 1), "g"), (p + "layers.%d.W.weight_v" % i, (2 * Cd, C, 3, 3), "v"),
                       (p + "layers.%d.W_o.weight_g" % i, (rows, 1, 1, 1), "g"), (p + "layers.%d.W_o.weight_v" % i, (rows, Cd, 1, 1), "v")]
         specs.append((p + "end.weight", (2, Cs, 1, 1), "end"))
+    if cfg.get("use_conv1x1"):                             # registered after WNs (waveflow.py:176-181): invconv1x1.{k}.weight [H, H, 1]
+        specs += [("invconv1x1.%d.weight" % k, (H, H, 1), "orth") for k in range(cfg["flows"])]
     return specs
 
 
@@ -213,7 +215,11 @@ WF_CONFIGS = {
     # 64 rows: the shipped height-dilation pattern 1,2,4,8,16,1,2,4 (waveflow.py:85), stride 4, 3x3 taps reaching 32 rows up
     "wf64": dict(flows=2, n_group=64, n_mels=10, dilation_channels=32, residual_channels=32, skip_channels=64),
 }
+# use_conv1x1=True: an invertible 1x1 conv over the height axis replaces the flip between flows (waveflow.py:203-206)
+WF_CONFIGS["wf8c"] = dict(WF_CONFIGS["wf8"], use_conv1x1=True)
+WF_CONFIGS["wf64c"] = dict(WF_CONFIGS["wf64"], use_conv1x1=True)
 WF_SHAPES = {"wf8": (2, 8 * 96, 3), "wf64": (2, 64 * 24, 6)}       # (batch, samples, mel frames)
+WF_SHAPES["wf8c"], WF_SHAPES["wf64c"] = WF_SHAPES["wf8"], WF_SHAPES["wf64"]
 
 
 def waveflow_inputs(tag, B, N, F, n_mels):
