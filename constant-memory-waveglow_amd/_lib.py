@@ -32,7 +32,7 @@ class WgConfig(C.Structure):
 
 
 class WgWfConfig(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("flows", "n_group", "n_mels", "res_ch", "dil_ch", "skip_ch", "precision")]
+    _fields_ = [(n, C.c_int32) for n in ("flows", "n_group", "n_mels", "res_ch", "dil_ch", "skip_ch", "precision", "use_conv1x1")]
 
 
 class WgWnDims(C.Structure):

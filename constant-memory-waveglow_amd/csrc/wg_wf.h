@@ -140,6 +140,7 @@ struct WfCoupleArgs {
     int row_sel;            // mode 2: the WN row being produced (grid.x = items)
     Geo g;
     int mode;
+    int noflip;             // use_conv1x1: x_next = cat(x[0], xout) (the 1x1 over the height axis follows) instead of cat(flip(xout), x[0])
 };
 __global__ __launch_bounds__(256) void wf_couple_kernel(const WfCoupleArgs a)
 {
@@ -148,12 +149,14 @@ __global__ __launch_bounds__(256) void wf_couple_kernel(const WfCoupleArgs a)
     const int H = g.rows, tid = threadIdx.x;
     const int row = a.mode == 2 ? blockIdx.x * H + a.row_sel : blockIdx.x;
     const int b = row / H, r = row - b * H;
+    const int x0row = b * H + (a.noflip ? 0 : H - 1);          // where x[0] goes in x_next
+    const int orow = b * H + (a.noflip ? r + 1 : H - 2 - r);   // where xout[r] goes
     float lsum = 0.f;
-    if (r == H - 1) {                                          // not a WN output row: x_next[H-1] = x[0] and its gradient
+    if (r == H - 1) {                                          // not a WN output row: x_next[x0row] = x[0] and its gradient
         for (int t = tid; t < g.T; t += 256) {
-            if (a.mode == 0) *paddr(a.Xn, g, row, 0, t) = *paddr(a.X, g, b * H, 0, t);
+            if (a.mode == 0) *paddr(a.Xn, g, x0row, 0, t) = *paddr(a.X, g, b * H, 0, t);
             if (a.mode == 1) {
-                *paddr(a.dX, g, b * H, 0, t) = *paddr(a.dXn, g, row, 0, t);
+                *paddr(a.dX, g, b * H, 0, t) = *paddr(a.dXn, g, x0row, 0, t);
                 *paddr(a.G, g, row, 0, t) = 0.f;
                 *paddr(a.G, g, row, 1, t) = 0.f;
             }
@@ -170,10 +173,10 @@ __global__ __launch_bounds__(256) void wf_couple_kernel(const WfCoupleArgs a)
         }
         const float es = expf(ls);
         if (a.mode == 0) {
-            *paddr(a.Xn, g, b * H + (H - 2 - r), 0, t) = fmaf(*paddr(a.X, g, row + 1, 0, t), es, tt);
+            *paddr(a.Xn, g, orow, 0, t) = fmaf(*paddr(a.X, g, row + 1, 0, t), es, tt);
             lsum += ls;
         } else if (a.mode == 1) {
-            const float gout = *paddr(a.dXn, g, b * H + (H - 2 - r), 0, t);
+            const float gout = *paddr(a.dXn, g, orow, 0, t);
             const float xv = *paddr(a.X, g, row + 1, 0, t);
             *paddr(a.dX, g, row + 1, 0, t) = gout * es;
             *paddr(a.G, g, row, 0, t) = gout * xv * es + a.dld[b];
@@ -192,8 +195,9 @@ __global__ __launch_bounds__(256) void wf_couple_kernel(const WfCoupleArgs a)
     }
     if (tid == 0) a.rowsum[row] = red[0];
 }
-// logdet[b] = sum over flows and rows of rowsum[k][b*H + h]
-__global__ void wf_logdet_kernel(const float *__restrict__ rowsum, int nflow, int items, int H, float *__restrict__ logdet)
+// logdet[b] = sum over flows and rows of rowsum[k][b*H + h]  (+ coef * logdet W_k of the 1x1 convs: mix != NULL, waveflow.py:206 / :229)
+__global__ void wf_logdet_kernel(const float *__restrict__ rowsum, int nflow, int items, int H, float *__restrict__ logdet,
+                                 const float *__restrict__ mix, int mix_stride, float coef)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= items) return;
@@ -202,8 +206,147 @@ __global__ void wf_logdet_kernel(const float *__restrict__ rowsum, int nflow, in
         float q = 0.f;
         for (int h = 0; h < H; ++h) q += rowsum[((size_t)k * items + b) * H + h];
         s += q;
+        if (mix) s += coef * mix[(size_t)k * mix_stride + 2 * H * H];
     }
     logdet[b] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// use_conv1x1: InvertibleConv1x1(n_group) over the HEIGHT axis (waveflow.py:179-181,203-206,224-229; efficient_modules.py:37-54).
+// Per flow the packed buffer holds [W (H*H) | W^-1 (H*H) | logdet W (NaN if det < 0, as torch.logdet)].
+// ------------------------------------------------------------------------------------------------
+#define WF_MAXH 128
+struct LuBigArgs {
+    const float *W[WG_MAX_FLOWS];
+    int n, c, ostride;
+    float *out;
+};
+// one workgroup per matrix: LU with partial pivoting in LDS (rows of c + 1 floats), log|det| and sign, then one thread per column
+// of the inverse (forward / back substitution in place in the output)
+__global__ __launch_bounds__(256) void lu_big_kernel(const LuBigArgs a)
+{
+    extern __shared__ float lsm[];
+    const int c = a.c, ld = c + 1, tid = threadIdx.x;
+    float *A = lsm;                                    // [c][c+1]
+    int *perm = reinterpret_cast<int *>(lsm + c * ld); // [c]
+    __shared__ float redv[256];
+    __shared__ int redi[256];
+    __shared__ float s_la;
+    __shared__ int s_sg;
+    const float *W = a.W[blockIdx.x];
+    float *o = a.out + (size_t)blockIdx.x * a.ostride, *Wi = o + c * c;
+    for (int e = tid; e < c * c; e += 256) { const float v = W[e]; o[e] = v; A[(e / c) * ld + e % c] = v; }
+    for (int i = tid; i < c; i += 256) perm[i] = i;
+    if (tid == 0) { s_la = 0.f; s_sg = 1; }
+    __syncthreads();
+    for (int q = 0; q < c; ++q) {
+        float best = -1.f;
+        int p = q;
+        for (int r = q + tid; r < c; r += 256) { const float v = fabsf(A[r * ld + q]); if (v > best) { best = v; p = r; } }
+        redv[tid] = best; redi[tid] = p;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (tid < w && (redv[tid + w] > redv[tid] || (redv[tid + w] == redv[tid] && redi[tid + w] < redi[tid]))) {
+                redv[tid] = redv[tid + w]; redi[tid] = redi[tid + w];
+            }
+            __syncthreads();
+        }
+        p = redi[0];
+        if (p != q)
+            for (int j = tid; j < c; j += 256) { const float t = A[q * ld + j]; A[q * ld + j] = A[p * ld + j]; A[p * ld + j] = t; }
+        __syncthreads();
+        const float piv = A[q * ld + q];
+        if (tid == 0) {
+            if (p != q) { const int t = perm[q]; perm[q] = perm[p]; perm[p] = t; s_sg = -s_sg; }
+            if (piv < 0.f) s_sg = -s_sg;
+            s_la += logf(fabsf(piv));
+        }
+        for (int r = q + 1 + tid; r < c; r += 256) A[r * ld + q] /= piv;
+        __syncthreads();
+        const int m = c - q - 1;
+        for (int e = tid; e < m * m; e += 256) {
+            const int r = q + 1 + e / m, j = q + 1 + e % m;
+            A[r * ld + j] = fmaf(-A[r * ld + q], A[q * ld + j], A[r * ld + j]);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) o[2 * c * c] = s_sg > 0 ? s_la : __builtin_nanf("");
+    for (int col = tid; col < c; col += 256) {
+        for (int r = 0; r < c; ++r) {                        // L y = P e_col
+            float s = perm[r] == col ? 1.f : 0.f;
+            for (int j = 0; j < r; ++j) s = fmaf(-A[r * ld + j], Wi[j * c + col], s);
+            Wi[r * c + col] = s;
+        }
+        for (int r = c - 1; r >= 0; --r) {                   // U x = y
+            float s = Wi[r * c + col];
+            for (int j = r + 1; j < c; ++j) s = fmaf(-A[r * ld + j], Wi[j * c + col], s);
+            Wi[r * c + col] = s / A[r * ld + r];
+        }
+    }
+}
+
+// dst[b*H + o][t] = sum_h M[o][h] src[b*H + h][t]   (transpose: M[h][o]); grid (T / 256, H / 8, items), one thread per t and 8 output rows
+#define WF_MIX_ROWS 8
+__global__ __launch_bounds__(256) void wf_hmix_kernel(PRef src, PRef dst, Geo g, const float *__restrict__ M, int transpose)
+{
+    __shared__ float w[WF_MIX_ROWS][WF_MAXH];
+    const int H = g.rows, o0 = blockIdx.y * WF_MIX_ROWS, b = blockIdx.z, t = blockIdx.x * 256 + threadIdx.x;
+    for (int e = threadIdx.x; e < WF_MIX_ROWS * H; e += 256) {
+        const int o = o0 + e / H, h = e % H;
+        w[e / H][h] = o < H ? (transpose ? M[h * H + o] : M[o * H + h]) : 0.f;
+    }
+    __syncthreads();
+    if (t >= g.T) return;
+    float acc[WF_MIX_ROWS];
+#pragma unroll
+    for (int i = 0; i < WF_MIX_ROWS; ++i) acc[i] = 0.f;
+    for (int h = 0; h < H; ++h) {
+        const float x = *paddr(src, g, b * H + h, 0, t);
+#pragma unroll
+        for (int i = 0; i < WF_MIX_ROWS; ++i) acc[i] = fmaf(w[i][h], x, acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < WF_MIX_ROWS; ++i)
+        if (o0 + i < H) *paddr(dst, g, b * H + o0 + i, 0, t) = acc[i];
+}
+
+// Gram partials of the 1x1 weight gradient: part[blk][o][h] = sum over this block's 64 columns of dz[o][t] u[h][t]
+// (blk = item * tiles + time tile); both tiles go through LDS, a thread owns H*H / 256 outputs.
+__global__ __launch_bounds__(256) void wf_hgram_kernel(PRef dZ, PRef U, Geo g, float *__restrict__ part)
+{
+    extern __shared__ float gsm[];                     // [2][H][65]
+    const int H = g.rows, b = blockIdx.y, t0 = blockIdx.x * 64, tid = threadIdx.x;
+    float *dz = gsm, *u = gsm + H * 65;
+    for (int e = tid; e < H * 64; e += 256) {
+        const int h = e >> 6, tl = e & 63;
+        const bool ok = t0 + tl < g.T;
+        dz[h * 65 + tl] = ok ? *paddr(dZ, g, b * H + h, 0, t0 + tl) : 0.f;
+        u[h * 65 + tl] = ok ? *paddr(U, g, b * H + h, 0, t0 + tl) : 0.f;
+    }
+    __syncthreads();
+    float *out = part + ((size_t)b * gridDim.x + blockIdx.x) * H * H;
+    for (int e = tid; e < H * H; e += 256) {
+        const int o = e / H, h = e % H;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int tl = 0; tl < 64; ++tl) acc = fmaf(dz[o * 65 + tl], u[h * 65 + tl], acc);
+        out[e] = acc;
+    }
+}
+// dW[o][h] = sum_blk part[blk][o][h] + W^-1[h][o] * T * sum_b dlogdet[b]       (efficient_modules.py:240-242)
+__global__ __launch_bounds__(256) void wf_hgram_reduce_kernel(const float *__restrict__ part, int nblk, int H, const float *__restrict__ Winv,
+                                                              const float *__restrict__ dld, int items, float Tn, float *__restrict__ dW)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= H * H) return;
+    float s0 = 0.f, s1 = 0.f;
+    int k = 0;
+    for (; k + 1 < nblk; k += 2) { s0 += part[(size_t)k * H * H + e]; s1 += part[(size_t)(k + 1) * H * H + e]; }
+    if (k < nblk) s0 += part[(size_t)k * H * H + e];
+    float gl = 0.f;
+    for (int b = 0; b < items; ++b) gl += dld[b];
+    const int o = e / H, h = e % H;
+    dW[e] = (s0 + s1) + Winv[h * H + o] * gl * Tn;
 }
 
 // S-plane row sum over the height axis: out[b][c][t] = sum_h in[b*H + h][c][t] (hi + lo summed in fp32, re-split).  Used for the

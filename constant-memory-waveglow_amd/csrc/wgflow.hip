@@ -1124,8 +1124,10 @@ int wf_check(const wg_wf_config *cf)
     return wn_check(wf_wn(cf));
 }
 struct WfPack {
-    size_t ones, up_scale, wn[WG_MAX_FLOWS], total;
+    size_t ones, up_scale, wn[WG_MAX_FLOWS], mix, total;
+    int mix_stride;             // use_conv1x1: per flow [W | W^-1 | logdet W] (floats from `mix`)
 };
+inline int wf_nparams(const wg_wf_config *cf) { return 3 + cf->flows * 37 + (cf->use_conv1x1 ? cf->flows : 0); }
 WfPack wf_pack_layout(const wg_wf_config *cf)
 {
     WfPack L;
@@ -1135,13 +1137,16 @@ WfPack wf_pack_layout(const wg_wf_config *cf)
     L.up_scale = take(cf->n_mels);
     const size_t wn = wn_pack_layout(wf_wn(cf)).total;
     for (int k = 0; k < cf->flows; ++k) L.wn[k] = take(wn);
+    L.mix_stride = (int)rupz((size_t)2 * cf->n_group * cf->n_group + 1, 64);
+    L.mix = take(cf->use_conv1x1 ? (size_t)cf->flows * L.mix_stride : 0);
     L.total = off;
     return L;
 }
 struct WfWs {
     Geo g, gi;              // one plane row per (item, height row) / one per item
     int auxp;
-    size_t Y, YS, X[2], rowsum, dX[2], dYrow, rs, gp, dwup, total;
+    size_t Y, YS, X[2], rowsum, dX[2], dYrow, rs, gp, dwup, Xt, dXt, gram, total;    // Xt / dXt / gram: use_conv1x1 only
+    int gram_blocks;
     WnWs wn;
 };
 WfWs wf_ws_layout(const wg_wf_config *cf, int B, int Wd, int mode)
@@ -1160,6 +1165,12 @@ WfWs wf_ws_layout(const wg_wf_config *cf, int B, int Wd, int mode)
     w.YS = bp.take((size_t)B * w.auxp * w.gi.P);
     w.X[0] = bp.take(xplane); w.X[1] = bp.take(xplane);
     w.rowsum = bp.take((size_t)cf->flows * w.g.B);
+    w.Xt = w.dXt = w.gram = 0;
+    w.gram_blocks = B * ((Wd + 63) / 64);
+    if (cf->use_conv1x1) {
+        w.Xt = bp.take(xplane);                                          // cat(x[0], xout): the 1x1's input
+        if (mode) { w.dXt = bp.take(xplane); w.gram = bp.take((size_t)w.gram_blocks * H * H); }
+    }
     w.dX[0] = w.dX[1] = w.dYrow = w.rs = w.gp = w.dwup = 0;
     if (mode) {
         w.dX[0] = bp.take(xplane); w.dX[1] = bp.take(xplane);
@@ -1192,8 +1203,13 @@ void wf_upsample(Ctx &cx, const wg_wf_config *cf, const float *const *p, const f
     WG_LAUNCH(cx, wf_upsample_fwd_kernel, dim3((W.gi.T + 255) / 256, cf->n_mels, W.gi.B), dim3(256), 0, a);
     run_to_splane(cx, W.gi, pref(ws + W.Y, W.auxp), cf->n_mels, ws + W.YS, W.auxp);
 }
+void run_hmix(Ctx &cx, const Geo &g, PRef src, PRef dst, const float *Mx, int transpose)
+{
+    WG_LAUNCH(cx, wf_hmix_kernel, dim3((g.T + 255) / 256, (g.rows + WF_MIX_ROWS - 1) / WF_MIX_ROWS, g.B / g.rows), dim3(256), 0, src, dst, g, Mx,
+              transpose);
+}
 void wf_couple(Ctx &cx, const WnRun &r, const float *endw, int mode, PRef X, PRef Xn, PRef dXn, PRef dX, const float *dld,
-               float *rowsum, int row_sel)
+               float *rowsum, int row_sel, int noflip = 0)
 {
     WfCoupleArgs a;
     memset(&a, 0, sizeof(a));
@@ -1201,7 +1217,7 @@ void wf_couple(Ctx &cx, const WnRun &r, const float *endw, int mode, PRef X, PRe
     a.S = pref(r.ws + r.w.skip, r.d.Cs); a.Cs = r.d.Cs;
     a.X = X; a.Xn = Xn; a.dXn = dXn; a.dX = dX;
     a.G = pref(r.ws + r.w.G, r.L.kp_end);
-    a.dld = dld; a.rowsum = rowsum; a.row_sel = row_sel; a.g = r.g; a.mode = mode;
+    a.dld = dld; a.rowsum = rowsum; a.row_sel = row_sel; a.g = r.g; a.mode = mode; a.noflip = noflip;
     WG_LAUNCH(cx, wf_couple_kernel, dim3(mode == 2 ? r.g.B / r.g.rows : r.g.B), dim3(256), 0, a);
 }
 }  // namespace
@@ -1642,7 +1658,7 @@ int wg_upsample(const wg_config *cf, const void *packed, const float *h, int B, 
 }
 
 // ---- WaveFlow -------------------------------------------------------------------------------------
-int wg_wf_param_count(const wg_wf_config *cf) { return cf ? 3 + cf->flows * 37 : WG_EINVAL; }
+int wg_wf_param_count(const wg_wf_config *cf) { return cf ? wf_nparams(cf) : WG_EINVAL; }
 size_t wg_wf_packed_bytes(const wg_wf_config *cf) { return wf_check(cf) ? 0 : wf_pack_layout(cf).total * sizeof(float); }
 size_t wg_wf_workspace_bytes(const wg_wf_config *cf, int B, int N, int mode)
 {
@@ -1679,6 +1695,15 @@ int wg_wf_pack_weights(const wg_wf_config *cf, const void *const *params, void *
     ImgBatch ib(&cx);
     for (int k = 0; k < cf->flows; ++k) wn_pack_images(ib, d, WL, pk + L.wn[k]);
     ib.flush();
+    if (cf->use_conv1x1) {                                   // W, W^-1, logdet W of every flow's 1x1 (efficient_modules.py:37-41,49-54)
+        LuBigArgs lu;
+        lu.n = cf->flows; lu.c = cf->n_group; lu.ostride = L.mix_stride; lu.out = pk + L.mix;
+        for (int k = 0; k < cf->flows; ++k) lu.W[k] = p[3 + 37 * cf->flows + k];
+        const size_t lds = ((size_t)lu.c * (lu.c + 1) + lu.c) * sizeof(float);
+        if (lds > 48 * 1024 && hipFuncSetAttribute((const void *)lu_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            cx.err = WG_ELAUNCH;
+        WG_LAUNCH(cx, lu_big_kernel, dim3(cf->flows), dim3(256), lds, lu);
+    }
     return cx.err;
 }
 
@@ -1727,13 +1752,17 @@ int wg_wf_forward(const wg_wf_config *cf, const void *const *params, const void 
     wf_upsample(cx, cf, p, pk, L, mel, F, W, ws);                                                                    // :183,187
     WnRun r;
     r.d = wf_wn(cf); r.L = wn_pack_layout(r.d); r.g = g; r.ws = ws; r.w = W.wn; r.Y = ws + W.Y; r.YS = ws + W.YS; r.save = 0;
+    const int conv = cf->use_conv1x1;
     for (int k = 0; k < cf->flows; ++k) {
         r.pk = pk + L.wn[k]; r.X = pref(xk(k), 1);
         wn_forward(cx, r);                                                                                           // :197
-        wf_couple(cx, r, p[3 + 37 * k + 36], 0, pref(xk(k), 1), pref(xk(k + 1), 1), pnull(), pnull(), nullptr,
-                  ws + W.rowsum + (size_t)k * g.B, 0);                                                               // :198-206
+        // x_next = cat(flip(xout), x0), or with the 1x1 conv W cat(x0, xout)                                        // :198-206
+        wf_couple(cx, r, p[3 + 37 * k + 36], 0, pref(xk(k), 1), pref(conv ? ws + W.Xt : xk(k + 1), 1), pnull(), pnull(), nullptr,
+                  ws + W.rowsum + (size_t)k * g.B, 0, conv);
+        if (conv) run_hmix(cx, g, pref(ws + W.Xt, 1), pref(xk(k + 1), 1), pk + L.mix + (size_t)k * L.mix_stride, 0);
     }
-    WG_LAUNCH(cx, wf_logdet_kernel, dim3((B + 63) / 64), dim3(64), 0, ws + W.rowsum, cf->flows, B, g.rows, logdet);
+    WG_LAUNCH(cx, wf_logdet_kernel, dim3((B + 63) / 64), dim3(64), 0, ws + W.rowsum, cf->flows, B, g.rows, logdet,
+              conv ? pk + L.mix : (const float *)nullptr, L.mix_stride, (float)g.T);
     WG_LAUNCH(cx, wf_unsqueeze_kernel, dim3((g.T + 255) / 256, g.B), dim3(256), 0, pref(xk(cf->flows), 1), g, N, z);  // :208
     return cx.err;
 }
@@ -1765,7 +1794,8 @@ int wg_wf_inverse(const wg_wf_config *cf, const void *const *params, const void 
     WnRun r;
     r.d = wf_wn(cf); r.L = wn_pack_layout(r.d); r.g = g; r.ws = ws; r.w = W.wn; r.Y = ws + W.Y; r.YS = ws + W.YS; r.save = 1;
     for (int k = cf->flows - 1; k >= 0; --k) {
-        WG_LAUNCH(cx, wf_flip_kernel, rgrid, dim3(256), 0, pref(Z, 1), pref(Zf, 1), g);                              // :222
+        if (cf->use_conv1x1) run_hmix(cx, g, pref(Z, 1), pref(Zf, 1), pk + L.mix + (size_t)k * L.mix_stride + (size_t)H * H, 0);   // z = W^-1 z  :224-226
+        else WG_LAUNCH(cx, wf_flip_kernel, rgrid, dim3(256), 0, pref(Z, 1), pref(Zf, 1), g);                         // :222
         WG_LAUNCH(cx, wf_copy_row_kernel, igrid, dim3(256), 0, pref(Zf, 1), pref(Xb, 1), g, 0, 0);                   // :228
         r.pk = pk + L.wn[k]; r.X = pref(Xb, 1);
         for (int row = 0; row < H - 1; ++row) {
@@ -1778,7 +1808,8 @@ int wg_wf_inverse(const wg_wf_config *cf, const void *const *params, const void 
         std::swap(Z, Xb);
     }
     // rowsum rows H-1 are never written by mode 2: they were zeroed with the workspace
-    WG_LAUNCH(cx, wf_logdet_kernel, dim3((B + 63) / 64), dim3(64), 0, ws + W.rowsum, cf->flows, B, H, logdet);
+    WG_LAUNCH(cx, wf_logdet_kernel, dim3((B + 63) / 64), dim3(64), 0, ws + W.rowsum, cf->flows, B, H, logdet,
+              cf->use_conv1x1 ? pk + L.mix : (const float *)nullptr, L.mix_stride, -(float)g.T);                     // :227-229
     WG_LAUNCH(cx, wf_unsqueeze_kernel, rgrid, dim3(256), 0, pref(Z, 1), g, N, x);
     return cx.err;
 }
@@ -1815,11 +1846,31 @@ int wg_wf_backward(const wg_wf_config *cf, const void *const *params, const void
     WnRun r;
     r.d = wf_wn(cf); r.L = wn_pack_layout(r.d); r.g = g; r.ws = ws; r.w = W.wn; r.Y = ws + W.Y; r.YS = ws + W.YS; r.save = 1;
     r.gi = W.gi; r.rs = ws + W.rs;
+    const int conv = cf->use_conv1x1, H = g.rows;
+    if (conv) {
+        const size_t lds = (size_t)2 * H * 65 * sizeof(float);
+        if (lds > 48 * 1024 && hipFuncSetAttribute((const void *)wf_hgram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            cx.err = WG_ELAUNCH;
+    }
     for (int k = cf->flows - 1; k >= 0; --k) {
         const float *Xk = (const float *)tape + (size_t)k * xplane;
+        if (conv) {
+            // Conv1x1 backward over the height axis (efficient_modules.py:235-242): u = W^-1 z (the 1x1's input, rebuilt from the taped
+            // flow output), dW = sum dz u^T + W^-T (sum_b dlogdet_b) W_time, du = W^T dz
+            const float *mx = pk + L.mix + (size_t)k * L.mix_stride;
+            const float *Xn = (const float *)tape + (size_t)(k + 1) * xplane;
+            run_hmix(cx, g, pref((float *)Xn, 1), pref(ws + W.Xt, 1), mx + (size_t)H * H, 0);
+            WG_LAUNCH(cx, wf_hgram_kernel, dim3((g.T + 63) / 64, B), dim3(256), (size_t)2 * H * 65 * sizeof(float), pref(dXn, 1), pref(ws + W.Xt, 1), g,
+                      ws + W.gram);
+            float *dWk = gr[3 + 37 * cf->flows + k];
+            if (dWk)
+                WG_LAUNCH(cx, wf_hgram_reduce_kernel, dim3((H * H + 255) / 256), dim3(256), 0, (const float *)(ws + W.gram), W.gram_blocks, H,
+                          mx + (size_t)H * H, dlogdet, B, (float)g.T, dWk);
+            run_hmix(cx, g, pref(dXn, 1), pref(ws + W.dXt, 1), mx, 1);
+        }
         r.pk = pk + L.wn[k]; r.X = pref((float *)Xk, 1);
         wn_forward(cx, r);
-        wf_couple(cx, r, p[3 + 37 * k + 36], 1, pref((float *)Xk, 1), pnull(), pref(dXn, 1), pref(dXc, 1), dlogdet, nullptr, 0);
+        wf_couple(cx, r, p[3 + 37 * k + 36], 1, pref((float *)Xk, 1), pnull(), pref(conv ? ws + W.dXt : dXn, 1), pref(dXc, 1), dlogdet, nullptr, 0, conv);
         wn_backward(cx, r, p + 3 + 37 * k, gr + 3 + 37 * k, pref(dXc, 1), ws + W.dYrow);
         std::swap(dXn, dXc);
     }

@@ -1,10 +1,12 @@
 """WaveFlow on the HIP flow engine: same constructor, parameter names and forward/reverse/infer contract as the reference's
-model/waveflow.py (use_conv1x1=False, the shipped configuration).  Audio [B, N] is viewed as [B, n_group (height), N/n_group (time)];
+model/waveflow.py (use_conv1x1=False is the shipped configuration; True puts an InvertibleConv1x1(n_group) over the height axis
+between the flows instead of the flip).  Audio [B, N] is viewed as [B, n_group (height), N/n_group (time)];
 each flow runs WN2D (8 layers of 3x3 dilated convs, causal along the height axis) on rows 0..H-2 and transforms rows 1..H-1.
 
 Module tree (state dicts interchange with the reference):
     upsampler.{0,1,2}     ReplicationPad1d((0,1)), ConvTranspose1d(n_mels, n_mels, 2s+1, s, padding s//2) + weight norm, LeakyReLU(0.4)
     WNs.{k}               WN2D: V, start, layers.{i}.{W, W_o}, end
+    invconv1x1.{k}        InvertibleConv1x1(n_group)            (use_conv1x1=True only; registered after WNs as upstream)
 """
 import warnings
 from typing import Tuple
@@ -16,6 +18,7 @@ from torch.autograd import Function
 from . import engine
 from ._lib import WgError, WgWfConfig, default_precision
 from .base import FlowBase
+from .efficient_modules import InvertibleConv1x1
 from .utils import add_weight_norms, conv_gv
 
 
@@ -102,9 +105,8 @@ class _WaveFlowFn(Function):
 class WaveFlow(FlowBase):
     def __init__(self, flows, n_group, n_mels, use_conv1x1, memory_efficient, reverse_mode=False, **kwargs):
         super().__init__(256, reverse_mode)
-        if use_conv1x1:
-            raise WgError("WaveFlow(use_conv1x1=True) is not built into the HIP engine (the shipped config uses False)")
         if reverse_mode:
+            # (base.py:20-28: forward would then be the row-by-row autoregressive loop, trained through reverse_mode_forward's buffers)
             raise WgError("WaveFlow(reverse_mode=True) is not built into the HIP engine")
         self.flows, self.n_group, self.n_mels = flows, n_group, n_mels
         self.sub_sr = self._hop_length // n_group
@@ -114,8 +116,12 @@ class WaveFlow(FlowBase):
             nn.LeakyReLU(0.4, True))
         self.upsampler.apply(add_weight_norms)
         self.WNs = nn.ModuleList(WN2D(n_group, n_mels, **kwargs) for _ in range(flows))
+        if use_conv1x1:                                          # waveflow.py:176-181 (the blocks are parameter containers here: the
+            self.invconv1x1 = nn.ModuleList(                     # 1x1 over the height axis runs inside wg_wf_forward / _inverse / _backward)
+                InvertibleConv1x1(n_group, memory_efficient=memory_efficient, reverse_mode=reverse_mode) for _ in range(flows))
         wn0 = self.WNs[0]
-        self._engine = engine.WaveFlowEngine(WgWfConfig(flows, n_group, n_mels, wn0.res_chs, wn0.dil_chs, wn0.skp_chs, default_precision()))
+        self._engine = engine.WaveFlowEngine(WgWfConfig(flows, n_group, n_mels, wn0.res_chs, wn0.dil_chs, wn0.skp_chs, default_precision(),
+                                                        int(bool(use_conv1x1))))
 
     def param_table(self):
         """C-ABI parameter table (include/wgflow.h): upsampler.1 bias, g, v; per flow the WN2D table."""
@@ -124,6 +130,8 @@ class WaveFlow(FlowBase):
         tab = [up.bias, g, v]
         for wn in self.WNs:
             tab += wn.param_table()
+        if hasattr(self, "invconv1x1"):
+            tab += [m.weight for m in self.invconv1x1]
         return tab
 
     def _check(self, x: Tensor, h: Tensor):

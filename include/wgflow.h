@@ -74,7 +74,8 @@ typedef struct wg_wn_dims {
 
 const char *wg_strerror(int code);
 /* ABI revision of this header (2: wg_config gained keep_activations; 3: wg_nll_loss / wg_train_step produce the logged
- * training scalars and take their scratch from the caller).  A binding built against another revision must not pass its
+ * training scalars and take their scratch from the caller, wg_melspec returns the power spectrogram on request, wg_wf_config gained
+ * use_conv1x1, wg_wf_upsample).  A binding built against another revision must not pass its
  * structs: the Python loader compares this with its own ABI_VERSION and refuses the library otherwise. */
 #define WG_ABI_VERSION 3
 int wg_abi_version(void);
@@ -206,12 +207,15 @@ int wg_train_step(const wg_config *cfg, const void *const *params, const void *p
  * WaveFlow(flows, n_group, n_mels, use_conv1x1=False, ..., dilation/residual/skip_channels, bias=False): audio [B,N] viewed as
  * [B, n_group (height), N/n_group (time)], 8-layer WN2D with 3x3 dilated convs causal along the height axis, autoregressive
  * affine coupling along the height axis, flip between flows.  Parameter table = named_parameters() order (3 + 37 per flow):
- *   upsampler.1.{bias, weight_g, weight_v}; WNs.k.{V.g, V.v, start.g, start.v, layers.i.{W.g, W.v, W_o.g, W_o.v} x 8, end.weight}.
+ *   upsampler.1.{bias, weight_g, weight_v}; WNs.k.{V.g, V.v, start.g, start.v, layers.i.{W.g, W.v, W_o.g, W_o.v} x 8, end.weight};
+ *   with use_conv1x1 followed by invconv1x1.k.weight for every flow (3 + 38 per flow).
  * Only WG_PREC_BF16X3_PLANES is built for this model.  The hop length is 256 (waveflow.py:160). */
 typedef struct wg_wf_config {
     int32_t flows, n_group, n_mels;
     int32_t res_ch, dil_ch, skip_ch;
     int32_t precision;
+    int32_t use_conv1x1;    /* WaveFlow(use_conv1x1=True) (waveflow.py:176-181,203-206,224-229): an InvertibleConv1x1(n_group) over the height
+                               axis replaces the flip between flows; the parameter table then ends with invconv1x1.{k}.weight [H,H,1] per flow */
 } wg_wf_config;
 int wg_wf_param_count(const wg_wf_config *cfg);
 size_t wg_wf_packed_bytes(const wg_wf_config *cfg);

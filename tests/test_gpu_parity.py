@@ -700,9 +700,10 @@ def test_shape_sweep_vs_oracle(dev, case):
 
 # ---- WaveFlow ---------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("name", ["wf8", "wf64"])
+@pytest.mark.parametrize("name", ["wf8", "wf64", "wf8c", "wf64c"])
 def test_waveflow_model_vs_reference_golden(dev, golden_dir, precision, name):
-    """WaveFlow forward + NLL + backward + row-by-row inverse against the reference's own run (model_wf*.npz) and the oracle."""
+    """WaveFlow forward + NLL + backward + row-by-row inverse against the reference's own run (model_wf*.npz) and the oracle.
+    "wf8c" / "wf64c": use_conv1x1=True (an invertible 1x1 conv over the height axis instead of the flip, waveflow.py:203-206)."""
     if precision != "bf16x3p":
         pytest.skip("WaveFlow's 2-D taps are built for the S-plane kernels only")
     from oracle import wf_oracle as wfo
@@ -713,7 +714,9 @@ def test_waveflow_model_vs_reference_golden(dev, golden_dir, precision, name):
     audio, mel = fill.waveflow_inputs(name, B, N, F, cfg["n_mels"])
     gold = np.load(os.path.join(golden_dir, "model_%s.npz" % name))
     ref = wfo.train_step(wfo.make_config(**cfg), fill.table(specs, P), audio, mel, fill.SIGMA, need_dmel=True)
-    m = cm.WaveFlow(use_conv1x1=False, memory_efficient=False, bias=False, **cfg)
+    conv = bool(cfg.get("use_conv1x1"))
+    m = cm.WaveFlow(memory_efficient=False, bias=False, **dict({"use_conv1x1": False}, **cfg))
+    assert [n for n, _ in m.named_parameters()] == [n for n, _, _ in specs]          # invconv1x1.* after WNs.*, as upstream
     m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
     m = m.to(dev)
     ht = T(mel, dev).requires_grad_(True)
@@ -740,6 +743,7 @@ def test_waveflow_model_vs_reference_golden(dev, golden_dir, precision, name):
     with torch.no_grad():
         x, ld = m.reverse(T(gold["z"], dev), ht.detach())
         y_up = npy(m._upsample_h(ht.detach()))
+    assert conv == hasattr(m, "invconv1x1")
     assert np.abs(npy(x) - gold["x_inv"]).max() < Z_ATOL
     assert np.abs(npy(x) - audio).max() < Z_ATOL
     assert logdet_close(npy(ld), gold["logdet_inv"], N)
