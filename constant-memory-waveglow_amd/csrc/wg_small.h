@@ -156,6 +156,7 @@ struct AffineArgs {
 };
 
 #define WG_AFF_T 64          // time steps per workgroup
+#define WG_AFF_LD 64         // skip-channel loads a lane keeps in flight
 __global__ __launch_bounds__(256) void end_affine_kernel(const AffineArgs a)
 {
     // out[m][t] = sum_k W_end[m][k] S[k][t] for the 2*ic <= 32 rows of the end conv: far too few rows for a matrix tile to pay, and
@@ -174,12 +175,14 @@ __global__ __launch_bounds__(256) void end_affine_kernel(const AffineArgs a)
     {
         const int kq = (a.Cs + 3) / 4, k0 = wave * kq, k1 = min(a.Cs, k0 + kq);
         const float *sp = paddr(a.S, g, b, 0, min(t, g.Tt - 1));        // columns in [T, Tt) read the zero padding; beyond Tt is clamped
-        for (int k = k0; k < k1; k += 16) {
-            float sv[16];
+        // 64 loads in flight per lane (a whole quarter of the usual 256 skip channels at once): with one utterance the grid is 32
+        // workgroups and the kernel's time is its chain of load round trips (25 -> 10 us per launch, 8 % of a synthesis call)
+        for (int k = k0; k < k1; k += WG_AFF_LD) {
+            float sv[WG_AFF_LD];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) sv[u] = (k + u < k1) ? sp[(size_t)(k + u) * g.P] : 0.f;
+            for (int u = 0; u < WG_AFF_LD; ++u) sv[u] = (k + u < k1) ? sp[(size_t)(k + u) * g.P] : 0.f;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
+            for (int u = 0; u < WG_AFF_LD; ++u) {
                 const float *w = a.endT + (size_t)min(k + u, a.Cs - 1) * 32;      // wave-uniform address: scalar / broadcast loads
                 if (rows <= 8) {
 #pragma unroll
@@ -266,17 +269,17 @@ __global__ __launch_bounds__(256) void end_affine_kernel(const AffineArgs a)
 __global__ void logdet_finalize_kernel(const float *__restrict__ lu, int ostride, int n_flows, float coef_T,
                                        const float *__restrict__ partial, int ntile, int B, float *__restrict__ logdet)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+    // one wave per batch item: the lanes split the n_flows * ntile partial sums (a serial walk by one thread was 26 us per call)
+    const int b = blockIdx.x, lane = threadIdx.x;
     float s = 0.f;
-    for (int k = 0; k < n_flows; ++k) {
-        s += coef_T * lu[(size_t)k * ostride + 2 * WG_MAXC * WG_MAXC];
-        const float *p = partial + ((size_t)k * B + b) * ntile;
-        float q = 0.f;
-        for (int i = 0; i < ntile; ++i) q += p[i];
-        s += q;
+    for (int e = lane; e < n_flows * ntile; e += 64) {
+        const int k = e / ntile, i = e - k * ntile;
+        s += partial[((size_t)k * B + b) * ntile + i];
     }
-    logdet[b] = s;
+    for (int k = lane; k < n_flows; k += 64) s += coef_T * lu[(size_t)k * ostride + 2 * WG_MAXC * WG_MAXC];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) logdet[b] = s;
 }
 __global__ void scalar_logdet_kernel(const float *lu, float coef_T, float *out) { out[0] = coef_T * lu[2 * WG_MAXC * WG_MAXC]; }
 

@@ -1452,7 +1452,7 @@ static int model_run_fwd_or_inv(const wg_config *cf, const void *packed, const f
         }
     }
     WG_LAUNCH(cx, unsqueeze_kernel, dim3((T + 255) / 256, B), dim3(256), 0, X, out, g, G, N);          // :179 / :207
-    WG_LAUNCH(cx, logdet_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, pk + M.lu, WG_LU_STRIDE, cf->n_flows,
+    WG_LAUNCH(cx, logdet_finalize_kernel, dim3(B), dim3(64), 0, pk + M.lu, WG_LU_STRIDE, cf->n_flows,
               inverse ? -(float)T : (float)T, partial, W.ntile, B, logdet);                            // :175 / :202
     return cx.err;
 }
