@@ -570,17 +570,6 @@ __device__ __forceinline__ void asm_wait_stage(Stage6 &s)
 {
     asm volatile("s_waitcnt vmcnt(6)" : "+v"(s.ah[0]), "+v"(s.ah[1]), "+v"(s.al[0]), "+v"(s.al[1]), "+v"(s.bh[0]), "+v"(s.bl[0])::"memory");
 }
-// three stages in flight: wait until all but the newest TWO have landed (the registers of all of them stay pinned)
-__device__ __forceinline__ void asm_wait_stage2(Stage6 &s, Stage6 &k)
-{
-    asm volatile("s_waitcnt vmcnt(12)" : "+v"(s.ah[0]), "+v"(s.ah[1]), "+v"(s.al[0]), "+v"(s.al[1]), "+v"(s.bh[0]), "+v"(s.bl[0]),
-                 "+v"(k.ah[0]), "+v"(k.ah[1]), "+v"(k.al[0]), "+v"(k.al[1]), "+v"(k.bh[0]), "+v"(k.bl[0])::"memory");
-}
-__device__ __forceinline__ void asm_wait_stage2(Stage8 &s, Stage8 &k)
-{
-    asm volatile("s_waitcnt vmcnt(16)" : WG_STAGE_REGS(s), "+v"(k.ah[0]), "+v"(k.ah[1]), "+v"(k.al[0]), "+v"(k.al[1]), "+v"(k.bh[0]), "+v"(k.bh[1]),
-                 "+v"(k.bl[0]), "+v"(k.bl[1])::"memory");
-}
 template <int NI> struct FragsW {
     bf16x8 ah[2], al[2], bh[NI], bl[NI];
 };
