@@ -326,6 +326,38 @@ def test_coupling_block(dev, golden_dir, cname, rev):
         assert np.allclose(a, b)                                                # efficient == naive (:160)
 
 
+def test_coupling_block_on_shared_b_tiles_vs_oracle(dev, precision):
+    """One coupling block at the shipped WN width (256 channels, so the gate conv has 512 rows) on 2 x 16 384 columns: 1 024 gate-conv
+    tiles = 2 per CU, the shape at which the engine runs the 256 x 128 form of the conv kernel (two compute groups sharing one B image,
+    convgemm16q_kernel<.., MG = 2>) -- checked against the oracle, forward and backward."""
+    if precision != "bf16x3p":
+        pytest.skip("the shared-B tile exists in the S-plane mode only")
+    wn = dict(in_channels=4, aux_channels=80, residual_channels=256, dilation_channels=256, skip_channels=256, depth=2, radix=3)
+    specs = fill.wn_param_specs("F.", 4, 80, 256, 256, 256, 2, 3)
+    tag = "coupling/mg2"
+    P = fill.fill_params(specs, tag + "/")
+    B, Tn = 2, 16384
+    x = fill.uniform(tag + "/x", (B, 8, Tn))
+    y = fill.normal(tag + "/y", (B, 80, Tn))
+    gz = fill.normal(tag + "/gz", x.shape)
+    gls = fill.normal(tag + "/gls", (B, 4, Tn))
+    z_ref, ls_ref = orc.coupling_apply(wn, fill.table(specs, P), x, y)
+    ref = orc.coupling_backward(wn, fill.table(specs, P), z_ref, y, gz, gls)
+    blk = cm.AffineCouplingBlock(cm.WN, True, zero_init=False, **wn)
+    blk.load_state_dict({n: torch.from_numpy(v) for n, v in P.items()})
+    blk = blk.to(dev)
+    xt, yt = T(x, dev).requires_grad_(True), T(y, dev).requires_grad_(True)
+    z, ls = blk(xt.clone(), yt)
+    ((z * T(gz, dev)).sum() + (ls * T(gls, dev)).sum()).backward()
+    assert np.abs(npy(z) - z_ref).max() < 1e-5 and np.abs(npy(ls) - ls_ref).max() < 1e-5
+    got = dict(dx=npy(xt.grad), dy=npy(yt.grad))
+    want = ref
+    assert relmax(got["dx"], want["dx"]) < GRAD_RTOL and relmax(got["dy"], want["dy"]) < GRAD_RTOL
+    named = dict(blk.named_parameters())
+    for i, (n, _, _) in enumerate(specs):
+        assert relmax(npy(named[n].grad), want["grads"][i]) < GRAD_RTOL, n
+
+
 def test_wn_forward_standalone(dev):
     wn = cm.WN(4, 80, 64, 64, 64, depth=4, zero_init=False).to(dev)
     specs = fill.wn_param_specs("", 4, 80, 64, 64, 64, 4, 3)
