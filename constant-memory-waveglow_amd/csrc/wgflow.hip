@@ -651,7 +651,10 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
             // traffic, no slower co-resident workgroup left to finish alone): gate conv 125.7 -> 118.6 us.  Only where the tiles deal out
             // evenly over the CUs: at 1.5 tiles per CU (the 256-row products of the training shape: 384 such tiles) the half-empty second
             // round costs more than the sharing saves (measured: step 81.8 -> 83.0 ms with every eligible launch on this path).
-            if (epi != EPI_DGATE && rup(mrows, WG_TILE) % 256 == 0 && ((ntiles / 2) % cus == 0 || ntiles / 2 >= 8 * cus)) {
+            // (1.69 such tiles per CU -- the gate conv of a 10 s utterance -- still gain 4 %: 20.2 -> 21.0 MHz; 1.5 per CU lose)
+            const int rounds = (ntiles / 2 + cus - 1) / cus;
+            const bool mg2_ok = ntiles / 2 >= cus && (double)(rounds * cus - ntiles / 2) <= 0.17 * rounds * cus;
+            if (epi != EPI_DGATE && rup(mrows, WG_TILE) % 256 == 0 && mg2_ok) {
                 as.nty = (int)grid.y / 2;
                 const dim3 g2(std::min(ntiles / 2, cus));
                 switch (epi) {
