@@ -1,0 +1,188 @@
+// wg_gemm16h.h -- the conv kernel for launches that cannot fill the chip: single-utterance synthesis (the gate conv of a 0.7 s utterance
+// is 4 x 32 tiles of 128 x 64), WaveFlow's row-by-row inverse.
+//
+// What bounds such a launch (in-kernel stamps, tools/experiments/infer_trace.py): the 27-chunk main loop of the 128 x 64 form runs at the
+// full 2.36 GHz with the matrix pipe 35 % busy; a chunk takes 460 ns because ONE CU takes in its operands (24 KB per chunk, 3/4 of them
+// L2 hits) at 52-58 GB/s -- the per-CU rate of MI355X_MICROARCH.md's gather table -- while half of the CUs have no workgroup.  Twice the
+// bytes in flight per CU did not change that rate (a two-compute-group form that split K inside the workgroup was built and measured:
+// 830 ns per two chunks), so the bytes per CU have to go down: this kernel uses 64 x 64 tiles, i.e. twice the workgroups (one per CU for
+// the utterance above) that each stream 16 KB per chunk -- the minimum of (rows + columns) at that tile count.
+//
+// Structure: convgemm16q's (wg_gemm16q.h) with the roles re-cut for the small tile.  4 compute waves, each the whole 64 rows x 16 columns
+// (the gate epilogue pairs rows r and r + 32 of a 64-row block, so a wave owns complete gate channels): 12 MFMAs per chunk and wave; 4
+// loader waves, ONE 16-byte piece of each of the four images (A hi, A lo, B hi, B lo) per lane and chunk, WG16H_DEPTH chunks in flight in
+// registers, two LDS buffers.  One barrier per chunk: behind it every wave has the chunk's fragments in registers (__syncthreads waits for
+// the LDS reads) and the next chunk is staged; the compute waves re-load each A fragment from the next buffer as soon as its three MFMAs
+// are issued.  One tile per workgroup.
+#pragma once
+#include "wg_gemm16q.h"
+
+#ifndef WG16H_DEPTH
+#define WG16H_DEPTH 3
+#endif
+struct Stage4 {
+    u32x4 ah, al, bh, bl;
+};
+__device__ __forceinline__ void asm_wait_stage_h(Stage4 &s)      // all but the newest WG16H_DEPTH - 1 stages have landed
+{
+    static_assert(WG16H_DEPTH >= 2 && WG16H_DEPTH <= 4, "");
+    if (WG16H_DEPTH == 2) asm volatile("s_waitcnt vmcnt(4)" : "+v"(s.ah), "+v"(s.al), "+v"(s.bh), "+v"(s.bl)::"memory");
+    if (WG16H_DEPTH == 3) asm volatile("s_waitcnt vmcnt(8)" : "+v"(s.ah), "+v"(s.al), "+v"(s.bh), "+v"(s.bl)::"memory");
+    if (WG16H_DEPTH == 4) asm volatile("s_waitcnt vmcnt(12)" : "+v"(s.ah), "+v"(s.al), "+v"(s.bh), "+v"(s.bl)::"memory");
+}
+#if defined(WG_DBG_TRACE) && defined(WG_DBG_TRACE_SMALL)
+#define WGH_TRACE(slot) do { if (EPI == EPI_GATE && lane == 0 && wave == 0) { \
+        wg_dbg_trace[blockIdx.x * 16 + (slot)] = wall_clock64(); wg_dbg_trace_cyc[blockIdx.x * 16 + (slot)] = clock64(); } } while (0)
+#else
+#define WGH_TRACE(slot) do { } while (0)
+#endif
+
+// grid: ntx (64-column tiles) x nty (64-ROW tiles) x ntz, flattened in blockIdx.x, time tile fastest
+template <int EPI>
+__global__ __launch_bounds__(512) void convgemm16h_kernel(const ConvGemm16sArgs aa)
+{
+    constexpr int D = WG16H_DEPTH;
+    constexpr int AIMG = 64 * WG16Q_ROWB, BIMG = 64 * WG16Q_ROWB;       // 4 KB each
+    constexpr int BUF = 2 * AIMG + 2 * BIMG;
+    constexpr int TT = 64;
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+    const ConvGemmArgs &a = aa.c;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const Geo g = a.g;
+    int nchunks = 0;
+    for (int s = 0; s < a.nseg; ++s) nchunks += (a.seg[s].nch + WG16_BK - 1) / WG16_BK;
+    const int nbar = (nchunks + D - 1) / D * D;               // barriers after the first: the loaders' iterations come in groups of D
+    const int id = (int)blockIdx.x;
+    const int tx = id % aa.ntx, q = id / aa.ntx, ty = q % aa.nty, tz = q / aa.nty;
+    const int t0 = tx * TT, m0 = ty * 64;
+    const int b = a.row_sel1 ? tz * g.rows + a.row_sel1 - 1 : tz;
+    if (m0 >= a.M) return;                                    // (M is padded to 128 rows in the image: the upper half tile may be empty)
+
+    if (wave >= 4) {
+        // ------------------------------- loader waves -------------------------------
+        const int lt = tid - 256;
+        const int r = lt & 63, kq = lt >> 6;                  // this lane's piece of every image: row / column r, k-group kq
+        const int l_off = wg16q_off(r, kq);
+        // A image of a chunk: [128-row block][k-group][row][8]: the 64-row half of block m0 / 128
+        const unsigned voff_a = (unsigned)((kq * 128 + (m0 & 64) + r) * 16);
+        const unsigned voff_b = (unsigned)((kq * g.P + r) * 16);
+        int cur_seg = 0, cur_c = 0, chunk = 0;
+#if defined(WG_DBG_NOLOAD)
+#define WG_LD(dst, base, voff) asm volatile("" : "=v"(dst) : "v"(voff), "s"(base))
+#else
+#define WG_LD(dst, base, voff) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
+#endif
+        const unsigned short *zsrc = aa.sseg[0].hi;           // plane position 0 of the first operand: always-zero halo
+        auto issue = [&](Stage4 &st) {                        // exactly 4 loads in straight-line code (tools/check_asm_loads.py)
+            const bool live = chunk < nchunks;
+            const int sg = min(cur_seg, a.nseg - 1);
+            const int nch = a.seg[sg].nch, shift = a.seg[sg].shift;
+            const SSeg ss = aa.sseg[sg];
+            int bsrc = b;
+            bool rowok = true;
+            if (g.rows > 0) {
+                const int item = b / g.rows, rr = b - item * g.rows + ss.row_off;
+                rowok = rr >= 0 && rr < g.rows;
+                bsrc = ss.per_item ? item : b + ss.row_off;
+            }
+            const bool blive = live && rowok, full = blive && (nch - cur_c > 16);
+            const unsigned short *ih = aa.img + ((size_t)chunk * a.lda + (m0 & ~127)) * WG16_BK, *il = ih + aa.img_stride;
+            const unsigned short *row0 = ss.hi + ((size_t)bsrc * (ss.Cp >> 3) + ((ss.ch0 + cur_c) >> 3)) * g.P * 8;
+            const unsigned short *pa = live ? ih : zsrc, *pl = live ? il : zsrc;
+            const unsigned va = live ? voff_a : 0u;
+            WG_LD(st.ah, pa, va);   WG_LD(st.al, pl, va);
+            const unsigned short *pb = blive ? row0 : zsrc, *pbl = blive ? row0 + ss.lo_off : zsrc;
+            const bool lane_ok = blive && (kq < 2 || full);
+            const unsigned vb = lane_ok ? voff_b + (unsigned)((g.H + t0 + shift) * 16) : 0u;
+            WG_LD(st.bh, pb, vb);   WG_LD(st.bl, pbl, vb);
+            if (live) {
+                ++chunk;
+                cur_c += WG16_BK;
+                if (cur_c >= nch) { cur_c = 0; ++cur_seg; }
+            }
+        };
+#undef WG_LD
+        auto write = [&](const Stage4 &st, int buf) {
+            char *sb = smem + buf * BUF + l_off;
+            *reinterpret_cast<u32x4 *>(sb) = st.ah;
+            *reinterpret_cast<u32x4 *>(sb + AIMG) = st.al;
+            *reinterpret_cast<u32x4 *>(sb + 2 * AIMG) = st.bh;
+            *reinterpret_cast<u32x4 *>(sb + 2 * AIMG + BIMG) = st.bl;
+        };
+        Stage4 st[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) issue(st[i]);             // chunks 0 .. D-1
+        asm_wait_stage_h(st[0]);
+        write(st[0], 0);
+        issue(st[0]);                                         // chunk D
+        WG16W_BAR();                                          // buffer 0 ready
+        // iteration c (between barrier c and barrier c + 1; the compute waves multiply chunk c): the stage holding chunk c + 1 has
+        // landed -> into the buffer chunk c - 1 was read from (those reads completed before barrier c), then chunk c + 1 + D is requested
+        for (int c = 0; c < nbar; c += D) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                Stage4 &s = st[(i + 1) % D];
+                asm_wait_stage_h(s);
+                write(s, (c + i + 1) & 1);
+                issue(s);
+                WG16W_BAR();
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the trailing zero-halo loads before the wave ends
+        return;
+    }
+    // ------------------------------- compute waves -------------------------------
+    const int wc = wave;                                      // 16-column block of the tile
+    f32x4 acc[4][1];
+    WGH_TRACE(8);
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int ao = wg16q_off(r16, kg), bo = wg16q_off(wc * 16 + r16, kg);
+    struct Frags { bf16x8 ah[4], al[4], bh, bl; };
+    auto rd = [&](const char *p) { return *reinterpret_cast<const bf16x8 *>(p); };
+    auto fetch = [&](Frags &f, const char *sb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f.ah[i] = rd(sb + ao + i * 1024); f.al[i] = rd(sb + AIMG + ao + i * 1024); }
+        f.bh = rd(sb + 2 * AIMG + bo); f.bl = rd(sb + 2 * AIMG + BIMG + bo);
+    };
+    if (EPI == EPI_STORE || EPI == EPI_RESSKIP) {
+        conv_acc_init_q<EPI, 1>(a, aa.saux, acc, t0, m0, b, 0, wc, lane);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][0][e] = 0.f;
+    }
+    WGH_TRACE(0);
+    WG16W_BAR();                                              // buffer 0 ready
+    WGH_TRACE(1);
+    Frags f0, f1;
+    fetch(f0, smem);
+    // one chunk: barrier (chunk c is in registers everywhere, chunk c + 1 is staged), request chunk c + 1's fragments into the other
+    // register set, multiply chunk c: the three products of a block are dependent, so the 12 MFMAs go product by product over the
+    // four blocks.  (behind the last chunk the request reads a buffer nothing uses)
+    auto step = [&](const Frags &f, Frags &fn, int c) {
+        __builtin_amdgcn_sched_barrier(0);
+        WG16W_BAR();
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(fn, smem + ((c & 1) ^ 1) * BUF);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.al[mb], f.bh, acc[mb][0], 0, 0, 0);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ah[mb], f.bl, acc[mb][0], 0, 0, 0);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ah[mb], f.bh, acc[mb][0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int c = 0;
+    for (; c + 1 < nchunks; c += 2) {
+        step(f0, f1, c);
+        step(f1, f0, c + 1);
+    }
+    if (c < nchunks) step(f0, f1, c);
+    for (int c = nchunks; c < nbar; ++c) WG16W_BAR();         // the loaders' spare iterations
+    WGH_TRACE(2);
+    conv_epilogue_q<EPI, 1>(a, aa.s0, acc, t0, m0, b, 0, wc, lane);
+    WGH_TRACE(3);
+}

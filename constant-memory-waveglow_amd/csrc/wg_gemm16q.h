@@ -34,8 +34,8 @@ __device__ __forceinline__ int wg16q_off(int row, int kg) { return row * WG16Q_R
 // ------------------------------------------------------------------------------------------------
 // epilogues in the 16x16 accumulator layout (same contracts as conv_acc_init / conv_epilogue_s)
 // ------------------------------------------------------------------------------------------------
-template <int EPI, int NI>
-__device__ __forceinline__ void conv_acc_init_q(const ConvGemmArgs &a, const SRef &saux, f32x4 (&acc)[4][2 * NI], int t0, int m0, int b, int wr, int wc,
+template <int EPI, int NB>
+__device__ __forceinline__ void conv_acc_init_q(const ConvGemmArgs &a, const SRef &saux, f32x4 (&acc)[4][NB], int t0, int m0, int b, int wr, int wc,
                                                 int lane)
 {
     const Geo g = a.g;
@@ -47,8 +47,8 @@ __device__ __forceinline__ void conv_acc_init_q(const ConvGemmArgs &a, const SRe
         for (int mb = 0; mb < 4; ++mb) {
             const int m = m0 + wr * 64 + mb * 16 + 4 * rq;
 #pragma unroll
-            for (int nb = 0; nb < 2 * NI; ++nb) {
-                const int t = t0 + wc * (32 * NI) + nb * 16 + col;
+            for (int nb = 0; nb < NB; ++nb) {
+                const int t = t0 + wc * (16 * NB) + nb * 16 + col;
                 u32x2 vh = {0u, 0u}, vl = {0u, 0u};
                 if (t < g.T && m < a.M) {
                     const size_t i = s_index(saux, g, b, m, t);
@@ -71,8 +71,8 @@ __device__ __forceinline__ void conv_acc_init_q(const ConvGemmArgs &a, const SRe
         else if (EPI == EPI_RESSKIP)                                              // nsplit is a multiple of 32: a block lies on one side
             base = mbase < a.nsplit ? paddr(a.aux0, g, b, mbase, t0) : (a.accumulate ? paddr(a.out1, g, b, mbase - a.nsplit, t0) : nullptr);
 #pragma unroll
-        for (int nb = 0; nb < 2 * NI; ++nb) {
-            const int tl = wc * (32 * NI) + nb * 16 + col;
+        for (int nb = 0; nb < NB; ++nb) {
+            const int tl = wc * (16 * NB) + nb * 16 + col;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const unsigned off = (unsigned)(4 * rq + e) * (unsigned)g.P + (unsigned)tl;
@@ -84,13 +84,12 @@ __device__ __forceinline__ void conv_acc_init_q(const ConvGemmArgs &a, const SRe
     }
 }
 
-template <int EPI, int NI>
-__device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRef &s0, f32x4 (&acc)[4][2 * NI], int t0, int m0, int b,
+template <int EPI, int NB>
+__device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRef &s0, f32x4 (&acc)[4][NB], int t0, int m0, int b,
                                                 int wr, int wc, int lane)
 {
     const Geo g = a.g;
     const int col = lane & 15, rq = lane >> 4;
-    constexpr int NB = 2 * NI;
     if (EPI == EPI_GATE) {
         // rows 0-31 of the wave tile are the tanh halves, rows 32-63 the sigmoid halves of the same 32 gate channels (pack_kernel's
         // 64-row interleave): channel chb + mbp*16 + 4 rq + e pairs acc[mbp] with acc[mbp + 2]
@@ -104,7 +103,7 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
         const unsigned s_grp = (unsigned)g.P * 8u;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            const unsigned tl = (unsigned)(wc * (32 * NI) + nb * 16 + col);
+            const unsigned tl = (unsigned)(wc * (16 * NB) + nb * 16 + col);
             if (t0 + (int)tl >= g.T) continue;
             float tw[8], sf[8], gv[8];
 #pragma unroll
@@ -148,7 +147,7 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
             const float *p0 = paddr(a.aux0, g, b, mbase, t0), *p1 = paddr(a.aux1, g, b, mbase, t0);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const int tl = wc * (32 * NI) + nb * 16 + col;
+                const int tl = wc * (16 * NB) + nb * 16 + col;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const unsigned off = (unsigned)(4 * rq + e) * (unsigned)g.P + (unsigned)tl;
@@ -162,7 +161,7 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const int t = t0 + wc * (32 * NI) + nb * 16 + col, m = m0 + wr * 64 + mb * 16 + 4 * rq;
+                const int t = t0 + wc * (16 * NB) + nb * 16 + col, m = m0 + wr * 64 + mb * 16 + 4 * rq;
                 if (t >= g.T || m >= a.M) continue;
                 float o[4], o2[4];
 #pragma unroll
@@ -190,7 +189,7 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
         float *base = dst.p ? paddr(dst, g, b, res ? mbase : mbase - a.nsplit, t0) : nullptr;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            const int tl = wc * (32 * NI) + nb * 16 + col, t = t0 + tl, m = mbase + 4 * rq;
+            const int tl = wc * (16 * NB) + nb * 16 + col, t = t0 + tl, m = mbase + 4 * rq;
             if (t >= g.T || m >= a.M) continue;
             float o[4];
 #pragma unroll
@@ -207,7 +206,12 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
 // the kernel: 8 waves, waves 0-3 multiply, waves 4-7 move operands (see convgemm16w_kernel for the protocol)
 // ------------------------------------------------------------------------------------------------
 #if defined(WG_DBG_TRACE)
-#define WGQ_TRACE(slot) do { if (EPI == EPI_GATE && NI == 2 && lane == 0 && wave == 0 && (slot) < 16) { \
+#if defined(WG_DBG_TRACE_SMALL)                           // stamp the 128 x 64 form (small grids) instead
+#define WGQ_TRACE_NI 1
+#else
+#define WGQ_TRACE_NI 2
+#endif
+#define WGQ_TRACE(slot) do { if (EPI == EPI_GATE && NI == WGQ_TRACE_NI && lane == 0 && wave == 0 && (slot) < 16) { \
         wg_dbg_trace[blockIdx.x * 16 + (slot)] = wall_clock64(); wg_dbg_trace_cyc[blockIdx.x * 16 + (slot)] = clock64(); } } while (0)
 #else
 #define WGQ_TRACE(slot) do { } while (0)
@@ -362,6 +366,7 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
     bf16x8 ah[4], al[4], bh[2], bl[2];
     auto rd = [&](const char *q) { return *reinterpret_cast<const bf16x8 *>(q); };
     int gc = 0;                                              // chunk index in this workgroup's stream; its buffer is gc & 1
+    WGQ_TRACE(8);                                            // (kernel entry)
     auto do_tile = [&](int k) {
         int t0, m0, b;
         tile_at(k, t0, m0, b);
@@ -372,7 +377,7 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
             WGQ_SB();
         }
         if (EPI == EPI_STORE || EPI == EPI_RESSKIP) {
-            conv_acc_init_q<EPI, NI>(a, aa.saux, acc, t0, m0, b, wr, wc, ln);
+            conv_acc_init_q<EPI, NB>(a, aa.saux, acc, t0, m0, b, wr, wc, ln);
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
 #if defined(WG_OPT_EPI_PRIO)
         __builtin_amdgcn_s_setprio(WG_OPT_EPI_PRIO);         // experiment: the epilogue's VALU / store issue ahead of the co-resident workgroup's waves
 #endif
-        conv_epilogue_q<EPI, NI>(a, aa.s0, acc, t0, m0, b, wr, wc, le);
+        conv_epilogue_q<EPI, NB>(a, aa.s0, acc, t0, m0, b, wr, wc, le);
 #if defined(WG_OPT_EPI_PRIO)
         __builtin_amdgcn_s_setprio(0);
 #endif

@@ -6,6 +6,7 @@
 #include "wg_gemm16.h"
 #include "wg_gemm16s.h"
 #include "wg_gemm16q.h"
+#include "wg_gemm16h.h"
 #include "wg_wsr.h"
 #include "wg_wf.h"
 #include "wg_mel.h"
@@ -637,6 +638,20 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
 #endif
             const dim3 gp = epi == EPI_DGATE ? dim3(as.ntx, as.nty, as.ntz) : dim3(std::min(ntiles, slots));
 #if !defined(WG_OPT_MFMA32)                       // default: the 16x16x32 form of the same kernel (wg_gemm16q.h)
+#if !defined(WG_OPT_NO_HTILE)
+            // at most half as many 128 x 64 tiles as CUs (one utterance being synthesised, WaveFlow's row-by-row inverse): such a launch
+            // is as long as its slowest CU needs to take in its operands -- 64 x 64 tiles, twice the workgroups (wg_gemm16h.h)
+            if (small && 2 * ntiles <= cus && epi != EPI_DGATE) {
+                as.nty = 2 * (int)grid.y;
+                const dim3 gh(as.ntx * as.nty * as.ntz);
+                switch (epi) {
+                case EPI_STORE: WG_LAUNCH(cx, convgemm16h_kernel<EPI_STORE>, gh, dim3(512), 0, as); break;
+                case EPI_GATE: WG_LAUNCH(cx, convgemm16h_kernel<EPI_GATE>, gh, dim3(512), 0, as); break;
+                case EPI_RESSKIP: WG_LAUNCH(cx, convgemm16h_kernel<EPI_RESSKIP>, gh, dim3(512), 0, as); break;
+                }
+                return;
+            }
+#endif
             if (small) {
                 switch (epi) {
                 case EPI_STORE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE, 1>), gp, dim3(512), 0, as); break;

@@ -223,6 +223,10 @@ def test_full_size_properties(dev):
         z1, ld1 = m(x[5:6].clone(), ht[5:6])
     assert float((z1 - z[5:6]).abs().max()) < 1e-5
     assert abs(float(ld1[0] - logdet[5])) < 1e-4 * abs(float(logdet[5])) + 1e-3
+    # ... and inverts alone as well (a launch of fewer tiles than CUs takes the 64 x 64-tile conv kernel, wg_gemm16h.h)
+    with torch.no_grad():
+        xr1, _ = m.reverse(z[5:6].detach().clone(), ht[5:6])
+    assert float((xr1 - x[5:6]).abs().max()) < Z_ATOL
     # linearity of the gradient in the batch: mean of two half-batch gradients == full-batch gradient (DP semantics)
     m.zero_grad()
     for sl in (slice(0, 12), slice(12, 24)):
