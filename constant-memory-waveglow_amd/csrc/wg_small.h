@@ -163,7 +163,10 @@ __global__ __launch_bounds__(256) void end_affine_kernel(const AffineArgs a)
     // the kernel is bound by reading S once.  A workgroup takes 64 time steps; its 4 waves split the skip channels, every lane
     // streams its quarter of S[:, t] (coalesced along t, 16 loads in flight) into 2*ic accumulators, LDS adds the four quarters.
     __shared__ float tile[32][WG_AFF_T + 1];
-    __shared__ float part[3][32][WG_AFF_T + 1];
+    // phase 1: each wave's block of W_end^T rows ([WG_AFF_LD][32] floats per wave); phase 2: the partial sums of waves 1-3
+    __shared__ __attribute__((aligned(16))) float stage[4 * WG_AFF_LD * 32];
+    float (*part)[32][WG_AFF_T + 1] = reinterpret_cast<float (*)[32][WG_AFF_T + 1]>(stage);
+    static_assert(sizeof(stage) >= 3 * 32 * (WG_AFF_T + 1) * sizeof(float), "");
     __shared__ float red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, t = blockIdx.x * WG_AFF_T + lane;
@@ -175,25 +178,45 @@ __global__ __launch_bounds__(256) void end_affine_kernel(const AffineArgs a)
     {
         const int kq = (a.Cs + 3) / 4, k0 = wave * kq, k1 = min(a.Cs, k0 + kq);
         const float *sp = paddr(a.S, g, b, 0, min(t, g.Tt - 1));        // columns in [T, Tt) read the zero padding; beyond Tt is clamped
+        float *wl = stage + wave * (WG_AFF_LD * 32);
         // 64 loads in flight per lane (a whole quarter of the usual 256 skip channels at once): with one utterance the grid is 32
-        // workgroups and the kernel's time is its chain of load round trips (25 -> 10 us per launch, 8 % of a synthesis call)
-        for (int k = k0; k < k1; k += WG_AFF_LD) {
+        // workgroups and the kernel's time is its chain of round trips.  The weights of those 64 channels come through LDS (one
+        // coalesced copy per wave, then broadcast reads): as wave-uniform global loads they were a chain of 64 scalar-cache misses,
+        // 25 us per launch = 10 % of a synthesis call
+        for (int kk = 0; kk < kq; kk += WG_AFF_LD) {                     // (same trip count in every wave: barriers inside)
+            const int k = k0 + kk;
             float sv[WG_AFF_LD];
 #pragma unroll
             for (int u = 0; u < WG_AFF_LD; ++u) sv[u] = (k + u < k1) ? sp[(size_t)(k + u) * g.P] : 0.f;
+            if (kk) __syncthreads();                                     // the previous block has been consumed
+            for (int i = lane; i < WG_AFF_LD * 8; i += 64) {             // rows k .. k+63 of endT are one contiguous 8 KB piece
+                const int row = k + (i >> 3);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < k1) v = reinterpret_cast<const float4 *>(a.endT + (size_t)k * 32)[i];
+                reinterpret_cast<float4 *>(wl)[i] = v;
+            }
+            __syncthreads();
 #pragma unroll
             for (int u = 0; u < WG_AFF_LD; ++u) {
-                const float *w = a.endT + (size_t)min(k + u, a.Cs - 1) * 32;      // wave-uniform address: scalar / broadcast loads
+                const float4 *w = reinterpret_cast<const float4 *>(wl + u * 32);         // same address in every lane: LDS broadcast
                 if (rows <= 8) {
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) acc[m] = fmaf(w[m], sv[u], acc[m]);
+                    const float4 w0 = w[0], w1 = w[1];
+                    acc[0] = fmaf(w0.x, sv[u], acc[0]); acc[1] = fmaf(w0.y, sv[u], acc[1]);
+                    acc[2] = fmaf(w0.z, sv[u], acc[2]); acc[3] = fmaf(w0.w, sv[u], acc[3]);
+                    acc[4] = fmaf(w1.x, sv[u], acc[4]); acc[5] = fmaf(w1.y, sv[u], acc[5]);
+                    acc[6] = fmaf(w1.z, sv[u], acc[6]); acc[7] = fmaf(w1.w, sv[u], acc[7]);
                 } else {
 #pragma unroll
-                    for (int m = 0; m < 32; ++m) acc[m] = fmaf(w[m], sv[u], acc[m]);
+                    for (int q = 0; q < 8; ++q) {
+                        const float4 wq = w[q];
+                        acc[4 * q] = fmaf(wq.x, sv[u], acc[4 * q]);         acc[4 * q + 1] = fmaf(wq.y, sv[u], acc[4 * q + 1]);
+                        acc[4 * q + 2] = fmaf(wq.z, sv[u], acc[4 * q + 2]); acc[4 * q + 3] = fmaf(wq.w, sv[u], acc[4 * q + 3]);
+                    }
                 }
             }
         }
     }
+    __syncthreads();                                                     // stage: weights -> partial sums
     if (wave > 0) {
 #pragma unroll
         for (int m = 0; m < 32; ++m)
