@@ -379,12 +379,19 @@ def main():
                 for frames in (63, 862):                                  # 16 128 samples and ~10 s of audio
                     hc = torch.randn(1, C2["n_mels"], frames, device=dev, generator=g)
                     model.infer(hc, 0.6)
-                    torch.cuda.synchronize()
+                    costs = []
+                    for _ in range(5):                                    # one call between two synchronisations, as inference.py:50-56
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        xs = model.infer(hc, 0.6)
+                        torch.cuda.synchronize()
+                        costs.append(time.perf_counter() - t1)
+                    out["inverse_khz_%d" % xs.numel()] = xs.numel() / sorted(costs)[2] / 1000.0
                     t1 = time.perf_counter()
-                    xs = model.infer(hc, 0.6)
+                    for _ in range(10):                                   # a queue of utterances: the host runs ahead of the device
+                        xs = model.infer(hc, 0.6)
                     torch.cuda.synchronize()
-                    cost = time.perf_counter() - t1
-                    out["inverse_khz_%d" % xs.numel()] = xs.numel() / cost / 1000.0
+                    out["inverse_khz_%d_queued" % xs.numel()] = xs.numel() * 10 / (time.perf_counter() - t1) / 1000.0
             out["inverse_khz"] = out["inverse_khz_%d" % (862 * 256)]
         if world == 1:
             # outside the metric (SURVEY.md 8d excludes the optimizer): one Adam step over all 53.66 M parameters on the flat buffers

@@ -326,48 +326,79 @@ __global__ void upsample_fwd_kernel(const float *__restrict__ h, const float *__
     if (yplain) yplain[((size_t)b * C + c) * g.T + j] = s;
 }
 
-// one block per mel channel: dbias, dw (then weight-norm backward), optional dh
+// one block per mel channel: dbias, dw (then weight-norm backward), optional dh.  Every sum keeps four independent accumulators per
+// thread (the block's time is its chain of load round trips: 80 blocks for WaveGlow, 311 us as single chains); all sums are reduced in a
+// fixed order (bitwise reproducible).  Dynamic LDS: [K] dw + [256] scratch + [256] tap partials.
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float *__restrict__ h, const float *__restrict__ w, PRef dY, Geo g,
                                                            int C, int F, int K, int S, int Pd,
                                                            const float *__restrict__ gparam, const float *__restrict__ v,
                                                            float *__restrict__ dbias, float *__restrict__ dg,
                                                            float *__restrict__ dv, float *__restrict__ dh)
 {
-    extern __shared__ float sm[];   // [K] dw + [256] scratch
-    float *dw = sm, *red = sm + K;
-    const int c = blockIdx.x, tid = threadIdx.x;
+    extern __shared__ float sm[];
+    float *dw = sm, *red = sm + K, *tp = sm + K + 256;
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto block_sum = [&](float x) {                            // every thread gets the sum over the block
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+        __syncthreads();
+        if (lane == 0) red[wave] = x;
+        __syncthreads();
+        return (red[0] + red[1]) + (red[2] + red[3]);
+    };
     // dbias
-    float sb = 0.f;
-    for (int e = tid; e < g.B * g.T; e += 256) sb += *paddr(dY, g, e / g.T, c, e % g.T);
-    red[tid] = sb;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-    if (tid == 0 && dbias) dbias[c] = red[0];
-    __syncthreads();
+    {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int b = 0; b < g.B; ++b) {
+            const float *row = paddr(dY, g, b, c, 0);
+            int t = tid;
+            for (; t + 768 < g.T; t += 1024) { s0 += row[t]; s1 += row[t + 256]; s2 += row[t + 512]; s3 += row[t + 768]; }
+            for (; t < g.T; t += 256) s0 += row[t];
+        }
+        const float sb = block_sum((s0 + s1) + (s2 + s3));
+        if (tid == 0 && dbias) dbias[c] = sb;
+    }
     // dw[kk] = sum_{b,i} h[b,c,i] * dY[b,c,S*i+kk-Pd].  Two shapes occur: many taps over few frames (WaveGlow: K = 65, F = 63)
-    // -> one thread per tap; few taps over many frames (WSRGlow: K = 3, F = 512 per item) -> the block reduces each tap.
+    // -> a thread per (tap, share of the batch items); few taps over many frames (WSRGlow: K = 3, F = 512 per item) -> the block
+    // reduces four taps at a time.
     if (K >= 32) {
-        for (int kk = tid; kk < K; kk += 256) {
+        const int nbg = max(1, 256 / K), bg = nbg > 1 ? tid / K : 0;
+        for (int kk = nbg > 1 ? tid % K : tid; kk < K && bg < nbg; kk += 256) {       // (one pass unless K > 256)
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            for (int b = bg; b < g.B; b += nbg) {
+                const float *hr = h + ((size_t)b * C + c) * F;
+                const float *row = paddr(dY, g, b, c, 0);
+                auto term = [&](int i) { const int j = S * i + kk - Pd; return (i < F && j >= 0 && j < g.T) ? hr[i] * row[j] : 0.f; };
+                for (int i = 0; i < F; i += 4) { s0 += term(i); s1 += term(i + 1); s2 += term(i + 2); s3 += term(i + 3); }
+            }
+            if (nbg > 1) tp[bg * K + kk] = (s0 + s1) + (s2 + s3);
+            else dw[kk] = (s0 + s1) + (s2 + s3);
+        }
+        __syncthreads();
+        if (nbg > 1 && tid < K) {
             float s = 0.f;
-            for (int b = 0; b < g.B; ++b)
-                for (int i = 0; i < F; ++i) {
-                    const int j = S * i + kk - Pd;
-                    if (j >= 0 && j < g.T) s += h[((size_t)b * C + c) * F + i] * *paddr(dY, g, b, c, j);
-                }
-            dw[kk] = s;
+            for (int q = 0; q < nbg; ++q) s += tp[q * K + tid];
+            dw[tid] = s;
         }
     } else {
-        for (int kk = 0; kk < K; ++kk) {
-            float s = 0.f;
+        for (int k0 = 0; k0 < K; k0 += 4) {
+            float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
             for (int e = tid; e < g.B * F; e += 256) {
-                const int b = e / F, i = e - b * F, j = S * i + kk - Pd;
-                if (j >= 0 && j < g.T) s += h[((size_t)b * C + c) * F + i] * *paddr(dY, g, b, c, j);
+                const int b = e / F, i = e - b * F;
+                const float hv = h[((size_t)b * C + c) * F + i];
+                const float *row = paddr(dY, g, b, c, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int j = S * i + k0 + q - Pd;
+                    if (k0 + q < K && j >= 0 && j < g.T) s[q] += hv * row[j];
+                }
             }
-            red[tid] = s;
-            __syncthreads();
-            for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-            if (tid == 0) dw[kk] = red[0];
-            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float t = block_sum(s[q]);
+                if (tid == 0 && k0 + q < K) dw[k0 + q] = t;
+            }
         }
     }
     __syncthreads();

@@ -1574,7 +1574,7 @@ static int model_backward(const wg_config *cf, const void *const *params, const 
     if (x_rebuilt) WG_LAUNCH(cx, unsqueeze_kernel, dim3((T + 255) / 256, B), dim3(256), 0, X, x_rebuilt, g, G, N);
     if (dx) WG_LAUNCH(cx, unsqueeze_kernel, dim3((T + 255) / 256, B), dim3(256), 0, dX, dx, g, G, N);
     // upsampler backward (+ its weight norm)
-    WG_LAUNCH(cx, upsample_bwd_kernel, dim3(cf->n_mels), dim3(256), (size_t)(cf->up_kernel + 256) * sizeof(float), h, pk + M.up_w,
+    WG_LAUNCH(cx, upsample_bwd_kernel, dim3(cf->n_mels), dim3(256), (size_t)(cf->up_kernel + 512) * sizeof(float), h, pk + M.up_w,
               pref(ws + W.dY, W.auxp), g, cf->n_mels, F, cf->up_kernel, cf->up_stride, cf->up_pad, p[1], p[2], gr[0], gr[1], gr[2], dh);
     record_event(cx, flow_events, cf->n_flows);
     return cx.err;

@@ -148,6 +148,7 @@ class ModelEngine:
         if len(params) != self.n_params:
             raise WgError("parameter table has %d entries, expected %d" % (len(params), self.n_params))
         if self.packed.stale(params) or self.packed.buf.device != device:
+            require_device(*params)
             nbytes = L.wg_packed_bytes(C.byref(self.cfg))
             if nbytes == 0:
                 raise WgError("WaveGlow configuration not supported by the HIP kernels "
@@ -189,7 +190,7 @@ class ModelEngine:
 
     @on_device
     def run(self, params, x, h, inverse):
-        require_device(x, h, *params)
+        require_device(x, h, params[0])            # (the whole table is checked when it is packed: _pack)
         x, h = x.contiguous(), h.contiguous()
         B, N = x.shape
         pk = self._pack(params, x.device)

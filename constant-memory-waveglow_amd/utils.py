@@ -27,6 +27,32 @@ def ensure_dir(path):
     os.makedirs(path, exist_ok=True)
 
 
+def conv_gv_slots(m):
+    """conv_gv as (owner dict, key) pairs: where the two table entries of a conv live in the module tree right now.  A parameter
+    replaced in place (`.to()`, `.half()`, load_state_dict, an optimizer step) stays behind the same slot; adding or removing weight
+    norm changes the keys, which a stale slot shows as a KeyError (SlotTable below rebuilds then)."""
+    if "weight_g" in m._parameters:
+        return (m._parameters, "weight_g"), (m._parameters, "weight_v")
+    return None, (m._parameters, "weight")
+
+
+class SlotTable:
+    """A module's C-ABI parameter table, resolved through cached (dict, key) slots instead of a walk over the module tree with
+    nn.Module.__getattr__ on every call (0.5 ms for WaveGlow's 459 entries: a sixth of a single-utterance synthesis call)."""
+
+    def __init__(self, build):
+        self._build, self._slots = build, None
+
+    def __call__(self):
+        if self._slots is not None:
+            try:
+                return [None if s is None else s[0][s[1]] for s in self._slots]
+            except KeyError:                # weight norm was added or removed somewhere: resolve the tree again
+                pass
+        self._slots = self._build()
+        return [None if s is None else s[0][s[1]] for s in self._slots]
+
+
 def conv_gv(m):
     """(g, v) parameter pair of a conv for the C-ABI parameter table: (weight_g, weight_v) under weight norm,
     (None, weight) for a plain conv."""

@@ -17,7 +17,7 @@ from . import engine
 from ._lib import WgError
 from .base import FlowBase
 from .efficient_modules import AffineCouplingBlock, InvertibleConv1x1
-from .utils import add_weight_norms, conv_gv
+from .utils import SlotTable, add_weight_norms, conv_gv, conv_gv_slots
 
 
 def fused_gate(x1: Tensor, x2: Tensor) -> Tensor:
@@ -69,17 +69,23 @@ class WN(nn.Module):
         if zero_init:
             nn.init.zeros_(self.end.weight)
         self._engine = None
+        self._table = None
 
     def hip_dims(self):
         return (self.in_chs, self.aux_chs, self.res_chs, self.dil_chs, self.skp_chs, len(self.layers), self.rdx)
 
+    def param_slots(self):
+        tab = list(conv_gv_slots(self.V)) + list(conv_gv_slots(self.start))
+        for layer in self.layers:
+            tab += list(conv_gv_slots(layer.W)) + list(conv_gv_slots(layer.W_o))
+        tab.append((self.end._parameters, "weight"))
+        return tab
+
     def param_table(self):
         """C-ABI order: V(g,v) start(g,v) [W(g,v) W_o(g,v)]*depth end  (include/wgflow.h)."""
-        tab = list(conv_gv(self.V)) + list(conv_gv(self.start))
-        for layer in self.layers:
-            tab += list(conv_gv(layer.W)) + list(conv_gv(layer.W_o))
-        tab.append(self.end.weight)
-        return tab
+        if self._table is None:
+            self._table = SlotTable(self.param_slots)
+        return self._table()
 
     def forward(self, x, y):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
@@ -149,18 +155,22 @@ class WaveGlow(FlowBase):
         self.z_split_sizes.append(c)
 
         self._half_table, self._half_key = None, None          # fp32 copies of half parameters (inference --half)
+        self._table = SlotTable(self.param_slots)
         wn0 = self.WNs[0].F
         self._engine = engine.ModelEngine(engine.make_config(
             flows, n_group, n_early_every, n_early_size, hop_size, n_mels,
             wn0.res_chs, wn0.dil_chs, wn0.skp_chs, len(wn0.layers), wn0.rdx, reverse_mode=reverse_mode))
 
+    def param_slots(self):
+        g, v = conv_gv_slots(self.upsampler)
+        tab = [(self.upsampler._parameters, "bias"), g, v] + [(m._parameters, "weight") for m in self.invconv1x1]
+        for blk in self.WNs:
+            tab += blk.F.param_slots()
+        return tab
+
     def param_table(self):
         """C-ABI parameter table (include/wgflow.h): upsampler bias,g,v; 1x1 weights; per flow the WN table."""
-        g, v = conv_gv(self.upsampler)
-        tab = [self.upsampler.bias, g, v] + [m.weight for m in self.invconv1x1]
-        for blk in self.WNs:
-            tab += blk.F.param_table()
-        return tab
+        return self._table()
 
     def _check(self, x: Tensor, h: Tensor):
         if x.dim() != 2 or h.dim() != 3:
@@ -180,13 +190,13 @@ class WaveGlow(FlowBase):
         self._check(z, h)
         if torch.is_grad_enabled() and (z.requires_grad or h.requires_grad):
             warnings.warn("WaveGlow.reverse runs without autograd in the HIP engine", stacklevel=3)
-        table = [None if t is None else t.detach() for t in self.param_table()]
+        table = self.param_table()                 # (the engine reads addresses and versions only: no autograd through this call)
         if z.dtype == torch.float16 or h.dtype == torch.float16 or any(t is not None and t.dtype == torch.float16 for t in table):
             # `inference.py --half` (model.half(), cond.half(), inference.py:33-36): the engine computes in fp32, so half tensors are
             # widened on the way in and the result is narrowed on the way out -- the half-precision storage contract, fp32 arithmetic
             if self._half_table is None or self._half_key != tuple((t.data_ptr(), t._version) for t in table if t is not None):
                 self._half_key = tuple((t.data_ptr(), t._version) for t in table if t is not None)
-                self._half_table = [None if t is None else t.float() for t in table]
+                self._half_table = [None if t is None else t.detach().float() for t in table]
             x, logdet = self._engine.run(self._half_table, z.detach().float(), h.detach().float(), True)
             return x.to(z.dtype), logdet.to(z.dtype)
         return self._engine.run(table, z.detach(), h.detach(), True)

@@ -200,6 +200,29 @@ def test_wsrglow_trainer_matches_autograd(dev, one_rank_rccl, name):
     assert float((coll.fg.flat[lo:hi] - tr.fg.flat[lo:hi]).abs().max()) <= 1e-5 * float(tr.fg.flat[lo:hi].abs().max())
 
 
+def test_autograd_model_gradients_through_one_rank_rccl(dev, one_rank_rccl):
+    """WaveFlow trains through autograd; its data-parallel step is GradSync.all_reduce_params (one flat buffer, one collective).
+    On a 1-rank RCCL group the mean all-reduce must hand every gradient back unchanged, bit for bit."""
+    from constant_memory_waveglow_amd.parallel import GradSync
+    name = "wf8"
+    cfg = fill.WF_CONFIGS[name]
+    B, N, F = fill.WF_SHAPES[name]
+    P = fill.fill_params(fill.waveflow_param_specs(cfg), name + "/")
+    audio, mel = fill.waveflow_inputs(name, B, N, F, cfg["n_mels"])
+    m = cm.WaveFlow(use_conv1x1=False, memory_efficient=False, bias=False, **cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    m = m.to(dev)
+    z, logdet = m(T(audio, dev), T(mel, dev))
+    cm.WaveGlowLoss(fill.SIGMA)(z, logdet).backward()
+    before = {n: p.grad.clone() for n, p in m.named_parameters()}
+    sync = GradSync(force_collectives=True)
+    sync.all_reduce_params(list(m.parameters()))
+    sync.broadcast_params(list(m.parameters()))
+    torch.cuda.synchronize()
+    for n, p in m.named_parameters():
+        assert torch.equal(before[n], p.grad), n
+
+
 def test_frozen_weight_v_still_gets_weight_g_gradient(dev):
     """weight_v frozen, weight_g trainable (a fine-tuning set-up the reference's autograd handles): the finalisation must still
     produce dg, and must not touch a dv buffer that does not exist."""
