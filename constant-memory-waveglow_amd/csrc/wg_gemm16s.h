@@ -1037,6 +1037,18 @@ struct WgSSeg {
     int Cp, ch0, nch, shift, blk0;
     int row_off, per_item;      // as SSeg (B operand only)
 };
+// A GROUP of products of one shape in one launch (the weight gradients of all layers of a WN, deferred to the end of its backward: one
+// layer alone is 8-28 tiles, i.e. a 64- or 18-way split of the time axis to fill the chip, and every split writes a full-size slab
+// that the finalisation reads back -- 130 MB of HBM traffic per layer; eight layers together need a 2- to 8-way split).  The groups
+// share every field of WgradSArgs except the operand planes, the tap shifts and the slab; grid z = group * nsplit + split.
+#define WG_GRP_MAX 8
+#define WG_GRP_SEG 4
+struct WgradGrp {
+    const unsigned short *a_hi[2];          // nullptr: that segment's rows are zero in this group
+    const unsigned short *b_hi[WG_GRP_SEG];
+    int b_shift[WG_GRP_SEG];
+    float *slab;
+};
 struct WgradSArgs {
     int nseg_a, nseg_b;
     WgSSeg sa[2];
@@ -1045,6 +1057,9 @@ struct WgradSArgs {
     int cpb, total_chunks, nsplit;      // 32-step chunks per batch item, B * cpb, blocks per tile (each takes an even share of the range)
     float *slab;
     int Mp, Np;
+    int ngroups;                        // 0: one product (sa / sb / slab as they are)
+    const unsigned short *zsrc;         // grouped launches: any S-plane (position 0 = zero halo)
+    WgradGrp grp[WG_GRP_MAX];
 };
 typedef short s4v __attribute__((ext_vector_type(4)));
 // rows r..r+3 (lo) and r+4..r+7 (hi) of the image, r a multiple of 8 plus the lane's row: the upper four rows are stored rotated
@@ -1064,14 +1079,15 @@ __device__ __forceinline__ bf16x8 tr_frag(const char *img, int rowoff, int col)
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
 }
-__device__ __forceinline__ const WgSSeg &find_sseg(const WgSSeg *s, int n, int blk)
+__device__ __forceinline__ int find_sseg_idx(const WgSSeg *s, int n, int blk)
 {
     int i = 0;
 #pragma unroll
     for (int j = 1; j < WG_MAX_SEG; ++j)
         if (j < n && blk >= s[j].blk0) i = j;
-    return s[i];
+    return i;
 }
+__device__ __forceinline__ const WgSSeg &find_sseg(const WgSSeg *s, int n, int blk) { return s[find_sseg_idx(s, n, blk)]; }
 
 // MT = 1 (default): 128 x 128 tile, 4 waves, two workgroups per CU.  MT = 2 (-DWG_OPT_WGRAD_TALL): 256 x 128 tile, 8 waves, one
 // workgroup per CU; streams 48 KB instead of 64 KB per chunk for the same MFMAs and is still slower (155 vs 137 us).
@@ -1090,6 +1106,8 @@ __global__ __launch_bounds__(256 * MT) void wgrad16s_kernel(const WgradSArgs a)
     const int wr = wave >> 1, wc = wave & 1;
     int bx, by, zs;
     xcd_remap(bx, by, zs);
+    int grp = 0;
+    if (a.ngroups) { grp = zs / a.nsplit; zs -= grp * a.nsplit; }
     const int n0 = bx * WG_TILE, m0 = by * (WG_TILE * MT);
     const Geo g = a.g;
 
@@ -1125,9 +1143,11 @@ __global__ __launch_bounds__(256 * MT) void wgrad16s_kernel(const WgradSArgs a)
         loffa[j] = tl * AROW + ((cg + 2 * ((tl >> 2) & 1)) & (16 * MT - 1)) * 16;
 #endif
         const int ma = m0 + 8 * cg;
-        const WgSSeg &sa = find_sseg(a.sa, a.nseg_a, ma >> 5);
+        const int ia = find_sseg_idx(a.sa, a.nseg_a, ma >> 5);
+        const WgSSeg &sa = a.sa[ia];
         const int ca = ma - sa.blk0 * 32;
-        pa[j] = (ma < a.Mp && ca < sa.nch) ? sa.hi + (((size_t)((sa.ch0 + ca) >> 3)) * g.P + g.H + tl) * 8 : nullptr;
+        const unsigned short *ha = a.ngroups ? a.grp[grp].a_hi[ia] : sa.hi;
+        pa[j] = (ma < a.Mp && ca < sa.nch && ha) ? ha + (((size_t)((sa.ch0 + ca) >> 3)) * g.P + g.H + tl) * 8 : nullptr;
         la[j] = sa.lo_off; sba[j] = (size_t)(sa.Cp >> 3) * g.P * 8;
     }
 #pragma unroll
@@ -1141,9 +1161,12 @@ __global__ __launch_bounds__(256 * MT) void wgrad16s_kernel(const WgradSArgs a)
         loffb[j] = tl * WG16_ROWT + ((cg + 2 * ((tl >> 2) & 1)) & 15) * 16;
 #endif
         const int nb = n0 + 8 * cg;
-        const WgSSeg &sb = find_sseg(a.sb, a.nseg_b, nb >> 5);
+        const int ib = find_sseg_idx(a.sb, a.nseg_b, nb >> 5);
+        const WgSSeg &sb = a.sb[ib];
         const int cb = nb - sb.blk0 * 32;
-        pb[j] = (nb < a.Np && cb < sb.nch) ? sb.hi + (((size_t)((sb.ch0 + cb) >> 3)) * g.P + g.H + sb.shift + tl) * 8 : nullptr;
+        const unsigned short *hb = a.ngroups ? a.grp[grp].b_hi[min(ib, WG_GRP_SEG - 1)] : sb.hi;
+        const int bshift = a.ngroups ? a.grp[grp].b_shift[min(ib, WG_GRP_SEG - 1)] : sb.shift;
+        pb[j] = (nb < a.Np && cb < sb.nch && hb) ? hb + (((size_t)((sb.ch0 + cb) >> 3)) * g.P + g.H + bshift + tl) * 8 : nullptr;
         lb_[j] = sb.lo_off; sbb[j] = (size_t)(sb.Cp >> 3) * g.P * 8;
         roff[j] = sb.row_off; pitem[j] = sb.per_item;
     }
@@ -1182,7 +1205,7 @@ __global__ __launch_bounds__(256 * MT) void wgrad16s_kernel(const WgradSArgs a)
     // the stream alone took 127 of this launch's 147 us at one chunk in flight (64 KB per CU).  Every issue is exactly eight loads
     // in straight-line code: lanes without a source row and chunks past the end read the zero halo (selected pointers, no branch
     // between a load and its wait; tools/check_asm_loads.py covers this kernel too).  (4 + 2 NB loads per issue.)
-    const unsigned short *zsrc = a.sa[0].hi;                 // plane position 0 of the first operand: always-zero halo
+    const unsigned short *zsrc = a.ngroups ? a.zsrc : a.sa[0].hi;    // plane position 0 of the first operand: always-zero halo
     int lb = c_begin / a.cpb, lt = (c_begin - lb * a.cpb) * WG16_BK, issued = 0;
 #define WG_LDP(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
     auto issue = [&](Stage &st) {
@@ -1244,7 +1267,7 @@ __global__ __launch_bounds__(256 * MT) void wgrad16s_kernel(const WgradSArgs a)
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the trailing zero-halo loads before the wave ends
     }
-    float *out = a.slab + (size_t)zs * a.Mp * a.Np;
+    float *out = (a.ngroups ? a.grp[grp].slab : a.slab) + (size_t)zs * a.Mp * a.Np;
     const int col = lane & 31;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)

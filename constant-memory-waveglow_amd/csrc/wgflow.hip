@@ -101,6 +101,18 @@ inline bool s_only_chain(const Ctx &cx, const WnD &d)
     (void)cx; (void)d; return false;
 #endif
 }
+// Weight gradients of all layers of a WN in two grouped launches after its layer loop (WgradGrp, wg_gemm16s.h) instead of two launches
+// per layer.  Needs every layer's gate gradient (kept anyway for the one-product conditioning gradient, fused_dy) and every layer's
+// dh (kept as its own S-plane: + (depth - 1) planes of C channels).
+inline bool fused_dy(const WnD &d);
+inline bool grouped_wgrad(int prec, const WnD &d)
+{
+#if defined(WG_OPT_NO_WGRAD_GROUP) || defined(WG_OPT_NO_S_ONLY)
+    (void)prec; (void)d; return false;
+#else
+    return prec == 2 && !d.mode2d && fused_dy(d) && d.depth <= WG_GRP_MAX && d.radix + 1 <= WG_GRP_SEG;
+#endif
+}
 inline bool fused_skip(const WnD &d)
 {
 #if defined(WG_OPT_NO_FUSED_SKIP)
@@ -437,6 +449,7 @@ struct WnWs {               // plane bases (float offsets) of one WN's activatio
     size_t H[16], tw[16], sf[16], gate[16], skip, G, dS, dH, dxy, slab;
     size_t HS[16], gateS[16], XaS, GS, dSS, dHS, dxyS;   // S-planes (precision 2), sized like the fp32 plane of the same tensor
     size_t dxy_step = 0, dxyS_step = 0;                  // fused_dy: layer i's dxy at dxy + i * step (0: one buffer for all layers)
+    size_t dHS_step = 0;                                 // grouped_wgrad: dh_i at dHS + i * step (0: accumulated in place in one plane)
     int nH;                 // 2 (ping-pong) or depth
     size_t slab_floats;
 };
@@ -456,6 +469,8 @@ void wn_ws_layout(Bump &bp, const WnD &d, int ic_max, const Geo &g, int mode, in
             w.GS = bp.take((size_t)g.B * rup(2 * ic_max, WG_BK) * g.P);
             w.dSS = bp.take(pS);
             w.dHS = bp.take(pC);
+            w.dHS_step = grouped_wgrad(prec, d) ? rupz(pC, 64) : 0;
+            for (int i = 1; i < d.depth && w.dHS_step; ++i) (void)bp.take(pC);
             w.dxyS_step = fused_dy(d) ? rupz(2 * pD, 64) : 0;
             w.dxyS = bp.take(2 * pD);
             for (int i = 1; i < d.depth && w.dxyS_step; ++i) (void)bp.take(2 * pD);
@@ -867,6 +882,56 @@ WgradOut run_wgrad(Ctx &cx, const Geo &g, const WSegSpec *sa, int nsa, const WSe
     return o;
 }
 
+// One launch for `ng` products of one shape (precision 2 only; every operand an S-plane).  gs[k]: the k-th product's segments -- all
+// groups have the same segment sizes, only the planes (sa[j].s may be nullptr: zero rows) and the tap shifts differ.  outs[k]: where
+// its slabs went.
+struct WgradGroupSpec {
+    WSegSpec sa[2];
+    WSegSpec sb[WG_GRP_SEG];
+};
+void run_wgrad_group(Ctx &cx, const Geo &g, const WgradGroupSpec *gs, int ng, int nsa, int nsb, const float *zero_plane, WgradOut *outs)
+{
+    WgradSArgs q;
+    memset(&q, 0, sizeof(q));
+    q.nseg_a = nsa; q.nseg_b = nsb; q.g = g;
+    q.cpb = g.Tt / WG16_BK; q.total_chunks = g.B * q.cpb;
+    int blk = 0;
+    for (int s = 0; s < nsa; ++s) {
+        const WSegSpec &x = gs[0].sa[s];
+        q.sa[s].hi = nullptr; q.sa[s].lo_off = (size_t)g.B * x.sCp * g.P;
+        q.sa[s].Cp = x.sCp; q.sa[s].ch0 = x.sch0; q.sa[s].nch = x.nch; q.sa[s].shift = 0; q.sa[s].blk0 = blk;
+        blk += rup(x.nch, 32) / 32;
+    }
+    q.Mp = rup(blk * 32, WG_TILE);
+    blk = 0;
+    for (int s = 0; s < nsb; ++s) {
+        const WSegSpec &x = gs[0].sb[s];
+        q.sb[s].hi = nullptr; q.sb[s].lo_off = (size_t)g.B * x.sCp * g.P;
+        q.sb[s].Cp = x.sCp; q.sb[s].ch0 = x.sch0; q.sb[s].nch = x.nch; q.sb[s].shift = 0; q.sb[s].blk0 = blk;
+        blk += rup(x.nch, 32) / 32;
+    }
+    q.Np = rup(blk * 32, WG_TILE);
+    const int tiles = (q.Mp / WG_TILE) * (q.Np / WG_TILE);
+    const size_t one = (size_t)q.Mp * q.Np;
+    q.nsplit = plan_wgrad_flat(g, tiles * ng);
+#if defined(WG_OPT_GRP_NSPLIT_MUL)                             // experiment: more, shorter workgroups (and more slab bytes)
+    q.nsplit = std::min(q.nsplit * WG_OPT_GRP_NSPLIT_MUL, std::max(1, q.total_chunks / 4));
+#endif
+    if (!cx.fq || ng > WG_GRP_MAX || nsb > WG_GRP_SEG) { if (!cx.err) cx.err = WG_EINVAL; return; }
+    while (q.nsplit > 1 && (size_t)q.nsplit * ng * one > cx.fq->cap) --q.nsplit;
+    float *slab = cx.fq->reserve((size_t)q.nsplit * ng * one);
+    if (cx.err) return;
+    q.ngroups = ng; q.zsrc = (const unsigned short *)zero_plane; q.slab = slab;
+    for (int k = 0; k < ng; ++k) {
+        for (int s = 0; s < nsa; ++s) q.grp[k].a_hi[s] = (const unsigned short *)gs[k].sa[s].s;
+        for (int s = 0; s < nsb; ++s) { q.grp[k].b_hi[s] = (const unsigned short *)gs[k].sb[s].s; q.grp[k].b_shift[s] = gs[k].sb[s].shift; }
+        q.grp[k].slab = slab + (size_t)k * q.nsplit * one;
+        outs[k].nsplit = q.nsplit; outs[k].Mp = q.Mp; outs[k].Np = q.Np; outs[k].slab = q.grp[k].slab;
+    }
+    TimerScope ts(WG_K_WGRAD, cx.st);
+    WG_LAUNCH(cx, wgrad16s_kernel<1>, dim3(q.Np / WG_TILE, q.Mp / WG_TILE, q.nsplit * ng), dim3(256), 0, q);
+}
+
 void run_finalize(Ctx &cx, const float *slab, const WgradOut &wo, int row0, int rows, int I, int R, int col0, int ci, int cr,
                   const float *gp, const float *vp, float *dg, float *dv,
                   const float *extra = nullptr, const float *esrc = nullptr, int n_extra = 0, float emul = 0.f)
@@ -997,6 +1062,10 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
     const bool fdy = dY && fused_dy(d);                       // every layer keeps its dxy; dy is one product after the loop
     const int Gc = r.L.kp_end;
     const bool sp = cx.prec == 2;
+    // the layers' weight gradients as two grouped launches behind the loop (needs every layer's dxy and dh kept: fdy, dHS_step)
+    const bool gw = grouped_wgrad(cx.prec, d) && fdy && s_only_chain(cx, d) && r.w.dHS_step && nd >= 2;
+    auto dHSp = [&](int j) { return ws + r.w.dHS + (size_t)j * r.w.dHS_step; };      // S-plane of dh_j (one plane for all j unless gw)
+    WgradGroupSpec gsT[WG_GRP_MAX], gsO[WG_GRP_MAX];
 #if !defined(WG_OPT_NO_FIN_BATCH)
     FinQueue fq(cx, slab, cap);                               // flushed when it goes out of scope: before the caller's next launch
 #endif
@@ -1017,10 +1086,14 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
         float *dxy = ws + r.w.dxy + (size_t)i * r.w.dxy_step;                    // (step 0: one buffer for all layers)
         float *dxyS = ws + r.w.dxyS + (size_t)i * r.w.dxyS_step;
         // dW_o = sum do (x) gate,  do = last ? dS : cat(dh_{i+1}, dS)
-        {
+        if (gw) {                                                              // (the last layer's group has no dh rows: zero, skipped by row0)
+            gsO[i].sa[0] = {nullptr, d.C, 0, d.C, 0, last ? nullptr : dHSp(i + 1), d.C, 0};
+            gsO[i].sa[1] = {nullptr, d.Cs, 0, d.Cs, 0, ws + r.w.dSS, d.Cs, 0};
+            gsO[i].sb[0] = {nullptr, d.Cd, 0, d.Cd, 0, ws + r.w.gateS[i], d.Cd, 0};
+        } else {
             WSegSpec sa[2];
             int nsa = 0;
-            if (!last) sa[nsa++] = {dH, d.C, 0, d.C, 0, sp ? ws + r.w.dHS : nullptr, d.C, 0};
+            if (!last) sa[nsa++] = {dH, d.C, 0, d.C, 0, sp ? dHSp(i + 1) : nullptr, d.C, 0};
             sa[nsa++] = {dS, d.Cs, 0, d.Cs, 0, sp ? ws + r.w.dSS : nullptr, d.Cs, 0};
             WSegSpec sb = {gate, d.Cd, 0, d.Cd, 0, sp ? ws + r.w.gateS[i] : nullptr, d.Cd, 0};
             WgradOut wo = run_wgrad(cx, g, sa, nsa, &sb, 1, slab, cap);
@@ -1030,13 +1103,21 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
         {
             SegSpec s[2];
             int ns = 0;
-            if (!last) s[ns++] = {dH, d.C, 0, d.C, 0, ws + r.w.dHS, d.C, 0};
+            if (!last) s[ns++] = {dH, d.C, 0, d.C, 0, dHSp(i + 1), d.C, 0};
             s[ns++] = {dS, d.Cs, 0, d.Cs, 0, ws + r.w.dSS, d.Cs, 0};
             run_convgemm(cx, g, r.pk + r.L.WoN[i], r.L.ld_WoN, d.Cd, s, ns, EPI_DGATE, sp ? pnull() : pref(dxy, 2 * d.Cd), pnull(), pnull(),
                          pref(ws + r.w.tw[i], d.Cd), pref(ws + r.w.sf[i], d.Cd), d.Cd, 0, sp ? sref(g, dxyS, 2 * d.Cd) : snull());
         }
         // dW (taps) and dV (conditioning) in one wgrad
-        {
+        if (gw) {
+            gsT[i].sa[0] = {nullptr, 2 * d.Cd, 0, 2 * d.Cd, 0, dxyS, 2 * d.Cd, 0};
+            for (int kt = 0; kt < d.radix; ++kt) {
+                int ts, ro;
+                d.tap(i, kt, ts, ro);
+                gsT[i].sb[kt] = {nullptr, d.C, 0, d.C, ts, ws + r.w.HS[i], d.C, 0};
+            }
+            gsT[i].sb[d.radix] = {nullptr, d.auxp(), 0, d.aux, 0, r.YS, d.auxp(), 0};
+        } else {
             WSegSpec sa = {dxy, 2 * d.Cd, 0, 2 * d.Cd, 0, sp ? dxyS : nullptr, 2 * d.Cd, 0};
             WSegSpec sb[WG_MAX_SEG];
             int nsb = 0;
@@ -1076,10 +1157,26 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
                 d.tap(i, kt, ts, ro);
                 s[ns++] = {dxy, 2 * d.Cd, 0, 2 * d.Cd, -ts, dxyS, 2 * d.Cd, 0, -ro, 0};
             }
-            const bool sod = s_only_chain(cx, d);            // dh as an S-plane only (accumulated in place from its own hi + lo)
-            run_convgemm(cx, g, r.pk + r.L.WT[i], r.L.ld_WT, d.C, s, ns, EPI_STORE, sod ? pnull() : pref(dH, d.C), pnull(), pnull(),
-                         (last || sod) ? pnull() : pref(dH, d.C), pnull(), 0, 0, sp ? sref(g, ws + r.w.dHS, d.C) : snull(),
-                         (sod && !last) ? sref(g, ws + r.w.dHS, d.C) : snull());
+            const bool sod = s_only_chain(cx, d);            // dh as an S-plane only (accumulated from dh_{i+1}'s hi + lo: in place, or
+            run_convgemm(cx, g, r.pk + r.L.WT[i], r.L.ld_WT, d.C, s, ns, EPI_STORE, sod ? pnull() : pref(dH, d.C), pnull(), pnull(),      // plane to plane with gw)
+                         (last || sod) ? pnull() : pref(dH, d.C), pnull(), 0, 0, sp ? sref(g, dHSp(i), d.C) : snull(),
+                         (sod && !last) ? sref(g, dHSp(i + 1), d.C) : snull());
+        }
+    }
+    if (gw) {
+        WgradOut wo[WG_GRP_MAX];
+        const int C32 = rup(d.C, 32);
+        run_wgrad_group(cx, g, gsT, nd, 1, d.radix + 1, ws + r.w.dSS, wo);
+        for (int i = 0; i < nd && !cx.err; ++i) {
+            run_finalize(cx, slab, wo[i], 0, 2 * d.Cd, d.C, d.radix, 0, 1, C32, p[4 + 4 * i], p[5 + 4 * i], grads[4 + 4 * i], grads[5 + 4 * i]);
+            const size_t ro = (size_t)i * 2 * d.Cd;
+            run_finalize(cx, slab, wo[i], 0, 2 * d.Cd, d.aux, 1, d.radix * C32, 1, 0, p[0] ? p[0] + ro : nullptr, p[1] + ro * d.aux,
+                         grads[0] ? grads[0] + ro : nullptr, grads[1] ? grads[1] + ro * d.aux : nullptr);
+        }
+        run_wgrad_group(cx, g, gsO, nd, 2, 1, ws + r.w.dSS, wo);
+        for (int i = 0; i < nd && !cx.err; ++i) {
+            const int last = i == nd - 1;
+            run_finalize(cx, slab, wo[i], last ? d.C : 0, d.wo_rows(i), d.Cd, 1, 0, 1, 0, p[6 + 4 * i], p[7 + 4 * i], grads[6 + 4 * i], grads[7 + 4 * i]);
         }
     }
     if (fdy) {                                                // dy += [V_0^T .. V_{d-1}^T] [dxy_0; ..; dxy_{d-1}]
@@ -1091,11 +1188,11 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
     }
     // start: dW_start = sum dh_0 (x) xa ; dxa += W_start^T dh_0
     {
-        WSegSpec sa = {dH, d.C, 0, d.C, 0, sp ? ws + r.w.dHS : nullptr, d.C, 0};
+        WSegSpec sa = {dH, d.C, 0, d.C, 0, sp ? dHSp(0) : nullptr, d.C, 0};
         WSegSpec sb = {r.X.p, r.X.Cp, r.X.ch0, d.ic, 0, sp ? ws + r.w.XaS : nullptr, r.L.kp_start, 0};
         WgradOut wo = run_wgrad(cx, g, &sa, 1, &sb, 1, slab, cap);
         run_finalize(cx, slab, wo, 0, d.C, d.ic, 1, 0, 1, 0, p[2], p[3], grads[2], grads[3]);
-        SegSpec s = {dH, d.C, 0, d.C, 0, ws + r.w.dHS, d.C, 0};
+        SegSpec s = {dH, d.C, 0, d.C, 0, dHSp(0), d.C, 0};
         run_convgemm(cx, g, r.pk + r.L.startN, r.L.ld_startN, d.ic, &s, 1, EPI_STORE, dX, pnull(), pnull(), dX, pnull(), 0, 0);
     }
 }
