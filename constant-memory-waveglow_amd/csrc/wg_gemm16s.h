@@ -1091,8 +1091,9 @@ __device__ __forceinline__ const WgSSeg &find_sseg(const WgSSeg *s, int n, int b
 
 // MT = 1 (default): 128 x 128 tile, 4 waves, two workgroups per CU.  MT = 2 (-DWG_OPT_WGRAD_TALL): 256 x 128 tile, 8 waves, one
 // workgroup per CU; streams 48 KB instead of 64 KB per chunk for the same MFMAs and is still slower (155 vs 137 us).
+// the workgroup's work: tile (bx, by) of the product, split index zs (grouped launches: group * nsplit + split)
 template <int MT>
-__global__ __launch_bounds__(256 * MT) void wgrad16s_kernel(const WgradSArgs a)
+__device__ __forceinline__ void wgrad16s_body(const WgradSArgs &a, int bx, int by, int zs)
 {
     constexpr int NT = 256 * MT;                // threads
     constexpr int AROW = 256 * MT + 64;         // A image row pitch (bytes): 128 MT channels + pad (pitch = 16 dwords mod 64: four
@@ -1104,8 +1105,6 @@ __global__ __launch_bounds__(256 * MT) void wgrad16s_kernel(const WgradSArgs a)
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    int bx, by, zs;
-    xcd_remap(bx, by, zs);
     int grp = 0;
     if (a.ngroups) { grp = zs / a.nsplit; zs -= grp * a.nsplit; }
     const int n0 = bx * WG_TILE, m0 = by * (WG_TILE * MT);
@@ -1280,4 +1279,30 @@ __global__ __launch_bounds__(256 * MT) void wgrad16s_kernel(const WgradSArgs a)
                 if (m < a.Mp && n < a.Np) out[(size_t)m * a.Np + n] = acc[mi][ni][r];
             }
         }
+}
+
+template <int MT>
+__global__ __launch_bounds__(256 * MT) void wgrad16s_kernel(const WgradSArgs a)
+{
+    int bx, by, zs;
+    xcd_remap(bx, by, zs);
+    wgrad16s_body<MT>(a, bx, by, zs);
+}
+
+// TWO (grouped) products of different shapes in one 1-D launch: workgroups [0, n0) belong to p[0], the rest to p[1].  The hardware
+// hands out workgroups in id order, so the short workgroups of the second product fill the slots the first one leaves (a WN's tap /
+// conditioning gradients are 448 workgroups of 756 chunks on 512 slots, its W_o gradients 512 of 189: 945 chunk times back to back,
+// 850 dealt out together).
+struct WgradPairArgs {
+    WgradSArgs p[2];
+    int n0, gx[2], gy[2], n[2];              // workgroups of p[0]; tile grid and workgroup count of each product
+};
+static_assert(sizeof(WgradPairArgs) <= 4096, "kernel arguments are limited to 4 KB");
+__global__ __launch_bounds__(256) void wgrad16s_pair_kernel(const WgradPairArgs pp)
+{
+    const int which = (int)blockIdx.x >= pp.n0;
+    int id = (int)blockIdx.x - (which ? pp.n0 : 0);
+    const int n = pp.n[which], gx = pp.gx[which], gy = pp.gy[which];
+    if ((n & 7) == 0) id = (id & 7) * (n >> 3) + (id >> 3);            // xcd_remap's relabelling, inside this product's range
+    wgrad16s_body<1>(pp.p[which], id % gx, (id / gx) % gy, id / (gx * gy));
 }

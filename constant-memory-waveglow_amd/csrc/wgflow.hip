@@ -501,6 +501,12 @@ void wn_ws_layout(Bump &bp, const WnD &d, int ic_max, const Geo &g, int mode, in
         s = std::max(s, slab_floats(g, WG_TILE, WG_TILE));
         // room for several products' slabs (FinQueue batches the finalisations of a WN): up to 8 of the largest, at most 384 MB
         s = std::max(s, std::min((size_t)8 * s, (size_t)96 << 20));
+        if (grouped_wgrad(prec, d)) {                            // both grouped products of a WN at once (run_wgrad_group_pair)
+            const size_t oneT = (size_t)rup(2 * d.Cd, WG_TILE) * nW, oneO = (size_t)rup(d.C + d.Cs, WG_TILE) * rup(d.Cd, WG_TILE);
+            const int nsT = plan_wgrad_flat(g, (int)(oneT / (WG_TILE * WG_TILE)) * d.depth);
+            const int nsO = plan_wgrad_flat(g, (int)(oneO / (WG_TILE * WG_TILE)) * d.depth);
+            s = std::max(s, rupz((size_t)nsT * d.depth * oneT, 64) + rupz((size_t)nsO * d.depth * oneO, 64) + 4096);
+        }
         w.slab_floats = s;
         w.slab = bp.take(s);
     }
@@ -790,6 +796,10 @@ struct FinQueue {
         off += n;
         return p;
     }
+    void ensure(size_t n)                                     // the next reserves, n floats in all, will not wrap the arena between them
+    {
+        if (off + n > cap) { flush(); off = 0; }
+    }
     void add(const FinJob &j)
     {
         if (b.n == WG_FIN_JOBS) flush();                      // (the arena keeps growing: the job being added still owns its slab)
@@ -889,10 +899,11 @@ struct WgradGroupSpec {
     WSegSpec sa[2];
     WSegSpec sb[WG_GRP_SEG];
 };
-void run_wgrad_group(Ctx &cx, const Geo &g, const WgradGroupSpec *gs, int ng, int nsa, int nsb, const float *zero_plane, WgradOut *outs)
+// shape and split of a grouped product (no slab yet)
+static bool shape_wgrad_group(Ctx &cx, const Geo &g, const WgradGroupSpec *gs, int ng, int nsa, int nsb, WgradSArgs &q)
 {
-    WgradSArgs q;
     memset(&q, 0, sizeof(q));
+    if (!cx.fq || ng > WG_GRP_MAX || nsb > WG_GRP_SEG || nsa > 2) { if (!cx.err) cx.err = WG_EINVAL; return false; }
     q.nseg_a = nsa; q.nseg_b = nsb; q.g = g;
     q.cpb = g.Tt / WG16_BK; q.total_chunks = g.B * q.cpb;
     int blk = 0;
@@ -912,24 +923,54 @@ void run_wgrad_group(Ctx &cx, const Geo &g, const WgradGroupSpec *gs, int ng, in
     }
     q.Np = rup(blk * 32, WG_TILE);
     const int tiles = (q.Mp / WG_TILE) * (q.Np / WG_TILE);
-    const size_t one = (size_t)q.Mp * q.Np;
     q.nsplit = plan_wgrad_flat(g, tiles * ng);
 #if defined(WG_OPT_GRP_NSPLIT_MUL)                             // experiment: more, shorter workgroups (and more slab bytes)
     q.nsplit = std::min(q.nsplit * WG_OPT_GRP_NSPLIT_MUL, std::max(1, q.total_chunks / 4));
 #endif
-    if (!cx.fq || ng > WG_GRP_MAX || nsb > WG_GRP_SEG) { if (!cx.err) cx.err = WG_EINVAL; return; }
-    while (q.nsplit > 1 && (size_t)q.nsplit * ng * one > cx.fq->cap) --q.nsplit;
-    float *slab = cx.fq->reserve((size_t)q.nsplit * ng * one);
-    if (cx.err) return;
-    q.ngroups = ng; q.zsrc = (const unsigned short *)zero_plane; q.slab = slab;
-    for (int k = 0; k < ng; ++k) {
-        for (int s = 0; s < nsa; ++s) q.grp[k].a_hi[s] = (const unsigned short *)gs[k].sa[s].s;
-        for (int s = 0; s < nsb; ++s) { q.grp[k].b_hi[s] = (const unsigned short *)gs[k].sb[s].s; q.grp[k].b_shift[s] = gs[k].sb[s].shift; }
+    while (q.nsplit > 1 && rupz((size_t)q.nsplit * ng * q.Mp * q.Np, 64) > cx.fq->cap) --q.nsplit;
+    q.ngroups = ng;
+    if (rupz((size_t)q.nsplit * ng * q.Mp * q.Np, 64) > cx.fq->cap) { if (!cx.err) cx.err = WG_EWORKSPACE; return false; }
+    return true;
+}
+static size_t group_slab_floats(const WgradSArgs &q) { return rupz((size_t)q.nsplit * q.ngroups * q.Mp * q.Np, 64); }
+// slabs (from the finalisation queue's arena) and the groups' planes
+static bool bind_wgrad_group(Ctx &cx, const WgradGroupSpec *gs, const float *zero_plane, WgradOut *outs, WgradSArgs &q)
+{
+    const size_t one = (size_t)q.Mp * q.Np;
+    float *slab = cx.fq->reserve(group_slab_floats(q));
+    if (cx.err) return false;
+    q.zsrc = (const unsigned short *)zero_plane; q.slab = slab;
+    for (int k = 0; k < q.ngroups; ++k) {
+        for (int s = 0; s < q.nseg_a; ++s) q.grp[k].a_hi[s] = (const unsigned short *)gs[k].sa[s].s;
+        for (int s = 0; s < q.nseg_b; ++s) { q.grp[k].b_hi[s] = (const unsigned short *)gs[k].sb[s].s; q.grp[k].b_shift[s] = gs[k].sb[s].shift; }
         q.grp[k].slab = slab + (size_t)k * q.nsplit * one;
         outs[k].nsplit = q.nsplit; outs[k].Mp = q.Mp; outs[k].Np = q.Np; outs[k].slab = q.grp[k].slab;
     }
+    return true;
+}
+void run_wgrad_group(Ctx &cx, const Geo &g, const WgradGroupSpec *gs, int ng, int nsa, int nsb, const float *zero_plane, WgradOut *outs)
+{
+    WgradSArgs q;
+    if (!shape_wgrad_group(cx, g, gs, ng, nsa, nsb, q) || !bind_wgrad_group(cx, gs, zero_plane, outs, q)) return;
     TimerScope ts(WG_K_WGRAD, cx.st);
     WG_LAUNCH(cx, wgrad16s_kernel<1>, dim3(q.Np / WG_TILE, q.Mp / WG_TILE, q.nsplit * ng), dim3(256), 0, q);
+}
+// two grouped products in one launch (wgrad16s_pair_kernel): the one with the longer workgroups first
+void run_wgrad_group_pair(Ctx &cx, const Geo &g, const WgradGroupSpec *gs0, int nsa0, int nsb0, WgradOut *outs0,
+                          const WgradGroupSpec *gs1, int nsa1, int nsb1, WgradOut *outs1, int ng, const float *zero_plane)
+{
+    WgradPairArgs pp;
+    if (!shape_wgrad_group(cx, g, gs0, ng, nsa0, nsb0, pp.p[0]) || !shape_wgrad_group(cx, g, gs1, ng, nsa1, nsb1, pp.p[1])) return;
+    if (group_slab_floats(pp.p[0]) + group_slab_floats(pp.p[1]) > cx.fq->cap) { if (!cx.err) cx.err = WG_EWORKSPACE; return; }   // (wn_ws_layout sizes for it)
+    cx.fq->ensure(group_slab_floats(pp.p[0]) + group_slab_floats(pp.p[1]));    // both slab sets live until the launch: no wrap between them
+    if (!bind_wgrad_group(cx, gs0, zero_plane, outs0, pp.p[0]) || !bind_wgrad_group(cx, gs1, zero_plane, outs1, pp.p[1])) return;
+    for (int w = 0; w < 2; ++w) {
+        pp.gx[w] = pp.p[w].Np / WG_TILE; pp.gy[w] = pp.p[w].Mp / WG_TILE;
+        pp.n[w] = pp.gx[w] * pp.gy[w] * pp.p[w].nsplit * ng;
+    }
+    pp.n0 = pp.n[0];
+    TimerScope ts(WG_K_WGRAD, cx.st);
+    WG_LAUNCH(cx, wgrad16s_pair_kernel, dim3(pp.n[0] + pp.n[1]), dim3(256), 0, pp);
 }
 
 void run_finalize(Ctx &cx, const float *slab, const WgradOut &wo, int row0, int rows, int I, int R, int col0, int ci, int cr,
@@ -1164,19 +1205,25 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
         }
     }
     if (gw) {
-        WgradOut wo[WG_GRP_MAX];
+        WgradOut wo[WG_GRP_MAX], woO[WG_GRP_MAX];
         const int C32 = rup(d.C, 32);
-        run_wgrad_group(cx, g, gsT, nd, 1, d.radix + 1, ws + r.w.dSS, wo);
+        bool pair = true;
+#if defined(WG_OPT_NO_WGRAD_PAIR)
+        pair = false;
+#endif
+        // (one after the other, each finalisation queued behind its own launch: the second product's slabs may then reuse the arena)
+        if (pair) run_wgrad_group_pair(cx, g, gsT, 1, d.radix + 1, wo, gsO, 2, 1, woO, nd, ws + r.w.dSS);
+        else run_wgrad_group(cx, g, gsT, nd, 1, d.radix + 1, ws + r.w.dSS, wo);
         for (int i = 0; i < nd && !cx.err; ++i) {
             run_finalize(cx, slab, wo[i], 0, 2 * d.Cd, d.C, d.radix, 0, 1, C32, p[4 + 4 * i], p[5 + 4 * i], grads[4 + 4 * i], grads[5 + 4 * i]);
             const size_t ro = (size_t)i * 2 * d.Cd;
             run_finalize(cx, slab, wo[i], 0, 2 * d.Cd, d.aux, 1, d.radix * C32, 1, 0, p[0] ? p[0] + ro : nullptr, p[1] + ro * d.aux,
                          grads[0] ? grads[0] + ro : nullptr, grads[1] ? grads[1] + ro * d.aux : nullptr);
         }
-        run_wgrad_group(cx, g, gsO, nd, 2, 1, ws + r.w.dSS, wo);
+        if (!pair) run_wgrad_group(cx, g, gsO, nd, 2, 1, ws + r.w.dSS, woO);
         for (int i = 0; i < nd && !cx.err; ++i) {
             const int last = i == nd - 1;
-            run_finalize(cx, slab, wo[i], last ? d.C : 0, d.wo_rows(i), d.Cd, 1, 0, 1, 0, p[6 + 4 * i], p[7 + 4 * i], grads[6 + 4 * i], grads[7 + 4 * i]);
+            run_finalize(cx, slab, woO[i], last ? d.C : 0, d.wo_rows(i), d.Cd, 1, 0, 1, 0, p[6 + 4 * i], p[7 + 4 * i], grads[6 + 4 * i], grads[7 + 4 * i]);
         }
     }
     if (fdy) {                                                // dy += [V_0^T .. V_{d-1}^T] [dxy_0; ..; dxy_{d-1}]
