@@ -701,6 +701,64 @@ __global__ __launch_bounds__(256) void finalize_batch_kernel(const FinBatch b)
     finalize_row(b.job[ji], (int)blockIdx.x - b.start[ji], dw, red);
 }
 
+// The same with ONE WAVE per weight row, four rows per block (dynamic LDS: 4 x maxcols floats): a row is 0.3-7 KB of slab per split,
+// so a block per row was 11 784 blocks of a few microseconds of dependent latency each for a WN (71 us, bound by block dispatch and
+// by four resident blocks per CU); a wave needs no block barrier and no 32 KB static row buffer.
+__device__ __forceinline__ void finalize_row_wave(const FinJob &j, int o, float *dw)
+{
+    const int lane = threadIdx.x & 63;
+    const int cols = j.I * j.R;
+    float esc = 0.f;
+    if (j.extra) {
+        for (int i = 0; i < j.n_extra; ++i) esc += j.extra_scale_src[i];
+        esc *= j.extra_mul;
+    }
+    const float *row = j.slab + (size_t)(j.row0 + o) * j.ldn + j.col0;
+    for (int r = 0; r < j.R; ++r)
+        for (int i = lane; i < j.I; i += 64) {
+            const size_t off = (size_t)r * j.cr + (size_t)i * j.ci;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int sp = 0;
+            for (; sp + 3 < j.nsplit; sp += 4) {
+                s0 += row[(size_t)sp * j.sstride + off];
+                s1 += row[(size_t)(sp + 1) * j.sstride + off];
+                s2 += row[(size_t)(sp + 2) * j.sstride + off];
+                s3 += row[(size_t)(sp + 3) * j.sstride + off];
+            }
+            for (; sp < j.nsplit; ++sp) s0 += row[(size_t)sp * j.sstride + off];
+            dw[i * j.R + r] = (s0 + s1) + (s2 + s3);
+        }
+    __builtin_amdgcn_wave_barrier();                     // (one wave: its LDS accesses execute in order)
+    float dot = 0.f, ss = 0.f;
+    for (int e = lane; e < cols; e += 64) {
+        float s = dw[e];
+        if (j.extra) { s += j.extra[(size_t)e * j.rows + o] * esc; dw[e] = s; }
+        if (j.g) { const float vv = j.v[(size_t)o * cols + e]; dot += s * vv; ss += vv * vv; }
+    }
+    if (!j.g) {
+        if (j.dv)
+            for (int e = lane; e < cols; e += 64) j.dv[(size_t)o * cols + e] = dw[e];
+        return;
+    }
+#pragma unroll
+    for (int q = 32; q > 0; q >>= 1) { dot += __shfl_xor(dot, q, 64); ss += __shfl_xor(ss, q, 64); }
+    const float nrm = sqrtf(ss);
+    if (lane == 0 && j.dg) j.dg[o] = dot / nrm;
+    if (!j.dv) return;
+    const float aa = j.g[o] / nrm, bq = dot / ss;
+    for (int e = lane; e < cols; e += 64) j.dv[(size_t)o * cols + e] = aa * (dw[e] - j.v[(size_t)o * cols + e] * bq);
+}
+__global__ __launch_bounds__(256) void finalize_batch_wave_kernel(const FinBatch b, int maxcols)
+{
+    extern __shared__ float dwall[];
+    const int gid = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (gid >= b.start[b.n]) return;
+    int ji = 0;
+    for (int q = 1; q < b.n; ++q)
+        if (gid >= b.start[q]) ji = q;
+    finalize_row_wave(b.job[ji], gid - b.start[ji], dwall + (size_t)(threadIdx.x >> 6) * maxcols);
+}
+
 // InvConv1x1Func.backward tail (efficient_modules.py:276-277): dW = -W^-T dw W^-T - W^-T * dlogdet * T,
 // dw = sum of the split-K slabs.  c <= WG_MAXC, one block.
 struct InvRevFinArgs {

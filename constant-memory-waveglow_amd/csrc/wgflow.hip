@@ -809,7 +809,16 @@ struct FinQueue {
     }
     void flush()
     {
-        if (b.n) WG_LAUNCH(cx, finalize_batch_kernel, dim3(b.start[b.n]), dim3(256), 0, b);
+        if (b.n) {
+            int maxcols = 0;
+            for (int i = 0; i < b.n; ++i) maxcols = std::max(maxcols, b.job[i].I * b.job[i].R);
+#if !defined(WG_OPT_FIN_BLOCK_ROWS)
+            if ((size_t)4 * maxcols * sizeof(float) <= 60 * 1024)      // one wave per row, four rows per block
+                WG_LAUNCH(cx, finalize_batch_wave_kernel, dim3((b.start[b.n] + 3) / 4), dim3(256), (size_t)4 * maxcols * sizeof(float), b, maxcols);
+            else
+#endif
+                WG_LAUNCH(cx, finalize_batch_kernel, dim3(b.start[b.n]), dim3(256), 0, b);
+        }
         b.n = 0;
     }
 };
