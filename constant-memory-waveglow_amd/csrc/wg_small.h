@@ -157,28 +157,31 @@ struct AffineArgs {
 
 #define WG_AFF_T 64          // time steps per workgroup
 #define WG_AFF_LD 64         // skip-channel loads a lane keeps in flight
+// NR = accumulator rows kept per lane: 8 where 2 * ic <= 8 (WaveGlow: n_group 8), 32 otherwise.  (With 32 accumulators next to the 64
+// loads in flight the kernel needed 250 VGPRs and 41 KB of LDS: two workgroups per CU, 38 us per launch at the training shape.)
+template <int NR>
 __global__ __launch_bounds__(256) void end_affine_kernel(const AffineArgs a)
 {
     // out[m][t] = sum_k W_end[m][k] S[k][t] for the 2*ic <= 32 rows of the end conv: far too few rows for a matrix tile to pay, and
     // the kernel is bound by reading S once.  A workgroup takes 64 time steps; its 4 waves split the skip channels, every lane
-    // streams its quarter of S[:, t] (coalesced along t, 16 loads in flight) into 2*ic accumulators, LDS adds the four quarters.
-    __shared__ float tile[32][WG_AFF_T + 1];
-    // phase 1: each wave's block of W_end^T rows ([WG_AFF_LD][32] floats per wave); phase 2: the partial sums of waves 1-3
-    __shared__ __attribute__((aligned(16))) float stage[4 * WG_AFF_LD * 32];
-    float (*part)[32][WG_AFF_T + 1] = reinterpret_cast<float (*)[32][WG_AFF_T + 1]>(stage);
-    static_assert(sizeof(stage) >= 3 * 32 * (WG_AFF_T + 1) * sizeof(float), "");
+    // streams its quarter of S[:, t] (coalesced along t, 64 loads in flight) into 2*ic accumulators, LDS adds the four quarters.
+    __shared__ float tile[NR][WG_AFF_T + 1];
+    // phase 1: each wave's block of W_end^T rows ([WG_AFF_LD][NR] floats per wave); phase 2: the partial sums of waves 1-3
+    constexpr int STAGE = (4 * WG_AFF_LD * NR > 3 * NR * (WG_AFF_T + 1)) ? 4 * WG_AFF_LD * NR : 3 * NR * (WG_AFF_T + 1);
+    __shared__ __attribute__((aligned(16))) float stage[STAGE];
+    float (*part)[NR][WG_AFF_T + 1] = reinterpret_cast<float (*)[NR][WG_AFF_T + 1]>(stage);
     __shared__ float red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, t = blockIdx.x * WG_AFF_T + lane;
     const Geo g = a.g;
     const int rows = 2 * a.ic;
-    float acc[32];
+    float acc[NR];
 #pragma unroll
-    for (int m = 0; m < 32; ++m) acc[m] = 0.f;
+    for (int m = 0; m < NR; ++m) acc[m] = 0.f;
     {
         const int kq = (a.Cs + 3) / 4, k0 = wave * kq, k1 = min(a.Cs, k0 + kq);
         const float *sp = paddr(a.S, g, b, 0, min(t, g.Tt - 1));        // columns in [T, Tt) read the zero padding; beyond Tt is clamped
-        float *wl = stage + wave * (WG_AFF_LD * 32);
+        float *wl = stage + wave * (WG_AFF_LD * NR);
         // 64 loads in flight per lane (a whole quarter of the usual 256 skip channels at once): with one utterance the grid is 32
         // workgroups and the kernel's time is its chain of round trips.  The weights of those 64 channels come through LDS (one
         // coalesced copy per wave, then broadcast reads): as wave-uniform global loads they were a chain of 64 scalar-cache misses,
@@ -189,29 +192,21 @@ __global__ __launch_bounds__(256) void end_affine_kernel(const AffineArgs a)
 #pragma unroll
             for (int u = 0; u < WG_AFF_LD; ++u) sv[u] = (k + u < k1) ? sp[(size_t)(k + u) * g.P] : 0.f;
             if (kk) __syncthreads();                                     // the previous block has been consumed
-            for (int i = lane; i < WG_AFF_LD * 8; i += 64) {             // rows k .. k+63 of endT are one contiguous 8 KB piece
-                const int row = k + (i >> 3);
+            for (int i = lane; i < WG_AFF_LD * (NR / 4); i += 64) {      // columns [0, NR) of rows k .. k+63 of endT ([Cs][32])
+                const int u = i / (NR / 4), q = i - u * (NR / 4);
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < k1) v = reinterpret_cast<const float4 *>(a.endT + (size_t)k * 32)[i];
+                if (k + u < k1) v = reinterpret_cast<const float4 *>(a.endT + (size_t)(k + u) * 32)[q];
                 reinterpret_cast<float4 *>(wl)[i] = v;
             }
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < WG_AFF_LD; ++u) {
-                const float4 *w = reinterpret_cast<const float4 *>(wl + u * 32);         // same address in every lane: LDS broadcast
-                if (rows <= 8) {
-                    const float4 w0 = w[0], w1 = w[1];
-                    acc[0] = fmaf(w0.x, sv[u], acc[0]); acc[1] = fmaf(w0.y, sv[u], acc[1]);
-                    acc[2] = fmaf(w0.z, sv[u], acc[2]); acc[3] = fmaf(w0.w, sv[u], acc[3]);
-                    acc[4] = fmaf(w1.x, sv[u], acc[4]); acc[5] = fmaf(w1.y, sv[u], acc[5]);
-                    acc[6] = fmaf(w1.z, sv[u], acc[6]); acc[7] = fmaf(w1.w, sv[u], acc[7]);
-                } else {
+                const float4 *w = reinterpret_cast<const float4 *>(wl + u * NR);         // same address in every lane: LDS broadcast
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const float4 wq = w[q];
-                        acc[4 * q] = fmaf(wq.x, sv[u], acc[4 * q]);         acc[4 * q + 1] = fmaf(wq.y, sv[u], acc[4 * q + 1]);
-                        acc[4 * q + 2] = fmaf(wq.z, sv[u], acc[4 * q + 2]); acc[4 * q + 3] = fmaf(wq.w, sv[u], acc[4 * q + 3]);
-                    }
+                for (int q = 0; q < NR / 4; ++q) {
+                    const float4 wq = w[q];
+                    acc[4 * q] = fmaf(wq.x, sv[u], acc[4 * q]);         acc[4 * q + 1] = fmaf(wq.y, sv[u], acc[4 * q + 1]);
+                    acc[4 * q + 2] = fmaf(wq.z, sv[u], acc[4 * q + 2]); acc[4 * q + 3] = fmaf(wq.w, sv[u], acc[4 * q + 3]);
                 }
             }
         }
@@ -219,13 +214,13 @@ __global__ __launch_bounds__(256) void end_affine_kernel(const AffineArgs a)
     __syncthreads();                                                     // stage: weights -> partial sums
     if (wave > 0) {
 #pragma unroll
-        for (int m = 0; m < 32; ++m)
+        for (int m = 0; m < NR; ++m)
             if (m < rows) part[wave - 1][m][lane] = acc[m];
     }
     __syncthreads();
     if (wave == 0) {
 #pragma unroll
-        for (int m = 0; m < 32; ++m)
+        for (int m = 0; m < NR; ++m)
             if (m < rows) tile[m][lane] = (acc[m] + part[0][m][lane]) + (part[1][m][lane] + part[2][m][lane]);
     }
     __syncthreads();

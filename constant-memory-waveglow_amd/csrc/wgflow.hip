@@ -1095,7 +1095,8 @@ void run_end_affine(Ctx &cx, const WnRun &r, int mode, PRef dX, float *log_s_out
     a.Gp = pref(r.ws + r.w.G, r.L.kp_end);
     a.log_s_out = log_s_out; a.dls_plain = dls_plain; a.dld = dld; a.partial = partial;
     a.g = r.g; a.mode = mode;
-    WG_LAUNCH(cx, end_affine_kernel, dim3(r.g.Tt / WG_AFF_T, r.g.B), dim3(256), 0, a);
+    if (2 * a.ic <= 8) WG_LAUNCH(cx, end_affine_kernel<8>, dim3(r.g.Tt / WG_AFF_T, r.g.B), dim3(256), 0, a);
+    else WG_LAUNCH(cx, end_affine_kernel<32>, dim3(r.g.Tt / WG_AFF_T, r.g.B), dim3(256), 0, a);
 }
 
 // backward through WN given the G plane (what autograd.grad at efficient_modules.py:143 evaluates).
@@ -2292,7 +2293,8 @@ int wg_wn_apply(const wg_wn_dims *dd, const void *packed, const float *x, const 
     memset(&a, 0, sizeof(a));
     a.endT = r.pk + r.L.endT; a.S = pref(ws + W.wn.skip, d.Cs); a.Cs = d.Cs; a.ic = d.ic; a.X = X;
     a.log_s_out = log_s; a.t_out = t; a.g = g; a.mode = AFF_RAW;
-    WG_LAUNCH(cx, end_affine_kernel, dim3(g.Tt / WG_AFF_T, g.B), dim3(256), 0, a);
+    if (2 * a.ic <= 8) WG_LAUNCH(cx, end_affine_kernel<8>, dim3(g.Tt / WG_AFF_T, g.B), dim3(256), 0, a);
+    else WG_LAUNCH(cx, end_affine_kernel<32>, dim3(g.Tt / WG_AFF_T, g.B), dim3(256), 0, a);
     return cx.err;
 }
 
