@@ -67,6 +67,56 @@ __global__ void mix_kernel(PRef X, const float *__restrict__ Mx, int transpose, 
     }
 }
 
+// Conv1x1Func.backward (efficient_modules.py:235-242) for c <= 8 in ONE pass over z and dz (a thread owns a time step):
+//   x = W^-1 z (in place, :235-237), dx = W^T dz (in place, :239), and this block's share of dW = sum_t dz x^T (:240) into
+//   part[block][c*c] -- five launches (two channel mixes, a 128x128-tile weight-gradient kernel for a c x c product, its slab
+//   reduction) were 50 us per flow of dependent latency.  The split-K finalisation sums the blocks' shares in a fixed order.
+#define WG_ICB_T 4
+template <int C>
+__global__ __launch_bounds__(256) void invconv_bwd_kernel(PRef X, PRef dX, const float *__restrict__ Wm, const float *__restrict__ Winv, Geo g,
+                                                          float *__restrict__ part)
+{
+    __shared__ float w[C * C], wi[C * C];
+    __shared__ float red[4][C * C];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < C * C; e += 256) { w[e] = Wm[e]; wi[e] = Winv[e]; }
+    __syncthreads();
+    const int b = blockIdx.y;
+    float acc[C * C];
+#pragma unroll
+    for (int e = 0; e < C * C; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int q = 0; q < WG_ICB_T; ++q) {                     // WG_ICB_T time steps per thread, 256 apart
+        const int t = (blockIdx.x * WG_ICB_T + q) * 256 + tid;
+        if (t >= g.T) continue;
+        float z[C], dz[C], x[C];
+#pragma unroll
+        for (int i = 0; i < C; ++i) { z[i] = *paddr(X, g, b, i, t); dz[i] = *paddr(dX, g, b, i, t); }
+#pragma unroll
+        for (int o = 0; o < C; ++o) {
+            float s = 0.f, d = 0.f;
+#pragma unroll
+            for (int i = 0; i < C; ++i) { s += wi[o * C + i] * z[i]; d += w[i * C + o] * dz[i]; }
+            x[o] = s;
+            *paddr(X, g, b, o, t) = s;
+            *paddr(dX, g, b, o, t) = d;
+        }
+#pragma unroll
+        for (int i = 0; i < C; ++i)
+#pragma unroll
+            for (int j = 0; j < C; ++j) acc[i * C + j] = fmaf(dz[i], x[j], acc[i * C + j]);
+    }
+#pragma unroll
+    for (int e = 0; e < C * C; ++e) {
+        float p = acc[e];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
+        if (lane == 0) red[wave][e] = p;
+    }
+    __syncthreads();
+    if (tid < C * C) part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (C * C) + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
 // LU (partial pivoting) of each flow's c x c weight: logdet (NaN if det<0, torch.logdet semantics) and inverse.
 // One thread per matrix; c <= WG_MAXC.  out layout per matrix: [W (c*c) | Winv (c*c) | logdet | pad..] stride `ostride`.
 struct LuJob {
@@ -538,9 +588,43 @@ struct PackArgs {
     int n;
     PackJob job[WG_JOBS];
 };
-__global__ void pack_kernel(const PackArgs a)
+__global__ __launch_bounds__(256) void pack_kernel(const PackArgs a)
 {
     const PackJob j = a.job[blockIdx.y];
+    if (j.mode == 0) {
+        // the transposing form through a 32 (k) x 64 (m) LDS tile: consecutive lanes read consecutive k of one source row (12 bytes
+        // apart for a k = 3 conv weight) and write consecutive m.  (Element by element in dst order every lane read its own source
+        // row: 19 us per launch, 31 launches per training step.)
+        __shared__ float tile[32][65];
+        const int tid = threadIdx.x;
+        const int tk = (j.Kp + 31) / 32, tm = (j.Mp + 63) / 64;
+        for (int tl = blockIdx.x; tl < tk * tm; tl += gridDim.x) {
+            const int k0 = (tl / tm) * 32, m0 = (tl % tm) * 64;
+            __syncthreads();
+            const int kk = tid & 31, k = k0 + kk;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int mm = (tid >> 5) + 8 * q, m = m0 + mm;
+                int o = m;
+                if (j.half > 0) {
+                    const int qq = m >> 6, r = m & 63;
+                    o = r < 32 ? qq * 32 + r : j.half + qq * 32 + (r - 32);
+                    if ((qq * 32 + (r & 31)) >= j.half) o = -1;
+                }
+                float val = 0.f;
+                if (o >= 0 && o < j.no && k < j.ni && m < j.Mp) val = j.scale[o] * j.src[(size_t)o * j.so + (size_t)k * j.si + j.off];
+                tile[kk][mm] = val;
+            }
+            __syncthreads();
+            const int m = m0 + (tid & 63);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int kw = (tid >> 6) + 4 * q;
+                if (k0 + kw < j.Kp && m < j.Mp) j.dst[(size_t)(k0 + kw) * j.ldd + m] = tile[kw][tid & 63];
+            }
+        }
+        return;
+    }
     const size_t total = (size_t)j.Kp * j.Mp;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
         const int k = (int)(e / j.Mp), m = (int)(e % j.Mp);

@@ -1698,6 +1698,24 @@ static int model_backward(const wg_config *cf, const void *const *params, const 
         const int c = flow_channels(cf, k);
         const float *lu = pk + M.lu + (size_t)k * WG_LU_STRIDE;
         PRef Xk = pref(ws + W.X, W.Gp, base), dXk = pref(ws + W.dX, W.Gp, base);
+#if !defined(WG_OPT_NO_FUSED_INVCONV_BWD)
+        const dim3 fgrid((T + 256 * WG_ICB_T - 1) / (256 * WG_ICB_T), B);
+        if (c <= 8 && (c & 1) == 0 && (size_t)fgrid.x * fgrid.y * c * c <= W.wn.slab_floats) {      // one pass: x, dx and the shares of dW
+            float *part = ws + W.wn.slab;
+            const float *Wm = lu, *Wi = lu + WG_MAXC * WG_MAXC;
+            switch (c) {
+            case 2: WG_LAUNCH(cx, invconv_bwd_kernel<2>, fgrid, dim3(256), 0, Xk, dXk, Wm, Wi, g, part); break;
+            case 4: WG_LAUNCH(cx, invconv_bwd_kernel<4>, fgrid, dim3(256), 0, Xk, dXk, Wm, Wi, g, part); break;
+            case 6: WG_LAUNCH(cx, invconv_bwd_kernel<6>, fgrid, dim3(256), 0, Xk, dXk, Wm, Wi, g, part); break;
+            default: WG_LAUNCH(cx, invconv_bwd_kernel<8>, fgrid, dim3(256), 0, Xk, dXk, Wm, Wi, g, part); break;
+            }
+            WgradOut wo;
+            wo.nsplit = (int)(fgrid.x * fgrid.y); wo.Mp = c; wo.Np = c;
+            run_finalize(cx, part, wo, 0, c, c, 1, 0, 1, 0, nullptr, nullptr, nullptr, gr[3 + k],
+                         lu + WG_MAXC * WG_MAXC, dlogdet, B, (float)T);                       // + W^-T dlogdet T :242
+            return;
+        }
+#endif
         run_mix(cx, g, Xk, c, lu + WG_MAXC * WG_MAXC, 0);                                     // x = W^-1 z   :235-237
         WSegSpec sa = {dXk.p, dXk.Cp, dXk.ch0, c, 0, nullptr, 0, 0}, sb = {Xk.p, Xk.Cp, Xk.ch0, c, 0, nullptr, 0, 0};
         const int prec_keep = cx.prec;
