@@ -1042,12 +1042,12 @@ struct WgSSeg {
 // that the finalisation reads back -- 130 MB of HBM traffic per layer; eight layers together need a 2- to 8-way split).  The groups
 // share every field of WgradSArgs except the operand planes, the tap shifts and the slab; grid z = group * nsplit + split.
 #define WG_GRP_MAX 8
-#define WG_GRP_SEG 4
 struct WgradGrp {
     const unsigned short *a_hi[2];          // nullptr: that segment's rows are zero in this group
-    const unsigned short *b_hi[WG_GRP_SEG];
-    int b_shift[WG_GRP_SEG];
-    float *slab;
+    const unsigned short *b_plane[2];       // the (at most two) distinct B planes of a group: the layer input (all its taps) and the
+    float *slab;                            // conditioning; WgradSArgs::b_plane_of says which one a segment reads
+    short b_shift[WG_MAX_SEG];              // time shift and plane-row offset of every B segment
+    short b_row[WG_MAX_SEG];
 };
 struct WgradSArgs {
     int nseg_a, nseg_b;
@@ -1058,6 +1058,7 @@ struct WgradSArgs {
     float *slab;
     int Mp, Np;
     int ngroups;                        // 0: one product (sa / sb / slab as they are)
+    unsigned char b_plane_of[WG_MAX_SEG];
     const unsigned short *zsrc;         // grouped launches: any S-plane (position 0 = zero halo)
     WgradGrp grp[WG_GRP_MAX];
 };
@@ -1163,11 +1164,11 @@ __device__ __forceinline__ void wgrad16s_body(const WgradSArgs &a, int bx, int b
         const int ib = find_sseg_idx(a.sb, a.nseg_b, nb >> 5);
         const WgSSeg &sb = a.sb[ib];
         const int cb = nb - sb.blk0 * 32;
-        const unsigned short *hb = a.ngroups ? a.grp[grp].b_hi[min(ib, WG_GRP_SEG - 1)] : sb.hi;
-        const int bshift = a.ngroups ? a.grp[grp].b_shift[min(ib, WG_GRP_SEG - 1)] : sb.shift;
+        const unsigned short *hb = a.ngroups ? a.grp[grp].b_plane[a.b_plane_of[ib]] : sb.hi;
+        const int bshift = a.ngroups ? (int)a.grp[grp].b_shift[ib] : sb.shift;
         pb[j] = (nb < a.Np && cb < sb.nch && hb) ? hb + (((size_t)((sb.ch0 + cb) >> 3)) * g.P + g.H + bshift + tl) * 8 : nullptr;
         lb_[j] = sb.lo_off; sbb[j] = (size_t)(sb.Cp >> 3) * g.P * 8;
-        roff[j] = sb.row_off; pitem[j] = sb.per_item;
+        roff[j] = a.ngroups ? (int)a.grp[grp].b_row[ib] : sb.row_off; pitem[j] = sb.per_item;
     }
     // this block's share of the flattened (batch item, chunk) range
     const int c_begin = (int)((long)zs * a.total_chunks / a.nsplit), c_end = (int)((long)(zs + 1) * a.total_chunks / a.nsplit);

@@ -101,16 +101,15 @@ inline bool s_only_chain(const Ctx &cx, const WnD &d)
     (void)cx; (void)d; return false;
 #endif
 }
-// Weight gradients of all layers of a WN in two grouped launches after its layer loop (WgradGrp, wg_gemm16s.h) instead of two launches
-// per layer.  Needs every layer's gate gradient (kept anyway for the one-product conditioning gradient, fused_dy) and every layer's
-// dh (kept as its own S-plane: + (depth - 1) planes of C channels).
-inline bool fused_dy(const WnD &d);
+// Weight gradients of all layers of a WN in ONE grouped launch after its layer loop (WgradGrp, wg_gemm16s.h) instead of two launches
+// per layer.  Needs every layer's gate gradient (the 1-D WN keeps them anyway for the one-product conditioning gradient, fused_dy)
+// and every layer's dh, each as its own S-plane: + (depth - 1) planes of 2 Cd and of C channels.
 inline bool grouped_wgrad(int prec, const WnD &d)
 {
-#if defined(WG_OPT_NO_WGRAD_GROUP) || defined(WG_OPT_NO_S_ONLY)
+#if defined(WG_OPT_NO_WGRAD_GROUP)
     (void)prec; (void)d; return false;
 #else
-    return prec == 2 && !d.mode2d && fused_dy(d) && d.depth <= WG_GRP_MAX && d.radix + 1 <= WG_GRP_SEG;
+    return prec == 2 && d.depth >= 2 && d.depth <= WG_GRP_MAX && d.radix + 1 <= WG_MAX_SEG;
 #endif
 }
 inline bool fused_skip(const WnD &d)
@@ -471,7 +470,7 @@ void wn_ws_layout(Bump &bp, const WnD &d, int ic_max, const Geo &g, int mode, in
             w.dHS = bp.take(pC);
             w.dHS_step = grouped_wgrad(prec, d) ? rupz(pC, 64) : 0;
             for (int i = 1; i < d.depth && w.dHS_step; ++i) (void)bp.take(pC);
-            w.dxyS_step = fused_dy(d) ? rupz(2 * pD, 64) : 0;
+            w.dxyS_step = (fused_dy(d) || grouped_wgrad(prec, d)) ? rupz(2 * pD, 64) : 0;
             w.dxyS = bp.take(2 * pD);
             for (int i = 1; i < d.depth && w.dxyS_step; ++i) (void)bp.take(2 * pD);
         }
@@ -906,13 +905,13 @@ WgradOut run_wgrad(Ctx &cx, const Geo &g, const WSegSpec *sa, int nsa, const WSe
 // its slabs went.
 struct WgradGroupSpec {
     WSegSpec sa[2];
-    WSegSpec sb[WG_GRP_SEG];
+    WSegSpec sb[WG_MAX_SEG];
 };
 // shape and split of a grouped product (no slab yet)
 static bool shape_wgrad_group(Ctx &cx, const Geo &g, const WgradGroupSpec *gs, int ng, int nsa, int nsb, WgradSArgs &q)
 {
     memset(&q, 0, sizeof(q));
-    if (!cx.fq || ng > WG_GRP_MAX || nsb > WG_GRP_SEG || nsa > 2) { if (!cx.err) cx.err = WG_EINVAL; return false; }
+    if (!cx.fq || ng > WG_GRP_MAX || nsb > WG_MAX_SEG || nsa > 2) { if (!cx.err) cx.err = WG_EINVAL; return false; }
     q.nseg_a = nsa; q.nseg_b = nsb; q.g = g;
     q.cpb = g.Tt / WG16_BK; q.total_chunks = g.B * q.cpb;
     int blk = 0;
@@ -926,8 +925,18 @@ static bool shape_wgrad_group(Ctx &cx, const Geo &g, const WgradGroupSpec *gs, i
     blk = 0;
     for (int s = 0; s < nsb; ++s) {
         const WSegSpec &x = gs[0].sb[s];
-        q.sb[s].hi = nullptr; q.sb[s].lo_off = (size_t)g.B * x.sCp * g.P;
+        q.sb[s].hi = nullptr; q.sb[s].lo_off = (size_t)(x.per_item ? g.B / g.rows : g.B) * x.sCp * g.P;
         q.sb[s].Cp = x.sCp; q.sb[s].ch0 = x.sch0; q.sb[s].nch = x.nch; q.sb[s].shift = 0; q.sb[s].blk0 = blk;
+        q.sb[s].row_off = 0; q.sb[s].per_item = x.per_item;
+        // the distinct planes of group 0 (at most two) name the planes of every group
+        int pl = -1, used = 0;
+        for (int u = 0; u < s; ++u) {
+            used = std::max(used, q.b_plane_of[u] + 1);
+            if (gs[0].sb[u].s == x.s) { pl = q.b_plane_of[u]; break; }
+        }
+        if (pl < 0) pl = used;
+        if (pl > 1) { if (!cx.err) cx.err = WG_EINVAL; return false; }
+        q.b_plane_of[s] = (unsigned char)pl;
         blk += rup(x.nch, 32) / 32;
     }
     q.Np = rup(blk * 32, WG_TILE);
@@ -951,7 +960,11 @@ static bool bind_wgrad_group(Ctx &cx, const WgradGroupSpec *gs, const float *zer
     q.zsrc = (const unsigned short *)zero_plane; q.slab = slab;
     for (int k = 0; k < q.ngroups; ++k) {
         for (int s = 0; s < q.nseg_a; ++s) q.grp[k].a_hi[s] = (const unsigned short *)gs[k].sa[s].s;
-        for (int s = 0; s < q.nseg_b; ++s) { q.grp[k].b_hi[s] = (const unsigned short *)gs[k].sb[s].s; q.grp[k].b_shift[s] = gs[k].sb[s].shift; }
+        q.grp[k].b_plane[0] = q.grp[k].b_plane[1] = nullptr;
+        for (int s = 0; s < q.nseg_b; ++s) {
+            q.grp[k].b_plane[q.b_plane_of[s]] = (const unsigned short *)gs[k].sb[s].s;
+            q.grp[k].b_shift[s] = (short)gs[k].sb[s].shift; q.grp[k].b_row[s] = (short)gs[k].sb[s].row_off;
+        }
         q.grp[k].slab = slab + (size_t)k * q.nsplit * one;
         outs[k].nsplit = q.nsplit; outs[k].Mp = q.Mp; outs[k].Np = q.Np; outs[k].slab = q.grp[k].slab;
     }
@@ -1113,8 +1126,8 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
     const bool fdy = dY && fused_dy(d);                       // every layer keeps its dxy; dy is one product after the loop
     const int Gc = r.L.kp_end;
     const bool sp = cx.prec == 2;
-    // the layers' weight gradients as two grouped launches behind the loop (needs every layer's dxy and dh kept: fdy, dHS_step)
-    const bool gw = grouped_wgrad(cx.prec, d) && fdy && s_only_chain(cx, d) && r.w.dHS_step && nd >= 2;
+    // the layers' weight gradients as ONE grouped launch behind the loop (every layer's dxy and dh is kept then: dxyS_step, dHS_step)
+    const bool gw = grouped_wgrad(cx.prec, d) && r.w.dHS_step && r.w.dxyS_step && nd >= 2;
     auto dHSp = [&](int j) { return ws + r.w.dHS + (size_t)j * r.w.dHS_step; };      // S-plane of dh_j (one plane for all j unless gw)
     WgradGroupSpec gsT[WG_GRP_MAX], gsO[WG_GRP_MAX];
 #if !defined(WG_OPT_NO_FIN_BATCH)
@@ -1165,9 +1178,9 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
             for (int kt = 0; kt < d.radix; ++kt) {
                 int ts, ro;
                 d.tap(i, kt, ts, ro);
-                gsT[i].sb[kt] = {nullptr, d.C, 0, d.C, ts, ws + r.w.HS[i], d.C, 0};
+                gsT[i].sb[kt] = {nullptr, d.C, 0, d.C, ts, ws + r.w.HS[i], d.C, 0, ro, 0};
             }
-            gsT[i].sb[d.radix] = {nullptr, d.auxp(), 0, d.aux, 0, r.YS, d.auxp(), 0};
+            gsT[i].sb[d.radix] = {nullptr, d.auxp(), 0, d.aux, 0, r.YS, d.auxp(), 0, 0, d.mode2d};
         } else {
             WSegSpec sa = {dxy, 2 * d.Cd, 0, 2 * d.Cd, 0, sp ? dxyS : nullptr, 2 * d.Cd, 0};
             WSegSpec sb[WG_MAX_SEG];
