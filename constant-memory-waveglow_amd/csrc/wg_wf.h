@@ -220,13 +220,15 @@ struct LuBigArgs {
     const float *W[WG_MAX_FLOWS];
     int n, c, ostride;
     float *out;
+    unsigned char cs[WG_MAX_FLOWS];     // per-matrix size (0: c) -- WaveGlow's 1x1 weights shrink with the early outputs
+    int inv_off, det_off;               // where W^-1 and logdet go inside a matrix's output record (0: c*c and 2*c*c)
 };
 // one workgroup per matrix: LU with partial pivoting in LDS (rows of c + 1 floats), log|det| and sign, then one thread per column
 // of the inverse (forward / back substitution in place in the output)
 __global__ __launch_bounds__(256) void lu_big_kernel(const LuBigArgs a)
 {
     extern __shared__ float lsm[];
-    const int c = a.c, ld = c + 1, tid = threadIdx.x;
+    const int c = a.cs[blockIdx.x] ? (int)a.cs[blockIdx.x] : a.c, ld = c + 1, tid = threadIdx.x;
     float *A = lsm;                                    // [c][c+1]
     int *perm = reinterpret_cast<int *>(lsm + c * ld); // [c]
     __shared__ float redv[256];
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(256) void lu_big_kernel(const LuBigArgs a)
     __shared__ float s_la;
     __shared__ int s_sg;
     const float *W = a.W[blockIdx.x];
-    float *o = a.out + (size_t)blockIdx.x * a.ostride, *Wi = o + c * c;
+    float *o = a.out + (size_t)blockIdx.x * a.ostride, *Wi = o + (a.inv_off ? a.inv_off : c * c);
     for (int e = tid; e < c * c; e += 256) { const float v = W[e]; o[e] = v; A[(e / c) * ld + e % c] = v; }
     for (int i = tid; i < c; i += 256) perm[i] = i;
     if (tid == 0) { s_la = 0.f; s_sg = 1; }
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256) void lu_big_kernel(const LuBigArgs a)
         }
         __syncthreads();
     }
-    if (tid == 0) o[2 * c * c] = s_sg > 0 ? s_la : __builtin_nanf("");
+    if (tid == 0) o[a.det_off ? a.det_off : 2 * c * c] = s_sg > 0 ? s_la : __builtin_nanf("");
     for (int col = tid; col < c; col += 256) {
         for (int r = 0; r < c; ++r) {                        // L y = P e_col
             float s = perm[r] == col ? 1.f : 0.f;

@@ -661,6 +661,8 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
 #if !defined(WG_OPT_NO_HTILE)
             // at most half as many 128 x 64 tiles as CUs (one utterance being synthesised, WaveFlow's row-by-row inverse): such a launch
             // is as long as its slowest CU needs to take in its operands -- 64 x 64 tiles, twice the workgroups (wg_gemm16h.h)
+            // (measured and not adopted: also where the 128 x 64 tiles are 1 - 1.5 per CU -- WSRGlow's gate conv, 384 such tiles --
+            // three 64 x 64 tiles on every CU instead: 52.9 against 50.5 ms per WSRGlow step)
             if (small && 2 * ntiles <= cus && epi != EPI_DGATE) {
                 as.nty = 2 * (int)grid.y;
                 const dim3 gh(as.ntx * as.nty * as.ntz);
@@ -1528,10 +1530,14 @@ int wg_pack_weights(const wg_config *cf, const void *const *params, void *packed
     float *ones = pk + M.ones;
     WG_LAUNCH(cx, fill_rows_kernel, dim3(WG_ONES / 256, 1, 1), dim3(256), 0, pref(ones, 1), Geo{1, WG_ONES, WG_ONES, 0, WG_ONES}, (const float *)nullptr, 1.0f);
     // 1x1 weights: LU -> logdet, inverse   (efficient_modules.py:221,235)
-    LuArgs lu;
-    lu.n = cf->n_flows; lu.out = pk + M.lu; lu.ostride = WG_LU_STRIDE;
-    for (int k = 0; k < cf->n_flows; ++k) { lu.job[k].W = p[3 + k]; lu.job[k].c = flow_channels(cf, k); }
-    WG_LAUNCH(cx, lu_kernel, dim3((cf->n_flows + 63) / 64), dim3(64), 0, lu);
+    // (one workgroup per matrix, the matrix in LDS: the one-thread-per-matrix lu_kernel, whose arrays live in scratch memory, took
+    // 0.11 ms for WaveGlow's 8 x 8 and 0.62 ms for WSRGlow's 16 x 16 weights at the head of every step)
+    LuBigArgs lu;
+    memset(&lu, 0, sizeof(lu));
+    lu.n = cf->n_flows; lu.c = cf->n_group; lu.out = pk + M.lu; lu.ostride = WG_LU_STRIDE;
+    lu.inv_off = WG_MAXC * WG_MAXC; lu.det_off = 2 * WG_MAXC * WG_MAXC;
+    for (int k = 0; k < cf->n_flows; ++k) { lu.W[k] = p[3 + k]; lu.cs[k] = (unsigned char)flow_channels(cf, k); }
+    WG_LAUNCH(cx, lu_big_kernel, dim3(cf->n_flows), dim3(256), ((size_t)cf->n_group * (cf->n_group + 1) + cf->n_group) * sizeof(float), lu);
     JobBatch jb(&cx);
     jb.norm(p[1], p[2], pk + M.up_scale, cf->n_mels, cf->up_kernel);
     for (int k = 0; k < cf->n_flows; ++k) {
@@ -1900,6 +1906,7 @@ int wg_wf_pack_weights(const wg_wf_config *cf, const void *const *params, void *
     ib.flush();
     if (cf->use_conv1x1) {                                   // W, W^-1, logdet W of every flow's 1x1 (efficient_modules.py:37-41,49-54)
         LuBigArgs lu;
+        memset(&lu, 0, sizeof(lu));
         lu.n = cf->flows; lu.c = cf->n_group; lu.ostride = L.mix_stride; lu.out = pk + L.mix;
         for (int k = 0; k < cf->flows; ++k) lu.W[k] = p[3 + 37 * cf->flows + k];
         const size_t lds = ((size_t)lu.c * (lu.c + 1) + lu.c) * sizeof(float);
