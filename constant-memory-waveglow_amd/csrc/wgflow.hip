@@ -814,7 +814,7 @@ struct FinQueue {
             int maxcols = 0;
             for (int i = 0; i < b.n; ++i) maxcols = std::max(maxcols, b.job[i].I * b.job[i].R);
 #if !defined(WG_OPT_FIN_BLOCK_ROWS)
-            if ((size_t)4 * maxcols * sizeof(float) <= 60 * 1024)      // one wave per row, four rows per block
+            if (maxcols <= 1024)        // one wave per row, four rows per block (long rows -- WSRGlow's 3659 conditioning columns -- keep a block each)
                 WG_LAUNCH(cx, finalize_batch_wave_kernel, dim3((b.start[b.n] + 3) / 4), dim3(256), (size_t)4 * maxcols * sizeof(float), b, maxcols);
             else
 #endif
