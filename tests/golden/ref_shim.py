@@ -144,8 +144,9 @@ def load_melspec():
         melscale_fbanks (htk):  all_freqs = linspace(0, sr // 2, n_freqs); m_pts = linspace(hz2mel(f_min), hz2mel(f_max), n_mels + 2),
                        hz2mel(f) = 2595 log10(1 + f / 700); f_pts = 700 (10^(m / 2595) - 1);
                        fb = max(0, min(-slopes[:, :-2] / f_diff[:-1], slopes[:, 2:] / f_diff[1:])), slopes = f_pts[None] - all_freqs[:, None]
-    So the fixtures pin the reflection pad and the log to the reference's own code, the STFT power to torch.stft, and the mel
-    filterbank to the published formula only.  The stand-in keeps the last power spectrogram in `.last_power` for the fixture.
+    So the fixtures pin the reflection pad and the log to the reference's own code and the STFT power to torch.stft; the mel
+    filterbank above is held to transformers.audio_utils.mel_filter_bank (an independent implementation of the same htk definition
+    that ships in this image) by make_golden.melspec_fixture, which also stores that matrix for the oracle's test.  The stand-in keeps the last power spectrogram in `.last_power` for the fixture.
     """
     load()
     import importlib

@@ -305,6 +305,21 @@ def test_training_metrics_formula():
 
 # ---- the oracle's own sanity ----------------------------------------------------------------------------------------------
 
+def test_mel_filterbank_matches_third_party_numbers(golden_dir):
+    """The HTK mel filterbank of oracle/mel_oracle.py against the matrix transformers.audio_utils.mel_filter_bank produced for the
+    same arguments (stored by make_golden.melspec_fixture, which also holds the torchaudio stand-in to it): the one part of MelSpec
+    that no code under /root/reference defines is pinned to an independent published implementation."""
+    from oracle import mel_oracle as mo
+    G = np.load(os.path.join(golden_dir, "cond_melspec.npz"))
+    kw = fill.MEL_KW
+    fb = np.asarray(mo.mel_filterbank(kw["sr"], kw["n_fft"], kw["n_mels"], 0.0, kw["f_max"]), dtype=np.float64)
+    want = G["filterbank/transformers"]
+    if fb.shape != want.shape:
+        fb = fb.T
+    assert fb.shape == want.shape == (kw["n_fft"] // 2 + 1, kw["n_mels"])
+    assert np.abs(fb - want).max() < 1e-6 and want.max() > 0.9
+
+
 def test_mel_oracle_properties():
     from oracle import mel_oracle as mo
     sr, n_fft, hop, n_mels = 22050, 1024, 256, 80
