@@ -141,45 +141,57 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
         return;
     }
     if (EPI == EPI_DGATE) {
-        // all auxiliary loads (tanh / sigmoid of the forward gate) first, then combine and store: the launch is bound by these bytes
-        f32x4 ax[4][NB], ay[4][NB];
+        // The auxiliary loads (tanh / sigmoid of the forward gate) of one 16-row block at a time, then combine and store it.  (All 128
+        // values loaded first took the kernel to 210 VGPRs, i.e. ONE workgroup per CU for a launch bound by these bytes.)
+#if defined(WG_OPT_DGATE_ALL)
+        constexpr int MBS = 4;
+#else
+        constexpr int MBS = 1;
+#endif
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            const int mbase = m0 + wr * 64 + mb * 16;
-            const float *p0 = paddr(a.aux0, g, b, mbase, t0), *p1 = paddr(a.aux1, g, b, mbase, t0);
+        for (int mb0 = 0; mb0 < 4; mb0 += MBS) {
+            f32x4 ax[MBS][NB], ay[MBS][NB];
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const int tl = wc * (16 * NB) + nb * 16 + col;
+            for (int q = 0; q < MBS; ++q) {
+                const int mbase = m0 + wr * 64 + (mb0 + q) * 16;
+                const float *p0 = paddr(a.aux0, g, b, mbase, t0), *p1 = paddr(a.aux1, g, b, mbase, t0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned off = (unsigned)(4 * rq + e) * (unsigned)g.P + (unsigned)tl;
-                    float x = 0.f, y = 0.f;
-                    // (non-temporal, like the stores that saved them: this is their only use)
-                    if (t0 + tl < g.T && mbase + 4 * rq + e < a.M) { x = __builtin_nontemporal_load(&p0[off]); y = __builtin_nontemporal_load(&p1[off]); }
-                    ax[mb][nb][e] = x; ay[mb][nb][e] = y;
-                }
-            }
-        }
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int tl = wc * (16 * NB) + nb * 16 + col;
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const int t = t0 + wc * (16 * NB) + nb * 16 + col, m = m0 + wr * 64 + mb * 16 + 4 * rq;
-                if (t >= g.T || m >= a.M) continue;
-                float o[4], o2[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = acc[mb][nb][e], tw = ax[mb][nb][e], sf = ay[mb][nb][e];
-                    o[e] = v * sf * (1.0f - tw * tw);
-                    o2[e] = v * tw * sf * (1.0f - sf);
-                    if (a.out0.p) {
-                        *paddr(a.out0, g, b, m + e, t) = o[e];
-                        *paddr(a.out0, g, b, a.nsplit + m + e, t) = o2[e];
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned off = (unsigned)(4 * rq + e) * (unsigned)g.P + (unsigned)tl;
+                        float x = 0.f, y = 0.f;
+                        // (non-temporal, like the stores that saved them: this is their only use)
+                        if (t0 + tl < g.T && mbase + 4 * rq + e < a.M) { x = __builtin_nontemporal_load(&p0[off]); y = __builtin_nontemporal_load(&p1[off]); }
+                        ax[q][nb][e] = x; ay[q][nb][e] = y;
                     }
                 }
-                s_store4(s0, g, b, m, t, o);
-                s_store4(s0, g, b, a.nsplit + m, t, o2);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < MBS; ++q)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int mb = mb0 + q;
+                    const int t = t0 + wc * (16 * NB) + nb * 16 + col, m = m0 + wr * 64 + mb * 16 + 4 * rq;
+                    if (t >= g.T || m >= a.M) continue;
+                    float o[4], o2[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = acc[mb][nb][e], tw = ax[q][nb][e], sf = ay[q][nb][e];
+                        o[e] = v * sf * (1.0f - tw * tw);
+                        o2[e] = v * tw * sf * (1.0f - sf);
+                        if (a.out0.p) {
+                            *paddr(a.out0, g, b, m + e, t) = o[e];
+                            *paddr(a.out0, g, b, a.nsplit + m + e, t) = o2[e];
+                        }
+                    }
+                    s_store4(s0, g, b, m, t, o);
+                    s_store4(s0, g, b, a.nsplit + m, t, o2);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         return;
     }
     // EPI_STORE / EPI_RESSKIP: the auxiliary values were the accumulators' initial value (conv_acc_init_q): stores only
