@@ -1,9 +1,15 @@
 #!/usr/bin/env python3
 """Headline benchmark: audio samples/s of WaveGlow-256ch forward + NLL backward on 16 000-sample segments.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu] [--no-inverse]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu] [--no-inverse] [--spawn]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process is only a LAUNCHER.  Before anything touches the GPU it
+starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child (one RCCL rank per GPU, per-GPU batch fixed: the
+reference's `batch_size //= gpus` read the other way round, train.py:51-53,73-78), relays the ranks' output to stderr and prints rank 0's
+JSON line as the last line of stdout; a failing child is a failing bench.  Under torch.distributed.run (WORLD_SIZE set) it is a rank, and
+WORLD_SIZE must equal --gpus.  `--spawn` forces the launcher for N = 1 as well (a 1-rank RCCL group through the same code path).
 
 A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
 z, logdet = model(x, h); loss = NLL(z, logdet); backward to all 459 parameter gradients (+ RCCL mean all-reduce
@@ -11,8 +17,10 @@ of the gradients when N > 1).  Data loading, mel computation, optimizer step and
 SURVEY.md 8d.  Per-GPU batch is fixed (weak scaling): configs[1] of BASELINE.json at N=1, configs[2] at N=8.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline     : the dominant kernel (dilated conv + conditioning + gate, convgemm_kernel<EPI_GATE>) timed with HIP
-                 events over the timed steps, algorithmic FLOPs / average launch duration vs the fp32 MFMA peak;
+  roofline     : the dominant kernel (dilated conv + conditioning + gate, convgemm16q_kernel<EPI_GATE>) timed with HIP
+                 events over the timed steps, algorithmic FLOPs / average launch duration vs the dense bf16 MFMA peak
+                 (2.5 PF; only algorithmic FLOPs are credited, the 3 issued bf16 products per fp32 product are overhead;
+                 `f32_mode` carries the exact-fp32 run against the 157.3 TF fp32 MFMA peak);
   cpu_baseline : the CPU oracle (a plain-C port of the reference's algorithm) timed on the host cores on one
                  16 000-sample segment of the same workload (rank 0, N=1 only);
   inverse_khz  : single-GPU synthesis speed, timed as the reference does (inference.py:50-56).
@@ -266,7 +274,7 @@ def f32_mode(dev, x, h):
         torch.cuda.empty_cache()
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -275,13 +283,109 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-inverse", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the WSRGlow / WaveFlow step timings (SURVEY.md 8f rows)")
-    args = ap.parse_args()
+    ap.add_argument("--spawn", action="store_true", help="go through the launcher even for --gpus 1 (a 1-rank RCCL group)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher only: print the child command and environment as JSON, start nothing")
+    ap.add_argument("--selftest", choices=("ok", "fail"), default=None,
+                    help="launcher / rank plumbing without a GPU: the ranks form a gloo group, reduce a number and rank 0 prints a JSON "
+                         "line ('fail': rank 1 exits with code 3 instead) -- what tests/test_bench_launcher_cpu.py runs")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launcher_plan(args, argv, port=None):
+    """(command, environment additions) of the child that runs the N ranks.  The reference gets its ranks from Lightning
+    (`pl.Trainer(gpus=N, strategy=DDPPlugin(...))`, train.py:73-78: one process per GPU); here torch.distributed.run starts them, with
+    the rendezvous on 127.0.0.1 (the container's hostname may not resolve).  `--spawn` / `--dry-run` are the launcher's own flags."""
+    own = {"--spawn", "--dry-run"}
+    rest = [a for a in argv if a not in own]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port if port is not None else _free_port()),
+           os.path.abspath(__file__)] + rest
+    env = {"HSA_ENABLE_IPC_MODE_LEGACY": "0",       # the host driver only supports dmabuf IPC (RCCL across processes)
+           "WG_BENCH_LAUNCHED": "1",                 # the ranks use the process group even when there is only one of them
+           "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // max(1, args.gpus))))}
+    return cmd, env
+
+
+def launch(args, argv):
+    """Parent side of `bench.py --gpus N`: never touches the GPU (torch.cuda.device_count() does not initialise it on this image),
+    starts the ranks as a CHILD process -- not an exec --, relays their output to stderr and rank 0's JSON line to stdout."""
+    import subprocess
+    cmd, extra = launcher_plan(args, argv)
+    if args.dry_run:
+        print(json.dumps({"launcher": True, "cmd": cmd, "env": extra, "n_ranks": args.gpus}))
+        return 0
+    if not args.selftest:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print("bench.py: --gpus %d but this node shows %d GPU(s)" % (args.gpus, have), file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.update(extra)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env, text=True, bufsize=1)
+    line = None
+    for raw in proc.stdout:                       # rank 0 prints the JSON line; anything else the ranks say goes to stderr
+        t = raw.strip()
+        if t.startswith("{") and '"metric"' in t:
+            line = t
+        else:
+            sys.stderr.write(raw)
+    rc = proc.wait()
+    if rc != 0:
+        print("bench.py: the %d-rank child exited with code %d" % (args.gpus, rc), file=sys.stderr)
+        return rc
+    if line is None:
+        print("bench.py: the ranks finished without a result line", file=sys.stderr)
+        return 1
+    sys.stderr.flush()
+    print(line, flush=True)
+    return 0
+
+
+def selftest_rank(args, world, rank):
+    """The rank side of the plumbing on CPU (gloo): rendezvous from the environment torch.distributed.run sets, a MAX reduction like the
+    one the timing uses, rank 0's line last on stdout."""
+    dist.init_process_group("gloo")
+    if args.selftest == "fail" and rank == 1:
+        os._exit(3)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "selftest", "value": float(t.item()), "n_gpus": world, "rccl_ranks": world,
+                          "steps": args.steps, "warmup": args.warmup, "launched": os.environ.get("WG_BENCH_LAUNCHED") == "1"}), flush=True)
+    dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    in_rank = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if not in_rank and (args.gpus > 1 or args.spawn or args.dry_run):
+        return launch(args, argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    use_dist = world > 1 or os.environ.get("WG_BENCH_FORCE_DIST") == "1"      # FORCE_DIST: exercise the RCCL path with one rank
+    if world != args.gpus:
+        # n_gpus in the line is the real world size; a mismatch with --gpus is a harness error, not something to paper over
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        return 2
+    if args.selftest:
+        return selftest_rank(args, world, rank)
+    # a group of ONE rank still runs the collectives when it was launched (or WG_BENCH_FORCE_DIST=1): the RCCL path on one GPU
+    use_dist = world > 1 or os.environ.get("WG_BENCH_FORCE_DIST") == "1" or os.environ.get("WG_BENCH_LAUNCHED") == "1"
     if use_dist:
+        os.environ["WG_BENCH_FORCE_DIST"] = "1" if world == 1 else os.environ.get("WG_BENCH_FORCE_DIST", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
@@ -357,7 +461,8 @@ def main():
             traffic_src += " (committed rocprofv3 --pmc summary of this command; not re-measured in this run)"
         out = {
             "metric": "audio samples/sec (fwd+bwd) WaveGlow-256ch seg=16000",
-            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "samples/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if use_dist else 0,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (contractions as split bf16x3 MFMA, fp32 accumulate)" if split else "f32", "data": "synthetic",
             "config": {"workload": "WaveGlow 256ch, 12 flows, seg=16000, batch=%d per GPU (waveglow_LJ_speech.json), "
@@ -422,7 +527,8 @@ def main():
         except Exception:
             pass
         print(json.dumps(out), flush=True)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

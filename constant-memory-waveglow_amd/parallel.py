@@ -129,8 +129,11 @@ class GradSync:
                     after_bucket(b)
 
     def all_reduce_params(self, params: Sequence[torch.Tensor]):
-        """Mean all-reduce of `p.grad` for models trained through autograd (WSRGlow, WaveFlow): the gradients are copied into one
-        flat buffer, reduced with ONE collective (WaveFlow: 5.95 M parameters = 24 MB) and copied back."""
+        """Mean all-reduce of `p.grad` for models trained through autograd (WaveFlow): the gradients are copied into one flat buffer,
+        reduced with ONE collective and copied back.  Not bucketed and not overlapped, on purpose: WaveFlow has 5.95 M parameters =
+        24 MB, i.e. 2 * 7/8 * 24 MB = 42 MB per GPU through >= 153 GB/s of xGMI = about 0.3 ms behind a 51 ms step (0.6 %), and its
+        autograd node (`_WaveFlowFn`) hands over all gradients at once when the backward call returns, so there is no earlier point
+        at which a bucket would be final.  (WaveGlow / WSRGlow, 215 / 919 MB, go through FlowTrainer's per-flow buckets.)"""
         if self.world == 1 and not self._force:
             return
         grads = [p.grad for p in params if p.grad is not None]
@@ -146,11 +149,23 @@ class GradSync:
             off += g.numel()
 
     def broadcast_params(self, params: Sequence[torch.Tensor], src: int = 0):
-        """replicas start identical (what DDP does when it wraps the module)"""
+        """Replicas start identical (what DDP does when it wraps the module): ONE broadcast of all parameters as a flat buffer
+        (WaveGlow-256ch: 459 tensors, 214.6 MB -- 459 separate collectives would each pay RCCL's launch latency), copied back into
+        the parameters on the receiving ranks."""
         if self.world == 1 and not self._force:
             return
-        for p in params:
-            dist.broadcast(p.data, src=src, group=self.pg)
+        params = [p for p in params if p is not None]
+        if not params:
+            return
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1) for p in params])
+            dist.broadcast(flat, src=src, group=self.pg)
+            if dist.get_rank(self.pg) != src or self._force:
+                off = 0
+                for p in params:
+                    n = p.numel()
+                    p.detach().copy_(flat[off:off + n].view_as(p))
+                    off += n
 
 
 METRIC_NAMES = ("logdet", "z_mean", "z_std", "loss")      # the keys LightModel.training_step logs (model/lightning.py:58-64)

@@ -1,0 +1,71 @@
+"""`bench.py --gpus N` as the driver issues it: the parent is a launcher that starts N ranks (one per GPU) as a child
+`torch.distributed.run`, relays rank 0's JSON line as the last stdout line and fails when a rank fails -- the role Lightning's
+DDPPlugin plays upstream (train.py:51-53,73-78).  No GPU here: the plan is checked dry, and the process plumbing with gloo ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(*argv, env=None, timeout=300):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH] + list(argv), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e,
+                          timeout=timeout)
+
+
+def test_dry_run_plan_is_one_rank_per_gpu_on_loopback():
+    r = _run("--gpus", "8", "--steps", "7", "--warmup", "2", "--dry-run")
+    assert r.returncode == 0, r.stderr
+    plan = json.loads(r.stdout.strip().splitlines()[-1])
+    cmd = plan["cmd"]
+    assert plan["n_ranks"] == 8
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    i = cmd.index(BENCH)
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "7", "--warmup", "2"]       # the ranks get the same flags, minus the launcher's own
+    assert plan["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and plan["env"]["WG_BENCH_LAUNCHED"] == "1"
+
+
+def test_plan_function_strips_launcher_flags():
+    sys.path.insert(0, ROOT)
+    import bench
+    args = bench.parse_args(["--gpus", "2", "--spawn", "--no-cpu"])
+    cmd, env = bench.launcher_plan(args, ["--gpus", "2", "--spawn", "--no-cpu"], port=12345)
+    assert "--spawn" not in cmd and cmd[-3:] == ["--gpus", "2", "--no-cpu"] and "12345" in cmd
+    assert int(env["OMP_NUM_THREADS"]) >= 1
+
+
+def test_launcher_starts_ranks_and_relays_rank0_line():
+    r = _run("--gpus", "2", "--steps", "4", "--warmup", "1", "--selftest", "ok")
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    line = json.loads(last)                                                       # the JSON line is the LAST thing on stdout
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["value"] == 2.0 and line["steps"] == 4 and line["launched"]
+
+
+def test_single_rank_through_the_launcher():
+    r = _run("--gpus", "1", "--spawn", "--selftest", "ok")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_failing_rank_fails_the_bench():
+    r = _run("--gpus", "2", "--selftest", "fail")
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]            # no result line from a failed run
+    assert "exited with code" in r.stderr
+
+
+def test_world_size_must_match_gpus():
+    r = _run("--gpus", "4", "--selftest", "ok", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr

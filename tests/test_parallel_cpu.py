@@ -83,8 +83,9 @@ def _worker(rank, world, port, q):
     assert torch.allclose(ps[0].grad, torch.full((5,), 1.5)) and torch.allclose(ps[1].grad, torch.arange(6, dtype=torch.float32).view(2, 3) * 1.5)
     assert ps[2].grad is None
     # replicas start identical
-    probe = [torch.full((3,), float(rank))]
-    sync.broadcast_params(probe)
+    probe = [torch.full((3,), float(rank)), None, torch.nn.Parameter(torch.full((2, 4), 7.0 + rank)), torch.full((1,), 5.0 * rank)]
+    sync.broadcast_params(probe)                                      # ONE flat collective over all of them, copied back per tensor
+    assert float(probe[2].detach().sum()) == 56.0 and float(probe[3][0]) == 0.0 and probe[2].shape == (2, 4)
     if rank == 0:
         full = orc.train_step(oc, tab, audio, h, fill.SIGMA)
         worst = max(float(np.abs(v.numpy() - g).max() / max(np.abs(g).max(), 1e-30)) for v, g in zip(fg.views, full["grads"]))
