@@ -1060,8 +1060,23 @@ struct WgradSArgs {
     int ngroups;                        // 0: one product (sa / sb / slab as they are)
     unsigned char b_plane_of[WG_MAX_SEG];
     const unsigned short *zsrc;         // grouped launches: any S-plane (position 0 = zero halo)
+    unsigned *sync;                     // grouped launches: one progress counter per (group, split), WG_SYNC_STRIDE apart, zeroed before the
+    int sync_n;                         // launch (nullptr: the tiles of a (group, split) run unsynchronised); sync_n = tiles per counter
     WgradGrp grp[WG_GRP_MAX];
 };
+// Soft lock-step of the workgroups that share operands.  The tiles of one (group, split) read the same A row tiles and B column tiles
+// chunk by chunk; left alone they drift apart over the hundreds of chunks of a launch (a CU's first workgroup wins issue arbitration
+// over its second one) until the shared lines have left the XCD's L2 and are fetched again: 6.3 GB of HBM traffic per paired launch
+// for 2.5 GB of operands (profiles/r02l_hbm_traffic.json).  Every WG_SYNC_EVERY chunks a workgroup adds one to its set's counter and
+// waits until all sync_n members have done so.  Performance hint only: the wait is bounded, and a workgroup that runs into the bound
+// once (a member that has not been dispatched yet) stops synchronising -- no result depends on the counter, nothing can hang on it.
+#define WG_SYNC_STRIDE 32
+#if !defined(WG_SYNC_EVERY)
+#define WG_SYNC_EVERY 4
+#endif
+#if !defined(WG_SYNC_SPINS)
+#define WG_SYNC_SPINS 256
+#endif
 typedef short s4v __attribute__((ext_vector_type(4)));
 // rows r..r+3 (lo) and r+4..r+7 (hi) of the image, r a multiple of 8 plus the lane's row: the upper four rows are stored rotated
 // by 32 bytes inside the 256-byte row payload (see the staging map of wgrad16s_kernel)
@@ -1170,6 +1185,7 @@ __device__ __forceinline__ void wgrad16s_body(const WgradSArgs &a, int bx, int b
         lb_[j] = sb.lo_off; sbb[j] = (size_t)(sb.Cp >> 3) * g.P * 8;
         roff[j] = a.ngroups ? (int)a.grp[grp].b_row[ib] : sb.row_off; pitem[j] = sb.per_item;
     }
+    unsigned *sync_ctr = (a.ngroups && a.sync) ? a.sync + (size_t)(grp * a.nsplit + zs) * WG_SYNC_STRIDE : nullptr;
     // this block's share of the flattened (batch item, chunk) range
     const int c_begin = (int)((long)zs * a.total_chunks / a.nsplit), c_end = (int)((long)(zs + 1) * a.total_chunks / a.nsplit);
     const int nchunks = c_end - c_begin;
@@ -1258,6 +1274,15 @@ __device__ __forceinline__ void wgrad16s_body(const WgradSArgs &a, int bx, int b
             store_stage(st, (c & 1) ^ 1);
             issue(st);
             mfma12(f1, acc);
+            if (sync_ctr && (c & (WG_SYNC_EVERY - 1)) == WG_SYNC_EVERY - 1 && tid == 0) {
+                __hip_atomic_fetch_add(sync_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned want = (unsigned)((c + 1) / WG_SYNC_EVERY) * (unsigned)a.sync_n;
+                int spins = 0;
+                while (__hip_atomic_load(sync_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    if (++spins > WG_SYNC_SPINS) { sync_ctr = nullptr; break; }     // (thread 0's copy: it alone uses the pointer)
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
             __syncthreads();
         };
         // always in pairs (after the last chunk the spare iteration multiplies a buffer of zero-halo data: adds exact zeros)

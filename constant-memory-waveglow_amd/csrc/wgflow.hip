@@ -7,6 +7,7 @@
 #include "wg_gemm16s.h"
 #include "wg_gemm16q.h"
 #include "wg_gemm16h.h"
+#include "wg_wgrad16t.h"
 #include "wg_wsr.h"
 #include "wg_wf.h"
 #include "wg_mel.h"
@@ -444,6 +445,64 @@ size_t slab_floats(const Geo &g, int Mp, int Np)
     return (size_t)std::max(p.nsplit, plan_wgrad_flat(g, tiles)) * Mp * Np;
 }
 
+// ---- wgrad16t_kernel (wg_wgrad16t.h): both grouped products of a WN on exactly one workgroup per CU ----
+// The plan: which slots of every XCD work on which product over which part of K, in at most WGT_PH_MAX phases (see the header).
+//   phase A: the larger product P0 (T0 tiles of 256 x 128 per layer) as n0 = 32 / T0 sets per XCD = s0 = 8 n0 / ng parts of K per layer;
+//            in the slots that leaves, n1 sets of P1 (T1 tiles) covering the first s1 parts of P0's length;
+//   phase B: the rest of P1's K range over all slots of every XCD.
+// A plan exists when the set counts divide evenly over the 8 XCDs and every part holds at least one chunk; it is used when its length
+// is within 20 % of the ideal (total work / 256 CUs).  nslab[i] = slabs per layer of product i.
+struct WgtPlan {
+    bool ok = false;
+    int nph = 0;
+    WgtPhase ph[WGT_PH_MAX];
+    int nslab[2] = {0, 0};
+    int length = 0;                                          // chunks on the longest slot
+};
+static WgtPlan plan_wgt(int tm0, int tn0, int tm1, int tn1, int ng, int K)
+{
+    WgtPlan pl;
+#if defined(WG_OPT_NO_WGRAD16T)
+    return pl;
+#endif
+    const int T0 = tm0 * tn0, T1 = tm1 * tn1;
+    if (T0 < 1 || T1 < 1 || T0 > 32 || T1 > 32 || ng < 1 || K < 1) return pl;
+    auto sets_per_xcd = [&](int room, int T) {               // most sets of T tiles in `room` slots whose total over 8 XCDs is a multiple of ng
+        int n = room / T;
+        while (n > 0 && (8 * n) % ng) --n;
+        return n;
+    };
+    const int n0 = sets_per_xcd(32, T0);
+    if (n0 == 0) return pl;
+    const int s0 = 8 * n0 / ng;
+    if (s0 > K) return pl;
+    const int dur = (K + s0 - 1) / s0;
+    pl.ph[pl.nph++] = WgtPhase{0, 0, n0 * T0, s0, 0, K, 0, 0, 0, 0};
+    pl.nslab[0] = s0;
+    const int n1 = sets_per_xcd(32 - n0 * T0, T1);
+    int kA1 = 0;
+    if (n1 > 0) {
+        const int s1 = 8 * n1 / ng;
+        kA1 = std::min(K, s1 * dur);
+        if (s1 > kA1) return pl;
+        pl.ph[pl.nph++] = WgtPhase{1, n0 * T0, n1 * T1, s1, 0, kA1, 0, 0, 0, 0};
+        pl.nslab[1] = s1;
+    }
+    int durB = 0;
+    if (kA1 < K) {
+        const int nB = sets_per_xcd(32, T1);
+        if (nB == 0) return pl;
+        const int sB = 8 * nB / ng;
+        if (sB > K - kA1) return pl;
+        durB = (K - kA1 + sB - 1) / sB;
+        pl.ph[pl.nph++] = WgtPhase{1, 0, nB * T1, sB, kA1, K, pl.nslab[1], 0, 0, 0};
+        pl.nslab[1] += sB;
+    }
+    pl.length = dur + durB;
+    const long work = (long)(T0 + T1) * ng * K;
+    pl.ok = (long)pl.length * 256 * 5 <= work * 6 + 8L * 256 * 5;
+    return pl;
+}
 struct WnWs {               // plane bases (float offsets) of one WN's activations
     size_t H[16], tw[16], sf[16], gate[16], skip, G, dS, dH, dxy, slab;
     size_t HS[16], gateS[16], XaS, GS, dSS, dHS, dxyS;   // S-planes (precision 2), sized like the fp32 plane of the same tensor
@@ -504,7 +563,13 @@ void wn_ws_layout(Bump &bp, const WnD &d, int ic_max, const Geo &g, int mode, in
             const size_t oneT = (size_t)rup(2 * d.Cd, WG_TILE) * nW, oneO = (size_t)rup(d.C + d.Cs, WG_TILE) * rup(d.Cd, WG_TILE);
             const int nsT = plan_wgrad_flat(g, (int)(oneT / (WG_TILE * WG_TILE)) * d.depth);
             const int nsO = plan_wgrad_flat(g, (int)(oneO / (WG_TILE * WG_TILE)) * d.depth);
-            s = std::max(s, rupz((size_t)nsT * d.depth * oneT, 64) + rupz((size_t)nsO * d.depth * oneO, 64) + 4096);
+            s = std::max(s, rupz((size_t)nsT * d.depth * oneT, 64) + rupz((size_t)nsO * d.depth * oneO, 64) + 4096
+                            + rupz((size_t)(nsT + nsO) * d.depth * WG_SYNC_STRIDE, 64));                     // (+ the lock-step counters)
+            if (g.rows == 0 && oneT / nW % 256 == 0 && rup(d.C + d.Cs, WG_TILE) % 256 == 0) {              // wgrad16t_kernel's own split
+                const WgtPlan pl = plan_wgt((int)(oneT / nW) / 256, nW / WG_TILE, rup(d.C + d.Cs, WG_TILE) / 256, rup(d.Cd, WG_TILE) / WG_TILE,
+                                            d.depth, g.B * (g.Tt / WG16_BK));
+                if (pl.ok) s = std::max(s, rupz((size_t)pl.nslab[0] * d.depth * oneT, 64) + rupz((size_t)pl.nslab[1] * d.depth * oneO, 64) + 4096);
+            }
         }
         w.slab_floats = s;
         w.slab = bp.take(s);
@@ -979,18 +1044,58 @@ void run_wgrad_group(Ctx &cx, const Geo &g, const WgradGroupSpec *gs, int ng, in
     TimerScope ts(WG_K_WGRAD, cx.st);
     WG_LAUNCH(cx, wgrad16s_kernel<1>, dim3(q.Np / WG_TILE, q.Mp / WG_TILE, q.nsplit * ng), dim3(256), 0, q);
 }
+static int wgt_valid_cols(const WgradSArgs &q)
+{
+    const WgSSeg &l = q.sb[q.nseg_b - 1];
+    return std::min(q.Np, rup(l.blk0 * 32 + l.nch, 16));
+}
+
 // two grouped products in one launch (wgrad16s_pair_kernel): the one with the longer workgroups first
 void run_wgrad_group_pair(Ctx &cx, const Geo &g, const WgradGroupSpec *gs0, int nsa0, int nsb0, WgradOut *outs0,
                           const WgradGroupSpec *gs1, int nsa1, int nsb1, WgradOut *outs1, int ng, const float *zero_plane)
 {
     WgradPairArgs pp;
     if (!shape_wgrad_group(cx, g, gs0, ng, nsa0, nsb0, pp.p[0]) || !shape_wgrad_group(cx, g, gs1, ng, nsa1, nsb1, pp.p[1])) return;
-    if (group_slab_floats(pp.p[0]) + group_slab_floats(pp.p[1]) > cx.fq->cap) { if (!cx.err) cx.err = WG_EWORKSPACE; return; }   // (wn_ws_layout sizes for it)
-    cx.fq->ensure(group_slab_floats(pp.p[0]) + group_slab_floats(pp.p[1]));    // both slab sets live until the launch: no wrap between them
+    // one workgroup per CU on 256 x 128 tiles (wg_wgrad16t.h) when the shape has a plan: 1-D planes, 256-row products
+    WgtPlan plan;
+    if (g.rows == 0 && pp.p[0].Mp % 256 == 0 && pp.p[1].Mp % 256 == 0)
+        plan = plan_wgt(pp.p[0].Mp / 256, pp.p[0].Np / WG_TILE, pp.p[1].Mp / 256, pp.p[1].Np / WG_TILE, ng, pp.p[0].total_chunks);
+    if (plan.ok) { pp.p[0].nsplit = plan.nslab[0]; pp.p[1].nsplit = plan.nslab[1]; }
+    // progress counters of the (group, split) sets of both products (soft lock-step, wg_gemm16s.h): one 128-byte line each
+    const size_t nctr0 = (size_t)pp.p[0].nsplit * ng, nctr1 = (size_t)pp.p[1].nsplit * ng;
+    size_t sync_floats = rupz((nctr0 + nctr1) * WG_SYNC_STRIDE, 64);
+#if !defined(WG_OPT_WGRAD_SYNC)                              // measured: holds the HBM traffic at the operand bytes and costs more than that saves
+    sync_floats = 0;
+#endif
+    if (plan.ok) sync_floats = 0;
+    if (group_slab_floats(pp.p[0]) + group_slab_floats(pp.p[1]) + sync_floats > cx.fq->cap) { if (!cx.err) cx.err = WG_EWORKSPACE; return; }   // (wn_ws_layout sizes for it)
+    cx.fq->ensure(group_slab_floats(pp.p[0]) + group_slab_floats(pp.p[1]) + sync_floats);    // all live until the launch: no wrap between them
     if (!bind_wgrad_group(cx, gs0, zero_plane, outs0, pp.p[0]) || !bind_wgrad_group(cx, gs1, zero_plane, outs1, pp.p[1])) return;
+    if (plan.ok) {
+        WgtArgs wa;
+        memset(&wa, 0, sizeof(wa));
+        wa.p[0] = pp.p[0]; wa.p[1] = pp.p[1];
+        wa.nph = plan.nph;
+        for (int i = 0; i < plan.nph; ++i) {
+            wa.ph[i] = plan.ph[i];
+            const WgradSArgs &q = wa.p[plan.ph[i].prod];
+            wa.ph[i].tn = q.Np / WG_TILE; wa.ph[i].tiles = (q.Mp / 256) * (q.Np / WG_TILE); wa.ph[i].ngroups = ng;
+        }
+        for (int w = 0; w < 2; ++w) wa.nvalid[w] = wgt_valid_cols(wa.p[w]);
+        TimerScope ts(WG_K_WGRAD, cx.st);
+        WG_LAUNCH(cx, wgrad16t_kernel, dim3(256), dim3(768), 0, wa);
+        return;
+    }
+    if (sync_floats) {
+        unsigned *ctr = reinterpret_cast<unsigned *>(cx.fq->reserve(sync_floats));
+        if (cx.err) return;
+        if (hipMemsetAsync(ctr, 0, sync_floats * sizeof(float), cx.st) != hipSuccess) { cx.err = WG_ELAUNCH; return; }
+        pp.p[0].sync = ctr; pp.p[1].sync = ctr + nctr0 * WG_SYNC_STRIDE;
+    }
     for (int w = 0; w < 2; ++w) {
         pp.gx[w] = pp.p[w].Np / WG_TILE; pp.gy[w] = pp.p[w].Mp / WG_TILE;
         pp.n[w] = pp.gx[w] * pp.gy[w] * pp.p[w].nsplit * ng;
+        pp.p[w].sync_n = pp.gx[w] * pp.gy[w];
     }
     pp.n0 = pp.n[0];
     TimerScope ts(WG_K_WGRAD, cx.st);

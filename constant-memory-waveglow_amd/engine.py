@@ -119,13 +119,21 @@ class PackedWeights:
     def __init__(self):
         self.buf = None
         self.key = None
+        self._pending = None
 
     def stale(self, params):
+        """True: `params` differ from what `buf` holds.  The buffer then counts as EMPTY until commit(): a pack that raises half way
+        (a CPU or half parameter further down the table, an unsupported configuration, a failed launch) must not leave a key behind
+        under which a retry would run on the old or half-written weights."""
         key = tuple((p.data_ptr(), p._version) if p is not None else None for p in params)
         if key != self.key or self.buf is None:
-            self.key = key
+            self.key, self._pending = None, key
             return True
         return False
+
+    def commit(self):
+        """the pack behind the last stale() succeeded"""
+        self.key = self._pending
 
 
 class ModelEngine:
@@ -156,6 +164,7 @@ class ModelEngine:
             if self.packed.buf is None or self.packed.buf.numel() < nbytes or self.packed.buf.device != device:
                 self.packed.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
             check(L.wg_pack_weights(C.byref(self.cfg), _table(params), _p(self.packed.buf), _stream()), "wg_pack_weights")
+            self.packed.commit()
         return self.packed.buf
 
     def _ws(self, B, N, mode, device):
@@ -319,6 +328,7 @@ class CouplingEngine:
             if self.packed.buf is None or self.packed.buf.numel() < nbytes or self.packed.buf.device != device:
                 self.packed.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
             check(L.wg_wn_pack_weights(C.byref(self.dims), _table(params), _p(self.packed.buf), _stream()), "wg_wn_pack_weights")
+            self.packed.commit()
         return self.packed.buf
 
     def _ws(self, B, T, mode, device):
@@ -488,6 +498,7 @@ class WaveFlowEngine:
         if len(params) != L.wg_wf_param_count(C.byref(self.cfg)):
             raise WgError("WaveFlow parameter table has %d entries" % len(params))
         if self.packed.stale(params) or self.packed.buf.device != device:
+            require_device(*params)
             nbytes = L.wg_wf_packed_bytes(C.byref(self.cfg))
             if nbytes == 0:
                 raise WgError("WaveFlow configuration not supported by the HIP kernels (n_group in {8,16,32,64,128}, channels "
@@ -495,6 +506,7 @@ class WaveFlowEngine:
             if self.packed.buf is None or self.packed.buf.numel() < nbytes or self.packed.buf.device != device:
                 self.packed.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
             check(L.wg_wf_pack_weights(C.byref(self.cfg), _table(params), _p(self.packed.buf), _stream()), "wg_wf_pack_weights")
+            self.packed.commit()
         return self.packed.buf
 
     def _ws(self, B, N, mode, device):

@@ -38,18 +38,37 @@ def conv_gv_slots(m):
 
 class SlotTable:
     """A module's C-ABI parameter table, resolved through cached (dict, key) slots instead of a walk over the module tree with
-    nn.Module.__getattr__ on every call (0.5 ms for WaveGlow's 459 entries: a sixth of a single-utterance synthesis call)."""
+    nn.Module.__getattr__ on every call (0.5 ms for WaveGlow's 459 entries: a sixth of a single-utterance synthesis call).
 
-    def __init__(self, build):
-        self._build, self._slots = build, None
+    The cache is only as good as the tree it was resolved from, so every call re-checks it cheaply: the table belongs to ONE owner
+    module (a shallow copy of the owner -- an nn.DataParallel-style replica -- shares this object through its __dict__ and gets its
+    own resolution), every parent -> child edge of the owner's tree must still hold the same child object (`model.WNs[k] = block`,
+    `model.upsampler = ...` re-resolve; ~400 dict lookups, 30 us), and a KeyError from a slot (weight norm added or removed) re-resolves
+    as before."""
 
-    def __call__(self):
-        if self._slots is not None:
+    def __init__(self, method: str):
+        self._method, self._slots, self._edges, self._owner = method, None, (), None
+
+    def _resolve(self, owner):
+        self._slots = getattr(owner, self._method)()
+        self._edges = [(m._modules, name, child) for m in owner.modules() for name, child in m._modules.items()]
+        self._owner = owner
+
+    def _valid(self, owner):
+        if self._slots is None or self._owner is not owner:
+            return False
+        for d, k, c in self._edges:
+            if d.get(k) is not c:
+                return False
+        return True
+
+    def __call__(self, owner):
+        if self._valid(owner):
             try:
                 return [None if s is None else s[0][s[1]] for s in self._slots]
             except KeyError:                # weight norm was added or removed somewhere: resolve the tree again
                 pass
-        self._slots = self._build()
+        self._resolve(owner)
         return [None if s is None else s[0][s[1]] for s in self._slots]
 
 

@@ -84,8 +84,8 @@ class WN(nn.Module):
     def param_table(self):
         """C-ABI order: V(g,v) start(g,v) [W(g,v) W_o(g,v)]*depth end  (include/wgflow.h)."""
         if self._table is None:
-            self._table = SlotTable(self.param_slots)
-        return self._table()
+            self._table = SlotTable("param_slots")
+        return self._table(self)
 
     def forward(self, x, y):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
@@ -155,7 +155,7 @@ class WaveGlow(FlowBase):
         self.z_split_sizes.append(c)
 
         self._half_table, self._half_key = None, None          # fp32 copies of half parameters (inference --half)
-        self._table = SlotTable(self.param_slots)
+        self._table = SlotTable("param_slots")
         wn0 = self.WNs[0].F
         self._engine = engine.ModelEngine(engine.make_config(
             flows, n_group, n_early_every, n_early_size, hop_size, n_mels,
@@ -170,7 +170,7 @@ class WaveGlow(FlowBase):
 
     def param_table(self):
         """C-ABI parameter table (include/wgflow.h): upsampler bias,g,v; 1x1 weights; per flow the WN table."""
-        return self._table()
+        return self._table(self)
 
     def _check(self, x: Tensor, h: Tensor):
         if x.dim() != 2 or h.dim() != 3:
