@@ -7,34 +7,45 @@
 //     of a (layer, split) -- which read the same A row tiles and B column tiles chunk by chunk -- drift apart over their 756 chunks
 //     until the shared lines have left the XCD's L2: 5.3-6.3 GB of HBM traffic per launch for 2.5 GB of operands.  (Holding them
 //     together with a progress counter per set does bring the traffic down to 2.4 GB -- measured, profiles/r03b_wgrad_sync.txt -- but a
-//     barrier every few chunks costs more than the bytes: 1.36 -> 2.25 ms.)
+//     rendezvous every few chunks costs more than the bytes: 1.36 -> 2.25 ms.)
 //   * v_mfma_f32_32x32x16_bf16 (the conv kernels gained from the 16x16x32 shape: same FLOPs per cycle, less energy on a chip whose
 //     clock is set by its power limit, wg_gemm16q.h) and a [t][c] LDS image with 320-byte rows whose staging write is a 2-way bank
 //     conflict (a third of the kernel's LDS cycles).
 //
 // This kernel:
-//   * ONE 12-wave workgroup per CU (8 compute + 4 loader waves, the protocol of convgemm16q_kernel<.., MG = 2>) on a 256 x 128 tile:
-//     48 KB of L2 -> LDS stream per chunk for two 128 x 128 tiles instead of 64 KB, and no second workgroup to lose arbitration:
-//     the CUs of a set run the same instruction stream on their own CU, which is what keeps them in step.
+//   * ONE 12-wave workgroup per CU -- 8 compute waves (4 x 2, a 64 x 64 tile each) + 4 loader waves -- on a 256 x 128 tile: 48 KB of
+//     L2 -> LDS stream per chunk for two 128 x 128 tiles instead of 64 KB, and no second workgroup to lose arbitration: the CUs of a set
+//     run the same instruction stream on their own CU, which keeps them in step without any cross-workgroup synchronisation (measured:
+//     2.7 GB of HBM traffic per launch, profiles/r03d_hbm_traffic.json).
 //   * the grid is exactly the chip: 256 workgroups, workgroup id -> (XCD = id & 7, slot = id >> 3).  The host plans PHASES
-//     (WgtPhase): in a phase a product's K range [k0, k1) is cut into `splits` parts and the tiles of one (layer, part) -- a SET: they
-//     share operands -- take consecutive slots of ONE XCD, so that set's operand lines are fetched into that XCD's L2 once.  At the
-//     headline shape: phase A = the tap / conditioning gradients (14 tiles per layer) as 2 parts on slots 0..27 of XCD `layer`, next
-//     to the first half of K of that layer's W_o gradient (4 tiles) on slots 28..31; phase B = the second half of K of the W_o
-//     gradients as 8 parts of 4 tiles over all 32 slots.  Every CU gets 768 + 96 chunks: the whole launch is one round with no tail
-//     (the 128 x 128 form dealt 448 long and 512 short workgroups onto 512 slots).
+//     (WgtPhase, plan_wgt in wgflow.hip): in a phase a product's K range [k0, k1) is cut into `splits` parts and the tiles of one
+//     (layer, part) -- a SET: they share operands -- take consecutive slots of ONE XCD, so that set's operand lines are fetched into
+//     that XCD's L2 once.  At the headline shape: phase A = the tap / conditioning gradients (14 tiles per layer) as 2 parts on slots
+//     0..27 of XCD `layer`, next to the first half of K of that layer's W_o gradient (4 tiles) on slots 28..31; phase B = the second
+//     half of K of the W_o gradients as 8 parts of 4 tiles over all 32 slots.  Every CU gets 768 + 96 chunks: the whole launch is one
+//     round with no tail (the 128 x 128 form dealt 448 long and 512 short workgroups onto 512 slots).
 //   * LDS image [t (32 rows)][c (128 channels)] with UNPADDED 256-byte rows; the 16-byte unit (8 channels of one time step) ch of
 //     row t sits at position ch ^ F(t), F(t) = ((t >> 3) & 1) << 3 | (t & 3) << 1 | ((t >> 2) & 1).  Under that swizzle BOTH the
 //     operand fetch (ds_read_b64_tr_b16: the 16-lane group g reads rows 8g + {0..3}, then 8g + 4 + {0..3}, of a 16-channel column
 //     block) and the loaders' staging write (eight consecutive lanes hold eight consecutive time steps of one channel group = one
-//     128-byte line of the S-plane) are bank-conflict free (tools/experiments/lds_tr_layout_check.py).
-//   * the column blocks of a tile beyond the product's last column (the conditioning segment ends at column 848 of 896) are not
-//     multiplied: no time on the critical path (the other waves of the workgroup still take a full chunk), but 4 % less MFMA energy.
+//     128-byte line of the S-plane) are bank-conflict free (tools/experiments/lds_tr_layout_check.py; PMC: 0 conflict cycles).
+//   * a ring of THREE chunk buffers in LDS and NO workgroup barrier in the chunk loop: loaders and compute waves hand chunks over
+//     through per-wave progress words in LDS (see the loader loop).  With a barrier per chunk the launch needed 2 470-2 570 cycles per
+//     chunk for the ~1 300-1 540 cycles its MFMAs take (profiles/r03c_wgrad_phases.txt).
+//   * the loader waves' addresses are scalar (an SGPR base per unit that the scalar unit advances, one constant lane offset): a loader
+//     wave shares its SIMD with two compute waves, and every vector-ALU instruction it issues is an MFMA issue slot lost.
 #pragma once
 #include "wg_gemm16q.h"
 #include <type_traits>
 
 #define WGT_PH_MAX 4
+#if !defined(WGT_POLL_SLEEP)
+#define WGT_POLL_SLEEP 2                                   // the loaders look at the compute waves' progress every 64 x this many cycles
+#endif
+#define WGT_SPIN_CAP (1 << 22)                             // polls of a hand-over word before a wave gives up (about a second) and the result is poisoned
+#if !defined(WGT_BAR_GROUP)
+#define WGT_BAR_GROUP 3                                    // the chunk's barrier sits in front of this MFMA group
+#endif
 #define WGT_IMG (32 * 256)                                 // one [32 t][128 c] bf16 image
 #define WGT_BUF (6 * WGT_IMG)                              // A: 2 row halves x (hi, lo); B: hi, lo  = 48 KB
 struct WgtPhase {
@@ -80,6 +91,10 @@ typedef __attribute__((address_space(3))) s4v *wgt_lds_s4p;
 // one MFMA operand (8 consecutive time steps of the lane's channel): two 4 x 16 transposing reads
 __device__ __forceinline__ bf16x8 wgt_frag(const char *p1, const char *p2)
 {
+#if defined(WG_DBG_B128READ)   // timing experiment only (garbage results): one 16-byte read per fragment instead of two transposing 8-byte reads
+    (void)p2;
+    return *reinterpret_cast<const bf16x8 *>((const char *)((size_t)p1 & ~(size_t)15));
+#endif
     const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wgt_lds_s4p)p1);
     const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wgt_lds_s4p)p2);
     bf16x8 r;
@@ -97,6 +112,12 @@ __device__ __forceinline__ void wgt_wait_stage(WgtStage &s)  // all but the newe
                  : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]), "+v"(s.h[3]), "+v"(s.h[4]), "+v"(s.h[5]), "+v"(s.l[0]), "+v"(s.l[1]), "+v"(s.l[2]),
                    "+v"(s.l[3]), "+v"(s.l[4]), "+v"(s.l[5])::"memory");
 }
+__device__ __forceinline__ void wgt_drain(WgtStage &s)       // every load has landed
+{
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(s.h[0]), "+v"(s.h[1]), "+v"(s.h[2]), "+v"(s.h[3]), "+v"(s.h[4]), "+v"(s.h[5]), "+v"(s.l[0]), "+v"(s.l[1]), "+v"(s.l[2]),
+                   "+v"(s.l[3]), "+v"(s.l[4]), "+v"(s.l[5])::"memory");
+}
 
 // (the arguments are read through the kernarg segment pointer: indexing the by-value parameter with a run-time product / layer number
 // makes the compiler copy all of it to scratch and index it there)
@@ -106,9 +127,11 @@ __global__ __launch_bounds__(768) void wgrad16t_kernel(const WgtArgs aa_by_value
 {
     (void)aa_by_value;
     const wgt_kargs_p aa = (wgt_kargs_p)__builtin_amdgcn_kernarg_segment_ptr();
-    __shared__ __attribute__((aligned(16))) char smem[2 * WGT_BUF];
+    __shared__ __attribute__((aligned(16))) char smem[3 * WGT_BUF];
     __shared__ int s_items[WGT_PH_MAX][8];
     __shared__ int s_nitems, s_total;
+    __shared__ volatile int s_fail;                           // a wave gave up waiting for a hand-over: the slabs are poisoned with NaN
+    __shared__ __attribute__((aligned(16))) unsigned s_ready[4], s_done[8];                // chunks staged, per loader wave / chunks read, per compute wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
@@ -124,7 +147,9 @@ __global__ __launch_bounds__(768) void wgrad16t_kernel(const WgtArgs aa_by_value
                 ++n;
             }
         }
-        s_nitems = n; s_total = total;
+        s_nitems = n; s_total = total; s_fail = 0;
+        for (int i = 0; i < 4; ++i) s_ready[i] = 0;
+        for (int i = 0; i < 8; ++i) s_done[i] = 0;
     }
     __syncthreads();
     const int nitems = __builtin_amdgcn_readfirstlane(s_nitems), total = __builtin_amdgcn_readfirstlane(s_total);
@@ -136,14 +161,31 @@ __global__ __launch_bounds__(768) void wgrad16t_kernel(const WgtArgs aa_by_value
         // ------------------------------- loader waves (4: twelve 16-byte units per lane and chunk) -------------------------------
         // 8 compute + 4 loader waves = 3 waves per SIMD = a 170-register budget: at 4 per SIMD (128 registers) the compute waves' 64
         // accumulators + 48 fragment registers + the swizzled addresses of the transposing reads spilled inside the chunk loop.
-        const int lt = tid - 512;
-        const int tl = lt & 31, cgl = lt >> 5;                // this lane's time step inside a chunk and channel group (0..7; and + 8)
-        const int dst0 = wgt_off(tl, cgl), dst1 = wgt_off(tl, cgl + 8);      // unit positions inside a [32][128] image
-        const unsigned short *zsrc = aa->p[0].zsrc;            // plane position 0: always-zero halo
-        // unit u = 0..5: A half 0 (channel groups cgl, cgl + 8), A half 1 (same), B (same)
-        const unsigned short *pu[6];
-        size_t lo_[6], sb_[6];
-        int it = 0, c = 0, ce = 0, bi = 0, ti = 0, gchunk = 0;     // item, chunk in K space, its (batch item, time) position
+        //
+        // A loader wave shares its SIMD with two compute waves, and every vector-ALU instruction it issues takes issue cycles from
+        // their MFMAs.  Per-lane 64-bit source pointers (a multiply-add, an add and four selects per load) cost the launch a third of
+        // its time -- the chunk took 2 470 cycles with the loads removed but the address arithmetic left in, 1 530 with the loader waves
+        // gone (profiles/r03c_wgrad_phases.txt).  So the addresses are SCALAR: a wave fetches, per unit, 2 channel groups x 32 time steps
+        // = 16 channels of one 32-channel block, which lie in ONE operand segment; its source is an SGPR pointer that the scalar unit
+        // advances chunk by chunk, plus one 32-bit lane offset that never changes.
+#if defined(WG_DBG_NOLOADER)   // timing experiment only: the compute waves alone (with their barriers)
+        return;
+#endif
+        const int lw = wave - 8;
+        const int tl = lane & 31, half = lane >> 5;           // this lane's time step inside a chunk; which of the wave's two channel groups
+        const unsigned voff = (unsigned)((half * gP + tl) * 16);
+        const int dst0 = wgt_off(tl, 2 * lw + half), dst1 = wgt_off(tl, 2 * lw + half + 8);      // unit positions inside a [32][128] image
+        const unsigned short *zsrc = aa->p[0].zsrc;           // plane position 0: always-zero halo
+        // unit u = 0..5: A half 0 (channel groups 2 lw + {0, 1}, then + 8), A half 1 (same), B (same).  All wave uniform:
+        const unsigned short *cur[6];                         // hi plane at the chunk being requested (channel group 2 lw (+ 8), time step 0 of the chunk)
+        long lo_[6], sb_[6];                                  // hi -> lo plane, one batch item further (elements)
+        bool ok[6];
+        int it = 0, c = 0, ce = 0, ti = 0, gchunk = 0;        // item, chunk in K space, its time position
+        auto uni = [](const unsigned short *q) {              // (keeps a pointer in scalar registers)
+            const unsigned long long v = (unsigned long long)q;
+            const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)v), hi32 = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+            return (const unsigned short *)(((unsigned long long)hi32 << 32) | lo32);
+        };
         auto setup = [&](int k) {
             // (wave-uniform values read back from LDS: readfirstlane keeps them in scalar registers, so that the kernel arguments they
             // index are fetched with scalar loads)
@@ -151,66 +193,79 @@ __global__ __launch_bounds__(768) void wgrad16t_kernel(const WgtArgs aa_by_value
             const int m0 = __builtin_amdgcn_readfirstlane(s_items[k][2]), n0 = __builtin_amdgcn_readfirstlane(s_items[k][3]);
             const wgt_sargs_p a = &aa->p[prod];
             c = __builtin_amdgcn_readfirstlane(s_items[k][4]); ce = __builtin_amdgcn_readfirstlane(s_items[k][5]);
-            bi = c / cpb; ti = (c - bi * cpb) * WG16_BK;
-            // (segments are selected by an unrolled scan with wave-uniform indices: a lane-dependent index into the kernel arguments
-            // would make the compiler keep a copy of all 4 KB of them in scratch)
+            const int bi = c / cpb;
+            ti = (c - bi * cpb) * WG16_BK;
+            // (segments are selected by an unrolled scan with constant indices: a run-time index into the kernel arguments would
+            // make the compiler keep a copy of all of them in scratch)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int ma = m0 + 128 * (u >> 1) + 8 * (cgl + 8 * (u & 1));
+                const int ma = m0 + 128 * (u >> 1) + 64 * (u & 1) + 16 * lw;      // first of the wave's 16 rows of this unit
                 int blk0 = 0, nch = 0, ch0 = 0, Cp = 0;
-                size_t lo = 0;
+                long lo = 0;
                 const unsigned short *ha = nullptr;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     if (j < a->nseg_a && (ma >> 5) >= a->sa[j].blk0) {
-                        blk0 = a->sa[j].blk0; nch = a->sa[j].nch; ch0 = a->sa[j].ch0; Cp = a->sa[j].Cp; lo = a->sa[j].lo_off;
+                        blk0 = a->sa[j].blk0; nch = a->sa[j].nch; ch0 = a->sa[j].ch0; Cp = a->sa[j].Cp; lo = (long)a->sa[j].lo_off;
                         ha = a->grp[grp].a_hi[j];
                     }
-                const int ca = ma - blk0 * 32;
-                pu[u] = (ma < a->Mp && ca < nch && ha) ? ha + (((size_t)((ch0 + ca) >> 3)) * gP + gH + tl) * 8 : nullptr;
-                lo_[u] = lo; sb_[u] = (size_t)(Cp >> 3) * gP * 8;
+                const int ca = ma - blk0 * 32;                // (segment sizes are multiples of 16 on this path: 16 rows are valid or none)
+                ok[u] = ma < a->Mp && ca < nch && ha != nullptr;
+                sb_[u] = (long)(Cp >> 3) * gP * 8; lo_[u] = lo;
+                cur[u] = uni(ok[u] ? ha + ((long)((ch0 + ca) >> 3) * gP + gH) * 8 + bi * sb_[u] + (long)ti * 8 : zsrc);
             }
 #pragma unroll
             for (int u = 4; u < 6; ++u) {
-                const int nb = n0 + 8 * (cgl + 8 * (u & 1));
+                const int nb = n0 + 64 * (u & 1) + 16 * lw;
                 int blk0 = 0, nch = 0, ch0 = 0, Cp = 0, bshift = 0;
-                size_t lo = 0;
+                long lo = 0;
                 const unsigned short *hb = nullptr;
 #pragma unroll
                 for (int j = 0; j < WG_MAX_SEG; ++j)
                     if (j < a->nseg_b && (nb >> 5) >= a->sb[j].blk0) {
-                        blk0 = a->sb[j].blk0; nch = a->sb[j].nch; ch0 = a->sb[j].ch0; Cp = a->sb[j].Cp; lo = a->sb[j].lo_off;
+                        blk0 = a->sb[j].blk0; nch = a->sb[j].nch; ch0 = a->sb[j].ch0; Cp = a->sb[j].Cp; lo = (long)a->sb[j].lo_off;
                         hb = a->b_plane_of[j] ? a->grp[grp].b_plane[1] : a->grp[grp].b_plane[0];
                         bshift = (int)a->grp[grp].b_shift[j];
                     }
                 const int cb = nb - blk0 * 32;
-                pu[u] = (nb < a->Np && cb < nch && hb) ? hb + (((size_t)((ch0 + cb) >> 3)) * gP + gH + bshift + tl) * 8 : nullptr;
-                lo_[u] = lo; sb_[u] = (size_t)(Cp >> 3) * gP * 8;
+                ok[u] = nb < a->Np && cb < nch && hb != nullptr;
+                sb_[u] = (long)(Cp >> 3) * gP * 8; lo_[u] = lo;
+                cur[u] = uni(ok[u] ? hb + ((long)((ch0 + cb) >> 3) * gP + gH + bshift) * 8 + bi * sb_[u] + (long)ti * 8 : zsrc);
             }
         };
         setup(0);
-#define WGT_LDP(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
-        // exactly twelve loads in straight-line code (tools/check_asm_loads.py): lanes without a source row and chunks past the end
-        // read the zero halo through selected pointers, no branch between a load and its wait
+#if defined(WG_DBG_NOLOAD)     // timing experiment only: the loaders write whatever their staging registers hold
+#define WGT_LDP(dst, base, vo) asm volatile("" : "=v"(dst) : "v"(vo), "s"(base))
+#else
+#define WGT_LDP(dst, base, vo) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(vo), "s"(base) : "memory")
+#endif
+        // exactly twelve loads in straight-line code (tools/check_asm_loads.py): units without a source and chunks past the end read the
+        // zero halo (selected base, lane offset 0), no branch between a load and its wait
         auto issue = [&](WgtStage &st) {
             const bool live = gchunk < total;
-            const size_t to = (size_t)ti * 8;
 #pragma unroll
             for (int u = 0; u < 6; ++u) {
-                const bool ok = live && pu[u];
-                const unsigned short *q = ok ? pu[u] + bi * sb_[u] + to : zsrc, *ql = ok ? q + lo_[u] : zsrc;
-                WGT_LDP(st.h[u], q);
-                WGT_LDP(st.l[u], ql);
+                const bool on = live && ok[u];
+                const unsigned short *q = on ? cur[u] : zsrc, *ql = on ? cur[u] + lo_[u] : zsrc;
+                const unsigned vo = on ? voff : 0u;
+                WGT_LDP(st.h[u], q, vo);
+                WGT_LDP(st.l[u], ql, vo);
             }
             if (live) {
                 ++gchunk;
                 ti += WG16_BK;
-                if (ti >= gTt) { ti = 0; ++bi; }
+                const bool wrap = ti >= gTt;                  // next batch item: one plane further, back to its first time step
+                if (wrap) ti = 0;
+#pragma unroll
+                for (int u = 0; u < 6; ++u) cur[u] += wrap ? sb_[u] - (long)(gTt - WG16_BK) * 8 : (long)WG16_BK * 8;
                 if (++c == ce && it + 1 < nitems) setup(++it);
             }
         };
 #undef WGT_LDP
         auto write = [&](const WgtStage &st, int buf) {
+#if defined(WG_DBG_NOWRITE)    // timing experiment only
+            return;
+#endif
             char *sb = smem + buf * WGT_BUF;
 #pragma unroll
             for (int u = 0; u < 6; ++u) {
@@ -220,27 +275,59 @@ __global__ __launch_bounds__(768) void wgrad16t_kernel(const WgtArgs aa_by_value
                 *reinterpret_cast<u32x4 *>(ih + (u < 4 ? 2 * WGT_IMG : WGT_IMG)) = st.l[u];
             }
         };
-        WgtStage s0, s1;
-        issue(s0);
-        issue(s1);
-        wgt_wait_stage(s0);
-        write(s0, 0);
-        issue(s0);
-        WG16W_BAR();                                          // buffer 0 ready
-        auto iter = [&](WgtStage &st, int cc) {
-            wgt_wait_stage(st);
-            write(st, (cc & 1) ^ 1);
-            issue(st);
-            WG16W_BAR();
+        // LDS ring of THREE chunk buffers and NO workgroup barrier in the chunk loop.  Chunk j lives in buffer j % 3.  The hand-over is
+        // a progress word per wave in LDS: a loader wave stores j + 1 into s_ready[its index] behind its twelve staging writes of
+        // chunk j; a compute wave stores j + 1 into s_done[its index] behind its last fragment request from chunk j.  Chunk j is complete
+        // when min(s_ready) > j; buffer j % 3 may be refilled (with chunk j + 3) when min(s_done) > j.  The LDS executes a wave's
+        // operations in order, so a progress store is ordered behind the data operations it stands for without any wait.  Everybody only
+        // ever waits for what it needs: the compute waves never wait for each other, and the loaders run up to two chunks ahead in LDS
+        // plus two in their register stages.
+        // Why: with one barrier per chunk (every wave of the workgroup at the same point of every chunk) the launch took 2 470-2 570 cycles
+        // per chunk for 1 536 cycles of MFMAs -- 1 890 with the compute waves alone and their barrier, 1 529 without barriers: phase-locked
+        // at a barrier the two compute waves of a SIMD wait for their fragments at the same moments instead of filling each other's gaps,
+        // and every wave waits for the slowest of twelve (profiles/r03c_wgrad_phases.txt).
+        auto wait_done = [&](unsigned want) {                 // every compute wave has read chunk want - 1
+            for (int spins = 0;;) {
+                const unsigned v = __hip_atomic_load(&s_done[lane & 7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                unsigned m = __builtin_amdgcn_readlane(v, 0);
+#pragma unroll
+                for (int i = 1; i < 8; ++i) m = min(m, (unsigned)__builtin_amdgcn_readlane(v, i));
+                if (m >= want) break;
+                __builtin_amdgcn_s_sleep(WGT_POLL_SLEEP);
+                if (++spins > WGT_SPIN_CAP) { s_fail = 1; break; }      // (a hand-over that never comes is a bug: poison the result, do not hang the GPU)
+            }
         };
-        for (int cc = 0; cc + 1 < total; cc += 2) {           // always in pairs: see convgemm16w_kernel
-            iter(s1, cc);
-            iter(s0, cc + 1);
+        WgtStage s0, s1;
+        issue(s0);                                            // chunk 0
+        issue(s1);                                            // chunk 1
+        int wb = 0, j = 0;                                    // chunk being staged and its buffer
+        auto iter = [&](WgtStage &st) {                       // chunk j (landed in `st`) -> LDS, chunk j + 2 requested
+            wgt_wait_stage(st);
+            if (j >= 3) wait_done((unsigned)(j - 2));
+            write(st, wb);
+            __hip_atomic_store(&s_ready[lw], (unsigned)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            wb = wb == 2 ? 0 : wb + 1;
+            ++j;
+            issue(st);
+        };
+        for (int cc = 0; cc + 1 < total; cc += 2) {           // (the two stages strictly alternate on every path: tools/check_asm_loads.py)
+            iter(s0);
+            iter(s1);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (total & 1) iter(s0);
+        // (the trailing loads -- zero-halo data nobody reads -- are retired HERE, with both stages named: a register the compiler
+        // believes dead it would hand out again while the load that targets it is still in flight)
+        wgt_drain(s0);
+        wgt_drain(s1);
         return;
     }
     // ------------------------------- compute waves: 4 (M) x 2 (N), a 64 x 64 tile each -------------------------------
+#if defined(WG_DBG_HALFWAVES)  // timing experiment only: ONE compute wave per SIMD (how fast is a wave's instruction stream alone?)
+    if (wave >= 4) return;
+#endif
+#if defined(WGT_COMPUTE_PRIO)
+    __builtin_amdgcn_s_setprio(WGT_COMPUTE_PRIO);            // experiment: the compute waves' instructions ahead of the loaders'
+#endif
     const int wm = wave >> 1, wc = wave & 1;
     const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
     const int t1 = 8 * fg + fq, t2 = t1 + 4;
@@ -250,12 +337,94 @@ __global__ __launch_bounds__(768) void wgrad16t_kernel(const WgtArgs aa_by_value
     const int ao2 = (wm >> 1) * WGT_IMG + wgt_off(t2, 8 * (wm & 1) + (fp >> 1)) + 8 * (fp & 1);
     const int bo1 = 4 * WGT_IMG + wgt_off(t1, 8 * wc + (fp >> 1)) + 8 * (fp & 1);
     const int bo2 = 4 * WGT_IMG + wgt_off(t2, 8 * wc + (fp >> 1)) + 8 * (fp & 1);
+#if defined(WGT_NO_SB)         // experiment: the compiler's own order of the chunk loop
+#define WGT_SB() do { } while (0)
+#else
 #define WGT_SB() __builtin_amdgcn_sched_barrier(0)
+#endif
+#if defined(WG_DBG_TRACE)      // phase stamps (slots 8..15 of the conv kernels' trace arrays): start, first barrier, then per item main loop / slab done
+#define WGT_TRACE(slot) do { if (lane == 0 && wave == 0 && (slot) < 8) { \
+        wg_dbg_trace[blockIdx.x * 16 + 8 + (slot)] = wall_clock64(); wg_dbg_trace_cyc[blockIdx.x * 16 + 8 + (slot)] = clock64(); } } while (0)
+#else
+#define WGT_TRACE(slot) do { } while (0)
+#endif
+    WGT_TRACE(0);
     f32x4 acc[4][4];
+    // fragments: the four A row blocks of the chunk (hi, lo) stay resident, B is double-buffered one group (column block) ahead
     bf16x8 ah[4], al[4], bh[2], bl[2];
     auto rdA = [&](const char *buf, int mb, int lo) { return wgt_frag(buf + lo * 2 * WGT_IMG + (ao1 ^ (mb << 5)), buf + lo * 2 * WGT_IMG + (ao2 ^ (mb << 5))); };
     auto rdB = [&](const char *buf, int nb, int lo) { return wgt_frag(buf + lo * WGT_IMG + (bo1 ^ (nb << 5)), buf + lo * WGT_IMG + (bo2 ^ (nb << 5))); };
-    int gc = 0;                                              // chunk index in this workgroup's stream; its buffer is gc & 1
+    int gc = 0, bcur = 0;                                    // chunk index in this workgroup's stream; its buffer (gc % 3)
+    // one chunk: 4 groups (column blocks) of 12 MFMAs.  Behind the first MFMAs of group nb the wave requests the B fragments of the next
+    // group (group 3: block 0 of the NEXT chunk, whose buffer has been complete since the previous barrier); in group 3 every A
+    // fragment is re-fetched from the next chunk as soon as its last MFMAs are issued (convgemm16q_kernel's register budget: a second
+    // set of A fragments, fetched a whole chunk ahead, spilled at three waves per SIMD).
+    auto wait_ready = [&](unsigned want) {                   // all four loader waves have staged chunk want - 1
+#if defined(WG_DBG_NOLOADER) || defined(WG_DBG_NOWAITREADY)
+        return;
+#endif
+        for (int spins = 0;;) {
+            const unsigned v = __hip_atomic_load(&s_ready[lane & 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned m = min(min((unsigned)__builtin_amdgcn_readlane(v, 0), (unsigned)__builtin_amdgcn_readlane(v, 1)),
+                                   min((unsigned)__builtin_amdgcn_readlane(v, 2), (unsigned)__builtin_amdgcn_readlane(v, 3)));
+            if (m >= want) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > WGT_SPIN_CAP) { s_fail = 1; break; }
+        }
+    };
+    auto chunk = [&](auto full_tag, int nbv) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int bnxt = bcur == 2 ? 0 : bcur + 1;
+        const char *cur = smem + bcur * WGT_BUF, *nxt = smem + bnxt * WGT_BUF;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const int cb = nb & 1, nx = cb ^ 1;
+#if !defined(WG_DBG_NOHANDOVER)
+            if (nb == 3 && gc + 1 < total) {
+                WGT_SB();
+                wait_ready((unsigned)(gc + 2));          // the next chunk is in LDS (it normally has been for a while)
+            }
+#endif
+            WGT_SB();
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+#if defined(WG_DBG_NOMFMA)     // timing experiment only: fragments are fetched, nothing is multiplied
+                if (false) {
+#else
+                if (FULL || nb < nbv) {
+#endif
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mb], bh[cb], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mb], bl[cb], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mb], bh[cb], acc[mb][nb], 0, 0, 0);
+                }
+                // the next group's B fragments in two halves behind the first and the second row block's MFMAs: fewer LDS instructions in a
+                // row between two MFMAs of this wave (a wave alone on its SIMD issues an MFMA every 23.5 instead of every 13.6 cycles)
+                if (mb == 0) {
+                    WGT_SB();
+                    bh[nx] = nb == 3 ? rdB(nxt, 0, 0) : rdB(cur, nb + 1, 0);
+                    WGT_SB();
+                }
+                if (mb == 1) {
+                    WGT_SB();
+                    bl[nx] = nb == 3 ? rdB(nxt, 0, 1) : rdB(cur, nb + 1, 1);
+#if !defined(WG_DBG_NOHANDOVER)
+                    if (nb == 2) {
+                        __hip_atomic_store(&s_done[wave], (unsigned)(gc + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+#endif
+                    WGT_SB();
+                }
+                if (nb == 3) {
+                    WGT_SB();
+                    ah[mb] = rdA(nxt, mb, 0); al[mb] = rdA(nxt, mb, 1);
+                    WGT_SB();
+                }
+            }
+            WGT_SB();
+        }
+        bcur = bnxt;
+        ++gc;
+    };
     for (int k = 0; k < nitems; ++k) {
         const int prod = __builtin_amdgcn_readfirstlane(s_items[k][0]), grp = __builtin_amdgcn_readfirstlane(s_items[k][1]);
         const int m0 = __builtin_amdgcn_readfirstlane(s_items[k][2]), n0 = __builtin_amdgcn_readfirstlane(s_items[k][3]);
@@ -263,64 +432,25 @@ __global__ __launch_bounds__(768) void wgrad16t_kernel(const WgtArgs aa_by_value
         const wgt_sargs_p a = &aa->p[prod];
         // column blocks of this wave that exist (wave uniform)
         const int nbv = __builtin_amdgcn_readfirstlane(max(0, min(4, ((prod ? aa->nvalid[1] : aa->nvalid[0]) - (n0 + wc * 64) + 15) >> 4)));
+        (void)nbv;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[i][j][q] = 0.f;
-        if (k == 0) WG16W_BAR();                             // buffer 0 ready (later items: published by the previous chunk's barrier)
-        {
-            const char *cur = smem + (gc & 1) * WGT_BUF;
+        if (k == 0) {
+            wait_ready(1u);                                  // chunk 0 is in LDS
+            WGT_TRACE(1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { ah[i] = rdA(cur, i, 0); al[i] = rdA(cur, i, 1); }
-            bh[0] = rdB(cur, 0, 0); bl[0] = rdB(cur, 0, 1);
+            for (int i = 0; i < 4; ++i) { ah[i] = rdA(smem, i, 0); al[i] = rdA(smem, i, 1); }
+            bh[0] = rdB(smem, 0, 0); bl[0] = rdB(smem, 0, 1);
         }
-        // (two instances of the chunk loop: the common one, every column block valid, is branch free)
-        auto chunks = [&](auto full_tag) {
-            constexpr bool FULL = decltype(full_tag)::value;
-            for (int c = 0; c < nch; ++c, ++gc) {
-                const char *cur = smem + (gc & 1) * WGT_BUF, *nxt = smem + ((gc & 1) ^ 1) * WGT_BUF;
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) {
-                    const int cb = nb & 1, nx = cb ^ 1;
-                    if (nb == 3) {
-                        // every fragment of this chunk is in registers (the B of this last group was requested a group ago): release
-                        // the buffer / publish the next one
-                        WGT_SB();
-                        if (gc + 1 < total || !(total & 1)) WG16W_BAR();
-                    }
-                    WGT_SB();
-#pragma unroll
-                    for (int mb = 0; mb < 4; ++mb) {
-                        if (FULL || nb < nbv) {
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mb], bh[cb], acc[mb][nb], 0, 0, 0);
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mb], bl[cb], acc[mb][nb], 0, 0, 0);
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mb], bh[cb], acc[mb][nb], 0, 0, 0);
-                        }
-                        if (mb == 0) {
-                            // the next group's B is requested BEHIND this group's first MFMAs (convgemm16q_kernel)
-                            WGT_SB();
-                            if (nb == 3) { bh[nx] = rdB(nxt, 0, 0); bl[nx] = rdB(nxt, 0, 1); }
-                            else { bh[nx] = rdB(cur, nb + 1, 0); bl[nx] = rdB(cur, nb + 1, 1); }
-                            WGT_SB();
-                        }
-                        if (nb == 3) {
-                            // (unconditional: after an item's last chunk these read LDS that nothing uses; the next item starts with its
-                            // own fetch)
-                            WGT_SB();
-                            ah[mb] = rdA(nxt, mb, 0); al[mb] = rdA(nxt, mb, 1);
-                            WGT_SB();
-                        }
-                    }
-                    WGT_SB();
-                }
-            }
-        };
-        if (nbv == 4) chunks(std::true_type{});
-        else chunks(std::false_type{});
+        for (int c = 0; c < nch; ++c) chunk(std::true_type{}, 4);
+        WGT_TRACE(2 + 2 * k);
         // the item's slab: block (mb, nb): rows mb * 16 + 4 (lane >> 4) + e, column nb * 16 + (lane & 15)
         float *out = a->grp[grp].slab + (size_t)__builtin_amdgcn_readfirstlane(s_items[k][6]) * a->Mp * a->Np;
+        const float poison = s_fail ? __builtin_nanf("") : 0.f;
         const int col = lane & 15, rq = lane >> 4;
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
@@ -330,9 +460,10 @@ __global__ __launch_bounds__(768) void wgrad16t_kernel(const WgtArgs aa_by_value
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int m = m0 + wm * 64 + mb * 16 + 4 * rq + e;
-                    if (m < a->Mp && n < a->Np) out[(size_t)m * a->Np + n] = acc[mb][nb][e];
+                    if (m < a->Mp && n < a->Np) out[(size_t)m * a->Np + n] = acc[mb][nb][e] + poison;
                 }
             }
+        WGT_TRACE(3 + 2 * k);
         WGT_SB();
     }
 #undef WGT_SB

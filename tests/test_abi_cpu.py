@@ -134,8 +134,8 @@ def test_hand_issued_loads_are_never_touched_before_their_wait():
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if "asm loads" in l]
     # conv: 4 epilogues x 2 tile widths for each MFMA shape (convgemm16q: 16x16x32, the default; convgemm16w: 32x32x16) + the three
-    # 256 x 128 (MG = 2) instantiations of convgemm16q; wgrad16s: 2 tile heights
-    assert len(lines) == 25 and all(l.rstrip().endswith(" 0 violations") for l in lines), r.stdout
+    # 256 x 128 (MG = 2) instantiations of convgemm16q; wgrad16s: 2 tile heights; wgrad16t
+    assert len(lines) == 26 and all(l.rstrip().endswith(" 0 violations") for l in lines), r.stdout
 
 
 def test_wsrglow_state_dict_layout_matches_reference(golden_dir):

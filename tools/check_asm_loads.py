@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Static check of the hand-issued global loads in the wave-specialised conv kernels (convgemm16w_kernel<*>).
+"""Static check of the hand-issued global loads in the wave-specialised conv kernels (convgemm16w / 16q / 16h _kernel<*>) and the weight-
+gradient kernels (wgrad16s_kernel, wgrad16s_pair_kernel, wgrad16t_kernel).
 
 The loader waves issue `global_load_dwordx4` from inline asm and retire them with hand-counted `s_waitcnt vmcnt(N)`; the
 compiler believes an asm output is valid right after the asm statement, so nothing but OUR waits keeps it from reading, copying
@@ -117,7 +118,7 @@ def main():
     cmd += ["-D" + d for d in a.defines.split(",") if d]
     subprocess.run(cmd, check=True)
     text = open(out).read().split("\n")
-    starts = [i for i, l in enumerate(text) if re.match(r"^_Z\d+(convgemm16[wxqh]_kernel|wgrad16s_kernel|wgrad16s_pair_kernel)\w*:", l)]
+    starts = [i for i, l in enumerate(text) if re.match(r"^_Z\d+(convgemm16[wxqh]_kernel|wgrad16s_kernel|wgrad16s_pair_kernel|wgrad16t_kernel)\w*:", l)]
     if not starts:
         print("no convgemm16w_kernel instantiation in the ISA")
         return 1
