@@ -96,7 +96,9 @@ struct WnD {
 // (2^-17 relative) now accumulates along the 8 layers of a WN instead of being refreshed from an exact fp32 chain.
 inline bool s_only_chain(const Ctx &cx, const WnD &d)
 {
-#if !defined(WG_OPT_NO_S_ONLY)
+#if !defined(WG_OPT_NO_S_ONLY) && !defined(WG_OPT_MFMA32) && !defined(WG_OPT_NO_WSPEC) && !defined(WG_OPT_DMA)
+    // (only convgemm16q / convgemm16h read the accumulate-into value from an S-plane -- ConvGemm16sArgs::saux --: the superseded
+    // kernels of the A/B builds ignore it and would lose the residual term)
     return cx.prec == 2 && !d.mode2d;                       // measured: step 78.8 -> 75.8 ms; errors against the oracle unchanged
 #else                                                       // (tools/experiments/err_report.py: z 3.8e-6, worst gradient 8.9e-6 of its max)
     (void)cx; (void)d; return false;
@@ -664,6 +666,24 @@ int device_cus()
     return n;
 }
 
+// Dynamic LDS beyond the 48 KB a kernel gets by default: the opt-in is set ONCE per (device, kernel) -- `slot` names the kernel -- and a
+// device that refuses it (this library is written for gfx950's 160 KB; other CDNA parts have 64 KB) makes the call fail with
+// WG_EUNSUPPORTED instead of a launch error further down.
+int ensure_dynamic_lds(const void *kernel, int slot, size_t bytes)
+{
+    static std::atomic<int> granted[16][4];
+    if (bytes <= 48 * 1024) return 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || slot < 0 || slot >= 4) return WG_ELAUNCH;
+    if (granted[dev][slot].load(std::memory_order_relaxed) >= (int)bytes) return 0;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return WG_EUNSUPPORTED;
+    }
+    granted[dev][slot].store((int)bytes, std::memory_order_relaxed);
+    return 0;
+}
+
 void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const SegSpec *segs, int nseg, int epi,
                   PRef out0, PRef out1, PRef out2, PRef aux0, PRef aux1, int nsplit, int accumulate, SRef s0 = snull(), SRef saux = snull())
 {
@@ -774,7 +794,7 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
             case EPI_DGATE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_DGATE, 2>), gp, dim3(512), 0, as); break;
             }
             return;
-#endif
+#else                                             // A/B build -DWG_OPT_MFMA32: the 32x32x16 kernel (tools/experiments/wg_gemm16_superseded.h)
             if (small) {
                 switch (epi) {
                 case EPI_STORE: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_STORE, 1>), gp, dim3(512), 0, as); break;
@@ -791,6 +811,7 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
             case EPI_DGATE: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_DGATE, 2>), gp, dim3(512), 0, as); break;
             }
             return;
+#endif
 #else                                             // A/B build: the symmetric software-pipelined kernel
             switch (epi) {
             case EPI_STORE: WG_LAUNCH(cx, convgemm16p_kernel<EPI_STORE>, grid, block, 0, as); break;
@@ -1413,6 +1434,10 @@ int wf_check(const wg_wf_config *cf)
     if (H != 8 && H != 16 && H != 32 && H != 64 && H != 128) return WG_EUNSUPPORTED;     // the keys of dilation_dict (waveflow.py:81-87)
     if (cf->precision != WG_PREC_BF16X3_PLANES) return WG_EUNSUPPORTED;                      // only the S-plane kernels know 2-D taps
     if (cf->n_mels * (2 * (256 / H) + 1) > WG_FIN_MAXCOLS) return WG_EUNSUPPORTED;           // upsampler weight row [n_mels x (2s+1)] in finalize's LDS
+    // use_conv1x1: the H x H weight is factored / its gradient gathered in ONE workgroup's LDS (lu_big_kernel: H (H + 2) floats,
+    // wf_hgram_kernel: 130 H floats = 66 560 B at H = 128): must fit gfx950's 160 KB; the opt-in itself is asked for once per device
+    // (ensure_dynamic_lds), and a device that refuses it fails that call with WG_EUNSUPPORTED
+    if (cf->use_conv1x1 && std::max((size_t)H * (H + 2), (size_t)130 * H) * sizeof(float) > 160 * 1024) return WG_EUNSUPPORTED;
     return wn_check(wf_wn(cf));
 }
 struct WfPack {
@@ -1886,7 +1911,7 @@ int wg_backward(const wg_config *cf, const void *const *params, const void *pack
 // The whole training step of model/lightning.py:52-56 in one call: z, logdet = model(x, h); loss = WaveGlowLoss(sigma)(z, logdet);
 // loss.backward().  Same kernels as wg_forward + wg_nll_loss + wg_nll_loss_backward + wg_backward, but the forward runs in the
 // backward's workspace and keeps the last flow's layers, so the backward starts without recomputing that flow and without a second
-// squeeze / upsample.  scratch: B*N + B floats (d loss / d z, d loss / d logdet).
+// squeeze / upsample.  scratch: wg_train_scratch_floats(B, N) floats (d loss / d z, d loss / d logdet, the loss kernels' partials).
 static void run_nll(Ctx &cx, const float *z, const float *logdet, int B, int N, float inv_s2, int elementwise_mean, float *loss,
                     float *metrics, float *part)
 {
@@ -2015,8 +2040,7 @@ int wg_wf_pack_weights(const wg_wf_config *cf, const void *const *params, void *
         lu.n = cf->flows; lu.c = cf->n_group; lu.ostride = L.mix_stride; lu.out = pk + L.mix;
         for (int k = 0; k < cf->flows; ++k) lu.W[k] = p[3 + 37 * cf->flows + k];
         const size_t lds = ((size_t)lu.c * (lu.c + 1) + lu.c) * sizeof(float);
-        if (lds > 48 * 1024 && hipFuncSetAttribute((const void *)lu_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            cx.err = WG_ELAUNCH;
+        if (!cx.err) cx.err = ensure_dynamic_lds((const void *)lu_big_kernel, 0, lds);
         WG_LAUNCH(cx, lu_big_kernel, dim3(cf->flows), dim3(256), lds, lu);
     }
     return cx.err;
@@ -2164,8 +2188,7 @@ int wg_wf_backward(const wg_wf_config *cf, const void *const *params, const void
     const int conv = cf->use_conv1x1, H = g.rows;
     if (conv) {
         const size_t lds = (size_t)2 * H * 65 * sizeof(float);
-        if (lds > 48 * 1024 && hipFuncSetAttribute((const void *)wf_hgram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            cx.err = WG_ELAUNCH;
+        if (!cx.err) cx.err = ensure_dynamic_lds((const void *)wf_hgram_kernel, 1, lds);
     }
     for (int k = cf->flows - 1; k >= 0; --k) {
         const float *Xk = (const float *)tape + (size_t)k * xplane;

@@ -322,7 +322,7 @@ def test_coupling_block(dev, golden_dir, cname, rev):
         for i, (n, _, _) in enumerate(specs):
             g = npy(named[n].grad)
             nrm = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
-            assert abs(nrm - gold[k + "/grad_norm"][i]) <= 1e-3 * gold[k + "/grad_norm"][i] + 1e-12, n
+            assert abs(nrm - gold[k + "/grad_norm"][i]) <= GRAD_RTOL * gold[k + "/grad_norm"][i] + 1e-12, n
             if k + "/grad::" + n in gold:
                 assert relmax(g, gold[k + "/grad::" + n]) < GRAD_RTOL, n
         res.append([npy(named[n].grad) for n, _, _ in specs])
