@@ -21,8 +21,9 @@ Rank 0 prints ONE JSON line with the contract fields plus
                  events over the timed steps, algorithmic FLOPs / average launch duration vs the dense bf16 MFMA peak
                  (2.5 PF; only algorithmic FLOPs are credited, the 3 issued bf16 products per fp32 product are overhead;
                  `f32_mode` carries the exact-fp32 run against the 157.3 TF fp32 MFMA peak);
-  cpu_baseline : the CPU oracle (a plain-C port of the reference's algorithm) timed on the host cores on one
-                 16 000-sample segment of the same workload (rank 0, N=1 only);
+  cpu_baseline : the CPU path (oracle/torch_cpu.py: the algorithm restated on ATen's CPU kernels, the library the reference runs
+                 on) timed on the host cores on one 16 000-sample segment of the same workload (rank 0, N=1 only), with the plain-C
+                 oracle next to it as `c_port`;
   inverse_khz  : single-GPU synthesis speed, timed as the reference does (inference.py:50-56).
 """
 import argparse
@@ -84,48 +85,72 @@ def _cpu_model():
     return "unknown"
 
 
-# on the SAME 8 cores the reference itself (torch-CPU / MKLDNN) runs the C2 B=1 step at ~7 980 samples/s and
-# the plain-C oracle timed here at ~2 300: multiply a "port" figure by this to estimate the reference's CPU path
-REF_OVER_PORT = 7980.0 / 2300.0
+def _physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:                                         # noqa: BLE001
+        pass
+    return os.cpu_count() or 1
 
 
 def cpu_baseline():
-    """Training steps of the CPU oracle (kind = "port") on the host cores: BASELINE.md section 4's plan -- C1 (64ch, 6 flows, B=2,
-    seg 4000) and the C2 network at B=1 and B=2, 1 warm-up + 3 timed runs each, median reported.  `value` is the C2 B=1 figure."""
+    """The CPU path timed on the host cores of the GPU box (rank 0, N = 1 only; BASELINE.md section 4's plan): training steps of
+    oracle/torch_cpu.py -- the path's algorithm restated on the library the reference itself runs on (ATen's CPU convolutions, a local
+    autograd graph per WN, activations rebuilt flow by flow), pinned to the reference's golden vectors by tests/test_oracle_golden.py --
+    at C1 (64ch, 6 flows, B=2, seg 4000) and at the C2 network with B=1 and B=2: 1 warm-up + 3 timed runs each, median reported, all
+    physical cores.  `value` is the C2 B=1 figure.  The plain-C oracle (oracle/wg_oracle.c, OpenMP), which the parity tests use as their
+    checker, is timed next to it on C2 B=1 as `c_port`."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import fill
+    from oracle import torch_cpu
     from oracle import wg_oracle as orc
-    # the oracle's loops expose 64-128 independent row blocks: cap the OpenMP team there (measured: more threads are slower)
-    cores = orc.set_threads(min(int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)), 64))
+    cores = torch_cpu.set_threads(_physical_cores())
 
-    def timed(cfg_name, cfg, B, N, F, runs=3):
-        specs = fill.model_param_specs(cfg)
-        tab = fill.table(specs, fill.fill_params(specs, cfg_name + "/"))
-        audio, h = fill.inputs(cfg_name + "/cpu%d" % B, B, N, F, cfg["n_mels"])
-        oc = orc.make_config(**cfg)
-        if runs > 1:
-            orc.train_step(oc, tab, audio, h, SIGMA)                   # warm-up (page-in, OpenMP team start)
+    def timed(step, B, N, runs=3):
+        step()                                                         # warm-up (page-in, thread pools, MKLDNN primitive cache)
         ts = []
         for _ in range(runs):
             t0 = time.perf_counter()
-            orc.train_step(oc, tab, audio, h, SIGMA)
+            step()
             ts.append(time.perf_counter() - t0)
         ts.sort()
         return {"samples_per_s": B * N / ts[len(ts) // 2], "median_s": ts[len(ts) // 2], "min_s": ts[0], "runs": runs, "batch": B}
 
+    def case(cfg_name, cfg, B, N, F):
+        specs = fill.model_param_specs(cfg)
+        tab = fill.table(specs, fill.fill_params(specs, cfg_name + "/"))
+        audio, h = fill.inputs(cfg_name + "/cpu%d" % B, B, N, F, cfg["n_mels"])
+        return specs, tab, audio, h
+
+    res = {}
     c1 = fill.CONFIGS["c1"]
-    # (B=2 runs are ~11 s each on 64 cores: one timed run behind the B=1 warm-up keeps the leg at about half a minute)
-    res = {"c1_b2": timed("c1", c1, 2, 4000, 16), "c2_b1": timed("c2", C2, 1, SEG, FRAMES), "c2_b2": timed("c2", C2, 2, SEG, FRAMES, runs=1)}
-    total = sum(r["median_s"] * (r["runs"] + (1 if r["runs"] > 1 else 0)) for r in res.values())
-    return {"value": res["c2_b1"]["samples_per_s"], "unit": "samples/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
-            "sample": "WaveGlow-256ch 12 flows fwd+NLL+bwd on 1 segment of 16000 samples (B=1): median of 3 runs after 1 warm-up; "
-                      "also C2 at B=2 (one run) and C1 (64ch, 6 flows, B=2, seg 4000; 3 runs); %.0f s of CPU work in all" % total,
-            "configs": res,
-            "ref_calibration": {"reference_over_port": REF_OVER_PORT,
-                                "note": "BASELINE.md section 2: the reference's own torch-CPU/MKLDNN path ran the C2 B=1 step 3.5x faster than "
-                                        "this plain-C port on the same 8 cores of the build container (7980 vs 2300 samples/s); the reference's "
-                                        "Python cannot travel to the GPU box, so the estimate for it is value * reference_over_port",
-                                "estimated_reference_value": res["c2_b1"]["samples_per_s"] * REF_OVER_PORT}}
+    _, tab, audio, h = case("c1", c1, 2, 4000, 16)
+    res["c1_b2"] = timed(lambda: torch_cpu.train_step(c1, tab, audio, h, SIGMA), 2, 4000)
+    for B in (1, 2):
+        _, tab, audio, h = case("c2", C2, B, SEG, FRAMES)
+        res["c2_b%d" % B] = timed(lambda: torch_cpu.train_step(C2, tab, audio, h, SIGMA), B, SEG)
+    total = sum(r["median_s"] * (r["runs"] + 1) for r in res.values())
+    # the C port: capped at 64 OpenMP threads (its loops expose 64-128 independent row blocks; more threads measured slower)
+    _, tab, audio, h = case("c2", C2, 1, SEG, FRAMES)
+    oc = orc.make_config(**C2)
+    cthreads = orc.set_threads(min(int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)), 64))
+    cport = timed(lambda: orc.train_step(oc, tab, audio, h, SIGMA), 1, SEG, runs=2)
+    cport.update({"unit": "samples/s", "cores": cthreads, "what": "oracle/wg_oracle.c (plain C + OpenMP), C2 B=1: 1 warm-up + 2 runs, median"})
+    return {"value": res["c2_b1"]["samples_per_s"], "unit": "samples/s", "cores": cores, "kind": "port",
+            "implementation": "torch-cpu: oracle/torch_cpu.py, the step restated on ATen's CPU kernels (F.conv1d / MKLDNN), "
+                              "constant-memory backward with a local autograd graph per WN; torch %s" % torch.__version__,
+            "cpu_model": _cpu_model(),
+            "sample": "WaveGlow-256ch 12 flows fwd+NLL+bwd on 1 segment of 16000 samples (B=1): median of 3 runs after 1 warm-up; also C2 at "
+                      "B=2 and C1 (64ch, 6 flows, B=2, seg 4000), 3 runs each; %.0f s of CPU work in all" % (total + cport["median_s"] * 3),
+            "configs": res, "c_port": cport,
+            "build_container_reference": {
+                "note": "measured in the BUILD container (8 cores of a Xeon, not this host), where the reference can be imported: the "
+                        "reference's own torch-CPU path 7 980 samples/s (BASELINE.md section 2), oracle/torch_cpu.py 9 590, the C port "
+                        "2 300, all on the C2 B=1 step -- context for how close `value` is to the reference's speed, not an extrapolation",
+                "reference_samples_per_s": 7980.0, "torch_cpu_samples_per_s": 9590.0, "c_port_samples_per_s": 2300.0}}
 
 
 def other_models(dev):
@@ -230,6 +255,59 @@ def other_models(dev):
         res["waveglow_memory_efficient_false"] = {"error": repr(e)}
     torch.cuda.empty_cache()
     return res
+
+
+KCLASS = {0: "conv store / residual / data-gradient (EPI_STORE)", 1: "gate conv (EPI_GATE)", 2: "residual + skip conv (EPI_RESSKIP)",
+          3: "gate backward (EPI_DGATE)", 4: "weight gradient"}
+HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def kernel_rooflines(trainer, x, h, split, steps=2, top=8):
+    """Per-SHAPE rooflines of the conv / weight-gradient launches of the training step: every such launch of `steps` extra steps is
+    bracketed with HIP events on the launch stream (wg_timer_create(-1, ..): all classes) and reported with the shape the library
+    attaches to it (wg_timer_read_info): class, M x K, columns, algorithmic HBM bytes.  Grouped by (class, M, K); per group: launches per
+    step, average duration, algorithmic TFLOP/s against the matrix peak (bf16 2.5 PF with three issued products per fp32 product = 833 TF
+    algorithmic; 157.3 TF in the exact-fp32 mode) and algorithmic GB/s against 8 TB/s; `bound` = whichever floor is higher."""
+    from constant_memory_waveglow_amd import _lib
+    L = _lib.lib()
+    cap = 4096 * steps
+    t = L.wg_timer_create(-1, cap)
+    torch.cuda.synchronize()
+    L.wg_timer_attach(t)
+    for _ in range(steps):
+        trainer.step(x, h)
+    torch.cuda.synchronize()
+    L.wg_timer_attach(None)
+    n = L.wg_timer_count(t)
+    ms = (C.c_float * n)()
+    info = (C.c_longlong * (5 * n))()
+    L.wg_timer_read(t, ms, n)
+    L.wg_timer_read_info(t, info, n)
+    L.wg_timer_destroy(t)
+    ms = np.frombuffer(ms, dtype=np.float32)
+    info = np.frombuffer(info, dtype=np.int64).reshape(n, 5)
+    peak_tf = BF16_MFMA_PEAK_TFLOPS / 3.0 if split else FP32_MFMA_PEAK_TFLOPS
+    groups = {}
+    for d, (cls, M, K, cols, by) in zip(ms, info):
+        groups.setdefault((int(cls), int(M), int(K)), []).append((float(d), int(cols), int(by)))
+    total_ms = float(ms.sum()) / steps
+    rows = []
+    for (cls, M, K), v in groups.items():
+        us = 1e3 * sum(a for a, _, _ in v) / len(v)
+        cols = v[0][1]
+        flop = 2.0 * M * K * cols
+        by = float(np.mean([b for _, _, b in v]))
+        tf, gbs = flop / (us * 1e-6) / 1e12, by / (us * 1e-6) / 1e9
+        f_m, f_h = tf / peak_tf, gbs / HBM_PEAK_GBS
+        rows.append({"kernel": KCLASS.get(cls, str(cls)), "M": M, "K": K, "columns": cols, "launches_per_step": len(v) / steps,
+                     "avg_us": us, "ms_per_step": us * len(v) / steps / 1e3, "flop_per_launch": flop, "bytes_per_launch": by,
+                     "tflops_algorithmic": tf, "gbs_algorithmic": gbs, "bound": "mfma" if f_m >= f_h else "hbm", "frac": max(f_m, f_h),
+                     "frac_mfma": f_m, "frac_hbm": f_h})
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    return {"timed_ms_per_step": total_ms, "mfma_peak_tflops_algorithmic": peak_tf, "hbm_peak_gbs": HBM_PEAK_GBS,
+            "note": "HIP events around every conv / weight-gradient launch of %d extra steps (the events cost a few per cent; the headline "
+                    "step is timed without them); bytes = every operand plane once + weights + epilogue planes" % steps,
+            "kernels": rows[:top]}
 
 
 def f32_mode(dev, x, h):
@@ -498,6 +576,14 @@ def main(argv=None):
                     torch.cuda.synchronize()
                     out["inverse_khz_%d_queued" % xs.numel()] = xs.numel() * 10 / (time.perf_counter() - t1) / 1000.0
             out["inverse_khz"] = out["inverse_khz_%d" % (862 * 256)]
+            # synthesis is the forward's FLOPs (13.38 MFLOP per sample) on the same matrix pipe: 2.5 PF bf16, three issued per product
+            peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+            out["inverse_roofline"] = {
+                "bound": "mfma", "unit": "TFLOP/s", "peak": peak, "flop_per_sample": FWD_FLOP_PER_SAMPLE,
+                "cases": {str(nn): {"khz": out["inverse_khz_%d" % nn], "achieved": out["inverse_khz_%d" % nn] * 1e3 * FWD_FLOP_PER_SAMPLE / 1e12,
+                                    "frac": out["inverse_khz_%d" % nn] * 1e3 * FWD_FLOP_PER_SAMPLE / 1e12 / peak} for nn in (63 * 256, 862 * 256)},
+                "note": "one call between two synchronisations as inference.py:50-56; a 16 128-sample utterance is a chain of ~250 small "
+                        "launches (64 x 64 tiles on every CU, DESIGN.md section 4a iii), the 10 s utterance fills the chip"}
         if world == 1:
             # outside the metric (SURVEY.md 8d excludes the optimizer): one Adam step over all 53.66 M parameters on the flat buffers
             from constant_memory_waveglow_amd.parallel import FlatAdam
@@ -510,6 +596,11 @@ def main(argv=None):
                 opt.step()
             torch.cuda.synchronize()
             out["adam_step_ms"] = (time.perf_counter() - t1) / 5 * 1e3
+        if world == 1:                                                # (extra steps on one rank only would wait for collectives forever)
+            try:
+                out["roofline"]["kernels"] = kernel_rooflines(trainer, x, h, split)
+            except Exception as e:                                    # noqa: BLE001 -- diagnostics never touch the headline line
+                out["roofline"]["kernels"] = {"error": repr(e)}
         if world == 1 and not args.no_extra:
             out["f32_mode"] = f32_mode(dev, x, h)
             out["other_models"] = other_models(dev)

@@ -168,9 +168,9 @@ __global__ __launch_bounds__(512) void convgemm16h_kernel(const ConvGemm16sArgs 
         fetch(fn, smem + ((c & 1) ^ 1) * BUF);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.al[mb], f.bh, acc[mb][0], 0, 0, 0);
+        for (int mb = 0; mb < 4; ++mb) if (!TwoP<EPI>::no_alo) acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.al[mb], f.bh, acc[mb][0], 0, 0, 0);
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ah[mb], f.bl, acc[mb][0], 0, 0, 0);
+        for (int mb = 0; mb < 4; ++mb) if (!TwoP<EPI>::no_blo) acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ah[mb], f.bl, acc[mb][0], 0, 0, 0);
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.ah[mb], f.bh, acc[mb][0], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);

@@ -430,8 +430,8 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
                 WGQ_SB();
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) {
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mb], bh[cur], acc[mb][nb], 0, 0, 0);
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mb], bl[cur], acc[mb][nb], 0, 0, 0);
+                    if (!TwoP<EPI>::no_alo) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mb], bh[cur], acc[mb][nb], 0, 0, 0);
+                    if (!TwoP<EPI>::no_blo) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mb], bl[cur], acc[mb][nb], 0, 0, 0);
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mb], bh[cur], acc[mb][nb], 0, 0, 0);
                     if (mb == 0) {
                         // the next group's B is requested BEHIND this group's first MFMAs: everything those wait for was requested a

@@ -74,6 +74,19 @@ __global__ void to_splane_kernel(PRef src, int nvalid, SRef dst, Geo g)
 // ------------------------------------------------------------------------------------------------
 // convgemm16s: A from the pre-split weight images, B from S-planes
 // ------------------------------------------------------------------------------------------------
+// EXPERIMENT -DWG_OPT_2P=<mask>: drop one cross term of the split product a b ~ a_lo b_hi + a_hi b_lo + a_hi b_hi in a class of products (the
+// error table in DESIGN.md section 4b; the default build multiplies all three everywhere).  Bits: 1 gate conv without a_lo b_hi (the
+// weights' low half), 2 gate conv without a_hi b_lo (the activations' low half), 4 store / residual / data-gradient convs without the
+// weights' low half, 8 gate backward without the weights' low half, 16 weight gradient without the low half of its A operand (the
+// gradient planes), 32 weight gradient without the low half of its B operand (the activations).
+#if !defined(WG_OPT_2P)
+#define WG_OPT_2P 0
+#endif
+template <int EPI> struct TwoP {
+    static constexpr bool no_alo = (EPI == EPI_GATE && (WG_OPT_2P & 1)) || ((EPI == EPI_STORE || EPI == EPI_RESSKIP) && (WG_OPT_2P & 4)) ||
+                                   (EPI == EPI_DGATE && (WG_OPT_2P & 8));
+    static constexpr bool no_blo = EPI == EPI_GATE && (WG_OPT_2P & 2);
+};
 struct SSeg {
     const unsigned short *hi;
     size_t lo_off;
@@ -116,8 +129,8 @@ __device__ __forceinline__ void mfma12(const Frags16 &f, f32x16 (&acc)[2][2])
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[mi], f.bh[ni], acc[mi][ni], 0, 0, 0);
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mi], f.bl[ni], acc[mi][ni], 0, 0, 0);
+            if (!(WG_OPT_2P & 16)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[mi], f.bh[ni], acc[mi][ni], 0, 0, 0);     // (mfma12 serves the
+            if (!(WG_OPT_2P & 32)) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mi], f.bl[ni], acc[mi][ni], 0, 0, 0);     // weight gradients only)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mi], f.bh[ni], acc[mi][ni], 0, 0, 0);
         }
 }

@@ -393,8 +393,8 @@ __global__ __launch_bounds__(768) void wgrad16t_kernel(const WgtArgs aa_by_value
 #else
                 if (FULL || nb < nbv) {
 #endif
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mb], bh[cb], acc[mb][nb], 0, 0, 0);
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mb], bl[cb], acc[mb][nb], 0, 0, 0);
+                    if (!(WG_OPT_2P & 16)) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mb], bh[cb], acc[mb][nb], 0, 0, 0);
+                    if (!(WG_OPT_2P & 32)) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mb], bl[cb], acc[mb][nb], 0, 0, 0);
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mb], bh[cb], acc[mb][nb], 0, 0, 0);
                 }
                 // the next group's B fragments in two halves behind the first and the second row block's MFMAs: fewer LDS instructions in a

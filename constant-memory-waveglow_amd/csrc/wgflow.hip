@@ -45,18 +45,23 @@ struct Ctx {
 // Diagnostics only: an attached timer brackets every launch of ONE kernel class with HIP events on the launch
 // stream (bench.py's roofline leg).  Detached (the default) it costs one relaxed pointer load per launch.
 struct KernelTimer {
-    int kernel_id, capacity, count;
+    int kernel_id, capacity, count;      // kernel_id < 0: every timed kernel class
     hipEvent_t *start, *stop;
+    long long *info;                     // per recorded launch: class, M, K, columns, algorithmic HBM bytes (wg_timer_read_info)
 };
 std::atomic<KernelTimer *> g_timer{nullptr};
 struct TimerScope {
     KernelTimer *t;
     hipStream_t st;
     int slot;
-    TimerScope(int id, hipStream_t s) : t(g_timer.load(std::memory_order_relaxed)), st(s), slot(-1)
+    // M x K product over `cols` columns, `bytes` = what the launch has to move at least (operand planes once + outputs + weights)
+    TimerScope(int id, hipStream_t s, long long M = 0, long long K = 0, long long cols = 0, long long bytes = 0)
+        : t(g_timer.load(std::memory_order_relaxed)), st(s), slot(-1)
     {
-        if (t && t->kernel_id == id && t->count < t->capacity) {
+        if (t && (t->kernel_id == id || t->kernel_id < 0) && t->count < t->capacity) {
             slot = t->count++;
+            long long *q = t->info + 5 * (size_t)slot;
+            q[0] = id; q[1] = M; q[2] = K; q[3] = cols; q[4] = bytes;
             (void)hipEventRecord(t->start[slot], st);
         }
     }
@@ -703,7 +708,23 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
         a.row_sel1 = cx.row_sel1;
         grid.z = g.B / g.rows;
     }
-    TimerScope ts(WG_K_CONV_STORE + epi, cx.st);
+    // what this launch has to move at least: every distinct source plane once (hi + lo bf16, or fp32), the weights, the outputs and
+    // auxiliary planes of its epilogue (fp32 planes 4 B, S-planes 2 + 2 B per element)
+    long long Ksum = 0, in_ch = 0;
+    for (int s = 0; s < nseg; ++s) {
+        Ksum += segs[s].nch;
+        bool seen = false;
+        for (int u = 0; u < s; ++u) seen = seen || (segs[u].src == segs[s].src && segs[u].s == segs[s].s && segs[u].ch0 == segs[s].ch0);
+        if (!seen) in_ch += segs[s].nch;
+    }
+    const long long cols = (long long)(cx.row_sel1 && g.rows > 0 ? g.B / g.rows : g.B) * g.T;
+    long long out_ch = 0;
+    if (epi == EPI_GATE) out_ch = (long long)(M / 2) * ((out0.p ? 1 : 0) + (out1.p ? 2 : 0) + (s0.hi ? 1 : 0));
+    else if (epi == EPI_DGATE) out_ch = (long long)M * 2 /* tanh, sigmoid in */ + 2LL * M * ((s0.hi ? 1 : 0) + (out0.p ? 1 : 0));
+    else if (epi == EPI_RESSKIP) out_ch = (long long)nsplit * (1 + (out0.p ? 1 : 0) + (s0.hi ? 1 : 0)) + (long long)(M - nsplit) * (1 + accumulate);
+    else out_ch = (long long)M * ((out0.p ? 1 : 0) + (s0.hi ? 1 : 0) + (aux0.p ? 1 : 0) + (saux.hi ? 1 : 0));
+    const long long alg_bytes = 4 * cols * (in_ch + out_ch) + 4LL * M * Ksum;
+    TimerScope ts(WG_K_CONV_STORE + epi, cx.st, M, Ksum, cols, alg_bytes);
     if (cx.prec) {
         ConvGemm16Args a16;
         int K = 0, nc = 0;
@@ -1103,7 +1124,25 @@ void run_wgrad_group_pair(Ctx &cx, const Geo &g, const WgradGroupSpec *gs0, int 
             wa.ph[i].tn = q.Np / WG_TILE; wa.ph[i].tiles = (q.Mp / 256) * (q.Np / WG_TILE); wa.ph[i].ngroups = ng;
         }
         for (int w = 0; w < 2; ++w) wa.nvalid[w] = wgt_valid_cols(wa.p[w]);
-        TimerScope ts(WG_K_WGRAD, cx.st);
+        // the launch as ONE entry of the kernel timer: 2 * M * K * cols = its algorithmic FLOPs with M = sum over layers and products of
+        // rows x columns of the gradient, K = 1, cols = time steps; bytes = every operand plane once (hi + lo) + the slabs
+        long long mm = 0, ch = 0, slabf = 0;
+        for (int w = 0; w < 2; ++w) {
+            const WgradSArgs &q = wa.p[w];
+            long long rows = 0, colsB = 0, distinct = 0;
+            for (int u = 0; u < q.nseg_a; ++u) rows += q.sa[u].nch;
+            for (int u = 0; u < q.nseg_b; ++u) {
+                colsB += q.sb[u].nch;
+                bool seen = false;
+                for (int v = 0; v < u; ++v) seen = seen || q.b_plane_of[v] == q.b_plane_of[u];
+                if (!seen) distinct += q.sb[u].nch;
+            }
+            mm += (long long)ng * rows * colsB;
+            ch += (long long)ng * (rows + distinct);
+            slabf += (long long)group_slab_floats(q);
+        }
+        const long long tsteps = (long long)g.B * g.T;
+        TimerScope ts(WG_K_WGRAD, cx.st, mm, 1, tsteps, 4 * ch * tsteps + 4 * slabf);
         WG_LAUNCH(cx, wgrad16t_kernel, dim3(256), dim3(768), 0, wa);
         return;
     }
@@ -1575,6 +1614,7 @@ void *wg_timer_create(int kernel_id, int capacity)
     t->kernel_id = kernel_id; t->capacity = capacity; t->count = 0;
     t->start = new hipEvent_t[capacity];
     t->stop = new hipEvent_t[capacity];
+    t->info = new long long[5 * (size_t)capacity]();
     for (int i = 0; i < capacity; ++i) { (void)hipEventCreate(&t->start[i]); (void)hipEventCreate(&t->stop[i]); }
     return t;
 }
@@ -1590,13 +1630,22 @@ int wg_timer_read(void *timer, float *ms, int n)
         if (hipEventElapsedTime(&ms[i], t->start[i], t->stop[i]) != hipSuccess) return WG_ELAUNCH;
     return m;
 }
+/* per recorded launch five values: kernel class (WG_K_*), M, K, columns of the product, algorithmic HBM bytes; returns launches written */
+int wg_timer_read_info(void *timer, long long *info, int n)
+{
+    KernelTimer *t = (KernelTimer *)timer;
+    if (!t || !info) return WG_EINVAL;
+    const int m = std::min(n, t->count);
+    memcpy(info, t->info, (size_t)m * 5 * sizeof(long long));
+    return m;
+}
 void wg_timer_destroy(void *timer)
 {
     KernelTimer *t = (KernelTimer *)timer;
     if (!t) return;
     if (g_timer.load() == t) g_timer.store(nullptr);
     for (int i = 0; i < t->capacity; ++i) { (void)hipEventDestroy(t->start[i]); (void)hipEventDestroy(t->stop[i]); }
-    delete[] t->start; delete[] t->stop; delete t;
+    delete[] t->start; delete[] t->stop; delete[] t->info; delete t;
 }
 
 int wg_param_count(const wg_config *cf) { return cf ? 3 + cf->n_flows + cf->n_flows * (4 + 4 * cf->depth + 1) : WG_EINVAL; }

@@ -89,10 +89,14 @@ int wg_abi_version(void);
 #define WG_K_CONV_RESSKIP 2  /* convgemm, W_o + residual/skip epilogue */
 #define WG_K_CONV_DGATE 3    /* convgemm, W_o^T + gate backward */
 #define WG_K_WGRAD 4         /* weight-gradient kernel */
-void *wg_timer_create(int kernel_id, int capacity);
+void *wg_timer_create(int kernel_id, int capacity);   /* kernel_id < 0: every class above */
 void  wg_timer_attach(void *timer);
 int   wg_timer_count(void *timer);
 int   wg_timer_read(void *timer, float *ms, int n);   /* after a stream sync; returns the number written */
+/* five values per recorded launch: class (WG_K_*), M, K, columns of the product (2 M K columns = its algorithmic FLOPs; a paired
+ * weight-gradient launch reports M = the summed sizes of its gradients, K = 1), algorithmic HBM bytes (every operand plane once, the
+ * weights, the outputs and auxiliary planes of the epilogue); launches that are not conv / weight-gradient products report zeros */
+int   wg_timer_read_info(void *timer, long long *info, int n);
 void  wg_timer_destroy(void *timer);
 
 /* ---- sizes -------------------------------------------------------------------------------- */

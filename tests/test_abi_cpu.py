@@ -170,3 +170,52 @@ def test_load_reference_checkpoint_strips_the_lightning_prefix():
     for (k, a), (_, b) in zip(src.state_dict().items(), dst.state_dict().items()):
         assert torch.equal(a, b), k
     load_reference_checkpoint(dst, src.state_dict())            # a bare state dict is accepted too
+
+
+def test_param_table_follows_replaced_submodules():
+    """The cached C-ABI parameter table (utils.SlotTable) must not keep handing out the parameters of a submodule that has been
+    replaced, nor the original's parameters to a shallow copy of the model (an nn.DataParallel-style replica shares the cache object)."""
+    import copy
+    import torch
+    import constant_memory_waveglow_amd as cm
+    kw = dict(flows=2, n_group=8, n_early_every=4, n_early_size=2, hop_size=256, n_mels=20, memory_efficient=True, dilation_channels=32,
+              residual_channels=32, skip_channels=32, depth=2, radix=3, bias=False)
+    m = cm.WaveGlow(**kw)
+    t0 = m.param_table()
+    assert t0[0] is m.upsampler.bias and m.param_table()[0] is t0[0]
+    # a parameter replaced in place (load_state_dict / .to()) stays behind the same slot
+    m.upsampler.bias = torch.nn.Parameter(torch.ones_like(m.upsampler.bias))
+    assert m.param_table()[0] is m.upsampler.bias
+    # a replaced block: the table must follow
+    other = cm.WaveGlow(**kw)
+    old_end = m.WNs[1].F.end.weight
+    m.WNs[1] = other.WNs[1]
+    tab = m.param_table()
+    assert tab[-1] is other.WNs[1].F.end.weight and tab[-1] is not old_end
+    m.upsampler = other.upsampler
+    assert m.param_table()[0] is other.upsampler.bias
+    # weight norm removed: keys change, the table re-resolves (g slot -> None, v slot -> weight)
+    m.apply(cm.remove_weight_norms)
+    tab = m.param_table()
+    assert tab[1] is None and tab[2] is m.upsampler.weight
+    # a shallow copy resolves its own tree
+    rep = copy.copy(m)
+    rep._modules = dict(m._modules)
+    rep._modules["upsampler"] = cm.WaveGlow(**kw).upsampler
+    assert rep.param_table()[0] is rep._modules["upsampler"].bias
+    assert m.param_table()[0] is m.upsampler.bias
+
+
+def test_packed_weights_key_is_committed_only_after_a_successful_pack():
+    """engine.PackedWeights: a pack that fails half way must not leave a key behind under which a retry would skip the pack."""
+    import torch
+    from constant_memory_waveglow_amd import engine
+    pw = engine.PackedWeights()
+    params = [torch.zeros(3), None, torch.zeros(2)]
+    pw.buf = torch.zeros(1)
+    assert pw.stale(params) and pw.key is None            # nothing valid until commit()
+    assert pw.stale(params)                               # the failed attempt left no key: still stale
+    pw.commit()
+    assert not pw.stale(params)
+    params[0].add_(1.0)                                   # a parameter changed (version counter): stale again, and empty until re-packed
+    assert pw.stale(params) and pw.key is None

@@ -347,3 +347,30 @@ def test_stft_decimate_oracle_matches_reference(golden_dir):
         y = mo.stft_decimate(x, r)
         assert y.shape == G[tag].shape == (B, (T + r - 1) // r)
         assert np.abs(y - G[tag]).max() < 2e-6
+
+
+@pytest.mark.parametrize("name", ["micro", "c1", "c2", "wsr_like"])
+def test_torch_cpu_step_matches_reference(golden_dir, name):
+    """oracle/torch_cpu.py (the restatement on ATen's CPU kernels that bench.py times as the CPU baseline) against the reference's golden
+    fixtures: z <= 1e-6, loss <= 1e-6, every gradient <= 1e-5 of its tensor's max (VERDICT r02 #6)."""
+    from oracle import torch_cpu
+    g = _load(golden_dir, "model_%s.npz" % name)
+    cfg = fill.CONFIGS[name]
+    B, N, F = fill.SHAPES[name]
+    specs = fill.model_param_specs(cfg)
+    P = fill.fill_params(specs, name + "/")
+    audio, h = fill.inputs(name, B, N, F, cfg["n_mels"])
+    r = torch_cpu.train_step(cfg, fill.table(specs, P), audio, h, fill.SIGMA, need_dh=True)
+    assert np.abs(r["z"] - g["z"]).max() < 1e-6 * max(1.0, float(np.abs(g["z"]).max()))
+    assert _logdet_close(r["logdet"], g["logdet"], N)
+    assert abs(r["loss"] - float(g["loss"])) < 1e-6
+    assert _relmax(r["dh"], g["dh"]) < 1e-5
+    for i, (n, _, _) in enumerate(specs):
+        gr = r["grads"][i].ravel()
+        scale = max(float(g["grad_max"][i]), 1e-30)
+        nh = min(gr.size, g["grad_head"].shape[1])
+        assert np.abs(gr[:nh] - g["grad_head"][i][:nh]).max() / scale < 1e-5, n
+        nrm = np.sqrt((gr.astype(np.float64) ** 2).sum())
+        assert abs(nrm - g["grad_norm"][i]) <= 1e-5 * g["grad_norm"][i] + 1e-12, n
+        if "grad::" + n in g:
+            assert _relmax(r["grads"][i], g["grad::" + n]) < 1e-5, n
