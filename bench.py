@@ -107,8 +107,6 @@ def cpu_baseline():
     import fill
     from oracle import torch_cpu
     from oracle import wg_oracle as orc
-    cores = torch_cpu.set_threads(_physical_cores())
-
     def timed(step, B, N, runs=3):
         step()                                                         # warm-up (page-in, thread pools, MKLDNN primitive cache)
         ts = []
@@ -128,6 +126,15 @@ def cpu_baseline():
     res = {}
     c1 = fill.CONFIGS["c1"]
     _, tab, audio, h = case("c1", c1, 2, 4000, 16)
+    # ATen's intra-op pool does not scale with the core count on these shapes (T = 500 .. 2000 columns per convolution): on the 64-core
+    # host of the GPU box all 64 threads ran the C2 step FIVE times slower than 8 threads do.  So the thread count is probed on the small
+    # configuration (a fraction of a second per try) and the fastest is used; `cores` reports the threads actually used.
+    phys = _physical_cores()
+    probe = {}
+    for n in sorted({min(phys, c) for c in (4, 8, 16, 32, phys)}):
+        torch_cpu.set_threads(n)
+        probe[n] = timed(lambda: torch_cpu.train_step(c1, tab, audio, h, SIGMA), 2, 4000, runs=2)["median_s"]
+    cores = torch_cpu.set_threads(min(probe, key=probe.get))
     res["c1_b2"] = timed(lambda: torch_cpu.train_step(c1, tab, audio, h, SIGMA), 2, 4000)
     for B in (1, 2):
         _, tab, audio, h = case("c2", C2, B, SEG, FRAMES)
@@ -145,7 +152,7 @@ def cpu_baseline():
             "cpu_model": _cpu_model(),
             "sample": "WaveGlow-256ch 12 flows fwd+NLL+bwd on 1 segment of 16000 samples (B=1): median of 3 runs after 1 warm-up; also C2 at "
                       "B=2 and C1 (64ch, 6 flows, B=2, seg 4000), 3 runs each; %.0f s of CPU work in all" % (total + cport["median_s"] * 3),
-            "configs": res, "c_port": cport,
+            "configs": res, "c_port": cport, "thread_probe_c1_s": {str(k): v for k, v in probe.items()}, "physical_cores": phys,
             "build_container_reference": {
                 "note": "measured in the BUILD container (8 cores of a Xeon, not this host), where the reference can be imported: the "
                         "reference's own torch-CPU path 7 980 samples/s (BASELINE.md section 2), oracle/torch_cpu.py 9 590, the C port "
