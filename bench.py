@@ -370,6 +370,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-extra", action="store_true", help="skip the WSRGlow / WaveFlow step timings (SURVEY.md 8f rows)")
     ap.add_argument("--spawn", action="store_true", help="go through the launcher even for --gpus 1 (a 1-rank RCCL group)")
     ap.add_argument("--dry-run", action="store_true", help="launcher only: print the child command and environment as JSON, start nothing")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="HARNESS TEST ONLY: more ranks than GPUs (rank r on GPU r %% n_gpus) over a gloo group -- RCCL refuses two ranks "
+                         "on one device; the line is marked and its value means nothing for scaling")
     ap.add_argument("--selftest", choices=("ok", "fail"), default=None,
                     help="launcher / rank plumbing without a GPU: the ranks form a gloo group, reduce a number and rank 0 prints a JSON "
                          "line ('fail': rank 1 exits with code 3 instead) -- what tests/test_bench_launcher_cpu.py runs")
@@ -408,7 +411,7 @@ def launch(args, argv):
     if args.dry_run:
         print(json.dumps({"launcher": True, "cmd": cmd, "env": extra, "n_ranks": args.gpus}))
         return 0
-    if not args.selftest:
+    if not args.selftest and not args.oversubscribe:
         have = torch.cuda.device_count()
         if have < args.gpus:
             print("bench.py: --gpus %d but this node shows %d GPU(s)" % (args.gpus, have), file=sys.stderr)
@@ -476,8 +479,13 @@ def main(argv=None):
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.oversubscribe:
+            local = local % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -546,7 +554,10 @@ def main(argv=None):
             traffic_src += " (committed rocprofv3 --pmc summary of this command; not re-measured in this run)"
         out = {
             "metric": "audio samples/sec (fwd+bwd) WaveGlow-256ch seg=16000",
-            "value": value, "unit": "samples/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if use_dist else 0,
+            "value": value, "unit": "samples/s", "n_gpus": world,
+            "rccl_ranks": dist.get_world_size() if use_dist and not args.oversubscribe else 0,
+            **({"oversubscribed": "HARNESS TEST: %d gloo ranks share %d GPU(s); not a scaling number" % (world, torch.cuda.device_count())}
+               if args.oversubscribe else {}),
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (contractions as split bf16x3 MFMA, fp32 accumulate)" if split else "f32", "data": "synthetic",

@@ -755,7 +755,13 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
             // persistent launch: one workgroup per resident slot (two per CU), each walking its share of the tile grid -- see the
             // kernel; the gate backward stays at one workgroup per tile.  -DWG_OPT_NO_PERSIST: one workgroup per tile everywhere.
             const int cus = device_cus();
-            const bool small = grid.x * grid.y * grid.z < 384;   // fewer 128x128 tiles than 3/4 of the workgroup slots: 128x64 tiles
+            bool small = grid.x * grid.y * grid.z < 384;         // fewer 128x128 tiles than 3/4 of the workgroup slots: 128x64 tiles
+#if defined(WG_OPT_NI1_MASK)                      // experiment: 128 x 64 tiles (twice the tiles: a fuller last round) for a class of launches
+            if ((WG_OPT_NI1_MASK & 1) && epi == EPI_STORE && Ksum <= 256) small = true;
+            if ((WG_OPT_NI1_MASK & 2) && epi == EPI_DGATE) small = true;
+            if ((WG_OPT_NI1_MASK & 4) && epi == EPI_STORE && Ksum >= 1024 && Ksum < 2048) small = true;
+            if ((WG_OPT_NI1_MASK & 8) && epi == EPI_STORE && Ksum >= 2048) small = true;
+#endif
             as.ntx = small ? (int)grid.x * 2 : (int)grid.x; as.nty = (int)grid.y; as.ntz = (int)grid.z;
             const int ntiles = as.ntx * as.nty * as.ntz;
             int slots = epi == EPI_DGATE ? ntiles : 2 * cus;
