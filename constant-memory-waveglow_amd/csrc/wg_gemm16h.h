@@ -37,15 +37,32 @@ __device__ __forceinline__ void asm_wait_stage_h(Stage4 &s)      // all but the 
 #define WGH_TRACE(slot) do { } while (0)
 #endif
 
-// grid: ntx (64-column tiles) x nty (64-ROW tiles) x ntz, flattened in blockIdx.x, time tile fastest
-template <int EPI>
-__global__ __launch_bounds__(512) void convgemm16h_kernel(const ConvGemm16sArgs aa)
+// A wave-uniform pointer into scalar registers, for an asm load's "s" operand.  IN_MEMORY = false (the launched kernel: the argument
+// block is in the kernarg segment, every address is scalar arithmetic already): nothing to do.  IN_MEMORY = true (the stage interpreter,
+// wg_stage.h: the block is read from LDS, the arithmetic is per lane): v_readfirstlane, and FIVE wait states behind it -- a VALU write of
+// an SGPR must be that far ahead of a vector-memory instruction that uses it as its address, and the compiler's hazard recogniser does
+// not look into the asm statement that holds the load (without the s_nop the loads went to stale bases: memory access faults).
+template <bool IN_MEMORY>
+__device__ __forceinline__ const unsigned short *wg_uniform_ptr(const unsigned short *q)
+{
+    if (!IN_MEMORY) return q;
+    const unsigned long long v = (unsigned long long)q;
+    unsigned lo32, hi32;
+    asm volatile("v_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3\n\ts_nop 4" : "=s"(lo32), "=s"(hi32) : "v"((unsigned)v), "v"((unsigned)(v >> 32)));
+    return (const unsigned short *)(((unsigned long long)hi32 << 32) | lo32);
+}
+#define WG16H_SMEM (2 * (4 * 64 * WG16Q_ROWB))              // two chunk buffers of A hi, A lo, B hi, B lo (4 KB each)
+// The tile `id` of the launch's grid: ntx (64-column tiles) x nty (64-ROW tiles) x ntz, time tile fastest.  A device function so that
+// the stage interpreter (wg_stage.h) runs the same code for one stage of a recorded launch sequence; row_sel1 overrides the argument
+// block's value there (the interpreter walks the height rows of WaveFlow's inverse with ONE recorded program).
+template <int EPI, bool IN_MEMORY = false>
+__device__ __forceinline__ void convgemm16h_body(const ConvGemm16sArgs &aa, int id, int row_sel1, char *smem)
 {
     constexpr int D = WG16H_DEPTH;
     constexpr int AIMG = 64 * WG16Q_ROWB, BIMG = 64 * WG16Q_ROWB;       // 4 KB each
     constexpr int BUF = 2 * AIMG + 2 * BIMG;
     constexpr int TT = 64;
-    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+    static_assert(2 * BUF == WG16H_SMEM, "");
     const ConvGemmArgs &a = aa.c;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -53,10 +70,9 @@ __global__ __launch_bounds__(512) void convgemm16h_kernel(const ConvGemm16sArgs 
     int nchunks = 0;
     for (int s = 0; s < a.nseg; ++s) nchunks += (a.seg[s].nch + WG16_BK - 1) / WG16_BK;
     const int nbar = (nchunks + D - 1) / D * D;               // barriers after the first: the loaders' iterations come in groups of D
-    const int id = (int)blockIdx.x;
     const int tx = id % aa.ntx, q = id / aa.ntx, ty = q % aa.nty, tz = q / aa.nty;
     const int t0 = tx * TT, m0 = ty * 64;
-    const int b = a.row_sel1 ? tz * g.rows + a.row_sel1 - 1 : tz;
+    const int b = row_sel1 ? tz * g.rows + row_sel1 - 1 : tz;
     if (m0 >= a.M) return;                                    // (M is padded to 128 rows in the image: the upper half tile may be empty)
 
     if (wave >= 4) {
@@ -89,10 +105,10 @@ __global__ __launch_bounds__(512) void convgemm16h_kernel(const ConvGemm16sArgs 
             const bool blive = live && rowok, full = blive && (nch - cur_c > 16);
             const unsigned short *ih = aa.img + ((size_t)chunk * a.lda + (m0 & ~127)) * WG16_BK, *il = ih + aa.img_stride;
             const unsigned short *row0 = ss.hi + ((size_t)bsrc * (ss.Cp >> 3) + ((ss.ch0 + cur_c) >> 3)) * g.P * 8;
-            const unsigned short *pa = live ? ih : zsrc, *pl = live ? il : zsrc;
+            const unsigned short *pa = wg_uniform_ptr<IN_MEMORY>(live ? ih : zsrc), *pl = wg_uniform_ptr<IN_MEMORY>(live ? il : zsrc);
             const unsigned va = live ? voff_a : 0u;
             WG_LD(st.ah, pa, va);   WG_LD(st.al, pl, va);
-            const unsigned short *pb = blive ? row0 : zsrc, *pbl = blive ? row0 + ss.lo_off : zsrc;
+            const unsigned short *pb = wg_uniform_ptr<IN_MEMORY>(blive ? row0 : zsrc), *pbl = wg_uniform_ptr<IN_MEMORY>(blive ? row0 + ss.lo_off : zsrc);
             const bool lane_ok = blive && (kq < 2 || full);
             const unsigned vb = lane_ok ? voff_b + (unsigned)((g.H + t0 + shift) * 16) : 0u;
             WG_LD(st.bh, pb, vb);   WG_LD(st.bl, pbl, vb);
@@ -185,4 +201,11 @@ __global__ __launch_bounds__(512) void convgemm16h_kernel(const ConvGemm16sArgs 
     WGH_TRACE(2);
     conv_epilogue_q<EPI, 1>(a, aa.s0, acc, t0, m0, b, 0, wc, lane);
     WGH_TRACE(3);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void convgemm16h_kernel(const ConvGemm16sArgs aa)
+{
+    __shared__ __attribute__((aligned(16))) char smem[WG16H_SMEM];
+    convgemm16h_body<EPI>(aa, (int)blockIdx.x, aa.c.row_sel1, smem);
 }

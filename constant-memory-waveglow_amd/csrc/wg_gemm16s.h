@@ -51,10 +51,9 @@ __device__ __forceinline__ u32x4 pair_units(const u32x2 &v0, const u32x2 &v1)
     return r;
 }
 
-// fp32 plane channels [ch0, ch0+nvalid) -> S-plane channels [0, Cp_dst) (zero filled beyond nvalid)
-__global__ void to_splane_kernel(PRef src, int nvalid, SRef dst, Geo g)
+// fp32 plane channels [ch0, ch0+nvalid) -> S-plane channels [0, Cp_dst) (zero filled beyond nvalid): time step t, channel group cg, plane row b
+__device__ __forceinline__ void to_splane_body(const PRef &src, int nvalid, const SRef &dst, const Geo &g, int t, int cg, int b)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x, cg = blockIdx.y, b = blockIdx.z;
     if (t >= g.T) return;
     float v[8];
 #pragma unroll
@@ -69,6 +68,10 @@ __global__ void to_splane_kernel(PRef src, int nvalid, SRef dst, Geo g)
     const size_t i = s_index(dst, g, b, cg * 8, t);
     *reinterpret_cast<u32x4 *>(dst.hi + i) = h;
     *reinterpret_cast<u32x4 *>(dst.hi + dst.lo_off + i) = l;
+}
+__global__ void to_splane_kernel(PRef src, int nvalid, SRef dst, Geo g)
+{
+    to_splane_body(src, nvalid, dst, g, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -142,18 +142,19 @@ struct WfCoupleArgs {
     int mode;
     int noflip;             // use_conv1x1: x_next = cat(x[0], xout) (the 1x1 over the height axis follows) instead of cat(flip(xout), x[0])
 };
-__global__ __launch_bounds__(256) void wf_couple_kernel(const WfCoupleArgs a)
+// (a device function: the stage interpreter, wg_stage.h, runs it as one stage; NT threads, `blk` = the block index, row_sel overrides a.row_sel)
+template <int NT>
+__device__ __forceinline__ void wf_couple_body(const WfCoupleArgs &a, int blk, int row_sel, float *red)
 {
-    __shared__ float red[256];
     const Geo g = a.g;
     const int H = g.rows, tid = threadIdx.x;
-    const int row = a.mode == 2 ? blockIdx.x * H + a.row_sel : blockIdx.x;
+    const int row = a.mode == 2 ? blk * H + row_sel : blk;
     const int b = row / H, r = row - b * H;
     const int x0row = b * H + (a.noflip ? 0 : H - 1);          // where x[0] goes in x_next
     const int orow = b * H + (a.noflip ? r + 1 : H - 2 - r);   // where xout[r] goes
     float lsum = 0.f;
     if (r == H - 1) {                                          // not a WN output row: x_next[x0row] = x[0] and its gradient
-        for (int t = tid; t < g.T; t += 256) {
+        for (int t = tid; t < g.T; t += NT) {
             if (a.mode == 0) *paddr(a.Xn, g, x0row, 0, t) = *paddr(a.X, g, b * H, 0, t);
             if (a.mode == 1) {
                 *paddr(a.dX, g, b * H, 0, t) = *paddr(a.dXn, g, x0row, 0, t);
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256) void wf_couple_kernel(const WfCoupleArgs a)
         if (tid == 0 && a.rowsum && a.mode == 0) a.rowsum[row] = 0.f;
         return;
     }
-    for (int t = tid; t < g.T; t += 256) {
+    for (int t = tid; t < g.T; t += NT) {
         float ls = 0.f, tt = 0.f;
         for (int c = 0; c < a.Cs; ++c) {
             const float s = *paddr(a.S, g, row, c, t);
@@ -189,15 +190,21 @@ __global__ __launch_bounds__(256) void wf_couple_kernel(const WfCoupleArgs a)
     if (a.mode == 1 || !a.rowsum) return;
     red[tid] = lsum;
     __syncthreads();
-    for (int q = 128; q > 0; q >>= 1) {
+    for (int q = NT / 2; q > 0; q >>= 1) {
         if (tid < q) red[tid] += red[tid + q];
         __syncthreads();
     }
     if (tid == 0) a.rowsum[row] = red[0];
 }
+__global__ __launch_bounds__(256) void wf_couple_kernel(const WfCoupleArgs a)
+{
+    __shared__ float red[256];
+    wf_couple_body<256>(a, (int)blockIdx.x, a.row_sel, red);
+}
 // logdet[b] = sum over flows and rows of rowsum[k][b*H + h]  (+ coef * logdet W_k of the 1x1 convs: mix != NULL, waveflow.py:206 / :229)
+// (fail != NULL and *fail != 0 -- a grid barrier of the row walk gave up, wg_stage.h --: logdet = NaN, so that a broken call is seen)
 __global__ void wf_logdet_kernel(const float *__restrict__ rowsum, int nflow, int items, int H, float *__restrict__ logdet,
-                                 const float *__restrict__ mix, int mix_stride, float coef)
+                                 const float *__restrict__ mix, int mix_stride, float coef, const int *__restrict__ fail = nullptr)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= items) return;
@@ -208,6 +215,7 @@ __global__ void wf_logdet_kernel(const float *__restrict__ rowsum, int nflow, in
         s += q;
         if (mix) s += coef * mix[(size_t)k * mix_stride + 2 * H * H];
     }
+    if (fail && *fail) s = __builtin_nanf("");
     logdet[b] = s;
 }
 

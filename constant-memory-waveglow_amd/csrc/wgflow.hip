@@ -11,6 +11,7 @@
 #include "wg_wsr.h"
 #include "wg_wf.h"
 #include "wg_mel.h"
+#include "wg_stage.h"
 
 #include <algorithm>
 #include <atomic>
@@ -18,6 +19,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 namespace {
 
@@ -33,10 +35,28 @@ struct Ctx {
     int prec;   // 0: exact fp32 MFMA; 1: bf16x3, operands split on the fly (wg_gemm16.h); 2: bf16x3 from pre-split S-planes (wg_gemm16s.h)
     int row_sel1;   // Geo::rows > 0 only: 0 = every plane row; r + 1 = the conv launches cover height row r of every item (WaveFlow's inverse)
     struct FinQueue *fq = nullptr;   // set inside wn_backward: weight-gradient slabs come from its arena, finalisations are batched
+    struct StageRec *rec = nullptr;  // set while a launch sequence is RECORDED for the stage interpreter (wg_stage.h): nothing is launched
+};
+// the launches of one row step of WaveFlow's inverse, as argument blocks (see wg_stage.h); ok = false: a launch that the interpreter
+// cannot run turned up (the caller then launches everything the ordinary way)
+struct StageRec {
+    std::vector<WgStage> st;
+    bool ok = true;
+    int widest = 0;
+    WgStage &add(int kind, int nblocks)
+    {
+        st.emplace_back();
+        WgStage &x = st.back();
+        memset(static_cast<void *>(&x), 0, sizeof(x));
+        x.kind = kind; x.nblocks = nblocks;
+        widest = std::max(widest, nblocks);
+        return x;
+    }
 };
 #define WG_LAUNCH(ctx, kern, grid, block, shmem, ...)                         \
     do {                                                                      \
-        if ((ctx).err == 0) {                                                 \
+        if ((ctx).rec) (ctx).rec->ok = false;   /* not a recordable launch */ \
+        else if ((ctx).err == 0) {                                            \
             hipLaunchKernelGGL(kern, grid, block, shmem, (ctx).st, __VA_ARGS__); \
             if (hipGetLastError() != hipSuccess) (ctx).err = WG_ELAUNCH;      \
         }                                                                     \
@@ -655,6 +675,14 @@ SRef sref(const Geo &g, const float *base, int Cp, int ch0 = 0)
 SRef snull() { SRef r; r.hi = nullptr; r.lo_off = 0; r.Cp = 8; r.ch0 = 0; return r; }
 void run_to_splane(Ctx &cx, const Geo &g, PRef src, int nvalid, const float *dst, int Cp_dst)
 {
+    if (cx.rec) {                                            // recorded for the row walk: only the current height row of every item is converted
+        if (!cx.row_sel1 || g.rows <= 0) { cx.rec->ok = false; return; }
+        const int items = g.B / g.rows, tb = (g.T + WGS_THREADS - 1) / WGS_THREADS;
+        WgStage &x = cx.rec->add(WGS_TOSPLANE, tb * (Cp_dst / 8) * items);
+        x.u.tsp.src = src; x.u.tsp.dst = sref(g, dst, Cp_dst); x.u.tsp.g = g;
+        x.u.tsp.nvalid = nvalid; x.u.tsp.cgs = Cp_dst / 8; x.u.tsp.items = items;
+        return;
+    }
     WG_LAUNCH(cx, to_splane_kernel, dim3((g.T + 255) / 256, Cp_dst / 8, g.B), dim3(256), 0, src, nvalid, sref(g, dst, Cp_dst), g);
 }
 
@@ -778,6 +806,10 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
             if (small && 2 * ntiles <= cus && epi != EPI_DGATE) {
                 as.nty = 2 * (int)grid.y;
                 const dim3 gh(as.ntx * as.nty * as.ntz);
+                if (cx.rec) {                                 // (the stage interpreter runs convgemm16h_body on this argument block)
+                    cx.rec->add(epi == EPI_STORE ? WGS_CONV_STORE : epi == EPI_GATE ? WGS_CONV_GATE : WGS_CONV_RESSKIP, (int)gh.x).u.conv = as;
+                    return;
+                }
                 switch (epi) {
                 case EPI_STORE: WG_LAUNCH(cx, convgemm16h_kernel<EPI_STORE>, gh, dim3(512), 0, as); break;
                 case EPI_GATE: WG_LAUNCH(cx, convgemm16h_kernel<EPI_GATE>, gh, dim3(512), 0, as); break;
@@ -1504,10 +1536,12 @@ WfPack wf_pack_layout(const wg_wf_config *cf)
     L.total = off;
     return L;
 }
+#define WF_PROG_STAGES 24       // a row step of WN2D: S-plane conversion, start, depth x (gate conv, residual / skip conv), end + coupling
 struct WfWs {
     Geo g, gi;              // one plane row per (item, height row) / one per item
     int auxp;
     size_t Y, YS, X[2], rowsum, dX[2], dYrow, rs, gp, dwup, Xt, dXt, gram, total;    // Xt / dXt / gram: use_conv1x1 only
+    size_t prog;            // the inverse's recorded row-step program (wg_stage.h): WF_PROG_STAGES argument blocks + the barrier words
     int gram_blocks;
     WnWs wn;
 };
@@ -1542,6 +1576,7 @@ WfWs wf_ws_layout(const wg_wf_config *cf, int B, int Wd, int mode)
         w.dwup = bp.take((size_t)cf->n_mels * cf->n_mels * (2 * s + 1));
     }
     wn_ws_layout(bp, d, 1, w.g, mode, cf->precision, w.wn);
+    w.prog = bp.take((WF_PROG_STAGES * sizeof(WgStage) + 256) / sizeof(float));
     w.total = bp.off + 4096;
     return w;
 }
@@ -1580,6 +1615,7 @@ void wf_couple(Ctx &cx, const WnRun &r, const float *endw, int mode, PRef X, PRe
     a.X = X; a.Xn = Xn; a.dXn = dXn; a.dX = dX;
     a.G = pref(r.ws + r.w.G, r.L.kp_end);
     a.dld = dld; a.rowsum = rowsum; a.row_sel = row_sel; a.g = r.g; a.mode = mode; a.noflip = noflip;
+    if (cx.rec && mode == 2) { cx.rec->add(WGS_WFCOUPLE, r.g.B / r.g.rows).u.cpl = a; return; }
     WG_LAUNCH(cx, wf_couple_kernel, dim3(mode == 2 ? r.g.B / r.g.rows : r.g.B), dim3(256), 0, a);
 }
 }  // namespace
@@ -2192,7 +2228,72 @@ int wg_wf_inverse(const wg_wf_config *cf, const void *const *params, const void 
         else WG_LAUNCH(cx, wf_flip_kernel, rgrid, dim3(256), 0, pref(Z, 1), pref(Zf, 1), g);                         // :222
         WG_LAUNCH(cx, wf_copy_row_kernel, igrid, dim3(256), 0, pref(Zf, 1), pref(Xb, 1), g, 0, 0);                   // :228
         r.pk = pk + L.wn[k]; r.X = pref(Xb, 1);
-        for (int row = 0; row < H - 1; ++row) {
+        // One row step's launches, recorded: they are the same for every row but for the row index, so ONE persistent kernel walks
+        // rows x stages on the device with a grid barrier where the launches had kernel boundaries (wg_stage.h).
+        // MEASURED and therefore OFF by default (-DWG_OPT_ROWWALK turns it on; bit-identical results): 105.8 against 99.3 ms for a 0.7 s
+        // utterance, 227 against 214 ms for 10 s.  A stage is not its launch overhead: the 64 x 64-tile conv of a row step is a chain of
+        // 21 chunk latencies on 8 of 256 CUs (~8 us), and a grid barrier with the release / acquire fences that make planes visible
+        // across XCDs (L2 write-back + invalidate) costs about what a kernel boundary does.  What the row step needs is more workgroups
+        // per stage (the K range of a tile split over several CUs), see DESIGN.md section 9.
+        bool walked = false;
+#if defined(WG_OPT_ROWWALK)
+        {
+            StageRec rec;
+            cx.rec = &rec;
+            cx.row_sel1 = 1;
+            wn_forward(cx, r);
+            wf_couple(cx, r, p[3 + 37 * k + 36], 2, pref(Zf, 1), pref(Xb, 1), pnull(), pnull(), nullptr, ws + W.rowsum + (size_t)k * g.B, 0);
+            cx.rec = nullptr;
+            cx.row_sel1 = 0;
+#if defined(WG_DBG_ROWWALK_HOSTREPLAY)   // debugging aid: the recorded program replayed launch by launch from the host
+            if (rec.ok && !cx.err) {
+                for (int row = 0; row < H - 1; ++row)
+                    for (size_t si = 0; si < rec.st.size(); ++si) {
+                        WgStage stg = rec.st[si];
+                        if (stg.kind <= WGS_CONV_RESSKIP) {
+                            stg.u.conv.c.row_sel1 = row + 1;
+                            const dim3 gh(stg.nblocks);
+                            if (stg.kind == WGS_CONV_STORE) WG_LAUNCH(cx, convgemm16h_kernel<EPI_STORE>, gh, dim3(512), 0, stg.u.conv);
+                            else if (stg.kind == WGS_CONV_GATE) WG_LAUNCH(cx, convgemm16h_kernel<EPI_GATE>, gh, dim3(512), 0, stg.u.conv);
+                            else WG_LAUNCH(cx, convgemm16h_kernel<EPI_RESSKIP>, gh, dim3(512), 0, stg.u.conv);
+                        } else if (stg.kind == WGS_TOSPLANE) {
+                            const WgsToSplane &t = stg.u.tsp;
+                            WG_LAUNCH(cx, to_splane_kernel, dim3((t.g.T + 255) / 256, t.cgs, t.g.B), dim3(256), 0, t.src, t.nvalid, t.dst, t.g);
+                        } else {
+                            stg.u.cpl.row_sel = row;
+                            WG_LAUNCH(cx, wf_couple_kernel, dim3(stg.nblocks), dim3(256), 0, stg.u.cpl);
+                        }
+                    }
+                walked = true;
+            } else
+#endif
+            if (rec.ok && !cx.err && !rec.st.empty() && rec.st.size() <= WF_PROG_STAGES) {
+                WgStage *prog = reinterpret_cast<WgStage *>(ws + W.prog);
+                unsigned *bar = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(prog) + WF_PROG_STAGES * sizeof(WgStage));
+                const int n = (int)rec.st.size();
+#if defined(WG_DBG_ROWWALK_MEMCPY)       // debugging aid: the program through a host copy (the buffer is leaked on purpose)
+                {
+                    WgStage *keep = new WgStage[n];
+                    memcpy(static_cast<void *>(keep), static_cast<const void *>(rec.st.data()), (size_t)n * sizeof(WgStage));
+                    if (hipMemcpyAsync(prog, keep, (size_t)n * sizeof(WgStage), hipMemcpyHostToDevice, cx.st) != hipSuccess) cx.err = WG_ELAUNCH;
+                }
+                for (int i = n; i < n; i += WGS_PER_STORE) {
+#else
+                for (int i = 0; i < n; i += WGS_PER_STORE) {
+#endif
+                    WgsStoreArgs sa;
+                    const int m = std::min(WGS_PER_STORE, n - i);
+                    memcpy(static_cast<void *>(sa.st), static_cast<const void *>(&rec.st[i]), (size_t)m * sizeof(WgStage));
+                    WG_LAUNCH(cx, wgs_store_kernel, dim3(1), dim3(256), 0, sa, m, prog + i);
+                }
+                if (!cx.err && hipMemsetAsync(bar, 0, 64, cx.st) != hipSuccess) cx.err = WG_ELAUNCH;
+                const int grid = std::max(1, std::min(rec.widest, device_cus()));     // every workgroup resident: the barrier needs them all
+                WG_LAUNCH(cx, wf_rowsteps_kernel, dim3(grid), dim3(WGS_THREADS), 0, (const WgStage *)prog, n, H - 1, bar, (int *)(bar + 8));
+                walked = true;
+            }
+        }
+#endif
+        for (int row = 0; row < H - 1 && !walked; ++row) {
             cx.row_sel1 = row + 1;
             wn_forward(cx, r);
             wf_couple(cx, r, p[3 + 37 * k + 36], 2, pref(Zf, 1), pref(Xb, 1), pnull(), pnull(), nullptr,
@@ -2202,8 +2303,9 @@ int wg_wf_inverse(const wg_wf_config *cf, const void *const *params, const void 
         std::swap(Z, Xb);
     }
     // rowsum rows H-1 are never written by mode 2: they were zeroed with the workspace
+    const int *walk_fail = reinterpret_cast<const int *>(reinterpret_cast<const char *>(ws + W.prog) + WF_PROG_STAGES * sizeof(WgStage)) + 8;
     WG_LAUNCH(cx, wf_logdet_kernel, dim3((B + 63) / 64), dim3(64), 0, ws + W.rowsum, cf->flows, B, H, logdet,
-              cf->use_conv1x1 ? pk + L.mix : (const float *)nullptr, L.mix_stride, -(float)g.T);                     // :227-229
+              cf->use_conv1x1 ? pk + L.mix : (const float *)nullptr, L.mix_stride, -(float)g.T, walk_fail);          // :227-229
     WG_LAUNCH(cx, wf_unsqueeze_kernel, rgrid, dim3(256), 0, pref(Z, 1), g, N, x);
     return cx.err;
 }
