@@ -810,6 +810,7 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                     cx.rec->add(epi == EPI_STORE ? WGS_CONV_STORE : epi == EPI_GATE ? WGS_CONV_GATE : WGS_CONV_RESSKIP, (int)gh.x).u.conv = as;
                     return;
                 }
+                // (2 or 4 k-steps per chunk and barrier measured slower: tools/experiments/wg_gemm16hk.h)
                 switch (epi) {
                 case EPI_STORE: WG_LAUNCH(cx, convgemm16h_kernel<EPI_STORE>, gh, dim3(512), 0, as); break;
                 case EPI_GATE: WG_LAUNCH(cx, convgemm16h_kernel<EPI_GATE>, gh, dim3(512), 0, as); break;

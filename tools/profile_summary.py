@@ -53,9 +53,32 @@ def pmc_summary(tag, paths):
     print("wrote", out)
 
 
+def shape_summary(tag, bench_json):
+    """python tools/profile_summary.py --shapes <tag> <bench line .json>: rocprofv3's kernel statistics lump every product that runs on one
+    kernel instantiation into one row (convgemm16q_kernel<0, 2, 1> is the residual conv, the data-gradient conv, the skip product, the
+    conditioning gradient and the start / end convs); the per-SHAPE table comes from the bench line, whose `roofline.kernels` object times
+    every conv / weight-gradient launch with HIP events and groups them by the (class, M, K) the library attaches to the launch
+    (wg_timer_read_info).  Written as profiles/<tag>_shape_rooflines.csv."""
+    d = json.loads(open(bench_json).read().strip().splitlines()[-1])
+    k = d["roofline"]["kernels"]
+    out = os.path.join(ROOT, "profiles", "%s_shape_rooflines.csv" % tag)
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel_class", "M", "K", "columns", "launches_per_step", "avg_us", "ms_per_step", "gflop_per_launch", "mb_per_launch",
+                    "tflops_algorithmic", "gbs_algorithmic", "bound", "frac_of_bound", "frac_mfma(peak %.0f TF)" % k["mfma_peak_tflops_algorithmic"],
+                    "frac_hbm(peak %.0f GB/s)" % k["hbm_peak_gbs"]])
+        for r in k["kernels"]:
+            w.writerow([r["kernel"], r["M"], r["K"], r["columns"], "%.1f" % r["launches_per_step"], "%.1f" % r["avg_us"], "%.2f" % r["ms_per_step"],
+                        "%.2f" % (r["flop_per_launch"] / 1e9), "%.1f" % (r["bytes_per_launch"] / 1e6), "%.1f" % r["tflops_algorithmic"],
+                        "%.0f" % r["gbs_algorithmic"], r["bound"], "%.3f" % r["frac"], "%.3f" % r["frac_mfma"], "%.3f" % r["frac_hbm"]])
+    print("wrote", out)
+
+
 def main():
     if sys.argv[1] == "--pmc":
         return pmc_summary(sys.argv[2], sys.argv[3:])
+    if sys.argv[1] == "--shapes":
+        return shape_summary(sys.argv[2], sys.argv[3])
     tag, stats = sys.argv[1], sys.argv[2]
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     rows = list(csv.DictReader(open(stats)))
