@@ -208,6 +208,31 @@ def other_models(dev):
         gfin = all(bool(torch.isfinite(p.grad).all()) for p in m.parameters())
         res["waveflow"] = {"workload": "WaveFlow 64ch 8 flows n_group 64, batch 12 x 16000, fwd+NLL+bwd", "ms_per_step": dt * 1e3,
                            "samples_per_s": 12 * 16000 / dt, "loss": checked(last["loss"]), "grads_finite": gfin}
+        # the same step with the contractions on the exact-fp32 MFMA (the 2-D taps exist in all three arithmetic modes since round 3)
+        old_prec = os.environ.get("WG_PRECISION")
+        os.environ["WG_PRECISION"] = "f32"
+        try:
+            torch.manual_seed(0)
+            m32 = cm.WaveFlow(flows=8, n_group=64, n_mels=80, use_conv1x1=False, memory_efficient=False, dilation_channels=64,
+                              residual_channels=64, skip_channels=64, bias=False)
+            m32.load_state_dict(m.state_dict())
+            m32 = m32.to(dev)
+
+            def step32():
+                m32.zero_grad(set_to_none=True)
+                m32._engine.packed.key = None
+                z, ld = m32(x, h)
+                loss = crit(z, ld)
+                loss.backward()
+                return loss
+            dt32 = timed(step32)
+            res["waveflow"]["f32_mode"] = {"ms_per_step": dt32 * 1e3, "samples_per_s": 12 * 16000 / dt32, "loss": checked(last["loss"])}
+            del m32
+        finally:
+            if old_prec is None:
+                os.environ.pop("WG_PRECISION", None)
+            else:
+                os.environ["WG_PRECISION"] = old_prec
         with torch.no_grad():                      # synthesis (row-by-row inverse): ~0.7 s and ~10 s of audio, as inference.py:50-56
             for frames in (63, 862):
                 hc = torch.randn(1, 80, frames, device=dev)

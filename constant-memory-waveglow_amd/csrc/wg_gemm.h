@@ -110,6 +110,8 @@ struct ConvSeg {
     const float *src;   // plane base
     int Cp, ch0, nch;   // rows per item, first row, channels in this segment (multiple of WG_BK)
     int shift;          // time shift of the tap
+    int row_off;        // Geo::rows > 0 (WaveFlow's height axis): the tap reads plane row b + row_off; rows outside the tile's own item read as zero
+    int per_item;       // Geo::rows > 0: the operand has ONE plane row per item (conditioning broadcast over the height axis)
 };
 
 struct ConvGemmArgs {
@@ -190,8 +192,9 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmArgs a)
     __shared__ __attribute__((aligned(16))) float Bs[2][WG_BK][WG_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int t0 = blockIdx.x * WG_TILE, m0 = blockIdx.y * WG_TILE, b = blockIdx.z;
     const Geo g = a.g;
+    const int t0 = blockIdx.x * WG_TILE, m0 = blockIdx.y * WG_TILE;
+    const int b = a.row_sel1 ? (int)blockIdx.z * g.rows + a.row_sel1 - 1 : (int)blockIdx.z;      // (row_sel1: blockIdx.z is the item, the tile its height row)
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -218,7 +221,15 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmArgs a)
             ra[j] = *reinterpret_cast<const f32x4 *>(a.A + (size_t)(krow + row) * a.lda + m0 + c4 * 4);
         }
         const ConvSeg sg = a.seg[cur_seg];
-        const float *base = sg.src + ((size_t)b * sg.Cp + sg.ch0 + cur_c) * g.P + g.H + t0 + sg.shift;
+        // 2-D taps (WaveFlow): another plane row of the same item (zero outside it), or the item's one row of a per-item operand
+        int bsrc = b;
+        bool rowok = true;
+        if (g.rows > 0) {
+            const int item = b / g.rows, rr = b - item * g.rows + sg.row_off;
+            rowok = rr >= 0 && rr < g.rows;
+            bsrc = sg.per_item ? item : (rowok ? b + sg.row_off : b);
+        }
+        const float *base = sg.src + ((size_t)bsrc * sg.Cp + sg.ch0 + cur_c) * g.P + g.H + t0 + sg.shift;
         if ((sg.shift & 3) == 0) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -232,6 +243,10 @@ __global__ __launch_bounds__(256) void convgemm_kernel(const ConvGemmArgs a)
                 const int row = (tid >> 7) + 2 * j, c = tid & 127;
                 rb[j] = base[(size_t)row * g.P + c];
             }
+        }
+        if (!rowok) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rb[j] = 0.f;
         }
         // advance
         krow += WG_BK;
@@ -291,6 +306,7 @@ struct WgSeg {
     int Cp, ch0, nch;   // valid channels (rows beyond are read as zero)
     int shift;
     int blk0;           // first 32-row block of this segment in the index space
+    int row_off, per_item;   // as ConvSeg (B operand only)
 };
 
 struct WgradArgs {
@@ -355,6 +371,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
     const float *pa[4];
     const float *pb[4];
     bool bal[4];
+    int roff[4], pitem[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int ma = m0 + lrow + 32 * j;
@@ -366,6 +383,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
         const int cb = nb - sb.blk0 * 32;
         pb[j] = (nb < a.Np && cb < sb.nch) ? sb.src + ((size_t)sb.ch0 + cb) * g.P + g.H + sb.shift + k4 : nullptr;
         bal[j] = (sb.shift & 3) == 0;
+        roff[j] = sb.row_off; pitem[j] = sb.per_item;
     }
     // per-batch strides of the two operands (rows per item differ per segment -> fold into pointer per j)
     size_t sba[4], sbb[4];
@@ -395,8 +413,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
             if (pa[j]) v = *reinterpret_cast<const f32x4 *>(pa[j] + lb * sba[j] + lt);
             ra[j] = v;
             f32x4 w = {0.f, 0.f, 0.f, 0.f};
-            if (pb[j]) {
-                const float *q = pb[j] + lb * sbb[j] + lt;
+            int bsrc = lb;
+            bool rowok = true;
+            if (g.rows > 0) {                              // 2-D taps: see ConvSeg
+                const int item = lb / g.rows, rr = lb - item * g.rows + roff[j];
+                rowok = rr >= 0 && rr < g.rows;
+                bsrc = pitem[j] ? item : lb + roff[j];
+            }
+            if (pb[j] && rowok) {
+                const float *q = pb[j] + bsrc * sbb[j] + lt;
                 if (bal[j]) w = *reinterpret_cast<const f32x4 *>(q);
                 else { w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; w[3] = q[3]; }
             }

@@ -97,7 +97,8 @@ __global__ __launch_bounds__(128 * MT) void convgemm16_kernel(const ConvGemm16Ar
     const ConvGemmArgs &a = aa.c;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int t0 = blockIdx.x * WG_TILE, m0 = blockIdx.y * (64 * MT), b = blockIdx.z;
+    const int t0 = blockIdx.x * WG_TILE, m0 = blockIdx.y * (64 * MT);
+    const int b = aa.c.row_sel1 ? (int)blockIdx.z * aa.c.g.rows + aa.c.row_sel1 - 1 : (int)blockIdx.z;      // (row_sel1: see convgemm_kernel)
     const Geo g = a.g;
 
     f32x16 acc[2][2];
@@ -131,8 +132,15 @@ __global__ __launch_bounds__(128 * MT) void convgemm16_kernel(const ConvGemm16Ar
             ra_hi[j] = *reinterpret_cast<const u32x4 *>(ih + (size_t)p * 8);
             ra_lo[j] = *reinterpret_cast<const u32x4 *>(ih + aa.img_stride + (size_t)p * 8);
         }
-        const float *base = sg.src + ((size_t)b * sg.Cp + sg.ch0 + cur_c + bk) * g.P + g.H + t0 + sg.shift;   // wave uniform
-        if (bk < nvalid) {
+        int bsrc = b;                                                        // 2-D taps (WaveFlow): see ConvSeg
+        bool rowok = true;
+        if (g.rows > 0) {
+            const int item = b / g.rows, rr = b - item * g.rows + sg.row_off;
+            rowok = rr >= 0 && rr < g.rows;
+            bsrc = sg.per_item ? item : (rowok ? b + sg.row_off : b);
+        }
+        const float *base = sg.src + ((size_t)bsrc * sg.Cp + sg.ch0 + cur_c + bk) * g.P + g.H + t0 + sg.shift;   // wave uniform
+        if (bk < nvalid && rowok) {
 #pragma unroll
             for (int j = 0; j < KPT; ++j) rb[j] = base[(size_t)j * g.P + bt];
         } else {
@@ -209,6 +217,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a)
     const float *pb[4];
     bool bal[4];
     size_t sba[4], sbb[4];
+    int roff[4], pitem[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int ma = m0 + lrow + 32 * j;
@@ -222,6 +231,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a)
         pb[j] = (nb < a.Np && cb < sb.nch) ? sb.src + ((size_t)sb.ch0 + cb) * g.P + g.H + sb.shift + k4 : nullptr;
         sbb[j] = (size_t)sb.Cp * g.P;
         bal[j] = (sb.shift & 3) == 0;
+        roff[j] = sb.row_off; pitem[j] = sb.per_item;
     }
     const int t_begin = ts * a.t_per_split;
     int t_end = t_begin + a.t_per_split;
@@ -241,8 +251,15 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a)
             if (pa[j]) v = *reinterpret_cast<const f32x4 *>(pa[j] + lb * sba[j] + lt);
             ra[j] = v;
             f32x4 w = {0.f, 0.f, 0.f, 0.f};
-            if (pb[j]) {
-                const float *q = pb[j] + lb * sbb[j] + lt;
+            int bsrc = lb;
+            bool rowok = true;
+            if (g.rows > 0) {                              // 2-D taps: see ConvSeg
+                const int item = lb / g.rows, rr = lb - item * g.rows + roff[j];
+                rowok = rr >= 0 && rr < g.rows;
+                bsrc = pitem[j] ? item : lb + roff[j];
+            }
+            if (pb[j] && rowok) {
+                const float *q = pb[j] + bsrc * sbb[j] + lt;
                 if (bal[j]) w = *reinterpret_cast<const f32x4 *>(q);
                 else { w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; w[3] = q[3]; }
             }

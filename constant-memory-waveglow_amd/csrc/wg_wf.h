@@ -201,6 +201,16 @@ __global__ __launch_bounds__(256) void wf_couple_kernel(const WfCoupleArgs a)
     __shared__ float red[256];
     wf_couple_body<256>(a, (int)blockIdx.x, a.row_sel, red);
 }
+// exact-fp32 mode: out[item][c][t] = sum over the item's height rows of src[item * H + h][c][t] (the conditioning gradient: the conditioning is
+// broadcast over the height axis); the S-plane modes use wf_rowsum_s_kernel
+__global__ void wf_rowsum_kernel(PRef src, Geo g, PRef out, Geo gi, int nch)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, item = blockIdx.z;
+    if (t >= g.T || c >= nch) return;
+    float s = 0.f;
+    for (int h = 0; h < g.rows; ++h) s += *paddr(src, g, item * g.rows + h, c, t);
+    *paddr(out, gi, item, c, t) = s;
+}
 // logdet[b] = sum over flows and rows of rowsum[k][b*H + h]  (+ coef * logdet W_k of the 1x1 convs: mix != NULL, waveflow.py:206 / :229)
 // (fail != NULL and *fail != 0 -- a grid barrier of the row walk gave up, wg_stage.h --: logdet = NaN, so that a broken call is seen)
 __global__ void wf_logdet_kernel(const float *__restrict__ rowsum, int nflow, int items, int H, float *__restrict__ logdet,

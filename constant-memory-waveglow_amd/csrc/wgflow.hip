@@ -726,13 +726,14 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
     for (int s = 0; s < nseg; ++s) {
         a.seg[s].src = segs[s].src; a.seg[s].Cp = segs[s].Cp; a.seg[s].ch0 = segs[s].ch0;
         a.seg[s].nch = segs[s].nch; a.seg[s].shift = segs[s].shift;
+        a.seg[s].row_off = segs[s].row_off; a.seg[s].per_item = segs[s].per_item;
     }
     a.g = g; a.epi = epi; a.nsplit = nsplit; a.accumulate = accumulate;
     a.out0 = out0; a.out1 = out1; a.out2 = out2; a.aux0 = aux0; a.aux1 = aux1;
     const int mrows = epi == EPI_GATE ? M : M;
     dim3 grid(g.Tt / WG_TILE, rup(mrows, WG_TILE) / WG_TILE, g.B), block(256);
     if (cx.row_sel1) {
-        if (g.rows <= 0 || cx.prec != 2) { if (!cx.err) cx.err = WG_EINVAL; return; }
+        if (g.rows <= 0) { if (!cx.err) cx.err = WG_EINVAL; return; }
         a.row_sel1 = cx.row_sel1;
         grid.z = g.B / g.rows;
     }
@@ -986,6 +987,7 @@ WgradOut run_wgrad(Ctx &cx, const Geo &g, const WSegSpec *sa, int nsa, const WSe
     for (int s = 0; s < nsb; ++s) {
         a.sb[s].src = sb[s].src; a.sb[s].Cp = sb[s].Cp; a.sb[s].ch0 = sb[s].ch0; a.sb[s].nch = sb[s].nch;
         a.sb[s].shift = sb[s].shift; a.sb[s].blk0 = blk;
+        a.sb[s].row_off = sb[s].row_off; a.sb[s].per_item = sb[s].per_item;
         blk += rup(sb[s].nch, 32) / 32;
     }
     a.Np = rup(blk * 32, WG_TILE);
@@ -1408,9 +1410,13 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
         if (dY && d.mode2d) {
             // the conditioning is broadcast over the height axis: sum dxy over the rows of an item first (64x fewer columns for
             // the product, no per-row gradient plane), then dy[item] += V_i^T rowsum
-            WG_LAUNCH(cx, wf_rowsum_s_kernel, dim3((g.T + 255) / 256, 2 * d.Cd / 8, r.gi.B), dim3(256), 0, sref(g, dxyS, 2 * d.Cd), g,
-                      sref(r.gi, r.rs, 2 * d.Cd), r.gi);
-            SegSpec s = {nullptr, 2 * d.Cd, 0, 2 * d.Cd, 0, r.rs, 2 * d.Cd, 0};
+            if (sp)
+                WG_LAUNCH(cx, wf_rowsum_s_kernel, dim3((g.T + 255) / 256, 2 * d.Cd / 8, r.gi.B), dim3(256), 0, sref(g, dxyS, 2 * d.Cd), g,
+                          sref(r.gi, r.rs, 2 * d.Cd), r.gi);
+            else                                              // exact-fp32 mode: the same sum on the fp32 plane (r.rs holds 2 Cd fp32 channels then)
+                WG_LAUNCH(cx, wf_rowsum_kernel, dim3((g.T + 255) / 256, 2 * d.Cd, r.gi.B), dim3(256), 0, pref(dxy, 2 * d.Cd), g,
+                          pref(r.rs, 2 * d.Cd), r.gi, 2 * d.Cd);
+            SegSpec s = {sp ? nullptr : r.rs, 2 * d.Cd, 0, 2 * d.Cd, 0, sp ? r.rs : nullptr, 2 * d.Cd, 0};
             run_convgemm(cx, r.gi, r.pk + r.L.VN[i], r.L.ld_VN, d.aux, &s, 1, EPI_STORE, pref(dY, d.auxp()), pnull(), pnull(),
                          pref(dY, d.auxp()), pnull(), 0, 0);
         } else if (dY && !fdy) {
@@ -1510,7 +1516,7 @@ int wf_check(const wg_wf_config *cf)
     if (!cf || cf->flows < 1 || cf->flows > WG_MAX_FLOWS || cf->n_mels < 1) return WG_EINVAL;
     const int H = cf->n_group;
     if (H != 8 && H != 16 && H != 32 && H != 64 && H != 128) return WG_EUNSUPPORTED;     // the keys of dilation_dict (waveflow.py:81-87)
-    if (cf->precision != WG_PREC_BF16X3_PLANES) return WG_EUNSUPPORTED;                      // only the S-plane kernels know 2-D taps
+    if (cf->precision < WG_PREC_F32 || cf->precision > WG_PREC_BF16X3_PLANES) return WG_EUNSUPPORTED;
     if (cf->n_mels * (2 * (256 / H) + 1) > WG_FIN_MAXCOLS) return WG_EUNSUPPORTED;           // upsampler weight row [n_mels x (2s+1)] in finalize's LDS
     // use_conv1x1: the H x H weight is factored / its gradient gathered in ONE workgroup's LDS (lu_big_kernel: H (H + 2) floats,
     // wf_hgram_kernel: 130 H floats = 66 560 B at H = 128): must fit gfx950's 160 KB; the opt-in itself is asked for once per device
@@ -1599,7 +1605,7 @@ void wf_upsample(Ctx &cx, const wg_wf_config *cf, const float *const *p, const f
     a.M = cf->n_mels; a.F = F; a.K = 2 * s + 1; a.s = s; a.pad = s / 2;
     a.Y = pref(ws + W.Y, W.auxp); a.gi = W.gi;
     WG_LAUNCH(cx, wf_upsample_fwd_kernel, dim3((W.gi.T + 255) / 256, cf->n_mels, W.gi.B), dim3(256), 0, a);
-    run_to_splane(cx, W.gi, pref(ws + W.Y, W.auxp), cf->n_mels, ws + W.YS, W.auxp);
+    if (cx.prec == 2) run_to_splane(cx, W.gi, pref(ws + W.Y, W.auxp), cf->n_mels, ws + W.YS, W.auxp);
 }
 void run_hmix(Ctx &cx, const Geo &g, PRef src, PRef dst, const float *Mx, int transpose)
 {

@@ -502,7 +502,7 @@ class WaveFlowEngine:
             nbytes = L.wg_wf_packed_bytes(C.byref(self.cfg))
             if nbytes == 0:
                 raise WgError("WaveFlow configuration not supported by the HIP kernels (n_group in {8,16,32,64,128}, channels "
-                              "multiples of 32, WG_PRECISION=bf16x3p)")
+                              "multiples of 32)")
             if self.packed.buf is None or self.packed.buf.numel() < nbytes or self.packed.buf.device != device:
                 self.packed.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
             check(L.wg_wf_pack_weights(C.byref(self.cfg), _table(params), _p(self.packed.buf), _stream()), "wg_wf_pack_weights")

@@ -740,8 +740,6 @@ def test_shape_sweep_vs_oracle(dev, case):
 def test_waveflow_model_vs_reference_golden(dev, golden_dir, precision, name):
     """WaveFlow forward + NLL + backward + row-by-row inverse against the reference's own run (model_wf*.npz) and the oracle.
     "wf8c" / "wf64c": use_conv1x1=True (an invertible 1x1 conv over the height axis instead of the flip, waveflow.py:203-206)."""
-    if precision != "bf16x3p":
-        pytest.skip("WaveFlow's 2-D taps are built for the S-plane kernels only")
     from oracle import wf_oracle as wfo
     cfg = fill.WF_CONFIGS[name]
     B, N, F = fill.WF_SHAPES[name]
@@ -789,8 +787,6 @@ def test_waveflow_model_vs_reference_golden(dev, golden_dir, precision, name):
 def test_waveflow_two_forwards_before_backward(dev, precision):
     """Two forwards of the same shape, then backward through BOTH (two losses / gradient accumulation): each autograd node owns
     the tape of its own forward, so the first backward recomputes from the first call's flow inputs, not the second's."""
-    if precision != "bf16x3p":
-        pytest.skip("WaveFlow's 2-D taps are built for the S-plane kernels only")
     name = "wf8"
     cfg = fill.WF_CONFIGS[name]
     B, N, F = fill.WF_SHAPES[name]
@@ -827,8 +823,6 @@ def test_waveflow_two_forwards_before_backward(dev, precision):
 def test_waveflow_full_size_properties(dev, precision):
     """BASELINE.json configs[3] at its full size (configs/waveflow_LJ_speech.json: 8 flows, 64 rows, 64 channels, batch 12 x 16000):
     size-independent properties instead of an oracle run."""
-    if precision != "bf16x3p":
-        pytest.skip("WaveFlow's 2-D taps are built for the S-plane kernels only")
     torch.manual_seed(0)
     m = cm.WaveFlow(flows=8, n_group=64, n_mels=80, use_conv1x1=False, memory_efficient=False, dilation_channels=64,
                     residual_channels=64, skip_channels=64, bias=False)
@@ -915,8 +909,6 @@ def test_wsrglow_full_size_properties(dev, precision):
 
 def test_waveflow_shipped_width_vs_oracle(dev, precision):
     """The shipped WaveFlow width (8 flows, 64 rows, 80 mels, 64 channels: one 128-row tile, K = 9*64 + 96) on a short segment."""
-    if precision != "bf16x3p":
-        pytest.skip("WaveFlow's 2-D taps are built for the S-plane kernels only")
     from oracle import wf_oracle as wfo
     name = "wf_full"
     cfg = dict(flows=8, n_group=64, n_mels=80, dilation_channels=64, residual_channels=64, skip_channels=64)
@@ -1059,8 +1051,6 @@ def test_half_inference_matches_fp32_engine(dev, precision):
 def test_waveflow_after_remove_weight_norms(dev, precision):
     """inference.py:19-22 folds the weight norm away before synthesis (model.apply(remove_weight_norms)); the engine then receives
     plain weights (NULL weight_g entries) and must give the same forward / inverse, and still train."""
-    if precision != "bf16x3p":
-        pytest.skip("WaveFlow's 2-D taps are built for the S-plane kernels only")
     name = "wf8"
     cfg = fill.WF_CONFIGS[name]
     B, N, F = fill.WF_SHAPES[name]
