@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "wg_wf_param_count", "wg_wf_packed_bytes", "wg_wf_workspace_bytes", "wg_wf_tape_bytes", "wg_wf_pack_weights", "wg_wf_upsample", "wg_wf_forward",
     "wg_wf_inverse", "wg_wf_backward", "wg_melspec_frames", "wg_melspec", "wg_lowpass_workspace_bytes", "wg_lowpass", "wg_train_step",
     "wg_nll_scratch_floats", "wg_train_scratch_floats",
-    "wg_timer_create", "wg_timer_attach", "wg_timer_count", "wg_timer_read", "wg_timer_read_info", "wg_timer_destroy",
+    "wg_timer_create", "wg_timer_attach", "wg_timer_count", "wg_timer_read", "wg_timer_read_info", "wg_timer_destroy", "wg_stat_wgrad16t_launches",
 ]
 K_CONV_STORE, K_CONV_GATE, K_CONV_RESSKIP, K_CONV_DGATE, K_WGRAD = range(5)
 
@@ -133,6 +133,8 @@ def lib():
     L.wg_timer_count.argtypes = [vp]
     L.wg_timer_read.argtypes = [vp, vp, i]
     L.wg_timer_read_info.argtypes = [vp, vp, i]
+    L.wg_stat_wgrad16t_launches.restype = C.c_longlong
+    L.wg_stat_wgrad16t_launches.argtypes = []
     L.wg_timer_destroy.argtypes = [vp]
     L.wg_timer_destroy.restype = None
     _LIB = L

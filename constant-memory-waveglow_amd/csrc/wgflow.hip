@@ -70,6 +70,7 @@ struct KernelTimer {
     long long *info;                     // per recorded launch: class, M, K, columns, algorithmic HBM bytes (wg_timer_read_info)
 };
 std::atomic<KernelTimer *> g_timer{nullptr};
+std::atomic<long long> g_wgrad16t_launches{0};               // diagnostics: launches of wgrad16t_kernel by this process (wg_stat_wgrad16t_launches)
 struct TimerScope {
     KernelTimer *t;
     hipStream_t st;
@@ -1185,6 +1186,7 @@ void run_wgrad_group_pair(Ctx &cx, const Geo &g, const WgradGroupSpec *gs0, int 
         const long long tsteps = (long long)g.B * g.T;
         TimerScope ts(WG_K_WGRAD, cx.st, mm, 1, tsteps, 4 * ch * tsteps + 4 * slabf);
         WG_LAUNCH(cx, wgrad16t_kernel, dim3(256), dim3(768), 0, wa);
+        g_wgrad16t_launches.fetch_add(1, std::memory_order_relaxed);
         return;
     }
     if (sync_floats) {
@@ -1656,6 +1658,7 @@ int wg_dbg_trace_read_cycles(unsigned long long *out, int n)
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(wg_dbg_trace_cyc), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif
+long long wg_stat_wgrad16t_launches(void) { return g_wgrad16t_launches.load(std::memory_order_relaxed); }
 void *wg_timer_create(int kernel_id, int capacity)
 {
     if (capacity < 1) return nullptr;

@@ -98,6 +98,9 @@ int   wg_timer_read(void *timer, float *ms, int n);   /* after a stream sync; re
  * weights, the outputs and auxiliary planes of the epilogue); launches that are not conv / weight-gradient products report zeros */
 int   wg_timer_read_info(void *timer, long long *info, int n);
 void  wg_timer_destroy(void *timer);
+/* diagnostics: how many times this process has launched wgrad16t_kernel (the one-workgroup-per-CU weight-gradient kernel; shapes
+ * without a plan take wgrad16s_pair_kernel) -- lets a test assert which kernel a shape ran on */
+long long wg_stat_wgrad16t_launches(void);
 
 /* ---- sizes -------------------------------------------------------------------------------- */
 int    wg_param_count(const wg_config *cfg);                 /* entries of the parameter table */

@@ -1072,3 +1072,38 @@ def test_waveflow_after_remove_weight_norms(dev, precision):
     z2, ld2 = m(T(audio, dev), T(mel, dev))
     cm.WaveGlowLoss(fill.SIGMA)(z2, ld2).backward()
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+
+
+@pytest.mark.parametrize("B,Tn,depth,planned", [(3, 1000, 8, True), (5, 130, 8, True), (2, 2000, 4, True), (4, 2000, 2, True),
+                                                (1, 300, 8, False), (2, 700, 2, False), (1, 64, 8, False), (2, 500, 3, False)])
+def test_weight_gradient_kernel_plans_vs_oracle(dev, precision, B, Tn, depth, planned):
+    """wgrad16t_kernel (one workgroup per CU, planned phases, wg_wgrad16t.h) at the shipped WN width over several (batch, length, depth)
+    combinations: different K ranges, part counts and phase shapes of the planner, against the oracle -- and cases WITHOUT a plan (fewer
+    chunks than the second phase has parts; a layer count that does not divide the 8 XCDs), which must take the two-workgroup kernel and
+    agree as well."""
+    if precision != "bf16x3p":
+        pytest.skip("the grouped weight-gradient launches exist in the S-plane mode only")
+    from constant_memory_waveglow_amd import _lib
+    wn = dict(in_channels=4, aux_channels=80, residual_channels=256, dilation_channels=256, skip_channels=256, depth=depth, radix=3)
+    specs = fill.wn_param_specs("F.", 4, 80, 256, 256, 256, depth, 3)
+    tag = "coupling/wgt%d_%d_%d" % (B, Tn, depth)
+    P = fill.fill_params(specs, tag + "/")
+    x = fill.uniform(tag + "/x", (B, 8, Tn))
+    y = fill.normal(tag + "/y", (B, 80, Tn))
+    gz = fill.normal(tag + "/gz", x.shape)
+    gls = fill.normal(tag + "/gls", (B, 4, Tn))
+    z_ref, _ = orc.coupling_apply(wn, fill.table(specs, P), x, y)
+    ref = orc.coupling_backward(wn, fill.table(specs, P), z_ref, y, gz, gls)
+    blk = cm.AffineCouplingBlock(cm.WN, True, zero_init=False, **wn)
+    blk.load_state_dict({n: torch.from_numpy(v) for n, v in P.items()})
+    blk = blk.to(dev)
+    xt, yt = T(x, dev).requires_grad_(True), T(y, dev).requires_grad_(True)
+    before = _lib.lib().wg_stat_wgrad16t_launches()
+    z, ls = blk(xt.clone(), yt)
+    ((z * T(gz, dev)).sum() + (ls * T(gls, dev)).sum()).backward()
+    torch.cuda.synchronize()
+    assert (_lib.lib().wg_stat_wgrad16t_launches() - before == 1) == planned
+    named = dict(blk.named_parameters())
+    for i, (n, _, _) in enumerate(specs):
+        assert relmax(npy(named[n].grad), ref["grads"][i]) < GRAD_RTOL, n
+    assert relmax(npy(xt.grad), ref["dx"]) < GRAD_RTOL and relmax(npy(yt.grad), ref["dy"]) < GRAD_RTOL
