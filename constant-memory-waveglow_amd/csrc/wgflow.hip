@@ -518,10 +518,10 @@ static WgtPlan plan_wgt(int tm0, int tn0, int tm1, int tn1, int ng, int K)
     }
     int durB = 0;
     if (kA1 < K) {
-        const int nB = sets_per_xcd(32, T1);
+        int nB = sets_per_xcd(32, T1);                        // (fewer sets when the rest of K is shorter than that many parts)
+        while (nB > 0 && 8 * nB / ng > K - kA1) nB = sets_per_xcd(nB * T1 - 1, T1);
         if (nB == 0) return pl;
         const int sB = 8 * nB / ng;
-        if (sB > K - kA1) return pl;
         durB = (K - kA1 + sB - 1) / sB;
         pl.ph[pl.nph++] = WgtPhase{1, 0, nB * T1, sB, kA1, K, pl.nslab[1], 0, 0, 0};
         pl.nslab[1] += sB;
