@@ -34,6 +34,19 @@ __device__ __forceinline__ int wg16q_off(int row, int kg) { return row * WG16Q_R
 // ------------------------------------------------------------------------------------------------
 // epilogues in the 16x16 accumulator layout (same contracts as conv_acc_init / conv_epilogue_s)
 // ------------------------------------------------------------------------------------------------
+// The saved tanh / sigmoid planes of a layer are private to these kernels (written by the gate conv of the recompute pass or of a
+// stored-activation forward, read once by the gate backward): they are kept CHANNEL-INTERLEAVED, [b][c / 4][t][4] fp32, so that the
+// four rows a lane owns at one column are ONE 16-byte unit -- a wave's access is 4 x 256 contiguous bytes instead of 16 x 64.  (In the
+// planar layout both sides moved 4 bytes per lane and instruction: the gate backward, bound by these bytes, ran at 3.7 TB/s.)
+#if !defined(WG_OPT_PLANAR_TS)
+#define WG_TS_INTERLEAVED 1
+#else
+#define WG_TS_INTERLEAVED 0
+#endif
+__device__ __forceinline__ float *paddr4(const PRef &r, const Geo &g, int b, int ch, int t)     // ch: a multiple of 4
+{
+    return r.p + (((size_t)b * (r.Cp >> 2) + ((r.ch0 + ch) >> 2)) * g.P + g.H + t) * 4;
+}
 template <int EPI, int NB>
 __device__ __forceinline__ void conv_acc_init_q(const ConvGemmArgs &a, const SRef &saux, f32x4 (&acc)[4][NB], int t0, int m0, int b, int wr, int wc,
                                                 int lane)
@@ -120,13 +133,22 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
                     for (int e = 0; e < 4; ++e) b0[off + (unsigned)e * (unsigned)g.P] = gv[4 * mbp + e];
                 }
                 if (b1) {
+                    // (non-temporal: the saved tanh / sigmoid planes are read once, by the gate backward of this layer, 15 layer
+                    // launches later: kept out of L2's way, -0.45 ms per training step)
+#if WG_TS_INTERLEAVED
+                    const int chq = chb + mbp * 16 + 4 * rq;
+                    f32x4 vt, vs;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { vt[e] = tw[4 * mbp + e]; vs[e] = sf[4 * mbp + e]; }
+                    __builtin_nontemporal_store(vt, reinterpret_cast<f32x4 *>(paddr4(a.out1, g, b, chq, t0 + (int)tl)));
+                    __builtin_nontemporal_store(vs, reinterpret_cast<f32x4 *>(paddr4(a.out2, g, b, chq, t0 + (int)tl)));
+#else
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        // (non-temporal: the saved tanh / sigmoid planes are read once, by the gate backward of this layer, 15 layer
-                        // launches later: kept out of L2's way, -0.45 ms per training step)
                         __builtin_nontemporal_store(tw[4 * mbp + e], &b1[off + (unsigned)e * (unsigned)g.P]);
                         __builtin_nontemporal_store(sf[4 * mbp + e], &b2[off + (unsigned)e * (unsigned)g.P]);
                     }
+#endif
                 }
                 u32x2 vh, vl;
                 unsigned hh, ll;
@@ -158,6 +180,16 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     const int tl = wc * (16 * NB) + nb * 16 + col;
+#if WG_TS_INTERLEAVED
+                    // (non-temporal, like the stores that saved them: this is their only use; M is a multiple of 4 here)
+                    f32x4 vx = {0.f, 0.f, 0.f, 0.f}, vy = {0.f, 0.f, 0.f, 0.f};
+                    if (t0 + tl < g.T && mbase + 4 * rq < a.M) {
+                        vx = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(paddr4(a.aux0, g, b, mbase + 4 * rq, t0 + tl)));
+                        vy = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(paddr4(a.aux1, g, b, mbase + 4 * rq, t0 + tl)));
+                    }
+                    ax[q][nb] = vx; ay[q][nb] = vy;
+                    (void)p0; (void)p1;
+#else
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const unsigned off = (unsigned)(4 * rq + e) * (unsigned)g.P + (unsigned)tl;
@@ -166,6 +198,7 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
                         if (t0 + tl < g.T && mbase + 4 * rq + e < a.M) { x = __builtin_nontemporal_load(&p0[off]); y = __builtin_nontemporal_load(&p1[off]); }
                         ax[q][nb][e] = x; ay[q][nb][e] = y;
                     }
+#endif
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
