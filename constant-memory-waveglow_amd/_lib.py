@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WGFLOW_LIB") or os.path.join(_HERE, "csrc", "libwgflow.so")   # WGFLOW_LIB: developer A/B builds
 _LIB = None
 
-ABI_VERSION = 3          # include/wgflow.h WG_ABI_VERSION (3: logged training scalars out of wg_nll_loss / wg_train_step)
+ABI_VERSION = 4          # include/wgflow.h WG_ABI_VERSION (4: wg_timer_read_info, wg_stat_wgrad16t_launches; WaveFlow in every precision)
 ABI_SYMBOLS = [
     "wg_strerror", "wg_abi_version", "wg_param_count", "wg_packed_bytes", "wg_workspace_bytes",
     "wg_wn_param_count", "wg_wn_packed_bytes", "wg_coupling_workspace_bytes", "wg_invconv_workspace_bytes",

@@ -75,9 +75,10 @@ typedef struct wg_wn_dims {
 const char *wg_strerror(int code);
 /* ABI revision of this header (2: wg_config gained keep_activations; 3: wg_nll_loss / wg_train_step produce the logged
  * training scalars and take their scratch from the caller, wg_melspec returns the power spectrogram on request, wg_wf_config gained
- * use_conv1x1, wg_wf_upsample).  A binding built against another revision must not pass its
+ * use_conv1x1, wg_wf_upsample; 4: wg_timer_create(-1, ..) times every kernel class, wg_timer_read_info, wg_stat_wgrad16t_launches,
+ * wg_wf_* accept every WG_PREC_*).  A binding built against another revision must not pass its
  * structs: the Python loader compares this with its own ABI_VERSION and refuses the library otherwise. */
-#define WG_ABI_VERSION 3
+#define WG_ABI_VERSION 4
 int wg_abi_version(void);
 
 /* Diagnostics (no counterpart upstream; the reference times with wall-clock time(), inference.py:39-53): while a
