@@ -1,0 +1,289 @@
+// wg_thin.h -- the two THIN products at the ends of WN's backward, each as ONE pass over its wide operand (precision 2).
+//
+// WN.start is a 1x1 conv from the coupling's ic <= 16 input channels to C residual channels, WN.end one from the Cs skip channels to
+// 2 ic outputs (model/waveglow.py:61-67,98-105).  Their backward is two products each -- the weight gradient and the data gradient --
+// whose one wide operand (dh_0 resp. skip: C x B T values, 49 MB at the headline shape) is the whole cost and whose other side is 4-8
+// rows.  As 128 x 128-tile MFMA launches they ran at 3 % tile occupancy with a 256-way split-K behind them:
+//     start: wgrad16s_kernel<1> 48 us + slab_reduce 8 us + convgemm16q<0> 17 us     end: wgrad16_kernel 24 + slab_reduce 7 + to_splane 4 + convgemm16q<0> 19
+// Here a workgroup streams 64-column tiles of the wide operand ONCE, coalesced, and produces both results from it on the vector ALU in
+// fp32 (the operands are the fp32 values themselves -- hi + lo of an S-plane is exact to 2^-17 -- so these are at least as exact as
+// the three-product MFMA form they replace):
+//   * the data gradient column by column (a lane owns one time step; the few weights sit in LDS and every read of them is a wave-wide broadcast);
+//   * the weight gradient through an LDS tile [channel][time] (pitch 65 floats: conflict-free both ways): thread c then walks the 64
+//     time steps of ITS channel against the thin operand's rows, which every lane reads from the same LDS address (broadcast).
+// A workgroup keeps its weight-gradient sums in registers over all its tiles and writes ONE partial; thin_fold_kernel adds the partials
+// in a fixed order (reproducible bit for bit) and run_finalize sees a single slab.
+#pragma once
+#include "wg_gemm16s.h"
+
+#define WGTH_TB 64                 // time steps per tile
+#define WGTH_LDT 65                // LDS pitch of a channel row
+#define WGTH_THREADS 256
+#define WGTH_MAXROWS 2             // channel rows per thread: C, Cs <= 512
+#define WGTH_BATCH 8                // start: channel groups (2 x 16 bytes per lane each) a wave has in flight
+#define WGTH_BATCH2 16              // end: 4-row groups (16 bytes per lane each) a wave has in flight
+
+#if !defined(WGTH_DBG)
+#define WGTH_DBG 0                  // timing bisection only: 1 no reduction, 2 no weight-gradient walk, 4 no tile / data-gradient work, 8 no loads
+#endif
+// out[e] = sum_p part[p][e] (np partials of n floats, n a multiple of 32): a block takes 8 columns of 16 bytes, thread (column, lane l of 32)
+// adds partials l, l + 32, ... (all its loads in flight), thread (column, 0) then adds the 32 lanes' sums in lane order -- a fixed order,
+// so the result is reproducible.  (Folding inside the producing launch -- the last workgroup to finish, found by an atomic ticket, one
+// or two levels -- was measured at 18-20 us of tail on a 20 us kernel, or 150-290 us when ONE workgroup walked all the partials: every
+// partial is a round trip to memory.  This launch is ~3 us.)
+__global__ __launch_bounds__(256) void thin_fold_kernel(const float *__restrict__ part, int np, int n, float *__restrict__ out)
+{
+    __shared__ f32x4 sums[32][8];
+    const int col = threadIdx.x & 7, l = threadIdx.x >> 3;
+    const int e = ((int)blockIdx.x * 8 + col) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int p0 = l; p0 < np; p0 += 32 * 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int p = p0 + 32 * q;
+            v[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p < np) v[q] = *reinterpret_cast<const f32x4 *>(part + (size_t)p * n + e);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += v[q];
+    }
+    sums[l][col] = s;
+    __syncthreads();
+    if (l == 0) {
+        f32x4 t = sums[0][col];
+        for (int q = 1; q < 32; ++q) t += sums[q][col];
+        *reinterpret_cast<f32x4 *>(out + e) = t;
+    }
+}
+// floats of the partial buffer for a grid of G workgroups: partials, result
+__host__ __device__ inline size_t wgth_part_floats(int G, int n) { return (size_t)(G + 1) * n; }
+
+// ------------------------------------------------------------------------------------------------
+// start:  dW[c][j] = sum_{b,t} dh[c][t] xa[j][t]        dxa[j][t] += sum_c W[c][j] dh[c][t]            (model/waveglow.py:98, backward)
+// ------------------------------------------------------------------------------------------------
+struct ThinStartArgs {
+    SRef dh;             // S-plane of dh_0, C channels
+    PRef X, dX;          // xa = X channels [ch0, ch0 + ic); dX likewise (accumulated into)
+    const float *W;      // fp32 k-major effective weights [C][ldw]: W[c][j]
+    int ldw, C, ic;
+    Geo g;
+    int tiles;           // B * Tt / 64
+    float *part;         // [gridDim.x][C * ICP]
+};
+template <int ICP>
+__global__ __launch_bounds__(WGTH_THREADS) void thin_start_kernel(const ThinStartArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float wgth_smem[];
+    float *tile = wgth_smem;                                   // [C][65]
+    float *xs = tile + (size_t)a.C * WGTH_LDT;                 // [64][ICP]
+    float *axs = xs + WGTH_TB * ICP;                           // [4][ICP][64]: the four waves' shares of dxa
+    float *Ws = axs + 4 * ICP * 64;                            // [C][ICP]: the weights (every read is wave-uniform: an LDS broadcast)
+    const int tid = threadIdx.x, tl = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const Geo g = a.g;
+    const int ncg = a.C >> 3, tpb = g.Tt / WGTH_TB;
+    float acc[WGTH_MAXROWS][ICP];
+#pragma unroll
+    for (int r = 0; r < WGTH_MAXROWS; ++r)
+#pragma unroll
+        for (int j = 0; j < ICP; ++j) acc[r][j] = 0.f;
+    for (int e = tid; e < a.C * ICP; e += WGTH_THREADS) Ws[e] = a.W[(size_t)(e / ICP) * a.ldw + (e % ICP)];
+    __syncthreads();
+    for (int tix = (int)blockIdx.x; tix < a.tiles; tix += (int)gridDim.x) {
+        const int b = tix / tpb, t0 = (tix - b * tpb) * WGTH_TB, t = t0 + tl;
+        const bool live = t < g.T;
+        // ---- phase 1: wave wv takes channel groups wv, wv + 4, ...: LDS tile + its share of dxa ----
+        float ax[ICP];
+#pragma unroll
+        for (int j = 0; j < ICP; ++j) ax[j] = 0.f;
+        for (int cg0 = wv; cg0 < ncg; cg0 += 4 * WGTH_BATCH) {   // all of a batch's loads are issued before the first is used
+            u32x4 h[WGTH_BATCH], l[WGTH_BATCH];
+#pragma unroll
+            for (int q = 0; q < WGTH_BATCH; ++q) {
+                const int cg = cg0 + 4 * q;
+                h[q] = u32x4{0u, 0u, 0u, 0u}; l[q] = h[q];
+                if (live && cg < ncg && !(WGTH_DBG & 8)) {
+                    const size_t i = s_index(a.dh, g, b, cg * 8, t);
+                    h[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.dh.hi + i));
+                    l[q] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a.dh.hi + a.dh.lo_off + i));
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < WGTH_BATCH; ++q) {
+                const int cg = cg0 + 4 * q;
+                if (cg < ncg && !(WGTH_DBG & 4)) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] = __uint_as_float(h[q][e] << 16) + __uint_as_float(l[q][e] << 16);
+                        v[2 * e + 1] = __uint_as_float(h[q][e] & 0xffff0000u) + __uint_as_float(l[q][e] & 0xffff0000u);
+                    }
+                    const float *wrow = Ws + cg * 8 * ICP;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        tile[(cg * 8 + e) * WGTH_LDT + tl] = v[e];
+#pragma unroll
+                        for (int j = 0; j < ICP; ++j) ax[j] += wrow[e * ICP + j] * v[e];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < ICP; ++j) axs[(wv * ICP + j) * 64 + tl] = ax[j];
+        for (int e = tid; e < WGTH_TB * ICP; e += WGTH_THREADS) {        // xa tile: e -> (j, time)
+            const int j = e >> 6, tt = e & 63;
+            xs[tt * ICP + j] = (j < a.ic && t0 + tt < g.T) ? *paddr(a.X, g, b, j, t0 + tt) : 0.f;
+        }
+        __syncthreads();
+        for (int e = tid; e < WGTH_TB * ICP; e += WGTH_THREADS) {        // dxa: the four shares, then into the gradient plane
+            const int j = e >> 6, tt = e & 63;
+            if (j < a.ic && t0 + tt < g.T) {
+                float *p = paddr(a.dX, g, b, j, t0 + tt);
+                *p += (axs[(0 * ICP + j) * 64 + tt] + axs[(1 * ICP + j) * 64 + tt]) + (axs[(2 * ICP + j) * 64 + tt] + axs[(3 * ICP + j) * 64 + tt]);
+            }
+        }
+        // ---- phase 2: thread c walks the 64 time steps of its channel ----
+#pragma unroll
+        for (int r = 0; r < WGTH_MAXROWS; ++r) {
+            const int c = tid + r * WGTH_THREADS;
+            if (c < a.C && !(WGTH_DBG & 2)) {
+                const float *row = tile + (size_t)c * WGTH_LDT;
+#pragma unroll 8
+                for (int tt = 0; tt < WGTH_TB; ++tt) {
+                    const float d = row[tt];
+#pragma unroll
+                    for (int j = 0; j < ICP; ++j) acc[r][j] += d * xs[tt * ICP + j];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int n = a.C * ICP;
+    float *mine = a.part + (size_t)blockIdx.x * n;
+#pragma unroll
+    for (int r = 0; r < WGTH_MAXROWS; ++r) {
+        const int c = tid + r * WGTH_THREADS;
+        if (c < a.C)
+#pragma unroll
+            for (int j = 0; j < ICP; ++j) mine[c * ICP + j] = acc[r][j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// end:  dW[k][m] = sum_{b,t} G[k][t] skip[m][t]        dS[m][t] = sum_k W[k][m] G[k][t]  -> S-plane       (model/waveglow.py:104, backward)
+// ------------------------------------------------------------------------------------------------
+struct ThinEndArgs {
+    PRef G;              // gradient of the WN output: K2 = 2 ic rows
+    PRef skip;           // Cs channels, fp32
+    SRef dS;             // S-plane out, Cs channels
+    const float *W;      // fp32 k-major [K2][ldw]: W[k][m]
+    int ldw, Cs, K2;
+    Geo g;
+    int tiles;
+    float *part;         // [gridDim.x][K2P * Cs]
+};
+template <int K2P>
+__global__ __launch_bounds__(WGTH_THREADS) void thin_end_kernel(const ThinEndArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float wgth_smem[];
+    float *tile = wgth_smem;                                   // [Cs][65]
+    float *gs = tile + (size_t)a.Cs * WGTH_LDT;                // [64][K2P]
+    float *Ws = gs + WGTH_TB * K2P;                            // [K2P][Cs]: the weights (every read is wave-uniform: an LDS broadcast)
+    const int tid = threadIdx.x, tl = tid & 63, lane = tl;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const Geo g = a.g;
+    const int ncg = a.Cs >> 3, tpb = g.Tt / WGTH_TB;
+    float acc[WGTH_MAXROWS][K2P];
+#pragma unroll
+    for (int r = 0; r < WGTH_MAXROWS; ++r)
+#pragma unroll
+        for (int k = 0; k < K2P; ++k) acc[r][k] = 0.f;
+    for (int e = tid; e < K2P * a.Cs; e += WGTH_THREADS) {
+        const int k = e / a.Cs, m = e - k * a.Cs;
+        Ws[e] = k < a.K2 ? a.W[(size_t)k * a.ldw + m] : 0.f;
+    }
+    __syncthreads();
+    for (int tix = (int)blockIdx.x; tix < a.tiles; tix += (int)gridDim.x) {
+        const int b = tix / tpb, t0 = (tix - b * tpb) * WGTH_TB, t = t0 + tl;
+        const bool live = t < g.T;
+        // ---- G column of this lane (requested first), then the skip tile into LDS: a wave load covers 4 channel rows x 64 time steps ----
+        float gk[K2P];
+#pragma unroll
+        for (int k = 0; k < K2P; ++k) gk[k] = (live && k < a.K2) ? *paddr(a.G, g, b, k, t) : 0.f;
+        {
+            const int r4 = lane >> 4, q4 = (lane & 15) * 4;
+            for (int mb = wv * 4; mb < a.Cs; mb += 16 * WGTH_BATCH2) {   // all of a batch's loads are issued before the first is used
+                f32x4 v[WGTH_BATCH2];
+#pragma unroll
+                for (int q = 0; q < WGTH_BATCH2; ++q) {
+                    const int m = mb + 16 * q + r4;
+                    v[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (m < a.Cs && !(WGTH_DBG & 8)) v[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(paddr(a.skip, g, b, m, t0 + q4)));
+                }
+#pragma unroll
+                for (int q = 0; q < WGTH_BATCH2; ++q) {
+                    const int m = mb + 16 * q + r4;
+                    if (m < a.Cs && !(WGTH_DBG & 4)) {
+                        float *dst = tile + (size_t)m * WGTH_LDT + q4;
+                        dst[0] = t0 + q4 + 0 < g.T ? v[q][0] : 0.f; dst[1] = t0 + q4 + 1 < g.T ? v[q][1] : 0.f;
+                        dst[2] = t0 + q4 + 2 < g.T ? v[q][2] : 0.f; dst[3] = t0 + q4 + 3 < g.T ? v[q][3] : 0.f;
+                    }
+                }
+            }
+        }
+        // ---- the data gradient: wave wv takes channel groups wv, wv + 4, ... ----
+        if (wv == 0) {
+#pragma unroll
+            for (int k = 0; k < K2P; ++k) gs[tl * K2P + k] = gk[k];
+        }
+        for (int cg = wv; cg < ncg && !(WGTH_DBG & 4); cg += 4) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+#pragma unroll
+            for (int k = 0; k < K2P; ++k) {
+                const float *wk = Ws + k * a.Cs + cg * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += wk[e] * gk[k];
+            }
+            if (live) {
+                u32x4 h, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsigned hh, ll;
+                    split2(v[2 * e], v[2 * e + 1], hh, ll);
+                    h[e] = hh; l[e] = ll;
+                }
+                const size_t i = s_index(a.dS, g, b, cg * 8, t);
+                *reinterpret_cast<u32x4 *>(a.dS.hi + i) = h;
+                *reinterpret_cast<u32x4 *>(a.dS.hi + a.dS.lo_off + i) = l;
+            }
+        }
+        __syncthreads();
+        // ---- the weight gradient: thread m walks the 64 time steps of its skip channel ----
+#pragma unroll
+        for (int r = 0; r < WGTH_MAXROWS; ++r) {
+            const int m = tid + r * WGTH_THREADS;
+            if (m < a.Cs && !(WGTH_DBG & 2)) {
+                const float *row = tile + (size_t)m * WGTH_LDT;
+#pragma unroll 8
+                for (int tt = 0; tt < WGTH_TB; ++tt) {
+                    const float s = row[tt];
+#pragma unroll
+                    for (int k = 0; k < K2P; ++k) acc[r][k] += s * gs[tt * K2P + k];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int n = K2P * a.Cs;
+    float *mine = a.part + (size_t)blockIdx.x * n;
+#pragma unroll
+    for (int r = 0; r < WGTH_MAXROWS; ++r) {
+        const int m = tid + r * WGTH_THREADS;
+        if (m < a.Cs)
+#pragma unroll
+            for (int k = 0; k < K2P; ++k) mine[(size_t)k * a.Cs + m] = acc[r][k];
+    }
+}

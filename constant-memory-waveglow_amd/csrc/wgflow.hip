@@ -12,6 +12,7 @@
 #include "wg_wf.h"
 #include "wg_mel.h"
 #include "wg_stage.h"
+#include "wg_thin.h"
 
 #include <algorithm>
 #include <atomic>
@@ -543,6 +544,7 @@ struct Bump {
     size_t off = 0;
     size_t take(size_t n) { size_t o = off; off += rupz(n, 64); return o; }
 };
+int device_cus();
 void wn_ws_layout(Bump &bp, const WnD &d, int ic_max, const Geo &g, int mode, int prec, WnWs &w)
 {
     const size_t pC = (size_t)g.B * d.C * g.P, pD = (size_t)g.B * d.Cd * g.P, pS = (size_t)g.B * d.Cs * g.P;
@@ -585,6 +587,7 @@ void wn_ws_layout(Bump &bp, const WnD &d, int ic_max, const Geo &g, int mode, in
         s = std::max(s, slab_floats(g, WG_TILE, rup(d.Cs, WG_TILE)));
         s = std::max(s, slab_floats(g, rup(d.C, WG_TILE), WG_TILE));
         s = std::max(s, slab_floats(g, WG_TILE, WG_TILE));
+        s = std::max(s, wgth_part_floats(2 * device_cus(), std::max(16 * d.C, 32 * d.Cs)) + 64);      // the thin products' partials (wg_thin.h)
         // room for several products' slabs (FinQueue batches the finalisations of a WN): up to 8 of the largest, at most 384 MB
         s = std::max(s, std::min((size_t)8 * s, (size_t)96 << 20));
         if (grouped_wgrad(prec, d)) {                            // both grouped products of a WN at once (run_wgrad_group_pair)
@@ -705,10 +708,10 @@ int device_cus()
 // WG_EUNSUPPORTED instead of a launch error further down.
 int ensure_dynamic_lds(const void *kernel, int slot, size_t bytes)
 {
-    static std::atomic<int> granted[16][4];
+    static std::atomic<int> granted[16][8];
     if (bytes <= 48 * 1024) return 0;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || slot < 0 || slot >= 4) return WG_ELAUNCH;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16 || slot < 0 || slot >= 8) return WG_ELAUNCH;
     if (granted[dev][slot].load(std::memory_order_relaxed) >= (int)bytes) return 0;
     if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
         (void)hipGetLastError();
@@ -1322,6 +1325,83 @@ void run_end_affine(Ctx &cx, const WnRun &r, int mode, PRef dX, float *log_s_out
     else WG_LAUNCH(cx, end_affine_kernel<32>, dim3(r.g.Tt / WG_AFF_T, r.g.B), dim3(256), 0, a);
 }
 
+// The thin products of WN's backward (wg_thin.h): precision 2, inside a FinQueue (the partials come from its arena).
+bool thin_ok(const Ctx &cx, const WnD &d)
+{
+#if defined(WG_OPT_NO_THIN)
+    return false;
+#else
+    return cx.prec == 2 && cx.fq && !cx.rec && d.ic <= 16 && d.C % 8 == 0 && d.Cs % 8 == 0 && d.C <= WGTH_MAXROWS * WGTH_THREADS &&
+           d.Cs <= WGTH_MAXROWS * WGTH_THREADS;
+#endif
+}
+static int thin_grid(int tiles)
+{
+    const int slots = 2 * device_cus(), rounds = (tiles + slots - 1) / slots;
+    return (tiles + rounds - 1) / rounds;
+}
+// dW_start = sum dh_0 (x) xa (finalised into dg / dv) ; dxa += W_start^T dh_0
+void run_thin_start(Ctx &cx, const WnRun &r, const float *dhS, PRef dX, const float *gp, const float *vp, float *dg, float *dv)
+{
+    const WnD &d = r.d;
+    const Geo &g = r.g;
+    const int icp = d.ic <= 4 ? 4 : d.ic <= 8 ? 8 : 16;
+    ThinStartArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dh = sref(g, const_cast<float *>(dhS), d.C);
+    a.X = r.X; a.dX = dX;
+    a.W = r.pk + r.L.startN; a.ldw = r.L.ld_startN; a.C = d.C; a.ic = d.ic;
+    a.g = g; a.tiles = g.B * (g.Tt / WGTH_TB);
+    const int grid = thin_grid(a.tiles), n = d.C * icp;
+    a.part = cx.fq->reserve(wgth_part_floats(grid, n));
+    float *out = a.part + (size_t)grid * n;
+    const size_t lds = ((size_t)d.C * WGTH_LDT + WGTH_TB * icp + 4 * icp * 64 + (size_t)d.C * icp) * sizeof(float);
+    if (cx.err) return;
+    switch (icp) {
+#define WG_THIN_CASE(P, SLOT)                                                                                         \
+    case P:                                                                                                           \
+        cx.err = ensure_dynamic_lds((const void *)thin_start_kernel<P>, SLOT, lds);                                   \
+        if (!cx.err) WG_LAUNCH(cx, thin_start_kernel<P>, dim3(grid), dim3(WGTH_THREADS), lds, a);                      \
+        break;
+        WG_THIN_CASE(4, 2) WG_THIN_CASE(8, 3) WG_THIN_CASE(16, 4)
+#undef WG_THIN_CASE
+    }
+    WG_LAUNCH(cx, thin_fold_kernel, dim3(n / 32), dim3(256), 0, (const float *)a.part, grid, n, out);
+    WgradOut wo;
+    wo.nsplit = 1; wo.Mp = d.C; wo.Np = icp; wo.slab = out;
+    run_finalize(cx, out, wo, 0, d.C, d.ic, 1, 0, 1, 0, gp, vp, dg, dv);
+}
+// dW_end = sum G (x) skip ; dS = W_end^T G as an S-plane
+void run_thin_end(Ctx &cx, const WnRun &r, float *G, int Gc, float *skip, float *dSS, float *dW)
+{
+    const WnD &d = r.d;
+    const Geo &g = r.g;
+    const int k2 = 2 * d.ic, k2p = k2 <= 8 ? 8 : k2 <= 16 ? 16 : 32;
+    ThinEndArgs a;
+    memset(&a, 0, sizeof(a));
+    a.G = pref(G, Gc); a.skip = pref(skip, d.Cs); a.dS = sref(g, dSS, d.Cs);
+    a.W = r.pk + r.L.endN; a.ldw = r.L.ld_endN; a.Cs = d.Cs; a.K2 = k2;
+    a.g = g; a.tiles = g.B * (g.Tt / WGTH_TB);
+    const int grid = thin_grid(a.tiles), n = k2p * d.Cs;
+    a.part = cx.fq->reserve(wgth_part_floats(grid, n));
+    float *out = a.part + (size_t)grid * n;
+    const size_t lds = ((size_t)d.Cs * WGTH_LDT + WGTH_TB * k2p + (size_t)k2p * d.Cs) * sizeof(float);
+    if (cx.err) return;
+    switch (k2p) {
+#define WG_THIN_CASE(P, SLOT)                                                                                         \
+    case P:                                                                                                           \
+        cx.err = ensure_dynamic_lds((const void *)thin_end_kernel<P>, SLOT, lds);                                     \
+        if (!cx.err) WG_LAUNCH(cx, thin_end_kernel<P>, dim3(grid), dim3(WGTH_THREADS), lds, a);                        \
+        break;
+        WG_THIN_CASE(8, 5) WG_THIN_CASE(16, 6) WG_THIN_CASE(32, 7)
+#undef WG_THIN_CASE
+    }
+    WG_LAUNCH(cx, thin_fold_kernel, dim3(n / 32), dim3(256), 0, (const float *)a.part, grid, n, out);
+    WgradOut wo;
+    wo.nsplit = 1; wo.Mp = k2p; wo.Np = d.Cs; wo.slab = out;
+    run_finalize(cx, out, wo, 0, k2, d.Cs, 1, 0, 1, 0, nullptr, nullptr, nullptr, dW);
+}
+
 // backward through WN given the G plane (what autograd.grad at efficient_modules.py:143 evaluates).
 // p/grads: this WN's parameter / gradient tables.  dX: gradient plane at the same ch0 as r.X (dxa accumulates into it).
 void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *grads, PRef dX, float *dY)
@@ -1346,13 +1426,16 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
     // end: dW_end = sum G (x) S ; dS = W_end^T G
     {
         // skip (fp32 only: it feeds the fp32 end conv) has no S-plane -> this small product runs on the on-the-fly kernel
-        WSegSpec sa = {G, Gc, 0, 2 * d.ic, 0, nullptr, 0, 0}, sb = {skip, d.Cs, 0, d.Cs, 0, nullptr, 0, 0};
-        WgradOut wo = run_wgrad(cx, g, &sa, 1, &sb, 1, slab, cap);
-        run_finalize(cx, slab, wo, 0, 2 * d.ic, d.Cs, 1, 0, 1, 0, nullptr, nullptr, nullptr, grads[4 + 4 * nd]);
-        if (sp) run_to_splane(cx, g, pref(G, Gc), Gc, ws + r.w.GS, Gc);
-        SegSpec s = {G, Gc, 0, Gc, 0, ws + r.w.GS, Gc, 0};
-        run_convgemm(cx, g, r.pk + r.L.endN, r.L.ld_endN, d.Cs, &s, 1, EPI_STORE, sp ? pnull() : pref(dS, d.Cs), pnull(), pnull(), pnull(), pnull(), 0, 0,
-                     sp ? sref(g, ws + r.w.dSS, d.Cs) : snull());
+        if (thin_ok(cx, d)) run_thin_end(cx, r, G, Gc, skip, ws + r.w.dSS, grads[4 + 4 * nd]);      // both in one pass over skip (wg_thin.h)
+        else {
+            WSegSpec sa = {G, Gc, 0, 2 * d.ic, 0, nullptr, 0, 0}, sb = {skip, d.Cs, 0, d.Cs, 0, nullptr, 0, 0};
+            WgradOut wo = run_wgrad(cx, g, &sa, 1, &sb, 1, slab, cap);
+            run_finalize(cx, slab, wo, 0, 2 * d.ic, d.Cs, 1, 0, 1, 0, nullptr, nullptr, nullptr, grads[4 + 4 * nd]);
+            if (sp) run_to_splane(cx, g, pref(G, Gc), Gc, ws + r.w.GS, Gc);
+            SegSpec s = {G, Gc, 0, Gc, 0, ws + r.w.GS, Gc, 0};
+            run_convgemm(cx, g, r.pk + r.L.endN, r.L.ld_endN, d.Cs, &s, 1, EPI_STORE, sp ? pnull() : pref(dS, d.Cs), pnull(), pnull(), pnull(), pnull(), 0, 0,
+                         sp ? sref(g, ws + r.w.dSS, d.Cs) : snull());
+        }
     }
     for (int i = nd - 1; i >= 0; --i) {
         const int rows = d.wo_rows(i), last = i == nd - 1;
@@ -1471,7 +1554,8 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
                      pref(dY, d.auxp()), pnull(), 0, 0);
     }
     // start: dW_start = sum dh_0 (x) xa ; dxa += W_start^T dh_0
-    {
+    if (thin_ok(cx, d)) run_thin_start(cx, r, dHSp(0), dX, p[2], p[3], grads[2], grads[3]);      // both in one pass over dh_0 (wg_thin.h)
+    else {
         WSegSpec sa = {dH, d.C, 0, d.C, 0, sp ? dHSp(0) : nullptr, d.C, 0};
         WSegSpec sb = {r.X.p, r.X.Cp, r.X.ch0, d.ic, 0, sp ? ws + r.w.XaS : nullptr, r.L.kp_start, 0};
         WgradOut wo = run_wgrad(cx, g, &sa, 1, &sb, 1, slab, cap);
