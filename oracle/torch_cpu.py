@@ -36,24 +36,27 @@ def _flow_channels(cfg, k):
 
 
 def _wn_forward(p, xa, y, depth, C, radix):
-    """p: this WN's tensors [Vg, Vv, Sg, Sv, (Wg, Wv, Og, Ov) * depth, End].  -> (log_s, t)"""
-    x = Fn.conv1d(xa, _wn(p[2], p[3]))
-    v = Fn.conv1d(y, _wn(p[0], p[1]))
+    """p: this WN's tensors [Vg, Vv, Sg, Sv, (Wg, Wv, Og, Ov) * depth, End] and, for WN(bias=True) (model/waveglow.py:58), the biases
+    behind them [V, start, (W, W_o) * depth, end].  -> (log_s, t)"""
+    nb = 4 + 4 * depth + 1
+    b = p[nb:] if len(p) > nb else [None] * (2 + 2 * depth + 1)
+    x = Fn.conv1d(xa, _wn(p[2], p[3]), b[1])
+    v = Fn.conv1d(y, _wn(p[0], p[1]), b[0])
     Cd = p[5].shape[0] // 2
     skip = None
     for i in range(depth):
         Wg, Wv, Og, Ov = p[4 + 4 * i: 8 + 4 * i]
         d = 2 ** i
-        xy = Fn.conv1d(x, _wn(Wg, Wv), padding=d * (radix - 1) // 2, dilation=d) + v[:, 2 * Cd * i: 2 * Cd * (i + 1)]
+        xy = Fn.conv1d(x, _wn(Wg, Wv), b[2 + 2 * i], padding=d * (radix - 1) // 2, dilation=d) + v[:, 2 * Cd * i: 2 * Cd * (i + 1)]
         gate = torch.tanh(xy[:, :Cd]) * torch.sigmoid(xy[:, Cd:])
-        o = Fn.conv1d(gate, _wn(Og, Ov))
+        o = Fn.conv1d(gate, _wn(Og, Ov), b[3 + 2 * i])
         if i < depth - 1:
             x = o[:, :C] + x
             s = o[:, C:]
         else:
             s = o
         skip = s if skip is None else skip + s
-    out = Fn.conv1d(skip, p[-1])
+    out = Fn.conv1d(skip, p[nb - 1], b[2 + 2 * depth])
     ic = out.shape[1] // 2
     return out[:, :ic], out[:, ic:]
 
@@ -75,7 +78,7 @@ def train_step(cfg, params, audio, h, sigma, need_dh=False):
     up = cfg["hop_size"] // G
     K = 2 * up + 1
     pad = K // 2 - up // 2
-    per_wn = 4 + 4 * depth + 1
+    per_wn = 4 + 4 * depth + 1 + (2 + 2 * depth + 1 if cfg.get("bias") else 0)
     wn_p = [P[3 + flows + k * per_wn: 3 + flows + (k + 1) * per_wn] for k in range(flows)]
 
     def upsample(bias, g, v, hh):

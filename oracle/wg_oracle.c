@@ -43,6 +43,7 @@ typedef struct {
     int32_t n_flows, n_group, n_early_every, n_early_size, n_mels;
     int32_t up_stride, up_kernel, up_pad;           /* ConvTranspose1d(n_mels, n_mels, k, stride, pad, groups=n_mels) */
     int32_t res_ch, dil_ch, skip_ch, depth, radix;  /* WN */
+    int32_t bias;                                   /* WN(bias=True) (waveglow.py:58): every conv of the WN carries a bias */
 } wgo_config;
 
 static void *xmalloc(size_t n)
@@ -299,9 +300,11 @@ static void upsample_bwd(const wgo_config *cf, const real *w, const float *h, in
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
     int in_ch, aux, C, Cd, Cs, depth, radix;
+    int bias;   /* the table then continues behind `end` with V.bias, start.bias, depth x (W.bias, W_o.bias), end.bias */
 } wn_dims;
 
-/* number of parameter-table entries of one WN: V(g,v) start(g,v) depth*(W g,v ; W_o g,v) end */
+/* number of parameter-table entries of one WN: V(g,v) start(g,v) depth*(W g,v ; W_o g,v) end  [+ the biases] */
+static int wn_entries(int depth, int bias) { return 4 + 4 * depth + 1 + (bias ? 2 + 2 * depth + 1 : 0); }
 static int wo_rows(const wn_dims *d, int i) { return i == d->depth - 1 ? d->Cs : d->C + d->Cs; }
 
 typedef struct {
@@ -310,6 +313,8 @@ typedef struct {
     real **W;     /* depth x [2Cd][C][radix] */
     real **Wo;    /* depth x [rows_i][Cd] */
     real *end;    /* [2 in_ch][Cs] */
+    const float *bV, *bS, *bE;     /* biases (views of the parameter table; NULL without bias): [2Cd*depth], [C], [2 in_ch] */
+    const float **bW, **bWo;       /* depth x [2Cd], depth x [rows_i] */
 } wn_weights;
 
 static void wn_weights_build(const wn_dims *d, const float *const *p, wn_weights *w)
@@ -329,13 +334,40 @@ static void wn_weights_build(const wn_dims *d, const float *const *p, wn_weights
     const float *e = p[4 + 4 * d->depth];
     w->end = ralloc((size_t)2 * d->in_ch * d->Cs);
     for (long j = 0; j < (long)2 * d->in_ch * d->Cs; ++j) w->end[j] = (real)e[j];
+    w->bV = w->bS = w->bE = NULL;
+    w->bW = (const float **)xmalloc(sizeof(float *) * d->depth);
+    w->bWo = (const float **)xmalloc(sizeof(float *) * d->depth);
+    for (int i = 0; i < d->depth; ++i) w->bW[i] = w->bWo[i] = NULL;
+    if (d->bias) {
+        const float *const *b = p + 4 + 4 * d->depth + 1;
+        w->bV = b[0]; w->bS = b[1];
+        for (int i = 0; i < d->depth; ++i) { w->bW[i] = b[2 + 2 * i]; w->bWo[i] = b[3 + 2 * i]; }
+        w->bE = b[2 + 2 * d->depth];
+    }
+}
+/* out[r][t] += b[r] */
+static void add_bias(real *out, int rows, int T, const float *b)
+{
+    if (!b) return;
+    for (int r = 0; r < rows; ++r)
+        for (int t = 0; t < T; ++t) out[(long)r * T + t] += (real)b[r];
+}
+/* db[r] += sum_t a[r][t] */
+static void bias_grad(real *db, const real *a, int rows, int T)
+{
+    if (!db) return;
+    for (int r = 0; r < rows; ++r) {
+        double s = 0;
+        for (int t = 0; t < T; ++t) s += (double)a[(long)r * T + t];
+        db[r] += (real)s;
+    }
 }
 
 static void wn_weights_free(const wn_dims *d, wn_weights *w)
 {
     free(w->V); free(w->start); free(w->end);
     for (int i = 0; i < d->depth; ++i) { free(w->W[i]); free(w->Wo[i]); }
-    free(w->W); free(w->Wo);
+    free(w->W); free(w->Wo); free((void *)w->bW); free((void *)w->bWo);
 }
 
 /* activations of ONE batch item kept for the backward pass */
@@ -366,6 +398,7 @@ static void wn_forward(const wn_dims *d, const wn_weights *w, const real *xa, co
     real *gate = ralloc((size_t)DT);
     memset(s->h, 0, sizeof(real) * CT);
     conv_tap_acc(s->h, d->C, T, w->start, d->in_ch, 1, xa, d->in_ch, 0);          /* waveglow.py:99 */
+    add_bias(s->h, d->C, T, w->bS);
     memset(s->skip, 0, sizeof(real) * d->Cs * T);
     for (int i = 0; i < d->depth; ++i) {
         const int dil = 1 << i;                                                     /* waveglow.py:61 */
@@ -375,6 +408,8 @@ static void wn_forward(const wn_dims *d, const wn_weights *w, const real *xa, co
             conv_tap_acc(xy, 2 * d->Cd, T, w->W[i] + k, (long)d->C * d->radix, d->radix, hi, d->C,
                          (k - (d->radix - 1) / 2) * dil);
         conv_tap_acc(xy, 2 * d->Cd, T, w->V + (long)i * 2 * d->Cd * d->aux, d->aux, 1, y, d->aux, 0); /* :100-102 */
+        add_bias(xy, 2 * d->Cd, T, w->bW[i]);
+        add_bias(xy, 2 * d->Cd, T, w->bV ? w->bV + (long)i * 2 * d->Cd : NULL);
         real *tw = s->tw + i * DT, *sf = s->sf + i * DT;
 #pragma omp parallel for schedule(static)
         for (long j = 0; j < DT; ++j) {                                             /* waveglow.py:13-15,43-44 */
@@ -385,6 +420,7 @@ static void wn_forward(const wn_dims *d, const wn_weights *w, const real *xa, co
         const int rows = wo_rows(d, i);
         memset(o, 0, sizeof(real) * rows * T);
         conv_tap_acc(o, rows, T, w->Wo[i], d->Cd, 1, gate, d->Cd, 0);               /* waveglow.py:45 */
+        add_bias(o, rows, T, w->bWo[i]);
         const real *sk = o;
         if (i < d->depth - 1) {                                                     /* waveglow.py:46 */
             real *hn = s->h + (i + 1) * CT;
@@ -395,12 +431,14 @@ static void wn_forward(const wn_dims *d, const wn_weights *w, const real *xa, co
     }
     memset(out, 0, sizeof(real) * 2 * d->in_ch * T);
     conv_tap_acc(out, 2 * d->in_ch, T, w->end, d->Cs, 1, s->skip, d->Cs, 0);        /* waveglow.py:105 */
+    add_bias(out, 2 * d->in_ch, T, w->bE);
     free(xy); free(o); free(gate);
 }
 
 /* gradient tables of one WN, in effective-weight space, accumulated over the batch */
 typedef struct {
     real *V, *start, **W, **Wo, *end;
+    real *bV, *bS, **bW, **bWo, *bE;      /* NULL without bias */
 } wn_wgrads;
 
 static void wn_wgrads_alloc(const wn_dims *d, wn_wgrads *g)
@@ -414,14 +452,23 @@ static void wn_wgrads_alloc(const wn_dims *d, wn_wgrads *g)
         g->W[i] = rzalloc((size_t)2 * d->Cd * d->C * d->radix);
         g->Wo[i] = rzalloc((size_t)wo_rows(d, i) * d->Cd);
     }
+    g->bV = g->bS = g->bE = NULL;
+    g->bW = (real **)xmalloc(sizeof(real *) * d->depth);
+    g->bWo = (real **)xmalloc(sizeof(real *) * d->depth);
+    for (int i = 0; i < d->depth; ++i) g->bW[i] = g->bWo[i] = NULL;
+    if (d->bias) {
+        g->bV = rzalloc((size_t)2 * d->Cd * d->depth); g->bS = rzalloc((size_t)d->C); g->bE = rzalloc((size_t)2 * d->in_ch);
+        for (int i = 0; i < d->depth; ++i) { g->bW[i] = rzalloc((size_t)2 * d->Cd); g->bWo[i] = rzalloc((size_t)wo_rows(d, i)); }
+    }
 }
 static void wn_wgrads_free(const wn_dims *d, wn_wgrads *g)
 {
     free(g->V); free(g->start); free(g->end);
-    for (int i = 0; i < d->depth; ++i) { free(g->W[i]); free(g->Wo[i]); }
-    free(g->W); free(g->Wo);
+    for (int i = 0; i < d->depth; ++i) { free(g->W[i]); free(g->Wo[i]); free(g->bW[i]); free(g->bWo[i]); }
+    free(g->W); free(g->Wo); free(g->bW); free(g->bWo); free(g->bV); free(g->bS); free(g->bE);
 }
 
+static void r2f(const real *a, float *b, long n);
 /* map effective-weight gradients through the weight-norm backward into the float grad table */
 static void wn_wgrads_emit(const wn_dims *d, const float *const *p, const wn_wgrads *g, float *const *out)
 {
@@ -433,6 +480,13 @@ static void wn_wgrads_emit(const wn_dims *d, const float *const *p, const wn_wgr
     }
     float *e = out[4 + 4 * d->depth];
     for (long j = 0; j < (long)2 * d->in_ch * d->Cs; ++j) e[j] = (float)g->end[j];
+    if (d->bias) {
+        float *const *b = out + 4 + 4 * d->depth + 1;
+        r2f(g->bV, b[0], (long)2 * d->Cd * d->depth);
+        r2f(g->bS, b[1], d->C);
+        for (int i = 0; i < d->depth; ++i) { r2f(g->bW[i], b[2 + 2 * i], 2 * d->Cd); r2f(g->bWo[i], b[3 + 2 * i], wo_rows(d, i)); }
+        r2f(g->bE, b[2 + 2 * d->depth], 2 * d->in_ch);
+    }
 }
 
 /* What autograd.grad(cat(log_s,t), [xa]+params(+y), grad_outputs=G) evaluates
@@ -449,6 +503,7 @@ static void wn_backward(const wn_dims *d, const wn_weights *w, const wn_saved *s
     real *gate = ralloc((size_t)DT);
     /* end: out = W_end . S */
     wgrad_tap_acc(g->end, d->Cs, 1, G, 2 * d->in_ch, s->skip, d->Cs, T, 0);
+    bias_grad(g->bE, G, 2 * d->in_ch, T);
     conv_tap_acc(dS, d->Cs, T, w->end, 1, d->Cs, G, 2 * d->in_ch, 0);  /* W_end^T . G */
     for (int i = d->depth - 1; i >= 0; --i) {
         const int dil = 1 << i;
@@ -460,6 +515,7 @@ static void wn_backward(const wn_dims *d, const wn_weights *w, const wn_saved *s
         else { memcpy(dout, dh, sizeof(real) * CT); memcpy(dout + CT, dS, sizeof(real) * ST); }
         for (long j = 0; j < DT; ++j) gate[j] = tw[j] * sf[j];
         wgrad_tap_acc(g->Wo[i], d->Cd, 1, dout, rows, gate, d->Cd, T, 0);
+        bias_grad(g->bWo[i], dout, rows, T);
         memset(dgate, 0, sizeof(real) * DT);
         conv_tap_acc(dgate, d->Cd, T, w->Wo[i], 1, d->Cd, dout, rows, 0);  /* W_o^T . do */
 #pragma omp parallel for schedule(static)
@@ -471,6 +527,8 @@ static void wn_backward(const wn_dims *d, const wn_weights *w, const wn_saved *s
             wgrad_tap_acc(g->W[i] + k, (long)d->C * d->radix, d->radix, dxy, 2 * d->Cd, hi, d->C, T,
                           (k - (d->radix - 1) / 2) * dil);
         wgrad_tap_acc(g->V + (long)i * 2 * d->Cd * d->aux, d->aux, 1, dxy, 2 * d->Cd, y, d->aux, T, 0);
+        bias_grad(g->bW[i], dxy, 2 * d->Cd, T);
+        bias_grad(g->bV ? g->bV + (long)i * 2 * d->Cd : NULL, dxy, 2 * d->Cd, T);
         if (dy) conv_tap_acc(dy, d->aux, T, w->V + (long)i * 2 * d->Cd * d->aux, 1, d->aux, dxy, 2 * d->Cd, 0);
         /* dh_i = (i<last ? dh_{i+1} : 0) + sum_k W[:,:,k]^T dxy[t-(k-mid)d]   (residual path waveglow.py:46) */
         if (i == d->depth - 1) memset(dh, 0, sizeof(real) * CT);
@@ -479,6 +537,7 @@ static void wn_backward(const wn_dims *d, const wn_weights *w, const wn_saved *s
                          -(k - (d->radix - 1) / 2) * dil);
     }
     wgrad_tap_acc(g->start, d->in_ch, 1, dh, d->C, xa, d->in_ch, T, 0);
+    bias_grad(g->bS, dh, d->C, T);
     memset(dxa, 0, sizeof(real) * d->in_ch * T);
     conv_tap_acc(dxa, d->in_ch, T, w->start, 1, d->in_ch, dh, d->C, 0);
     free(dS); free(dh); free(dout); free(dgate); free(dxy); free(gate);
@@ -605,7 +664,7 @@ WGO_API int wgo_invconv_reverse_backward(const float *W, int c, const float *xo,
 
 static void wn_dims_fill(wn_dims *d, int in_ch, int aux, int C, int Cd, int Cs, int depth, int radix)
 {
-    d->in_ch = in_ch; d->aux = aux; d->C = C; d->Cd = Cd; d->Cs = Cs; d->depth = depth; d->radix = radix;
+    d->in_ch = in_ch; d->aux = aux; d->C = C; d->Cd = Cd; d->Cs = Cs; d->depth = depth; d->radix = radix; d->bias = 0;
 }
 
 /* AffineCouplingBlock forward / reverse (efficient_modules.py:77-96); x is [B][2*in_ch][T].
@@ -738,7 +797,7 @@ WGO_API int wgo_coupling_reverse_backward(int in_ch, int aux, int C, int Cd, int
  *   for k: WNs.{k}.F.{V.g, V.v, start.g, start.v, layers.{i}.{W.g, W.v, W_o.g, W_o.v}, end.weight}
  * a NULL `*_g` entry means the conv carries a plain weight in the `*_v` slot.
  * ---------------------------------------------------------------------------------------- */
-WGO_API int wgo_param_count(const wgo_config *cf) { return 3 + cf->n_flows + cf->n_flows * (4 + 4 * cf->depth + 1); }
+WGO_API int wgo_param_count(const wgo_config *cf) { return 3 + cf->n_flows + cf->n_flows * wn_entries(cf->depth, cf->bias); }
 
 static int flow_channels(const wgo_config *cf, int k)
 {
@@ -747,7 +806,7 @@ static int flow_channels(const wgo_config *cf, int k)
         if (j % cf->n_early_every == 0) c -= cf->n_early_size;          /* waveglow.py:140-142 */
     return c;
 }
-static int wn_table_off(const wgo_config *cf, int k) { return 3 + cf->n_flows + k * (4 + 4 * cf->depth + 1); }
+static int wn_table_off(const wgo_config *cf, int k) { return 3 + cf->n_flows + k * wn_entries(cf->depth, cf->bias); }
 
 typedef struct {
     const wgo_config *cf;
@@ -777,6 +836,7 @@ static void model_weights_build(const wgo_config *cf, const float *const *p, mod
         lu_logdet_inverse(m->W[k], c, &la, &sg, m->Wi[k]);
         m->logdetW[k] = sg > 0 ? la : (real)NAN;
         wn_dims_fill(&m->d[k], c / 2, cf->n_mels, cf->res_ch, cf->dil_ch, cf->skip_ch, cf->depth, cf->radix);
+        m->d[k].bias = cf->bias;
         wn_weights_build(&m->d[k], p + wn_table_off(cf, k), &m->w[k]);
     }
 }

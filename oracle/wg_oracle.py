@@ -18,18 +18,18 @@ class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n_flows", "n_group", "n_early_every", "n_early_size", "n_mels",
         "up_stride", "up_kernel", "up_pad",
-        "res_ch", "dil_ch", "skip_ch", "depth", "radix")]
+        "res_ch", "dil_ch", "skip_ch", "depth", "radix", "bias")]
 
 
 def make_config(flows, n_group, n_early_every, n_early_size, hop_size, n_mels,
                 dilation_channels=256, residual_channels=256, skip_channels=256,
-                depth=8, radix=3, **_unused):
+                depth=8, radix=3, bias=False, **_unused):
     """Same keyword names as the reference's WaveGlow(**arch.args) (model/waveglow.py:109-118)."""
     up = hop_size // n_group                      # waveglow.py:125
     k = up * 2 + 1                                # :126
     pad = k // 2 - up // 2                        # :128-129
     return Config(flows, n_group, n_early_every, n_early_size, n_mels, up, k, pad,
-                  residual_channels, dilation_channels, skip_channels, depth, radix)
+                  residual_channels, dilation_channels, skip_channels, depth, radix, int(bool(bias)))
 
 
 def build(force=False):

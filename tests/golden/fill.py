@@ -69,8 +69,10 @@ def flow_channels(cfg, k):
     return c
 
 
-def wn_param_specs(prefix, in_ch, aux, C, Cd, Cs, depth, radix):
-    """(name, shape, kind) of one WN in the reference's parameter order (model/waveglow.py:70-96)."""
+def wn_param_specs(prefix, in_ch, aux, C, Cd, Cs, depth, radix, bias=False):
+    """(name, shape, kind) of one WN in the reference's parameter order (model/waveglow.py:70-96).  bias=True (waveglow.py:58): the
+    biases follow behind `end.weight` -- V, start, per layer (W, W_o), end -- which is the order of the C ABI's / the oracle's table
+    (the reference's own named_parameters() interleaves them; state dicts go by name, so only the table order is ours)."""
     specs = [(prefix + "V.weight_g", (2 * Cd * depth, 1, 1), "g"), (prefix + "V.weight_v", (2 * Cd * depth, aux, 1), "v"),
              (prefix + "start.weight_g", (C, 1, 1), "g"), (prefix + "start.weight_v", (C, in_ch, 1), "v")]
     for i in range(depth):
@@ -80,6 +82,12 @@ def wn_param_specs(prefix, in_ch, aux, C, Cd, Cs, depth, radix):
                   (prefix + "layers.%d.W_o.weight_g" % i, (rows, 1, 1), "g"),
                   (prefix + "layers.%d.W_o.weight_v" % i, (rows, Cd, 1), "v")]
     specs.append((prefix + "end.weight", (2 * in_ch, Cs, 1), "end"))
+    if bias:
+        specs += [(prefix + "V.bias", (2 * Cd * depth,), "bias"), (prefix + "start.bias", (C,), "bias")]
+        for i in range(depth):
+            rows = Cs if i == depth - 1 else C + Cs
+            specs += [(prefix + "layers.%d.W.bias" % i, (2 * Cd,), "bias"), (prefix + "layers.%d.W_o.bias" % i, (rows,), "bias")]
+        specs.append((prefix + "end.bias", (2 * in_ch,), "bias"))
     return specs
 
 
@@ -95,7 +103,7 @@ def model_param_specs(cfg):
     for k in range(cfg["flows"]):
         c = flow_channels(cfg, k)
         specs += wn_param_specs("WNs.%d.F." % k, c // 2, M, cfg["residual_channels"], cfg["dilation_channels"],
-                                cfg["skip_channels"], cfg["depth"], cfg["radix"])
+                                cfg["skip_channels"], cfg["depth"], cfg["radix"], bias=cfg.get("bias", False))
     return specs
 
 
@@ -140,6 +148,8 @@ CONFIGS = {
     "c2": dict(flows=12, n_group=8, n_early_every=4, n_early_size=2, hop_size=256, n_mels=80,
                dilation_channels=256, residual_channels=256, skip_channels=256, depth=8, radix=3),
 }
+# WN(bias=True) (model/waveglow.py:58; no shipped config sets it): the micro model with a bias on every conv of every WN
+CONFIGS["micro_bias"] = dict(CONFIGS["micro"], bias=True)
 # the WaveGlow core of WSRGlow (model/wsrglow.py:22-25: n_group = hop = 8r, stride-1 upsampler, very wide conditioning), scaled
 # down: odd conditioning width (not a multiple of 8), 16 squeezed channels, upsample factor 1
 CONFIGS["wsr_like"] = dict(flows=4, n_group=16, n_early_every=2, n_early_size=2, hop_size=16, n_mels=83,
@@ -152,6 +162,7 @@ CONFIGS["wsr3"] = dict(flows=12, n_group=24, n_early_every=4, n_early_size=2, ho
 WSR_TABLES = [("mu_enc.1.weight", (256, 400)), ("angle_embed.embed.weight", (120, 50))]
 SHAPES = {  # (batch, samples, mel frames)
     "micro": (2, 512, 8),
+    "micro_bias": (2, 512, 8),
     "c1": (2, 4000, 16),
     "c2": (1, 16000, 63),
     "wsr_like": (2, 16 * 300, 300),
