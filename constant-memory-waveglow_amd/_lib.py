@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WGFLOW_LIB") or os.path.join(_HERE, "csrc", "libwgflow.so")   # WGFLOW_LIB: developer A/B builds
 _LIB = None
 
-ABI_VERSION = 4          # include/wgflow.h WG_ABI_VERSION (4: wg_timer_read_info, wg_stat_wgrad16t_launches; WaveFlow in every precision)
+ABI_VERSION = 5          # include/wgflow.h WG_ABI_VERSION (5: wg_config / wg_wn_dims gained bias)
 ABI_SYMBOLS = [
     "wg_strerror", "wg_abi_version", "wg_param_count", "wg_packed_bytes", "wg_workspace_bytes",
     "wg_wn_param_count", "wg_wn_packed_bytes", "wg_coupling_workspace_bytes", "wg_invconv_workspace_bytes",
@@ -28,7 +28,8 @@ K_CONV_STORE, K_CONV_GATE, K_CONV_RESSKIP, K_CONV_DGATE, K_WGRAD = range(5)
 class WgConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "n_flows", "n_group", "n_early_every", "n_early_size", "n_mels",
-        "up_stride", "up_kernel", "up_pad", "res_ch", "dil_ch", "skip_ch", "depth", "radix", "precision", "reverse_mode", "keep_activations")]
+        "up_stride", "up_kernel", "up_pad", "res_ch", "dil_ch", "skip_ch", "depth", "radix", "precision", "reverse_mode", "keep_activations",
+        "bias")]
 
 
 class WgWfConfig(C.Structure):
@@ -36,7 +37,7 @@ class WgWfConfig(C.Structure):
 
 
 class WgWnDims(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("in_ch", "aux_ch", "res_ch", "dil_ch", "skip_ch", "depth", "radix", "precision")]
+    _fields_ = [(n, C.c_int32) for n in ("in_ch", "aux_ch", "res_ch", "dil_ch", "skip_ch", "depth", "radix", "precision", "bias")]
 
 
 PREC_F32, PREC_BF16X3, PREC_BF16X3_PLANES = 0, 1, 2

@@ -191,6 +191,7 @@ enum { AFF_FWD = 0, AFF_REV = 1, AFF_BWD = 2, AFF_BWD_REV = 3, AFF_RAW = 4 };
 
 struct AffineArgs {
     const float *endT;      // [Cs][32]  endT[k][m] = W_end[m][k] (m < 2*ic, else 0)
+    const float *bias;      // nullable: end.bias [2*ic] (WN(bias=True))
     PRef S;                 // skip plane
     int Cs, ic;
     PRef X;                 // flow state, ch0 = first channel of this flow (xa rows [0,ic), xb rows [ic,2ic))
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256) void end_affine_kernel(const AffineArgs a)
     if (wave == 0) {
 #pragma unroll
         for (int m = 0; m < NR; ++m)
-            if (m < rows) tile[m][lane] = (acc[m] + part[0][m][lane]) + (part[1][m][lane] + part[2][m][lane]);
+            if (m < rows) tile[m][lane] = (acc[m] + part[0][m][lane]) + (part[1][m][lane] + part[2][m][lane]) + (a.bias ? a.bias[m] : 0.f);
     }
     __syncthreads();
 

@@ -96,6 +96,14 @@ struct TimerScope {
 struct WnD {
     int ic, aux, C, Cd, Cs, depth, radix;
     int prec = 0;
+    // WN(bias=True) (model/waveglow.py:58): every conv of the WN has a bias.  Built WITHOUT touching a kernel: a bias is one more K
+    // segment -- 32 channels of a plane of ones -- whose weight rows hold the bias (row 0; two rows where two biases meet, the dilated
+    // conv's and V's; one row per layer in the all-layers skip product), and in the weight-gradient products one more block of 32
+    // B columns whose column 0 is the bias gradient.  The parameter table continues behind `end` with V.bias, start.bias,
+    // depth x (W.bias, W_o.bias), end.bias.
+    int bias = 0;
+    int kb() const { return bias ? 32 : 0; }
+    int pb(int j) const { return 4 + 4 * depth + 1 + j; }    // table index of bias j: V, start, (W_i, W_o_i) x depth, end
     // WaveFlow's WN2D (model/waveflow.py:70-135) is this same network with a 3x3 kernel over (height, time): radix 9, tap
     // kt = 3 kh + kw reads plane row r + (kh - 2) * hd[layer] (causal along the height axis) at time shift (kw - 1) * 2^layer, and
     // the conditioning has one plane row per item.  The planes then hold one height row per plane row (Geo::rows).
@@ -108,7 +116,7 @@ struct WnD {
     }
     int auxp() const { return rup(aux, WG_BK); }
     int wo_rows(int i) const { return i == depth - 1 ? Cs : C + Cs; }
-    int nparams() const { return 4 + 4 * depth + 1; }
+    int nparams() const { return 4 + 4 * depth + 1 + (bias ? 2 + 2 * depth + 1 : 0); }
     int maxdil() const { return 1 << (depth - 1); }
 };
 
@@ -139,7 +147,9 @@ inline bool grouped_wgrad(int prec, const WnD &d)
 #if defined(WG_OPT_NO_WGRAD_GROUP)
     (void)prec; (void)d; return false;
 #else
-    return prec == 2 && d.depth >= 2 && d.depth <= WG_GRP_MAX && d.radix + 1 <= WG_MAX_SEG;
+    // (WnD::bias: the plane of ones would be a third distinct B plane of a group, WgradGrp::b_plane holds two -- such WNs take the
+    // per-layer launches; no shipped config sets bias)
+    return prec == 2 && !d.bias && d.depth >= 2 && d.depth <= WG_GRP_MAX && d.radix + 1 <= WG_MAX_SEG;
 #endif
 }
 inline bool fused_skip(const WnD &d)
@@ -147,7 +157,7 @@ inline bool fused_skip(const WnD &d)
 #if defined(WG_OPT_NO_FUSED_SKIP)
     (void)d; return false;
 #else
-    return d.depth <= WG_MAX_SEG;
+    return d.depth + (d.bias ? 1 : 0) <= WG_MAX_SEG;
 #endif
 }
 
@@ -180,6 +190,7 @@ int wn_check(const WnD &d)
     if (d.ic < 1 || d.aux < 1 || d.depth < 1 || d.depth > 16) return WG_EINVAL;
     if (d.mode2d ? d.radix != 9 : (d.radix != 1 && d.radix != 3)) return WG_EUNSUPPORTED;   // 1-D: kernels 1 and 3; 2-D: 3x3
     if (d.C % 32 || d.Cd % 32 || d.Cs % 32) return WG_EUNSUPPORTED;       // MFMA tile granularity
+    if (d.bias && (d.mode2d || d.radix + 2 > WG_MAX_SEG)) return WG_EUNSUPPORTED;   // the ones segment needs a free K-segment slot (WN2D: 9 taps + conditioning fill all ten)
     if (2 * d.ic > WG_MAXC) return WG_EUNSUPPORTED;                       // end-conv rows handled by one MFMA tile
     if (d.C * d.radix > WG_FIN_MAXCOLS || d.aux > WG_FIN_MAXCOLS || d.Cd > WG_FIN_MAXCOLS) return WG_EUNSUPPORTED;
     return 0;
@@ -190,7 +201,7 @@ int wn_check(const WnD &d)
 // ------------------------------------------------------------------------------------------------
 struct WnPack {
     size_t scale_V, scale_start, scale_W[16], scale_Wo[16];
-    size_t startT, startN, endT, endN;
+    size_t startT, startN, endT, endN, bias_end;
     size_t Acat[16], WoT[16], WoN[16], WT[16], VN[16], WskT, VNall;
     int ld_startT, ld_startN, ld_endN, ld_Acat, ld_WoT[16], ld_WoN, ld_WT, ld_VN, ld_WskT;
     int kp_start, kp_end, kcat;
@@ -221,21 +232,23 @@ WnPack wn_pack_layout(const WnD &d)
     L.ld_VN = rup(d.aux, WG_TILE);
     // a matrix = fp32 k-major [K][ld] followed by its split bf16 image (mat_img)
     auto take_mat = [&](int K, int ld) { return take(mat_floats(K, ld)); };
-    L.startT = take_mat(L.kp_start, L.ld_startT);
+    const int kb = d.kb();                                   // rows of the ones segment behind a forward matrix's K rows (WnD::bias)
+    L.startT = take_mat(L.kp_start + kb, L.ld_startT);
     L.startN = take_mat(d.C, L.ld_startN);
     L.endT = take((size_t)d.Cs * 32);
     L.endN = take_mat(L.kp_end, L.ld_endN);
     for (int i = 0; i < d.depth; ++i) {
         L.ld_WoT[i] = rup(d.wo_rows(i), WG_TILE);
-        L.Acat[i] = take_mat(L.kcat, L.ld_Acat);
-        L.WoT[i] = take_mat(d.Cd, L.ld_WoT[i]);
+        L.Acat[i] = take_mat(L.kcat + kb, L.ld_Acat);
+        L.WoT[i] = take_mat(d.Cd + kb, L.ld_WoT[i]);
         L.WoN[i] = take_mat(d.wo_rows(i), L.ld_WoN);
         L.WT[i] = take_mat(d.radix * 2 * d.Cd, L.ld_WT);
         L.VN[i] = take_mat(2 * d.Cd, L.ld_VN);
     }
     // the skip rows of every layer's W_o, stacked along K: skip = sum_i Wskip_i gate_i as ONE product over all the gates
     L.ld_WskT = rup(d.Cs, WG_TILE);
-    L.WskT = take_mat(d.depth * d.Cd, L.ld_WskT);
+    L.WskT = take_mat(d.depth * d.Cd + kb, L.ld_WskT);
+    L.bias_end = take(32);
     // V^T of every layer stacked along K: dy = sum_i V_i^T dxy_i as ONE product over all the layers' dxy (fused_dy)
     L.VNall = take_mat(d.depth * 2 * d.Cd, L.ld_VN);
     L.total = off;
@@ -322,6 +335,25 @@ void wn_pack_mats(JobBatch &jb, const WnD &d, const WnPack &L, const float *cons
             jb.pack(pk + L.VNall + (size_t)i * 2 * d.Cd * L.ld_VN, L.ld_VN, 2 * d.Cd, L.ld_VN, 1, 2 * d.Cd, d.aux, 0,
                     vV + (size_t)i * 2 * d.Cd * d.aux, pk + L.scale_V + (size_t)i * 2 * d.Cd, d.aux, 1, 0);
     }
+    if (!d.bias) return;
+    // WnD::bias: the 32 rows of the ones segment behind each forward matrix.  A bias row is a mode-0 job with ONE k (ni = 1, so = 1):
+    // dst[0][m] = bias[perm(m)]; `Kp` rows of the job's region beyond the first are zero filled.  Jobs of one launch run concurrently,
+    // so no two of them cover the same row.
+    auto bias_rows = [&](float *mat, int ld, int row, int nrows, int nvalid, int half, const float *b) {
+        jb.pack(mat + (size_t)row * ld, ld, nrows, ld, 0, nvalid, 1, half, b, ones, 1, 1, 0);
+    };
+    const float *bV = p[d.pb(0)], *bS = p[d.pb(1)], *bE = p[d.pb(2 + 2 * d.depth)];
+    bias_rows(pk + L.startT, L.ld_startT, L.kp_start, 32, d.C, 0, bS);
+    for (int i = 0; i < d.depth; ++i) {
+        const float *bW = p[d.pb(2 + 2 * i)], *bWo = p[d.pb(3 + 2 * i)];
+        const int rows = d.wo_rows(i);
+        bias_rows(pk + L.Acat[i], L.ld_Acat, L.kcat, 1, 2 * d.Cd, d.Cd, bW);                              // row 0: the dilated conv's bias
+        bias_rows(pk + L.Acat[i], L.ld_Acat, L.kcat + 1, 31, 2 * d.Cd, d.Cd, bV + (size_t)i * 2 * d.Cd);  // row 1: V's slice; rows 2.. zero
+        bias_rows(pk + L.WoT[i], L.ld_WoT[i], d.Cd, 32, rows, 0, bWo);
+        bias_rows(pk + L.WskT, L.ld_WskT, d.depth * d.Cd + i, 1, d.Cs, 0, bWo + (rows - d.Cs));           // row i: layer i's skip rows
+    }
+    bias_rows(pk + L.WskT, L.ld_WskT, d.depth * d.Cd + d.depth, 32 - d.depth, 0, 0, ones);                // (zero rows)
+    jb.pack(pk + L.bias_end, 32, 1, 32, 1, 1, 2 * d.ic, 0, bE, ones, 2 * d.ic, 1, 0);                     // end.bias, read by end_affine_kernel
 }
 
 struct ImgBatch {
@@ -353,7 +385,9 @@ struct ImgBatch {
 void wn_pack_images(ImgBatch &ib, const WnD &d, const WnPack &L, float *pk)
 {
     int one[WG_MAX_SEG];
-    one[0] = L.kp_start; ib.add(pk + L.startT, L.ld_startT, one, 1);
+    const int nb = d.bias ? 1 : 0;                           // WnD::bias: the ones segment closes the segment list of every forward matrix
+    one[1] = 32;
+    one[0] = L.kp_start; ib.add(pk + L.startT, L.ld_startT, one, 1 + nb);
     one[0] = d.C;        ib.add(pk + L.startN, L.ld_startN, one, 1);
     one[0] = L.kp_end;   ib.add(pk + L.endN, L.ld_endN, one, 1);
     for (int i = 0; i < d.depth; ++i) {
@@ -361,8 +395,9 @@ void wn_pack_images(ImgBatch &ib, const WnD &d, const WnPack &L, float *pk)
         int ns = 0;
         for (int kt = 0; kt < d.radix; ++kt) sg[ns++] = d.C;
         sg[ns++] = d.auxp();
+        if (nb) sg[ns++] = 32;
         ib.add(pk + L.Acat[i], L.ld_Acat, sg, ns);
-        one[0] = d.Cd; ib.add(pk + L.WoT[i], L.ld_WoT[i], one, 1);
+        one[0] = d.Cd; ib.add(pk + L.WoT[i], L.ld_WoT[i], one, 1 + nb);
         ns = 0;
         if (i < d.depth - 1) sg[ns++] = d.C;
         sg[ns++] = d.Cs;
@@ -372,10 +407,11 @@ void wn_pack_images(ImgBatch &ib, const WnD &d, const WnPack &L, float *pk)
         ib.add(pk + L.WT[i], L.ld_WT, sg, ns);
         one[0] = 2 * d.Cd; ib.add(pk + L.VN[i], L.ld_VN, one, 1);
     }
-    if (d.depth <= WG_MAX_SEG) {                             // WskT: one K segment of Cd rows per layer (deeper WNs keep the per-layer skip)
+    if (d.depth + nb <= WG_MAX_SEG) {                        // WskT: one K segment of Cd rows per layer (deeper WNs keep the per-layer skip)
         int sgs[WG_MAX_SEG];
         for (int i = 0; i < d.depth; ++i) sgs[i] = d.Cd;
-        ib.add(pk + L.WskT, L.ld_WskT, sgs, d.depth);
+        if (nb) sgs[d.depth] = 32;
+        ib.add(pk + L.WskT, L.ld_WskT, sgs, d.depth + nb);
         for (int i = 0; i < d.depth; ++i) sgs[i] = 2 * d.Cd;
         if (fused_dy(d)) ib.add(pk + L.VNall, L.ld_VN, sgs, d.depth);
     }
@@ -400,9 +436,10 @@ WnD flow_wn(const wg_config *cf, int k)
     d.ic = flow_channels(cf, k) / 2;
     d.aux = cf->n_mels; d.C = cf->res_ch; d.Cd = cf->dil_ch; d.Cs = cf->skip_ch; d.depth = cf->depth; d.radix = cf->radix;
     d.prec = cf->precision;
+    d.bias = cf->bias ? 1 : 0;
     return d;
 }
-int wn_table_off(const wg_config *cf, int k) { return 3 + cf->n_flows + k * (4 + 4 * cf->depth + 1); }
+int wn_table_off(const wg_config *cf, int k) { return 3 + cf->n_flows + k * flow_wn(cf, 0).nparams(); }
 
 struct ModelPack {
     size_t ones, lu, up_scale, up_w, up_bias, wn[WG_MAX_FLOWS];
@@ -537,6 +574,7 @@ struct WnWs {               // plane bases (float offsets) of one WN's activatio
     size_t HS[16], gateS[16], XaS, GS, dSS, dHS, dxyS;   // S-planes (precision 2), sized like the fp32 plane of the same tensor
     size_t dxy_step = 0, dxyS_step = 0;                  // fused_dy: layer i's dxy at dxy + i * step (0: one buffer for all layers)
     size_t dHS_step = 0;                                 // grouped_wgrad: dh_i at dHS + i * step (0: accumulated in place in one plane)
+    size_t ones = 0, onesS = 0;                          // WnD::bias: 32 channels of ones on [0, T) (fp32 plane, S-plane), filled by every WN pass
     int nH;                 // 2 (ping-pong) or depth
     size_t slab_floats;
 };
@@ -564,6 +602,10 @@ void wn_ws_layout(Bump &bp, const WnD &d, int ic_max, const Geo &g, int mode, in
             for (int i = 1; i < d.depth && w.dxyS_step; ++i) (void)bp.take(2 * pD);
         }
     }
+    if (d.bias) {
+        w.ones = bp.take((size_t)g.B * 32 * g.P);
+        w.onesS = bp.take((size_t)g.B * 32 * g.P);
+    }
     w.nH = mode ? d.depth : 2;
     for (int i = 0; i < w.nH; ++i) w.H[i] = bp.take(pC);
     for (int i = 0; i < d.depth; ++i) {
@@ -581,23 +623,24 @@ void wn_ws_layout(Bump &bp, const WnD &d, int ic_max, const Geo &g, int mode, in
         w.dxy = bp.take(2 * pD);
         for (int i = 1; i < d.depth && w.dxy_step; ++i) (void)bp.take(2 * pD);
         size_t s = 0;
-        const int nW = rup(d.radix * rup(d.C, 32) + rup(d.aux, 32), WG_TILE);
+        const int kb = d.kb();                                   // (the ones segment: 32 more B columns in every weight-gradient product)
+        const int nW = rup(d.radix * rup(d.C, 32) + rup(d.aux, 32) + kb, WG_TILE), nO = rup(rup(d.Cd, 32) + kb, WG_TILE);
         s = std::max(s, slab_floats(g, rup(2 * d.Cd, WG_TILE), nW));
-        s = std::max(s, slab_floats(g, rup(d.C + d.Cs, WG_TILE), rup(d.Cd, WG_TILE)));
-        s = std::max(s, slab_floats(g, WG_TILE, rup(d.Cs, WG_TILE)));
+        s = std::max(s, slab_floats(g, rup(d.C + d.Cs, WG_TILE), nO));
+        s = std::max(s, slab_floats(g, WG_TILE, rup(rup(d.Cs, 32) + kb, WG_TILE)));
         s = std::max(s, slab_floats(g, rup(d.C, WG_TILE), WG_TILE));
         s = std::max(s, slab_floats(g, WG_TILE, WG_TILE));
         s = std::max(s, wgth_part_floats(2 * device_cus(), std::max(16 * d.C, 32 * d.Cs)) + 64);      // the thin products' partials (wg_thin.h)
         // room for several products' slabs (FinQueue batches the finalisations of a WN): up to 8 of the largest, at most 384 MB
         s = std::max(s, std::min((size_t)8 * s, (size_t)96 << 20));
         if (grouped_wgrad(prec, d)) {                            // both grouped products of a WN at once (run_wgrad_group_pair)
-            const size_t oneT = (size_t)rup(2 * d.Cd, WG_TILE) * nW, oneO = (size_t)rup(d.C + d.Cs, WG_TILE) * rup(d.Cd, WG_TILE);
+            const size_t oneT = (size_t)rup(2 * d.Cd, WG_TILE) * nW, oneO = (size_t)rup(d.C + d.Cs, WG_TILE) * nO;
             const int nsT = plan_wgrad_flat(g, (int)(oneT / (WG_TILE * WG_TILE)) * d.depth);
             const int nsO = plan_wgrad_flat(g, (int)(oneO / (WG_TILE * WG_TILE)) * d.depth);
             s = std::max(s, rupz((size_t)nsT * d.depth * oneT, 64) + rupz((size_t)nsO * d.depth * oneO, 64) + 4096
                             + rupz((size_t)(nsT + nsO) * d.depth * WG_SYNC_STRIDE, 64));                     // (+ the lock-step counters)
             if (g.rows == 0 && oneT / nW % 256 == 0 && rup(d.C + d.Cs, WG_TILE) % 256 == 0) {              // wgrad16t_kernel's own split
-                const WgtPlan pl = plan_wgt((int)(oneT / nW) / 256, nW / WG_TILE, rup(d.C + d.Cs, WG_TILE) / 256, rup(d.Cd, WG_TILE) / WG_TILE,
+                const WgtPlan pl = plan_wgt((int)(oneT / nW) / 256, nW / WG_TILE, rup(d.C + d.Cs, WG_TILE) / 256, nO / WG_TILE,
                                             d.depth, g.B * (g.Tt / WG16_BK));
                 if (pl.ok) s = std::max(s, rupz((size_t)pl.nslab[0] * d.depth * oneT, 64) + rupz((size_t)pl.nslab[1] * d.depth * oneO, 64) + 4096);
             }
@@ -1253,6 +1296,31 @@ struct WnRun {
     float *rs;           // mode2d: S-plane [items][2 Cd][P] for the height-axis sum of dxy
 };
 
+// WnD::bias: the plane of ones the bias rows multiply (every WN pass refills it: a workspace may have served another shape in between)
+__global__ void ones_fill_kernel(float *f32, unsigned short *hi, size_t lo_off, Geo g)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (p >= g.P) return;
+    const bool in = p >= g.H && p < g.H + g.T;
+    for (int c = 0; c < 32; ++c) f32[((size_t)b * 32 + c) * g.P + p] = in ? 1.f : 0.f;
+    if (hi) {
+        const unsigned w = in ? 0x3F803F80u : 0u;             // bf16(1.0) twice; the lo array is zero
+        const u32x4 h = {w, w, w, w}, z = {0u, 0u, 0u, 0u};
+        for (int cg = 0; cg < 4; ++cg) {
+            const size_t i = (((size_t)b * 4 + cg) * g.P + p) * 8;
+            *reinterpret_cast<u32x4 *>(hi + i) = h;
+            *reinterpret_cast<u32x4 *>(hi + lo_off + i) = z;
+        }
+    }
+}
+SegSpec ones_seg(Ctx &cx, const WnRun &r, bool fill)
+{
+    float *f = r.ws + r.w.ones, *sp = cx.prec == 2 ? r.ws + r.w.onesS : nullptr;
+    if (fill) WG_LAUNCH(cx, ones_fill_kernel, dim3((r.g.P + 255) / 256, r.g.B), dim3(256), 0, f, (unsigned short *)sp, (size_t)r.g.B * 32 * r.g.P, r.g);
+    SegSpec s = {f, 32, 0, 32, 0, sp, 32, 0};
+    return s;
+}
+
 void wn_forward(Ctx &cx, const WnRun &r)
 {
     const WnD &d = r.d;
@@ -1260,10 +1328,12 @@ void wn_forward(Ctx &cx, const WnRun &r)
     float *ws = r.ws;
     const bool sp = cx.prec == 2;
     if (sp) run_to_splane(cx, g, r.X, d.ic, ws + r.w.XaS, r.L.kp_start);      // xa -> S-plane (re-based to channel 0)
-    SegSpec s0 = {r.X.p, r.X.Cp, r.X.ch0, r.L.kp_start, 0, ws + r.w.XaS, r.L.kp_start, 0};
+    const int nb = d.bias ? 1 : 0;
+    const SegSpec sone = d.bias ? ones_seg(cx, r, true) : SegSpec{};
+    SegSpec s0[2] = {{r.X.p, r.X.Cp, r.X.ch0, r.L.kp_start, 0, ws + r.w.XaS, r.L.kp_start, 0}, sone};
     const int cols0 = (cx.row_sel1 && g.rows > 0 ? g.B / g.rows : g.B) * g.Tt;
     const bool so = s_only_chain(cx, d) && fused_skip(d) && cols0 >= WG_FUSED_SKIP_MIN_COLS;      // residual stream as S-planes only
-    run_convgemm(cx, g, r.pk + r.L.startT, r.L.ld_startT, d.C, &s0, 1, EPI_STORE, so ? pnull() : pref(ws + r.w.H[0], d.C), pnull(), pnull(),
+    run_convgemm(cx, g, r.pk + r.L.startT, r.L.ld_startT, d.C, s0, 1 + nb, EPI_STORE, so ? pnull() : pref(ws + r.w.H[0], d.C), pnull(), pnull(),
                  pnull(), pnull(), 0, 0, sp ? sref(g, ws + r.w.HS[0], d.C) : snull());             // waveglow.py:99
     // one long product (depth x Cd / 32 chunks in a row) only pays where launches are bound by bytes, not by their chunk latency chain:
     // single-utterance synthesis (2 048 columns) lost 9 % with it, the training shapes gain 2.5 % per step
@@ -1282,28 +1352,30 @@ void wn_forward(Ctx &cx, const WnRun &r)
             sg[ns++] = {Hin, d.C, 0, d.C, ts, ws + r.w.HS[hin], d.C, 0, ro, 0};
         }
         sg[ns++] = {r.Y, d.auxp(), 0, d.auxp(), 0, r.YS, d.auxp(), 0, 0, d.mode2d};
+        if (nb) sg[ns++] = sone;
         // fp32 gate plane: only the on-the-fly weight-gradient kernel still reads it (backward); the S-plane feeds W_o
         run_convgemm(cx, g, r.pk + r.L.Acat[i], r.L.ld_Acat, 2 * d.Cd, sg, ns, EPI_GATE, sp ? pnull() : pref(gate, d.Cd),
                      r.save ? pref(ws + r.w.tw[i], d.Cd) : pnull(), r.save ? pref(ws + r.w.sf[i], d.Cd) : pnull(),
                      pnull(), pnull(), 0, 0, sp ? sref(g, gateS, d.Cd) : snull());                 // waveglow.py:42-44
-        SegSpec sgt = {gate, d.Cd, 0, d.Cd, 0, gateS, d.Cd, 0};
+        SegSpec sgt[2] = {{gate, d.Cd, 0, d.Cd, 0, gateS, d.Cd, 0}, sone};
         const int last = i == d.depth - 1;
         if (fs) {
             // residual rows only: h_{i+1} = h_i + Wres_i gate_i (the first C rows of W_o); the skip rows of all layers follow in one product
             if (!last)
-                run_convgemm(cx, g, r.pk + r.L.WoT[i], r.L.ld_WoT[i], d.C, &sgt, 1, EPI_STORE, so ? pnull() : pref(Hout, d.C), pnull(), pnull(),
+                run_convgemm(cx, g, r.pk + r.L.WoT[i], r.L.ld_WoT[i], d.C, sgt, 1 + nb, EPI_STORE, so ? pnull() : pref(Hout, d.C), pnull(), pnull(),
                              so ? pnull() : pref(Hin, d.C), pnull(), 0, 0, sp ? sref(g, ws + r.w.HS[hout], d.C) : snull(),
                              so ? sref(g, ws + r.w.HS[hin], d.C) : snull());                                   // :45-46
             continue;
         }
-        run_convgemm(cx, g, r.pk + r.L.WoT[i], r.L.ld_WoT[i], d.wo_rows(i), &sgt, 1, EPI_RESSKIP, pref(Hout, d.C),
+        run_convgemm(cx, g, r.pk + r.L.WoT[i], r.L.ld_WoT[i], d.wo_rows(i), sgt, 1 + nb, EPI_RESSKIP, pref(Hout, d.C),
                      pref(ws + r.w.skip, d.Cs), pnull(), pref(Hin, d.C), pnull(), last ? 0 : d.C, i > 0,
                      (sp && !last) ? sref(g, ws + r.w.HS[hout], d.C) : snull());                   // :45-46,104
     }
     if (fs) {                                                 // cum_skip = sum_i skip_i (waveglow.py:104) = [Wskip_0 .. Wskip_{d-1}] [gate_0; ..; gate_{d-1}]
         SegSpec sk[WG_MAX_SEG];
         for (int i = 0; i < d.depth; ++i) sk[i] = {ws + r.w.gate[i], d.Cd, 0, d.Cd, 0, ws + r.w.gateS[i], d.Cd, 0};
-        run_convgemm(cx, g, r.pk + r.L.WskT, r.L.ld_WskT, d.Cs, sk, d.depth, EPI_STORE, pref(ws + r.w.skip, d.Cs), pnull(), pnull(),
+        if (nb) sk[d.depth] = sone;
+        run_convgemm(cx, g, r.pk + r.L.WskT, r.L.ld_WskT, d.Cs, sk, d.depth + nb, EPI_STORE, pref(ws + r.w.skip, d.Cs), pnull(), pnull(),
                      pnull(), pnull(), 0, 0);
     }
 }
@@ -1315,6 +1387,7 @@ void run_end_affine(Ctx &cx, const WnRun &r, int mode, PRef dX, float *log_s_out
     AffineArgs a;
     memset(&a, 0, sizeof(a));
     a.endT = r.pk + r.L.endT;
+    a.bias = r.d.bias ? r.pk + r.L.bias_end : nullptr;
     a.S = pref(r.ws + r.w.skip, r.d.Cs);
     a.Cs = r.d.Cs; a.ic = r.d.ic;
     a.X = r.X; a.dX = dX;
@@ -1331,7 +1404,7 @@ bool thin_ok(const Ctx &cx, const WnD &d)
 #if defined(WG_OPT_NO_THIN)
     return false;
 #else
-    return cx.prec == 2 && cx.fq && !cx.rec && d.ic <= 16 && d.C % 8 == 0 && d.Cs % 8 == 0 && d.C <= WGTH_MAXROWS * WGTH_THREADS &&
+    return cx.prec == 2 && cx.fq && !cx.rec && !d.bias && d.ic <= 16 && d.C % 8 == 0 && d.Cs % 8 == 0 && d.C <= WGTH_MAXROWS * WGTH_THREADS &&
            d.Cs <= WGTH_MAXROWS * WGTH_THREADS;
 #endif
 }
@@ -1420,6 +1493,17 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
     const bool gw = grouped_wgrad(cx.prec, d) && r.w.dHS_step && r.w.dxyS_step && nd >= 2;
     auto dHSp = [&](int j) { return ws + r.w.dHS + (size_t)j * r.w.dHS_step; };      // S-plane of dh_j (one plane for all j unless gw)
     WgradGroupSpec gsT[WG_GRP_MAX], gsO[WG_GRP_MAX];
+    // WnD::bias: the plane of ones closes the B side of every weight-gradient product; column 0 of its 32-column block is the bias gradient
+    const int nb = d.bias ? 1 : 0;
+    WSegSpec wone = {nullptr, 32, 0, 32, 0, nullptr, 32, 0};
+    if (nb) {
+        const SegSpec so1 = ones_seg(cx, r, true);
+        wone.src = so1.src; wone.s = so1.s;
+    }
+    auto fin_bias = [&](const float *slabp, const WgradOut &wo, int row0, int rows, int col0, float *db) {
+        if (nb && db) run_finalize(cx, slabp, wo, row0, rows, 1, 1, col0, 1, 0, nullptr, nullptr, nullptr, db);
+    };
+    auto gb = [&](int j) -> float * { return nb ? grads[d.pb(j)] : nullptr; };      // gradient of bias j (WnD::pb), nullable
 #if !defined(WG_OPT_NO_FIN_BATCH)
     FinQueue fq(cx, slab, cap);                               // flushed when it goes out of scope: before the caller's next launch
 #endif
@@ -1428,9 +1512,11 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
         // skip (fp32 only: it feeds the fp32 end conv) has no S-plane -> this small product runs on the on-the-fly kernel
         if (thin_ok(cx, d)) run_thin_end(cx, r, G, Gc, skip, ws + r.w.dSS, grads[4 + 4 * nd]);      // both in one pass over skip (wg_thin.h)
         else {
-            WSegSpec sa = {G, Gc, 0, 2 * d.ic, 0, nullptr, 0, 0}, sb = {skip, d.Cs, 0, d.Cs, 0, nullptr, 0, 0};
-            WgradOut wo = run_wgrad(cx, g, &sa, 1, &sb, 1, slab, cap);
+            WSegSpec sa = {G, Gc, 0, 2 * d.ic, 0, nullptr, 0, 0}, sb[2] = {{skip, d.Cs, 0, d.Cs, 0, nullptr, 0, 0}, wone};
+            sb[1].s = nullptr;                                 // (skip has no S-plane: the on-the-fly kernel reads the fp32 ones)
+            WgradOut wo = run_wgrad(cx, g, &sa, 1, sb, 1 + nb, slab, cap);
             run_finalize(cx, slab, wo, 0, 2 * d.ic, d.Cs, 1, 0, 1, 0, nullptr, nullptr, nullptr, grads[4 + 4 * nd]);
+            fin_bias(slab, wo, 0, 2 * d.ic, rup(d.Cs, 32), gb(2 + 2 * nd));
             if (sp) run_to_splane(cx, g, pref(G, Gc), Gc, ws + r.w.GS, Gc);
             SegSpec s = {G, Gc, 0, Gc, 0, ws + r.w.GS, Gc, 0};
             run_convgemm(cx, g, r.pk + r.L.endN, r.L.ld_endN, d.Cs, &s, 1, EPI_STORE, sp ? pnull() : pref(dS, d.Cs), pnull(), pnull(), pnull(), pnull(), 0, 0,
@@ -1447,14 +1533,16 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
             gsO[i].sa[0] = {nullptr, d.C, 0, d.C, 0, last ? nullptr : dHSp(i + 1), d.C, 0};
             gsO[i].sa[1] = {nullptr, d.Cs, 0, d.Cs, 0, ws + r.w.dSS, d.Cs, 0};
             gsO[i].sb[0] = {nullptr, d.Cd, 0, d.Cd, 0, ws + r.w.gateS[i], d.Cd, 0};
+            gsO[i].sb[1] = wone;
         } else {
             WSegSpec sa[2];
             int nsa = 0;
             if (!last) sa[nsa++] = {dH, d.C, 0, d.C, 0, sp ? dHSp(i + 1) : nullptr, d.C, 0};
             sa[nsa++] = {dS, d.Cs, 0, d.Cs, 0, sp ? ws + r.w.dSS : nullptr, d.Cs, 0};
-            WSegSpec sb = {gate, d.Cd, 0, d.Cd, 0, sp ? ws + r.w.gateS[i] : nullptr, d.Cd, 0};
-            WgradOut wo = run_wgrad(cx, g, sa, nsa, &sb, 1, slab, cap);
+            WSegSpec sb[2] = {{gate, d.Cd, 0, d.Cd, 0, sp ? ws + r.w.gateS[i] : nullptr, d.Cd, 0}, wone};
+            WgradOut wo = run_wgrad(cx, g, sa, nsa, sb, 1 + nb, slab, cap);
             run_finalize(cx, slab, wo, 0, rows, d.Cd, 1, 0, 1, 0, p[6 + 4 * i], p[7 + 4 * i], grads[6 + 4 * i], grads[7 + 4 * i]);
+            fin_bias(slab, wo, 0, rows, rup(d.Cd, 32), gb(3 + 2 * i));
         }
         // dgate = W_o^T do  ->  dxy (gate backward, waveglow.py:13-15)
         {
@@ -1474,6 +1562,7 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
                 gsT[i].sb[kt] = {nullptr, d.C, 0, d.C, ts, ws + r.w.HS[i], d.C, 0, ro, 0};
             }
             gsT[i].sb[d.radix] = {nullptr, d.auxp(), 0, d.aux, 0, r.YS, d.auxp(), 0, 0, d.mode2d};
+            gsT[i].sb[d.radix + 1] = wone;
         } else {
             WSegSpec sa = {dxy, 2 * d.Cd, 0, 2 * d.Cd, 0, sp ? dxyS : nullptr, 2 * d.Cd, 0};
             WSegSpec sb[WG_MAX_SEG];
@@ -1484,8 +1573,11 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
                 sb[nsb++] = {Hi, d.C, 0, d.C, ts, sp ? ws + r.w.HS[i] : nullptr, d.C, 0, ro, 0};
             }
             sb[nsb++] = {r.Y, d.auxp(), 0, d.aux, 0, sp ? r.YS : nullptr, d.auxp(), 0, 0, d.mode2d};
+            if (nb) sb[nsb++] = wone;
             WgradOut wo = run_wgrad(cx, g, &sa, 1, sb, nsb, slab, cap);
             const int C32 = rup(d.C, 32);
+            fin_bias(slab, wo, 0, 2 * d.Cd, d.radix * C32 + rup(d.aux, 32), gb(2 + 2 * i));                          // W_i.bias and V.bias share
+            fin_bias(slab, wo, 0, 2 * d.Cd, d.radix * C32 + rup(d.aux, 32), gb(0) ? gb(0) + (size_t)i * 2 * d.Cd : nullptr);   // the pre-activation
             run_finalize(cx, slab, wo, 0, 2 * d.Cd, d.C, d.radix, 0, 1, C32, p[4 + 4 * i], p[5 + 4 * i], grads[4 + 4 * i], grads[5 + 4 * i]);
             const size_t ro = (size_t)i * 2 * d.Cd;
             run_finalize(cx, slab, wo, 0, 2 * d.Cd, d.aux, 1, d.radix * C32, 1, 0, p[0] ? p[0] + ro : nullptr, p[1] + ro * d.aux,
@@ -1532,18 +1624,21 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
         pair = false;
 #endif
         // (one after the other, each finalisation queued behind its own launch: the second product's slabs may then reuse the arena)
-        if (pair) run_wgrad_group_pair(cx, g, gsT, 1, d.radix + 1, wo, gsO, 2, 1, woO, nd, ws + r.w.dSS);
-        else run_wgrad_group(cx, g, gsT, nd, 1, d.radix + 1, ws + r.w.dSS, wo);
+        if (pair) run_wgrad_group_pair(cx, g, gsT, 1, d.radix + 1 + nb, wo, gsO, 2, 1 + nb, woO, nd, ws + r.w.dSS);
+        else run_wgrad_group(cx, g, gsT, nd, 1, d.radix + 1 + nb, ws + r.w.dSS, wo);
         for (int i = 0; i < nd && !cx.err; ++i) {
             run_finalize(cx, slab, wo[i], 0, 2 * d.Cd, d.C, d.radix, 0, 1, C32, p[4 + 4 * i], p[5 + 4 * i], grads[4 + 4 * i], grads[5 + 4 * i]);
             const size_t ro = (size_t)i * 2 * d.Cd;
             run_finalize(cx, slab, wo[i], 0, 2 * d.Cd, d.aux, 1, d.radix * C32, 1, 0, p[0] ? p[0] + ro : nullptr, p[1] + ro * d.aux,
                          grads[0] ? grads[0] + ro : nullptr, grads[1] ? grads[1] + ro * d.aux : nullptr);
+            fin_bias(slab, wo[i], 0, 2 * d.Cd, d.radix * C32 + rup(d.aux, 32), gb(2 + 2 * i));
+            fin_bias(slab, wo[i], 0, 2 * d.Cd, d.radix * C32 + rup(d.aux, 32), gb(0) ? gb(0) + ro : nullptr);
         }
-        if (!pair) run_wgrad_group(cx, g, gsO, nd, 2, 1, ws + r.w.dSS, woO);
+        if (!pair) run_wgrad_group(cx, g, gsO, nd, 2, 1 + nb, ws + r.w.dSS, woO);
         for (int i = 0; i < nd && !cx.err; ++i) {
             const int last = i == nd - 1;
             run_finalize(cx, slab, woO[i], last ? d.C : 0, d.wo_rows(i), d.Cd, 1, 0, 1, 0, p[6 + 4 * i], p[7 + 4 * i], grads[6 + 4 * i], grads[7 + 4 * i]);
+            fin_bias(slab, woO[i], last ? d.C : 0, d.wo_rows(i), rup(d.Cd, 32), gb(3 + 2 * i));
         }
     }
     if (fdy) {                                                // dy += [V_0^T .. V_{d-1}^T] [dxy_0; ..; dxy_{d-1}]
@@ -1557,9 +1652,10 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
     if (thin_ok(cx, d)) run_thin_start(cx, r, dHSp(0), dX, p[2], p[3], grads[2], grads[3]);      // both in one pass over dh_0 (wg_thin.h)
     else {
         WSegSpec sa = {dH, d.C, 0, d.C, 0, sp ? dHSp(0) : nullptr, d.C, 0};
-        WSegSpec sb = {r.X.p, r.X.Cp, r.X.ch0, d.ic, 0, sp ? ws + r.w.XaS : nullptr, r.L.kp_start, 0};
-        WgradOut wo = run_wgrad(cx, g, &sa, 1, &sb, 1, slab, cap);
+        WSegSpec sb[2] = {{r.X.p, r.X.Cp, r.X.ch0, d.ic, 0, sp ? ws + r.w.XaS : nullptr, r.L.kp_start, 0}, wone};
+        WgradOut wo = run_wgrad(cx, g, &sa, 1, sb, 1 + nb, slab, cap);
         run_finalize(cx, slab, wo, 0, d.C, d.ic, 1, 0, 1, 0, p[2], p[3], grads[2], grads[3]);
+        fin_bias(slab, wo, 0, d.C, rup(d.ic, 32), gb(1));
         SegSpec s = {dH, d.C, 0, d.C, 0, dHSp(0), d.C, 0};
         run_convgemm(cx, g, r.pk + r.L.startN, r.L.ld_startN, d.ic, &s, 1, EPI_STORE, dX, pnull(), pnull(), dX, pnull(), 0, 0);
     }
@@ -1784,7 +1880,7 @@ void wg_timer_destroy(void *timer)
     delete[] t->start; delete[] t->stop; delete[] t->info; delete t;
 }
 
-int wg_param_count(const wg_config *cf) { return cf ? 3 + cf->n_flows + cf->n_flows * (4 + 4 * cf->depth + 1) : WG_EINVAL; }
+int wg_param_count(const wg_config *cf) { return cf ? 3 + cf->n_flows + cf->n_flows * flow_wn(cf, 0).nparams() : WG_EINVAL; }
 size_t wg_packed_bytes(const wg_config *cf) { return cfg_check(cf) ? 0 : model_pack_layout(cf).total * sizeof(float); }
 size_t wg_workspace_bytes(const wg_config *cf, int B, int N, int mode)
 {
@@ -1801,9 +1897,10 @@ static WnD wnd_from(const wg_wn_dims *d)
     WnD w;
     w.ic = d->in_ch; w.aux = d->aux_ch; w.C = d->res_ch; w.Cd = d->dil_ch; w.Cs = d->skip_ch; w.depth = d->depth; w.radix = d->radix;
     w.prec = d->precision;
+    w.bias = d->bias ? 1 : 0;
     return w;
 }
-int wg_wn_param_count(const wg_wn_dims *d) { return d ? 4 + 4 * d->depth + 1 : WG_EINVAL; }
+int wg_wn_param_count(const wg_wn_dims *d) { return d ? wnd_from(d).nparams() : WG_EINVAL; }
 size_t wg_wn_packed_bytes(const wg_wn_dims *d)
 {
     if (!d || wn_check(wnd_from(d))) return 0;
@@ -2709,6 +2806,7 @@ int wg_wn_apply(const wg_wn_dims *dd, const void *packed, const float *x, const 
     AffineArgs a;
     memset(&a, 0, sizeof(a));
     a.endT = r.pk + r.L.endT; a.S = pref(ws + W.wn.skip, d.Cs); a.Cs = d.Cs; a.ic = d.ic; a.X = X;
+    a.bias = d.bias ? r.pk + r.L.bias_end : nullptr;
     a.log_s_out = log_s; a.t_out = t; a.g = g; a.mode = AFF_RAW;
     if (2 * a.ic <= 8) WG_LAUNCH(cx, end_affine_kernel<8>, dim3(g.Tt / WG_AFF_T, g.B), dim3(256), 0, a);
     else WG_LAUNCH(cx, end_affine_kernel<32>, dim3(g.Tt / WG_AFF_T, g.B), dim3(256), 0, a);

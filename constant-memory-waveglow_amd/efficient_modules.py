@@ -111,7 +111,7 @@ class AffineCouplingBlock(Reversible):
             raise WgError("AffineCouplingBlock runs on the fused HIP WN kernels; transform_type must be "
                           "constant_memory_waveglow_amd.WN (got %r)" % (transform_type,))
         self._memory_efficient = bool(memory_efficient)
-        self._engine = engine.CouplingEngine(WgWnDims(*self.F.hip_dims(), _default_precision()))
+        self._engine = engine.CouplingEngine(WgWnDims(*self.F.hip_dims(), _default_precision(), int(getattr(self.F, "has_bias", False))))
 
     def _run(self, x: Tensor, y: Tensor, reverse: bool) -> Tuple[Tensor, Tensor]:
         z, log_s = _Coupling.apply(x, y, self, reverse, *self.F.parameters())

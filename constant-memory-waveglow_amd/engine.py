@@ -80,13 +80,13 @@ def _table(tensors):
 
 
 def make_config(flows, n_group, n_early_every, n_early_size, hop_size, n_mels,
-                residual_channels, dilation_channels, skip_channels, depth, radix, precision=None, reverse_mode=False):
+                residual_channels, dilation_channels, skip_channels, depth, radix, precision=None, reverse_mode=False, bias=False):
     up = hop_size // n_group                  # reference model/waveglow.py:125
     k = up * 2 + 1                            # :126
     pad = k // 2 - up // 2                    # :128-129
     return WgConfig(flows, n_group, n_early_every, n_early_size, n_mels, up, k, pad,
                     residual_channels, dilation_channels, skip_channels, depth, radix,
-                    _lib.default_precision() if precision is None else precision, int(bool(reverse_mode)))
+                    _lib.default_precision() if precision is None else precision, int(bool(reverse_mode)), 0, int(bool(bias)))
 
 
 class _Buffers:

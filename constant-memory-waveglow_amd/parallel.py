@@ -55,12 +55,12 @@ class FlatGrads:
         return self.flat[s:e]
 
 
-def waveglow_buckets(n_flows: int, depth: int, extra: int = 0) -> List[int]:
+def waveglow_buckets(n_flows: int, depth: int, extra: int = 0, bias: bool = False) -> List[int]:
     """bucket id per parameter-table entry: flow k (its WN and its 1x1 weight) -> bucket k; upsampler -> bucket n_flows;
     `extra` trailing entries (WSRGlow's two embedding tables) -> bucket n_flows + 1."""
     ids = [n_flows] * 3 + list(range(n_flows))
     for k in range(n_flows):
-        ids += [k] * (4 + 4 * depth + 1)
+        ids += [k] * (4 + 4 * depth + 1 + (2 + 2 * depth + 1 if bias else 0))
     return ids + [n_flows + 1] * extra
 
 
@@ -195,7 +195,7 @@ class FlowTrainer:
         self.flow_table = [t for t in model.param_table()]              # the C-ABI table of the flow (wg_train_step)
         self.table = self.flow_table + self.frontend
         wn0 = model.WNs[0].F
-        ids = waveglow_buckets(len(model.WNs), len(wn0.layers), extra=len(self.frontend))
+        ids = waveglow_buckets(len(model.WNs), len(wn0.layers), extra=len(self.frontend), bias=getattr(wn0, "has_bias", False))
         live = [(t, b) for t, b in zip(self.table, ids) if t is not None]
         self.fg = FlatGrads([t for t, _ in live], [b for _, b in live], tail=len(METRIC_NAMES))
         it = iter(self.fg.views)

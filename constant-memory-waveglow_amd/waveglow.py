@@ -50,8 +50,7 @@ class WN(nn.Module):
     def __init__(self, in_channels, aux_channels, dilation_channels=256, residual_channels=256, skip_channels=256,
                  depth=8, radix=3, bias=False, zero_init=True):
         super().__init__()
-        if bias:
-            raise WgError("WN(bias=True) is not built into the HIP kernels (every reference config uses bias=False)")
+        self.has_bias = bool(bias)
         self.dilations = [2 ** i for i in range(depth)]
         self.in_chs, self.aux_chs = in_channels, aux_channels
         self.res_chs, self.dil_chs, self.skp_chs, self.rdx = residual_channels, dilation_channels, skip_channels, radix
@@ -68,6 +67,8 @@ class WN(nn.Module):
         self.end = nn.Conv1d(skip_channels, 2 * in_channels, 1, bias=bias)
         if zero_init:
             nn.init.zeros_(self.end.weight)
+            if bias:
+                nn.init.zeros_(self.end.bias)
         self._engine = None
         self._table = None
 
@@ -79,10 +80,15 @@ class WN(nn.Module):
         for layer in self.layers:
             tab += list(conv_gv_slots(layer.W)) + list(conv_gv_slots(layer.W_o))
         tab.append((self.end._parameters, "weight"))
+        if self.has_bias:                                  # behind `end`: V, start, per layer (W, W_o), end  (wg_config.bias)
+            tab += [(self.V._parameters, "bias"), (self.start._parameters, "bias")]
+            for layer in self.layers:
+                tab += [(layer.W._parameters, "bias"), (layer.W_o._parameters, "bias")]
+            tab.append((self.end._parameters, "bias"))
         return tab
 
     def param_table(self):
-        """C-ABI order: V(g,v) start(g,v) [W(g,v) W_o(g,v)]*depth end  (include/wgflow.h)."""
+        """C-ABI order: V(g,v) start(g,v) [W(g,v) W_o(g,v)]*depth end [+ the biases, WN(bias=True)]  (include/wgflow.h)."""
         if self._table is None:
             self._table = SlotTable("param_slots")
         return self._table(self)
@@ -92,7 +98,7 @@ class WN(nn.Module):
             warnings.warn("WN.forward on its own runs without autograd; gradients flow through AffineCouplingBlock", stacklevel=2)
         if self._engine is None:
             from ._lib import WgWnDims, default_precision
-            self._engine = engine.CouplingEngine(WgWnDims(*self.hip_dims(), default_precision()))
+            self._engine = engine.CouplingEngine(WgWnDims(*self.hip_dims(), default_precision(), int(self.has_bias)))
         return self._engine.wn([None if t is None else t.detach() for t in self.param_table()], x.detach(), y.detach())
 
 
@@ -159,7 +165,7 @@ class WaveGlow(FlowBase):
         wn0 = self.WNs[0].F
         self._engine = engine.ModelEngine(engine.make_config(
             flows, n_group, n_early_every, n_early_size, hop_size, n_mels,
-            wn0.res_chs, wn0.dil_chs, wn0.skp_chs, len(wn0.layers), wn0.rdx, reverse_mode=reverse_mode))
+            wn0.res_chs, wn0.dil_chs, wn0.skp_chs, len(wn0.layers), wn0.rdx, reverse_mode=reverse_mode, bias=wn0.has_bias))
 
     def param_slots(self):
         g, v = conv_gv_slots(self.upsampler)

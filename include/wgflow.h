@@ -64,21 +64,25 @@ typedef struct wg_config {
                                                         there; wg_backward with the same workspace reads them instead of recomputing each WN.
                                                         The caller guarantees nothing else used that workspace in between.  0 = the
                                                         constant-memory scheme (only one flow's layers exist at a time). */
+    int32_t bias;                                    /* WN(bias=True) (waveglow.py:58): every conv of every WN carries a bias.  The WN's
+                                                        part of the parameter table then continues behind `end.weight` with V.bias,
+                                                        start.bias, depth x (layers.i.W.bias, layers.i.W_o.bias), end.bias */
 } wg_config;
 
 /* Dimensions of one WN as AffineCouplingBlock builds it (efficient_modules.py:58-65, waveglow.py:50-59). */
 typedef struct wg_wn_dims {
     int32_t in_ch, aux_ch, res_ch, dil_ch, skip_ch, depth, radix;
     int32_t precision;                               /* WG_PREC_* */
+    int32_t bias;                                    /* WN(bias=True): see wg_config.bias (the block-level table grows the same way) */
 } wg_wn_dims;
 
 const char *wg_strerror(int code);
 /* ABI revision of this header (2: wg_config gained keep_activations; 3: wg_nll_loss / wg_train_step produce the logged
  * training scalars and take their scratch from the caller, wg_melspec returns the power spectrogram on request, wg_wf_config gained
  * use_conv1x1, wg_wf_upsample; 4: wg_timer_create(-1, ..) times every kernel class, wg_timer_read_info, wg_stat_wgrad16t_launches,
- * wg_wf_* accept every WG_PREC_*).  A binding built against another revision must not pass its
+ * wg_wf_* accept every WG_PREC_*; 5: wg_config and wg_wn_dims gained bias).  A binding built against another revision must not pass its
  * structs: the Python loader compares this with its own ABI_VERSION and refuses the library otherwise. */
-#define WG_ABI_VERSION 4
+#define WG_ABI_VERSION 5
 int wg_abi_version(void);
 
 /* Diagnostics (no counterpart upstream; the reference times with wall-clock time(), inference.py:39-53): while a

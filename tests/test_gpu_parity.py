@@ -57,12 +57,13 @@ def build(name, dev, mem_eff=True, reverse_mode=False):
     cfg = fill.CONFIGS[name]
     specs = fill.model_param_specs(cfg)
     P = fill.fill_params(specs, name + "/")
-    m = cm.WaveGlow(memory_efficient=mem_eff, bias=False, reverse_mode=reverse_mode, **cfg)
+    kw = dict(cfg)
+    m = cm.WaveGlow(memory_efficient=mem_eff, bias=kw.pop("bias", False), reverse_mode=reverse_mode, **kw)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
     return m.to(dev), cfg, specs, P
 
 
-@pytest.mark.parametrize("name", ["micro", "c1", "wsr_like"])
+@pytest.mark.parametrize("name", ["micro", "micro_bias", "c1", "wsr_like"])
 def test_model_step_vs_oracle_and_golden(dev, golden_dir, name):
     m, cfg, specs, P = build(name, dev)
     B, N, F = fill.SHAPES[name]
@@ -113,7 +114,30 @@ def test_wide_batch_step_vs_oracle(dev):
     assert np.abs(npy(xr) - audio).max() < Z_ATOL
 
 
-@pytest.mark.parametrize("name", ["micro", "c1"])
+def test_bias_wide_batch_step_vs_oracle(dev):
+    """WN(bias=True) (model/waveglow.py:58) at 4 608 columns per launch: the one-product skip sum (its bias rows: one per layer), the
+    S-plane-only residual stream and the grouped weight-gradient launch with the ones segment.  Against the float64 oracle."""
+    m, cfg, specs, P = build("micro_bias", dev)
+    B, N, F = 9, 8 * 512, 64
+    audio, h = fill.inputs("micro_bias_x9", B, N, F, cfg["n_mels"])
+    ref = orc.train_step(orc.make_config(**cfg), fill.table(specs, P), audio, h, fill.SIGMA, need_dh=True, double=True)
+    x, ht = T(audio, dev), T(h, dev).requires_grad_(True)
+    z, logdet = m(x, ht)
+    loss = cm.WaveGlowLoss(fill.SIGMA)(z, logdet)
+    loss.backward()
+    assert np.abs(npy(z) - ref["z"]).max() < Z_ATOL
+    assert logdet_close(npy(logdet), ref["logdet"], N)
+    assert abs(float(loss) - ref["loss"]) < LOSS_ATOL
+    assert relmax(npy(ht.grad), ref["dh"]) < GRAD_RTOL
+    named = dict(m.named_parameters())
+    for i, (n, _, _) in enumerate(specs):
+        assert relmax(npy(named[n].grad), ref["grads"][i]) < GRAD_RTOL, n
+    with torch.no_grad():
+        xr, _ = m.reverse(z.detach(), ht.detach())
+    assert np.abs(npy(xr) - audio).max() < Z_ATOL
+
+
+@pytest.mark.parametrize("name", ["micro", "micro_bias", "c1"])
 def test_model_inverse_and_infer(dev, golden_dir, name):
     m, cfg, specs, P = build(name, dev)
     B, N, F = fill.SHAPES[name]
@@ -328,6 +352,45 @@ def test_coupling_block(dev, golden_dir, cname, rev):
         res.append([npy(named[n].grad) for n, _, _ in specs])
     for a, b in zip(*res):
         assert np.allclose(a, b)                                                # efficient == naive (:160)
+
+
+@pytest.mark.parametrize("rev", [False, True])
+def test_coupling_block_with_bias_vs_torch_cpu(dev, rev):
+    """AffineCouplingBlock(WN, bias=True) (model/waveglow.py:58, efficient_modules.py:57-96) through the block-level entry points
+    (wg_coupling_apply / wg_coupling_backward with wg_wn_dims.bias), both directions, against plain torch autograd on the CPU over
+    oracle/torch_cpu.py's WN (itself pinned to the reference's bias golden by tests/test_oracle_golden.py)."""
+    from oracle import torch_cpu
+    ic, aux, C, depth, B, Tn = 3, 20, 32, 3, 2, 200
+    wn = dict(in_channels=ic, aux_channels=aux, residual_channels=C, dilation_channels=C, skip_channels=C, depth=depth, radix=3)
+    specs = fill.wn_param_specs("F.", ic, aux, C, C, C, depth, 3, bias=True)
+    tag = "coupling/bias"
+    P = fill.fill_params(specs, tag + "/")
+    x = fill.uniform(tag + "/x", (B, 2 * ic, Tn))
+    y = fill.normal(tag + "/y", (B, aux, Tn))
+    gz = fill.normal(tag + "/gz", x.shape)
+    gls = fill.normal(tag + "/gls", (B, ic, Tn))
+    # reference: autograd over the restated WN
+    pt = [torch.from_numpy(P[n]).requires_grad_(True) for n, _, _ in specs]
+    xr, yr = torch.from_numpy(x).requires_grad_(True), torch.from_numpy(y).requires_grad_(True)
+    log_s, t = torch_cpu._wn_forward(pt, xr[:, :ic], yr, depth, C, 3)
+    if rev:
+        zr, lsr = torch.cat((xr[:, :ic], (xr[:, ic:] - t) / torch.exp(log_s)), 1), -log_s      # efficient_modules.py:90-96
+    else:
+        zr, lsr = torch.cat((xr[:, :ic], xr[:, ic:] * torch.exp(log_s) + t), 1), log_s         # :77-88
+    ((zr * torch.from_numpy(gz)).sum() + (lsr * torch.from_numpy(gls)).sum()).backward()
+    blk = cm.AffineCouplingBlock(cm.WN, True, zero_init=False, bias=True, **wn)
+    blk.load_state_dict({n: torch.from_numpy(v) for n, v in P.items()})
+    blk = blk.to(dev)
+    xt, yt = T(x, dev).requires_grad_(True), T(y, dev).requires_grad_(True)
+    z, ls = blk.reverse(xt.clone(), yt) if rev else blk(xt.clone(), yt)
+    ((z * T(gz, dev)).sum() + (ls * T(gls, dev)).sum()).backward()
+    assert np.abs(npy(z) - zr.detach().numpy()).max() < 1e-5 and np.abs(npy(ls) - lsr.detach().numpy()).max() < 1e-5
+    assert relmax(npy(xt.grad), xr.grad.numpy()) < GRAD_RTOL and relmax(npy(yt.grad), yr.grad.numpy()) < GRAD_RTOL
+    named = dict(blk.named_parameters())
+    for (n, _, _), ref in zip(specs, pt):
+        assert relmax(npy(named[n].grad), ref.grad.numpy()) < GRAD_RTOL, n
+    ls_raw, t_raw = blk.F(T(x[:, :ic].copy(), dev), T(y, dev))                                  # WN.forward on its own (wg_wn_apply)
+    assert np.abs(npy(ls_raw) - log_s.detach().numpy()).max() < 1e-5 and np.abs(npy(t_raw) - t.detach().numpy()).max() < 1e-5
 
 
 def test_coupling_block_on_shared_b_tiles_vs_oracle(dev, precision):

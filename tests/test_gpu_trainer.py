@@ -38,7 +38,8 @@ def build(name, dev, mem_eff=True):
     cfg = fill.CONFIGS[name]
     specs = fill.model_param_specs(cfg)
     P = fill.fill_params(specs, name + "/")
-    m = cm.WaveGlow(memory_efficient=mem_eff, bias=False, **cfg)
+    kw = dict(cfg)
+    m = cm.WaveGlow(memory_efficient=mem_eff, bias=kw.pop("bias", False), **kw)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
     return m.to(dev), cfg
 
@@ -114,7 +115,7 @@ def one_rank_rccl(dev):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,mem_eff", [("micro", True), ("c1", True), ("c1", False)])
+@pytest.mark.parametrize("name,mem_eff", [("micro", True), ("micro_bias", True), ("micro_bias", False), ("c1", True), ("c1", False)])
 def test_rccl_path_one_rank_is_bit_equal(dev, one_rank_rccl, name, mem_eff):
     """FlowTrainer.step through the collective path (events from inside wg_train_step, side stream, async all-reduce) == the
     plain step, bit for bit: gradients, z, logdet, loss and the reduced metrics."""
@@ -221,6 +222,29 @@ def test_autograd_model_gradients_through_one_rank_rccl(dev, one_rank_rccl):
     torch.cuda.synchronize()
     for n, p in m.named_parameters():
         assert torch.equal(before[n], p.grad), n
+
+
+def test_trainer_with_bias_matches_autograd(dev):
+    """WaveGlow(bias=True): FlowTrainer.step (wg_train_step, the biases in their flow's gradient bucket) leaves in p.grad what
+    loss.backward() through the autograd node leaves, for every parameter including the biases."""
+    m0, cfg = build("micro_bias", dev)
+    m1, _ = build("micro_bias", dev)
+    B, N, F = fill.SHAPES["micro_bias"]
+    audio, h = fill.inputs("micro_bias", B, N, F, cfg["n_mels"])
+    x, ht = T(audio, dev), T(h, dev)
+    tr = FlowTrainer(m0, fill.SIGMA)
+    loss, z, logdet = tr.step(x, ht)
+    z1, ld1 = m1(x, ht)
+    l1 = cm.WaveGlowLoss(fill.SIGMA)(z1, ld1)
+    l1.backward()
+    assert torch.equal(z, z1) and abs(float(loss) - float(l1)) < 1e-6
+    n_bias = 0
+    for (n, p0), (_, p1) in zip(m0.named_parameters(), m1.named_parameters()):
+        assert p0.grad is not None and p1.grad is not None, n
+        scale = max(float(p1.grad.abs().max()), 1e-30)
+        assert float((p0.grad - p1.grad).abs().max()) / scale < 1e-5, n
+        n_bias += n.endswith(".bias") and ".F." in n
+    assert n_bias == cfg["flows"] * (2 + 2 * cfg["depth"] + 1)
 
 
 def test_frozen_weight_v_still_gets_weight_g_gradient(dev):
