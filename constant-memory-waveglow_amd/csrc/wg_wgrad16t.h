@@ -38,7 +38,7 @@
 #include "wg_gemm16q.h"
 #include <type_traits>
 
-#define WGT_PH_MAX 4
+#define WGT_PH_MAX 8
 #if !defined(WGT_POLL_SLEEP)
 #define WGT_POLL_SLEEP 2                                   // the loaders look at the compute waves' progress every 64 x this many cycles
 #endif
@@ -54,7 +54,13 @@ struct WgtPhase {
     int splits, k0, k1;        // chunk range [k0, k1) of the flattened (batch item, 32-step chunk) axis, cut into `splits` parts
     int slab0;                 // part s of this phase writes slab slab0 + s of its (product, layer)
     int tn, tiles, ngroups;    // of the product (copied here so that nothing indexes the kernel arguments with a run-time value):
-};                             // 128-column tiles per row of tiles, tiles per set, layers
+                               // 128-column tiles per row of tiles, tiles per set, layers
+    // A product whose row of tiles is wider than an XCD has slots (WSRGlow: 35 column tiles x 2 row tiles per layer) is cut into `nsub`
+    // column SUB-SETS of `tns` tile columns per layer (`tiles` = row tiles x tns then; they still share the A operand, and each its own
+    // B columns), and a phase may start at set `set0` of the enumeration (layer, sub-set, part): the sets then take several ROUNDS of
+    // the chip, one phase entry each (plan_wgt_rounds in wgflow.hip).  nsub = 1, tns = tn, set0 = 0: the whole row of tiles, as above.
+    int nsub, tns, set0;
+};
 struct WgtArgs {
     WgradSArgs p[2];           // segments, planes and slabs of the two products (as wgrad16s_pair_kernel); p[].nsplit = slabs per layer
     WgtPhase ph[WGT_PH_MAX];
@@ -75,13 +81,16 @@ __device__ __forceinline__ bool wgt_item(const __attribute__((address_space(4)))
     const __attribute__((address_space(4))) WgtPhase &p = aa->ph[ph];                           // (ph is a compile-time constant at every call: no dynamic index into the arguments)
     if (r < p.off || r >= p.off + p.per_xcd) return false;
     const int local = xcd * p.per_xcd + (r - p.off);
-    const int tn = p.tn, T = p.tiles, ng = p.ngroups;
-    const int set = local / T, tile = local - set * T;
-    const int grp = set / p.splits, split = set - grp * p.splits;
-    if (grp >= ng) return false;
+    const int T = p.tiles, tns = p.tns, nsub = p.nsub;
+    const int set = p.set0 + local / T, tile = local % T;
+    const int unit = set / p.splits, split = set - unit * p.splits;
+    const int grp = unit / nsub, sub = unit - grp * nsub;
+    if (grp >= p.ngroups) return false;
+    const int nt = sub * tns + tile % tns;                  // (a ragged last sub-set leaves slots idle)
+    if (nt >= p.tn) return false;
     const int len = p.k1 - p.k0;
     it.prod = p.prod; it.grp = grp;
-    it.m0 = (tile / tn) * 256; it.n0 = (tile % tn) * WG_TILE;
+    it.m0 = (tile / tns) * 256; it.n0 = nt * WG_TILE;
     it.cb = p.k0 + (int)((long)split * len / p.splits); it.ce = p.k0 + (int)((long)(split + 1) * len / p.splits);
     it.slab = p.slab0 + split;
     return it.ce > it.cb;

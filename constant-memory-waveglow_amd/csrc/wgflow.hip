@@ -543,7 +543,7 @@ static WgtPlan plan_wgt(int tm0, int tn0, int tm1, int tn1, int ng, int K)
     const int s0 = 8 * n0 / ng;
     if (s0 > K) return pl;
     const int dur = (K + s0 - 1) / s0;
-    pl.ph[pl.nph++] = WgtPhase{0, 0, n0 * T0, s0, 0, K, 0, 0, 0, 0};
+    pl.ph[pl.nph++] = WgtPhase{0, 0, n0 * T0, s0, 0, K, 0, 0, 0, 0, 0, 0, 0};
     pl.nslab[0] = s0;
     const int n1 = sets_per_xcd(32 - n0 * T0, T1);
     int kA1 = 0;
@@ -551,7 +551,7 @@ static WgtPlan plan_wgt(int tm0, int tn0, int tm1, int tn1, int ng, int K)
         const int s1 = 8 * n1 / ng;
         kA1 = std::min(K, s1 * dur);
         if (s1 > kA1) return pl;
-        pl.ph[pl.nph++] = WgtPhase{1, n0 * T0, n1 * T1, s1, 0, kA1, 0, 0, 0, 0};
+        pl.ph[pl.nph++] = WgtPhase{1, n0 * T0, n1 * T1, s1, 0, kA1, 0, 0, 0, 0, 0, 0, 0};
         pl.nslab[1] = s1;
     }
     int durB = 0;
@@ -561,13 +561,71 @@ static WgtPlan plan_wgt(int tm0, int tn0, int tm1, int tn1, int ng, int K)
         if (nB == 0) return pl;
         const int sB = 8 * nB / ng;
         durB = (K - kA1 + sB - 1) / sB;
-        pl.ph[pl.nph++] = WgtPhase{1, 0, nB * T1, sB, kA1, K, pl.nslab[1], 0, 0, 0};
+        pl.ph[pl.nph++] = WgtPhase{1, 0, nB * T1, sB, kA1, K, pl.nslab[1], 0, 0, 0, 0, 0, 0};
         pl.nslab[1] += sB;
     }
     pl.length = dur + durB;
     const long work = (long)(T0 + T1) * ng * K;
     pl.ok = (long)pl.length * 256 * 5 <= work * 6 + 8L * 256 * 5;
     return pl;
+}
+// The general form: ROUNDS.  Product 0's row of tiles is cut into column sub-sets of `tns` tile columns (tm0 * tns <= 32 slots), n0 of
+// them per XCD and round; every K range is cut into the same s0 parts, so a round is as long as one part and (layer, sub-set, part)
+// items are dealt round after round (WgtPhase::set0).  Product 1's sets (4 tiles at the usual widths) sit in the slots product 0 leaves
+// free, in parts no longer than product 0's, or -- where there are none -- in rounds of their own behind it.  Covers what the two-phase
+// plan above cannot: rows of tiles wider than an XCD (WSRGlow's conditioning: 35 column tiles), layer counts that do not divide 8.
+static WgtPlan plan_wgt_rounds(int tm0, int tn0, int tm1, int tn1, int ng, int K)
+{
+    WgtPlan best;
+#if defined(WG_OPT_NO_WGRAD16T) || defined(WG_OPT_NO_WGT_ROUNDS)
+    return best;
+#endif
+    const int T1 = tm1 * tn1;
+    if (tm0 < 1 || tn0 < 1 || T1 < 1 || T1 > 32 || tm0 > 32 || ng < 1 || K < 1) return best;
+    const long work = ((long)tm0 * tn0 + T1) * ng * K;
+    for (int tns = std::min(tn0, 32 / tm0); tns >= 1; --tns) {
+        const int T0 = tm0 * tns, n0 = 32 / T0, nsub = (tn0 + tns - 1) / tns, n1 = (32 - n0 * T0) / T1;
+        for (int s0 = 1; s0 <= 8 && s0 <= K; ++s0) {
+            const int rounds0 = (ng * nsub * s0 + 8 * n0 - 1) / (8 * n0), len0 = (K + s0 - 1) / s0;
+            WgtPlan pl;
+            bool fits = rounds0 <= WGT_PH_MAX;
+            for (int r = 0; r < rounds0 && fits; ++r)
+                pl.ph[pl.nph++] = WgtPhase{0, 0, n0 * T0, s0, 0, K, 0, 0, T0, 0, nsub, tns, r * 8 * n0};
+            pl.nslab[0] = s0;
+            pl.length = rounds0 * len0;
+            int s1 = 0, rounds1 = 0;
+            if (fits && n1 >= 1) {                            // beside product 0: parts no longer than its parts
+                s1 = (K + len0 - 1) / len0;
+                rounds1 = (ng * s1 + 8 * n1 - 1) / (8 * n1);
+                if (s1 > 8 || rounds1 > rounds0 || pl.nph + rounds1 > WGT_PH_MAX) s1 = 0;
+                for (int r = 0; r < rounds1 && s1; ++r)
+                    pl.ph[pl.nph++] = WgtPhase{1, n0 * T0, n1 * T1, s1, 0, K, 0, 0, T1, 0, 1, tn1, r * 8 * n1};
+            }
+            if (fits && !s1) {                                // rounds of its own, all 32 slots of an XCD
+                const int nf = 32 / T1;
+                int bs = 0, bl = 0, br = 0;
+                for (int q = 1; q <= 8 && q <= K; ++q) {
+                    const int rr = (ng * q + 8 * nf - 1) / (8 * nf), ll = rr * ((K + q - 1) / q);
+                    if (!bs || ll < bl) { bs = q; bl = ll; br = rr; }
+                }
+                s1 = bs; rounds1 = br;
+                if (pl.nph + rounds1 > WGT_PH_MAX) fits = false;
+                for (int r = 0; r < rounds1 && fits; ++r)
+                    pl.ph[pl.nph++] = WgtPhase{1, 0, nf * T1, s1, 0, K, 0, 0, T1, 0, 1, tn1, r * 8 * nf};
+                pl.length += bl;
+            }
+            if (!fits) continue;
+            pl.nslab[1] = s1;
+            pl.ok = (long)pl.length * 256 * 5 <= work * 6 + 8L * 256 * 5;
+            if (pl.ok && (!best.ok || pl.length < best.length || (pl.length == best.length && pl.nph < best.nph))) best = pl;
+        }
+    }
+    return best;
+}
+static WgtPlan plan_wgt_any(int tm0, int tn0, int tm1, int tn1, int ng, int K)
+{
+    const WgtPlan a = plan_wgt(tm0, tn0, tm1, tn1, ng, K);
+    return a.ok ? a : plan_wgt_rounds(tm0, tn0, tm1, tn1, ng, K);
 }
 struct WnWs {               // plane bases (float offsets) of one WN's activations
     size_t H[16], tw[16], sf[16], gate[16], skip, G, dS, dH, dxy, slab;
@@ -640,7 +698,7 @@ void wn_ws_layout(Bump &bp, const WnD &d, int ic_max, const Geo &g, int mode, in
             s = std::max(s, rupz((size_t)nsT * d.depth * oneT, 64) + rupz((size_t)nsO * d.depth * oneO, 64) + 4096
                             + rupz((size_t)(nsT + nsO) * d.depth * WG_SYNC_STRIDE, 64));                     // (+ the lock-step counters)
             if (g.rows == 0 && oneT / nW % 256 == 0 && rup(d.C + d.Cs, WG_TILE) % 256 == 0) {              // wgrad16t_kernel's own split
-                const WgtPlan pl = plan_wgt((int)(oneT / nW) / 256, nW / WG_TILE, rup(d.C + d.Cs, WG_TILE) / 256, nO / WG_TILE,
+                const WgtPlan pl = plan_wgt_any((int)(oneT / nW) / 256, nW / WG_TILE, rup(d.C + d.Cs, WG_TILE) / 256, nO / WG_TILE,
                                             d.depth, g.B * (g.Tt / WG16_BK));
                 if (pl.ok) s = std::max(s, rupz((size_t)pl.nslab[0] * d.depth * oneT, 64) + rupz((size_t)pl.nslab[1] * d.depth * oneO, 64) + 4096);
             }
@@ -1189,7 +1247,7 @@ void run_wgrad_group_pair(Ctx &cx, const Geo &g, const WgradGroupSpec *gs0, int 
     // one workgroup per CU on 256 x 128 tiles (wg_wgrad16t.h) when the shape has a plan: 1-D planes, 256-row products
     WgtPlan plan;
     if (g.rows == 0 && pp.p[0].Mp % 256 == 0 && pp.p[1].Mp % 256 == 0)
-        plan = plan_wgt(pp.p[0].Mp / 256, pp.p[0].Np / WG_TILE, pp.p[1].Mp / 256, pp.p[1].Np / WG_TILE, ng, pp.p[0].total_chunks);
+        plan = plan_wgt_any(pp.p[0].Mp / 256, pp.p[0].Np / WG_TILE, pp.p[1].Mp / 256, pp.p[1].Np / WG_TILE, ng, pp.p[0].total_chunks);
     if (plan.ok) { pp.p[0].nsplit = plan.nslab[0]; pp.p[1].nsplit = plan.nslab[1]; }
     // progress counters of the (group, split) sets of both products (soft lock-step, wg_gemm16s.h): one 128-byte line each
     const size_t nctr0 = (size_t)pp.p[0].nsplit * ng, nctr1 = (size_t)pp.p[1].nsplit * ng;
@@ -1209,7 +1267,8 @@ void run_wgrad_group_pair(Ctx &cx, const Geo &g, const WgradGroupSpec *gs0, int 
         for (int i = 0; i < plan.nph; ++i) {
             wa.ph[i] = plan.ph[i];
             const WgradSArgs &q = wa.p[plan.ph[i].prod];
-            wa.ph[i].tn = q.Np / WG_TILE; wa.ph[i].tiles = (q.Mp / 256) * (q.Np / WG_TILE); wa.ph[i].ngroups = ng;
+            wa.ph[i].tn = q.Np / WG_TILE; wa.ph[i].ngroups = ng;
+            if (!wa.ph[i].tiles) { wa.ph[i].tiles = (q.Mp / 256) * (q.Np / WG_TILE); wa.ph[i].nsub = 1; wa.ph[i].tns = wa.ph[i].tn; wa.ph[i].set0 = 0; }
         }
         for (int w = 0; w < 2; ++w) wa.nvalid[w] = wgt_valid_cols(wa.p[w]);
         // the launch as ONE entry of the kernel timer: 2 * M * K * cols = its algorithmic FLOPs with M = sum over layers and products of

@@ -1137,22 +1137,25 @@ def test_waveflow_after_remove_weight_norms(dev, precision):
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
 
 
-@pytest.mark.parametrize("B,Tn,depth,planned", [(3, 1000, 8, True), (5, 130, 8, True), (2, 2000, 4, True), (4, 2000, 2, True),
-                                                (1, 300, 8, True), (2, 700, 2, True), (1, 64, 8, True), (2, 500, 3, False)])
-def test_weight_gradient_kernel_plans_vs_oracle(dev, precision, B, Tn, depth, planned):
-    """wgrad16t_kernel (one workgroup per CU, planned phases, wg_wgrad16t.h) at the shipped WN width over several (batch, length, depth)
-    combinations: different K ranges, part counts and phase shapes of the planner, against the oracle -- and cases WITHOUT a plan (fewer
-    chunks than the second phase has parts; a layer count that does not divide the 8 XCDs), which must take the two-workgroup kernel and
-    agree as well."""
+@pytest.mark.parametrize("B,Tn,depth,aux,ch,planned", [(3, 1000, 8, 80, 256, True), (5, 130, 8, 80, 256, True), (2, 2000, 4, 80, 256, True),
+                                                       (4, 2000, 2, 80, 256, True), (1, 300, 8, 80, 256, True), (2, 700, 2, 80, 256, True),
+                                                       (1, 64, 8, 80, 256, True), (2, 500, 3, 80, 256, True), (2, 512, 8, 1500, 256, True),
+                                                       (3, 700, 5, 3659, 256, True), (2, 500, 3, 80, 64, False)])
+def test_weight_gradient_kernel_plans_vs_oracle(dev, precision, B, Tn, depth, aux, ch, planned):
+    """wgrad16t_kernel (one workgroup per CU, planned phases, wg_wgrad16t.h) at the shipped WN width over several (batch, length, depth,
+    conditioning width) combinations: different K ranges, part counts and phase shapes of the two planners -- the two-phase plan of the
+    headline shape; the ROUNDS plan for a layer count that does not divide the 8 XCDs and for rows of tiles wider than an XCD (WSRGlow's
+    3 659 conditioning channels: 35 column tiles in sub-sets of 7) -- against the oracle, and a case WITHOUT a plan (a 64-channel WN: its
+    products have 128 rows, the kernel's tiles 256), which must take the two-workgroup kernel and agree as well."""
     if precision != "bf16x3p":
         pytest.skip("the grouped weight-gradient launches exist in the S-plane mode only")
     from constant_memory_waveglow_amd import _lib
-    wn = dict(in_channels=4, aux_channels=80, residual_channels=256, dilation_channels=256, skip_channels=256, depth=depth, radix=3)
-    specs = fill.wn_param_specs("F.", 4, 80, 256, 256, 256, depth, 3)
-    tag = "coupling/wgt%d_%d_%d" % (B, Tn, depth)
+    wn = dict(in_channels=4, aux_channels=aux, residual_channels=ch, dilation_channels=ch, skip_channels=ch, depth=depth, radix=3)
+    specs = fill.wn_param_specs("F.", 4, aux, ch, ch, ch, depth, 3)
+    tag = "coupling/wgt%d_%d_%d" % (B, Tn, depth) + ("" if aux == 80 else "_%d" % aux) + ("" if ch == 256 else "_c%d" % ch)
     P = fill.fill_params(specs, tag + "/")
     x = fill.uniform(tag + "/x", (B, 8, Tn))
-    y = fill.normal(tag + "/y", (B, 80, Tn))
+    y = fill.normal(tag + "/y", (B, aux, Tn))
     gz = fill.normal(tag + "/gz", x.shape)
     gls = fill.normal(tag + "/gls", (B, 4, Tn))
     z_ref, _ = orc.coupling_apply(wn, fill.table(specs, P), x, y)
