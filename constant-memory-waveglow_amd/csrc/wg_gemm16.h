@@ -315,6 +315,72 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const WgradArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// pack + image in one pass (round 3): a pack job whose rows are whole chunks of its matrix's image writes the image straight from
+// the 32 (k) x 64 (m) LDS tile it builds anyway -- no fp32 matrix written and read back (and none written at all where nothing reads
+// it: PackJob::dst == nullptr).  pack_kernel + img_kernel moved 40 bytes per parameter per layout, this moves 12-20.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void packimg_kernel(const PackArgs a)
+{
+    const PackJob j = a.job[blockIdx.y];
+    if (!j.img) { pack_job_plain(j); return; }
+    __shared__ float tile[32][65];
+    const int tid = threadIdx.x;
+    const int tk = (j.Kp + 31) / 32, tm = (j.Mp + 63) / 64;
+    for (int tl = blockIdx.x; tl < tk * tm; tl += gridDim.x) {
+        const int kc = tl / tm, k0 = kc * 32, m0 = (tl - kc * tm) * 64;
+        __syncthreads();
+        if (j.mode == 0) {                                    // consecutive lanes read consecutive k of one source row (see pack_job_plain)
+            const int kk = tid & 31, k = k0 + kk;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int mm = (tid >> 5) + 8 * q, m = m0 + mm;
+                int o = m;
+                if (j.half > 0) {
+                    const int qq = m >> 6, r = m & 63;
+                    o = r < 32 ? qq * 32 + r : j.half + qq * 32 + (r - 32);
+                    if ((qq * 32 + (r & 31)) >= j.half) o = -1;
+                }
+                float val = 0.f;
+                if (o >= 0 && o < j.no && k < j.ni && m < j.Mp) val = j.scale[o] * j.src[(size_t)o * j.so + (size_t)k * j.si + j.off];
+                tile[kk][mm] = val;
+            }
+        } else {                                              // mode 1: consecutive lanes read consecutive m of source row k
+            const int mm = tid & 63, m = m0 + mm;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int kk = (tid >> 6) + 4 * q, k = k0 + kk;
+                float val = 0.f;
+                if (k < j.no && m < j.ni) val = j.scale[k] * j.src[(size_t)k * j.so + (size_t)m * j.si + j.off];
+                tile[kk][mm] = val;
+            }
+        }
+        __syncthreads();
+        if (j.dst) {
+            const int m = m0 + (tid & 63);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int kw = (tid >> 6) + 4 * q;
+                if (k0 + kw < j.Kp && m < j.Mp) j.dst[(size_t)(k0 + kw) * j.ldd + m] = tile[kw][tid & 63];
+            }
+        }
+        // image unit: thread -> (m = tid >> 2, 8 k values (tid & 3) * 8 ..): the layout img_kernel writes
+        const int m = tid >> 2, k8 = (tid & 3) * 8, mr = m0 + m;
+        if (mr < j.ldd) {
+            u32x4 vh, vl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned hh, ll;
+                split2(tile[k8 + 2 * e][m], tile[k8 + 2 * e + 1][m], hh, ll);
+                vh[e] = hh; vl[e] = ll;
+            }
+            const size_t o = ((size_t)(j.chunk0 + kc) * j.ldd + (mr & ~127)) * 32 + (size_t)(k8 >> 3) * 1024 + (size_t)(mr & 127) * 8;
+            *reinterpret_cast<u32x4 *>(j.img + o) = vh;
+            *reinterpret_cast<u32x4 *>(j.img + (size_t)j.nchunks * j.ldd * 32 + o) = vl;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // pre-split weight images: A32 [K][lda] (k-major fp32, segments of nch rows) -> [chunk][lda][32] hi | lo
 // one block per (chunk, 64 columns)
 // ------------------------------------------------------------------------------------------------

@@ -584,14 +584,17 @@ struct PackJob {
     int ldd, Kp, Mp;
     int mode, no, ni, half;
     int so, si, off;
+    // fused weight image (packimg_kernel, wg_gemm16.h): the job's rows are chunks [chunk0, chunk0 + ceil(Kp / 32)) of the split bf16
+    // image of its matrix (nchunks chunks in all; hi, then lo); dst may then be nullptr (no fp32 copy wanted).  img == nullptr: fp32 only.
+    unsigned short *img;
+    int chunk0, nchunks;
 };
 struct PackArgs {
     int n;
     PackJob job[WG_JOBS];
 };
-__global__ __launch_bounds__(256) void pack_kernel(const PackArgs a)
+__device__ __forceinline__ void pack_job_plain(const PackJob &j)
 {
-    const PackJob j = a.job[blockIdx.y];
     if (j.mode == 0) {
         // the transposing form through a 32 (k) x 64 (m) LDS tile: consecutive lanes read consecutive k of one source row (12 bytes
         // apart for a k = 3 conv weight) and write consecutive m.  (Element by element in dst order every lane read its own source
@@ -643,6 +646,10 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs a)
         }
         j.dst[(size_t)k * j.ldd + m] = val;
     }
+}
+__global__ __launch_bounds__(256) void pack_kernel(const PackArgs a)
+{
+    pack_job_plain(a.job[blockIdx.y]);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -255,6 +255,15 @@ WnPack wn_pack_layout(const WnD &d)
     return L;
 }
 
+// weight images written by the pack jobs themselves (packimg_kernel) instead of a second pass over fp32 matrices
+inline bool wn_pack_fused(const WnD &d)
+{
+#if defined(WG_OPT_NO_PACK_FUSE)
+    (void)d; return false;
+#else
+    return !d.bias;
+#endif
+}
 struct JobBatch {
     Ctx *ctx;
     NormArgs na;
@@ -273,6 +282,19 @@ struct JobBatch {
         PackJob &j = pa.job[pa.n++];
         j.dst = dst; j.src = src; j.scale = scale; j.ldd = ldd; j.Kp = Kp; j.Mp = Mp; j.mode = mode;
         j.no = no; j.ni = ni; j.half = half; j.so = so; j.si = si; j.off = off;
+        j.img = nullptr; j.chunk0 = 0; j.nchunks = 0;
+    }
+    // rows [row, row + Kp) of the k-major matrix A32 ([Ktot][ld] fp32 + its split image, mat_floats): with `fuse` the job writes its
+    // chunks of the image itself (packimg_kernel) and the fp32 rows only if `want32`; without, it is a plain pack job (img_kernel follows)
+    void pack_m(bool fuse, float *A32, int Ktot, int ld, int row, bool want32, int Kp, int mode, int no, int ni, int half,
+                const float *src, const float *scale, int so, int si, int off)
+    {
+        pack(A32 + (size_t)row * ld, ld, Kp, ld, mode, no, ni, half, src, scale, so, si, off);
+        if (!fuse) return;
+        PackJob &j = pa.job[pa.n - 1];
+        j.img = mat_img(A32, Ktot, ld); j.chunk0 = row / 32; j.nchunks = (Ktot + 31) / 32;
+        if (!want32) j.dst = nullptr;
+        if (row % 32 && !ctx->err) ctx->err = WG_EINVAL;
     }
     void flush_norm()
     {
@@ -285,7 +307,7 @@ struct JobBatch {
     void flush_pack()
     {
         if (!pa.n) return;
-        WG_LAUNCH(*ctx, pack_kernel, dim3(512, pa.n), dim3(256), 0, pa);     // grid-stride over each job: 64 blocks left 230 M-parameter models dispatch-starved
+        WG_LAUNCH(*ctx, packimg_kernel, dim3(512, pa.n), dim3(256), 0, pa);  // grid-stride over each job: 64 blocks left 230 M-parameter models dispatch-starved
         pa.n = 0;
     }
 };
@@ -303,37 +325,42 @@ void wn_pack_norms(JobBatch &jb, const WnD &d, const WnPack &L, const float *con
 void wn_pack_mats(JobBatch &jb, const WnD &d, const WnPack &L, const float *const *p, float *pk, float *ones)
 {
     const float *vV = p[1], *vS = p[3], *wE = p[4 + 4 * d.depth];
+    // Every matrix the MFMA kernels read is written as its split image by the pack job itself (JobBatch::pack_m); the fp32 k-major
+    // copy is kept where something reads it: everywhere outside the S-plane mode, and for the small start / end matrices (wg_thin.h,
+    // end_affine_kernel).  With biases (WnD::bias) the plain two-step form stays: the bias rows do not start on chunk boundaries.
+    const bool fuse = wn_pack_fused(d), f32 = d.prec != 2;
+    const int kb = d.kb();
     // start: src [C][ic]
-    jb.pack(pk + L.startT, L.ld_startT, L.kp_start, L.ld_startT, 0, d.C, d.ic, 0, vS, pk + L.scale_start, d.ic, 1, 0);
-    jb.pack(pk + L.startN, L.ld_startN, d.C, L.ld_startN, 1, d.C, d.ic, 0, vS, pk + L.scale_start, d.ic, 1, 0);
+    jb.pack_m(fuse, pk + L.startT, L.kp_start + kb, L.ld_startT, 0, true, L.kp_start, 0, d.C, d.ic, 0, vS, pk + L.scale_start, d.ic, 1, 0);
+    jb.pack_m(fuse, pk + L.startN, d.C, L.ld_startN, 0, true, d.C, 1, d.C, d.ic, 0, vS, pk + L.scale_start, d.ic, 1, 0);
     // end: src [2ic][Cs], plain weight (scale = ones)
     jb.pack(pk + L.endT, 32, d.Cs, 32, 0, 2 * d.ic, d.Cs, 0, wE, ones, d.Cs, 1, 0);
-    jb.pack(pk + L.endN, L.ld_endN, L.kp_end, L.ld_endN, 1, 2 * d.ic, d.Cs, 0, wE, ones, d.Cs, 1, 0);
+    jb.pack_m(fuse, pk + L.endN, L.kp_end, L.ld_endN, 0, true, L.kp_end, 1, 2 * d.ic, d.Cs, 0, wE, ones, d.Cs, 1, 0);
     for (int i = 0; i < d.depth; ++i) {
         const float *vW = p[5 + 4 * i], *vWo = p[7 + 4 * i];
         const int rows = d.wo_rows(i);
         float *acat = pk + L.Acat[i];
         for (int kt = 0; kt < d.radix; ++kt)   // rows kt*C.. : A[kt*C + c][perm m] = W[o][c][kt]
-            jb.pack(acat + (size_t)kt * d.C * L.ld_Acat, L.ld_Acat, d.C, L.ld_Acat, 0, 2 * d.Cd, d.C, d.Cd, vW,
-                    pk + L.scale_W[i], d.C * d.radix, d.radix, kt);
+            jb.pack_m(fuse, acat, L.kcat + kb, L.ld_Acat, kt * d.C, f32, d.C, 0, 2 * d.Cd, d.C, d.Cd, vW,
+                      pk + L.scale_W[i], d.C * d.radix, d.radix, kt);
         // conditioning rows: A[radix*C + j][perm m] = V[i*2Cd + o][j]
-        jb.pack(acat + (size_t)d.radix * d.C * L.ld_Acat, L.ld_Acat, d.auxp(), L.ld_Acat, 0, 2 * d.Cd, d.aux, d.Cd,
-                vV + (size_t)i * 2 * d.Cd * d.aux, pk + L.scale_V + (size_t)i * 2 * d.Cd, d.aux, 1, 0);
-        jb.pack(pk + L.WoT[i], L.ld_WoT[i], d.Cd, L.ld_WoT[i], 0, rows, d.Cd, 0, vWo, pk + L.scale_Wo[i], d.Cd, 1, 0);
+        jb.pack_m(fuse, acat, L.kcat + kb, L.ld_Acat, d.radix * d.C, f32, d.auxp(), 0, 2 * d.Cd, d.aux, d.Cd,
+                  vV + (size_t)i * 2 * d.Cd * d.aux, pk + L.scale_V + (size_t)i * 2 * d.Cd, d.aux, 1, 0);
+        jb.pack_m(fuse, pk + L.WoT[i], d.Cd + kb, L.ld_WoT[i], 0, f32, d.Cd, 0, rows, d.Cd, 0, vWo, pk + L.scale_Wo[i], d.Cd, 1, 0);
         {   // rows i*Cd .. of WskT: A[i*Cd + j][m] = Wo_i[skip row m][j]  (the skip rows follow the C residual rows, except on the last layer)
             const int r0 = rows - d.Cs;
-            jb.pack(pk + L.WskT + (size_t)i * d.Cd * L.ld_WskT, L.ld_WskT, d.Cd, L.ld_WskT, 0, d.Cs, d.Cd, 0, vWo + (size_t)r0 * d.Cd,
-                    pk + L.scale_Wo[i] + r0, d.Cd, 1, 0);
+            jb.pack_m(fuse, pk + L.WskT, d.depth * d.Cd + kb, L.ld_WskT, i * d.Cd, f32, d.Cd, 0, d.Cs, d.Cd, 0, vWo + (size_t)r0 * d.Cd,
+                      pk + L.scale_Wo[i] + r0, d.Cd, 1, 0);
         }
-        jb.pack(pk + L.WoN[i], L.ld_WoN, rows, L.ld_WoN, 1, rows, d.Cd, 0, vWo, pk + L.scale_Wo[i], d.Cd, 1, 0);
+        jb.pack_m(fuse, pk + L.WoN[i], rows, L.ld_WoN, 0, f32, rows, 1, rows, d.Cd, 0, vWo, pk + L.scale_Wo[i], d.Cd, 1, 0);
         for (int kt = 0; kt < d.radix; ++kt)   // A[kt*2Cd + o][c] = W[o][c][kt]
-            jb.pack(pk + L.WT[i] + (size_t)kt * 2 * d.Cd * L.ld_WT, L.ld_WT, 2 * d.Cd, L.ld_WT, 1, 2 * d.Cd, d.C, 0, vW,
-                    pk + L.scale_W[i], d.C * d.radix, d.radix, kt);
-        jb.pack(pk + L.VN[i], L.ld_VN, 2 * d.Cd, L.ld_VN, 1, 2 * d.Cd, d.aux, 0, vV + (size_t)i * 2 * d.Cd * d.aux,
-                pk + L.scale_V + (size_t)i * 2 * d.Cd, d.aux, 1, 0);
+            jb.pack_m(fuse, pk + L.WT[i], d.radix * 2 * d.Cd, L.ld_WT, kt * 2 * d.Cd, f32, 2 * d.Cd, 1, 2 * d.Cd, d.C, 0, vW,
+                      pk + L.scale_W[i], d.C * d.radix, d.radix, kt);
+        jb.pack_m(fuse, pk + L.VN[i], 2 * d.Cd, L.ld_VN, 0, f32, 2 * d.Cd, 1, 2 * d.Cd, d.aux, 0, vV + (size_t)i * 2 * d.Cd * d.aux,
+                  pk + L.scale_V + (size_t)i * 2 * d.Cd, d.aux, 1, 0);
         if (fused_dy(d))
-            jb.pack(pk + L.VNall + (size_t)i * 2 * d.Cd * L.ld_VN, L.ld_VN, 2 * d.Cd, L.ld_VN, 1, 2 * d.Cd, d.aux, 0,
-                    vV + (size_t)i * 2 * d.Cd * d.aux, pk + L.scale_V + (size_t)i * 2 * d.Cd, d.aux, 1, 0);
+            jb.pack_m(fuse, pk + L.VNall, d.depth * 2 * d.Cd, L.ld_VN, i * 2 * d.Cd, f32, 2 * d.Cd, 1, 2 * d.Cd, d.aux, 0,
+                      vV + (size_t)i * 2 * d.Cd * d.aux, pk + L.scale_V + (size_t)i * 2 * d.Cd, d.aux, 1, 0);
     }
     if (!d.bias) return;
     // WnD::bias: the 32 rows of the ones segment behind each forward matrix.  A bias row is a mode-0 job with ONE k (ni = 1, so = 1):
@@ -384,6 +411,7 @@ struct ImgBatch {
 // split images of every matrix convgemm reads (after the fp32 matrices have been packed)
 void wn_pack_images(ImgBatch &ib, const WnD &d, const WnPack &L, float *pk)
 {
+    if (wn_pack_fused(d)) return;                            // the pack jobs wrote the images themselves (wn_pack_mats)
     int one[WG_MAX_SEG];
     const int nb = d.bias ? 1 : 0;                           // WnD::bias: the ones segment closes the segment list of every forward matrix
     one[1] = 32;
@@ -1592,7 +1620,7 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
             gsO[i].sa[0] = {nullptr, d.C, 0, d.C, 0, last ? nullptr : dHSp(i + 1), d.C, 0};
             gsO[i].sa[1] = {nullptr, d.Cs, 0, d.Cs, 0, ws + r.w.dSS, d.Cs, 0};
             gsO[i].sb[0] = {nullptr, d.Cd, 0, d.Cd, 0, ws + r.w.gateS[i], d.Cd, 0};
-            gsO[i].sb[1] = wone;
+            if (nb) gsO[i].sb[1] = wone;
         } else {
             WSegSpec sa[2];
             int nsa = 0;
@@ -1621,7 +1649,7 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
                 gsT[i].sb[kt] = {nullptr, d.C, 0, d.C, ts, ws + r.w.HS[i], d.C, 0, ro, 0};
             }
             gsT[i].sb[d.radix] = {nullptr, d.auxp(), 0, d.aux, 0, r.YS, d.auxp(), 0, 0, d.mode2d};
-            gsT[i].sb[d.radix + 1] = wone;
+            if (nb) gsT[i].sb[d.radix + 1] = wone;             // (WN2D: 9 taps + conditioning fill all ten slots; it has no bias)
         } else {
             WSegSpec sa = {dxy, 2 * d.Cd, 0, 2 * d.Cd, 0, sp ? dxyS : nullptr, 2 * d.Cd, 0};
             WSegSpec sb[WG_MAX_SEG];
