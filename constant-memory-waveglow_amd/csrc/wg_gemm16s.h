@@ -190,8 +190,8 @@ struct WgSSeg {
 #define WG_GRP_MAX 8
 struct WgradGrp {
     const unsigned short *a_hi[2];          // nullptr: that segment's rows are zero in this group
-    const unsigned short *b_plane[2];       // the (at most two) distinct B planes of a group: the layer input (all its taps) and the
-    float *slab;                            // conditioning; WgradSArgs::b_plane_of says which one a segment reads
+    const unsigned short *b_plane[3];       // the (at most three) distinct B planes of a group: the layer input (all its taps), the
+    float *slab;                            // conditioning, the ones of a WN with biases; WgradSArgs::b_plane_of says which one a segment reads
     short b_shift[WG_MAX_SEG];              // time shift and plane-row offset of every B segment
     short b_row[WG_MAX_SEG];
 };

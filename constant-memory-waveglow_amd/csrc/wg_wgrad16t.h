@@ -233,7 +233,7 @@ __global__ __launch_bounds__(768) void wgrad16t_kernel(const WgtArgs aa_by_value
                 for (int j = 0; j < WG_MAX_SEG; ++j)
                     if (j < a->nseg_b && (nb >> 5) >= a->sb[j].blk0) {
                         blk0 = a->sb[j].blk0; nch = a->sb[j].nch; ch0 = a->sb[j].ch0; Cp = a->sb[j].Cp; lo = (long)a->sb[j].lo_off;
-                        hb = a->b_plane_of[j] ? a->grp[grp].b_plane[1] : a->grp[grp].b_plane[0];
+                        hb = a->b_plane_of[j] == 0 ? a->grp[grp].b_plane[0] : a->b_plane_of[j] == 1 ? a->grp[grp].b_plane[1] : a->grp[grp].b_plane[2];
                         bshift = (int)a->grp[grp].b_shift[j];
                     }
                 const int cb = nb - blk0 * 32;

@@ -147,9 +147,7 @@ inline bool grouped_wgrad(int prec, const WnD &d)
 #if defined(WG_OPT_NO_WGRAD_GROUP)
     (void)prec; (void)d; return false;
 #else
-    // (WnD::bias: the plane of ones would be a third distinct B plane of a group, WgradGrp::b_plane holds two -- such WNs take the
-    // per-layer launches; no shipped config sets bias)
-    return prec == 2 && !d.bias && d.depth >= 2 && d.depth <= WG_GRP_MAX && d.radix + 1 <= WG_MAX_SEG;
+    return prec == 2 && d.depth >= 2 && d.depth <= WG_GRP_MAX && d.radix + 1 + (d.bias ? 1 : 0) <= WG_MAX_SEG;
 #endif
 }
 inline bool fused_skip(const WnD &d)
@@ -1211,14 +1209,14 @@ static bool shape_wgrad_group(Ctx &cx, const Geo &g, const WgradGroupSpec *gs, i
         q.sb[s].hi = nullptr; q.sb[s].lo_off = (size_t)(x.per_item ? g.B / g.rows : g.B) * x.sCp * g.P;
         q.sb[s].Cp = x.sCp; q.sb[s].ch0 = x.sch0; q.sb[s].nch = x.nch; q.sb[s].shift = 0; q.sb[s].blk0 = blk;
         q.sb[s].row_off = 0; q.sb[s].per_item = x.per_item;
-        // the distinct planes of group 0 (at most two) name the planes of every group
+        // the distinct planes of group 0 (at most three) name the planes of every group
         int pl = -1, used = 0;
         for (int u = 0; u < s; ++u) {
             used = std::max(used, q.b_plane_of[u] + 1);
             if (gs[0].sb[u].s == x.s) { pl = q.b_plane_of[u]; break; }
         }
         if (pl < 0) pl = used;
-        if (pl > 1) { if (!cx.err) cx.err = WG_EINVAL; return false; }
+        if (pl > 2) { if (!cx.err) cx.err = WG_EINVAL; return false; }
         q.b_plane_of[s] = (unsigned char)pl;
         blk += rup(x.nch, 32) / 32;
     }
@@ -1243,7 +1241,7 @@ static bool bind_wgrad_group(Ctx &cx, const WgradGroupSpec *gs, const float *zer
     q.zsrc = (const unsigned short *)zero_plane; q.slab = slab;
     for (int k = 0; k < q.ngroups; ++k) {
         for (int s = 0; s < q.nseg_a; ++s) q.grp[k].a_hi[s] = (const unsigned short *)gs[k].sa[s].s;
-        q.grp[k].b_plane[0] = q.grp[k].b_plane[1] = nullptr;
+        q.grp[k].b_plane[0] = q.grp[k].b_plane[1] = q.grp[k].b_plane[2] = nullptr;
         for (int s = 0; s < q.nseg_b; ++s) {
             q.grp[k].b_plane[q.b_plane_of[s]] = (const unsigned short *)gs[k].sb[s].s;
             q.grp[k].b_shift[s] = (short)gs[k].sb[s].shift; q.grp[k].b_row[s] = (short)gs[k].sb[s].row_off;
