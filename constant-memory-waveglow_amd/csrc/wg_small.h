@@ -812,12 +812,13 @@ __global__ __launch_bounds__(256) void finalize_kernel(const FinJob j)
 }
 // Several tensors in one launch (one block per weight row of every job): a WN layer's backward ends in three of these small
 // launches, each too short to fill the GPU; the weight gradients of a whole WN are finalised together instead (FinQueue).
-#define WG_FIN_JOBS 24
+#define WG_FIN_JOBS 32     // a WN of 8 layers queues 26 jobs (end, 8 x (W, V, W_o), start): one launch
 struct FinBatch {
     int n;
     int start[WG_FIN_JOBS + 1];     // prefix sums of the jobs' row counts: the grid is exactly their total
     FinJob job[WG_FIN_JOBS];
 };
+static_assert(sizeof(FinBatch) + 16 <= 4096, "kernel arguments are limited to 4 KB");
 __global__ __launch_bounds__(256) void finalize_batch_kernel(const FinBatch b)
 {
     __shared__ float dw[WG_FIN_MAXCOLS];

@@ -726,7 +726,10 @@ void wn_ws_layout(Bump &bp, const WnD &d, int ic_max, const Geo &g, int mode, in
             if (g.rows == 0 && oneT / nW % 256 == 0 && rup(d.C + d.Cs, WG_TILE) % 256 == 0) {              // wgrad16t_kernel's own split
                 const WgtPlan pl = plan_wgt_any((int)(oneT / nW) / 256, nW / WG_TILE, rup(d.C + d.Cs, WG_TILE) / 256, nO / WG_TILE,
                                             d.depth, g.B * (g.Tt / WG16_BK));
-                if (pl.ok) s = std::max(s, rupz((size_t)pl.nslab[0] * d.depth * oneT, 64) + rupz((size_t)pl.nslab[1] * d.depth * oneO, 64) + 4096);
+                // (+ the thin products' partials of the same backward: the start product reserves after the grouped slabs, and a wrap of the
+                // arena there means a second finalisation launch per WN for one small job)
+                if (pl.ok) s = std::max(s, rupz((size_t)pl.nslab[0] * d.depth * oneT, 64) + rupz((size_t)pl.nslab[1] * d.depth * oneO, 64) + 4096
+                                            + 2 * (wgth_part_floats(2 * device_cus(), std::max(16 * d.C, 32 * d.Cs)) + 64));
             }
         }
         w.slab_floats = s;
