@@ -287,11 +287,17 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
     for (int s = 0; s < a.nseg; ++s) nchunks += (a.seg[s].nch + WG16_BK - 1) / WG16_BK;
     constexpr bool PERSIST = EPI != EPI_DGATE;                // (the gate backward keeps one workgroup per tile: see convgemm16w_kernel)
     const int ntiles = aa.ntx * aa.nty * aa.ntz, G = (int)gridDim.x;
-    const int mine = PERSIST ? (ntiles - 1 - (int)blockIdx.x) / G + 1 : 1;
+    // (xcd_items: the workgroup's XCD owns ntz / 8 plane rows = xl tiles, dealt to its G / 8 workgroups; see ConvGemm16sArgs)
+    const int xper = aa.ntx * aa.nty, xl = aa.xcd_items * xper, xslots = G >> 3, xslot = (int)blockIdx.x >> 3;
+    const int mine = !PERSIST ? 1 : aa.xcd_items ? (xslot < xl ? (xl - 1 - xslot) / xslots + 1 : 0) : (ntiles - 1 - (int)blockIdx.x) / G + 1;
     const int total = mine * nchunks;
     auto tile_at = [&](int k, int &t0, int &m0, int &b) {
         if constexpr (PERSIST) {
-            const int id = (int)blockIdx.x + k * G;
+            int id = (int)blockIdx.x + k * G;
+            if (aa.xcd_items) {                                 // local tile -> (plane row of this XCD, time tile, row tile): row tiles adjacent
+                const int local = xslot + k * xslots, zl = local / xper, rem = local - zl * xper;
+                id = (((int)blockIdx.x & 7) + 8 * zl) * xper + (rem % aa.nty) * aa.ntx + rem / aa.nty;
+            }
             const int tx = id % aa.ntx, q = id / aa.ntx, ty = q % aa.nty, tz = q / aa.nty;
             t0 = tx * TT; m0 = ty * (WG_TILE * MG);
             b = a.row_sel1 ? tz * g.rows + a.row_sel1 - 1 : tz;
@@ -308,7 +314,8 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
         __builtin_amdgcn_s_setprio(WG_OPT_LOADER_PRIO);      // experiment: the loaders' few instructions never queue behind the compute waves
 #endif
         const int bt = NI == 2 ? (lt & 127) : (lt & 63), cg0 = NI == 2 ? (lt >> 7) : (lt >> 6);     // B unit: position, k-group
-        int cur_seg = 0, cur_c = 0, chunk = 0;
+        const int nil = aa.tap_il * aa.tap_chunks;            // chunks walked interleaved over the taps (ConvGemm16sArgs::tap_il; 0: none)
+        int cur_seg = aa.tap_il, cur_c = 0, chunk = nil, v = 0; // v: position in the tile's walk; (cur_seg, cur_c, chunk): the sequential part behind
         int gchunk = 0, tk = 0, t0, m0, b;
         tile_at(0, t0, m0, b);
         const unsigned voff_a = (unsigned)lt * 16u;
@@ -329,7 +336,12 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
         const unsigned short *zsrc = aa.sseg[0].hi;           // plane position 0 of the first operand: always-zero halo
         auto issue = [&](Stage &st) {                         // exactly 4 + 2 NI loads in straight-line code (tools/check_asm_loads.py)
             const bool live = gchunk < total;
-            const int sg = min(cur_seg, a.nseg - 1);
+            const bool il = v < nil;
+            // (a division per chunk: counters kept by increments instead measured 4 % SLOWER per step -- they took the address chain out of
+            // the scalar unit)
+            const int sgi = il ? v % aa.tap_il : cur_seg, cbi = il ? v / aa.tap_il : 0;
+            const int ci = il ? cbi * WG16_BK : cur_c, chi = il ? sgi * aa.tap_chunks + cbi : chunk;
+            const int sg = min(sgi, a.nseg - 1);
             const int nch = a.seg[sg].nch, shift = a.seg[sg].shift;
             const SSeg ss = aa.sseg[sg];
             int bsrc = b;
@@ -339,11 +351,11 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
                 rowok = r >= 0 && r < g.rows;
                 bsrc = ss.per_item ? item : b + ss.row_off;
             }
-            const bool blive = live && rowok, full = blive && (nch - cur_c > 16);
-            const unsigned short *ih = aa.img + ((size_t)chunk * a.lda + m0) * WG16_BK, *il = ih + aa.img_stride;
-            const unsigned short *row0 = ss.hi + ((size_t)bsrc * (ss.Cp >> 3) + ((ss.ch0 + cur_c) >> 3)) * g.P * 8;
+            const bool blive = live && rowok, full = blive && (nch - ci > 16);
+            const unsigned short *ih = aa.img + ((size_t)chi * a.lda + m0) * WG16_BK, *il_ = ih + aa.img_stride;
+            const unsigned short *row0 = ss.hi + ((size_t)bsrc * (ss.Cp >> 3) + ((ss.ch0 + ci) >> 3)) * g.P * 8;
             const unsigned short *pa0 = live ? ih : zsrc, *pa1 = live ? ih + A_NEXT : zsrc;
-            const unsigned short *pl0 = live ? il : zsrc, *pl1 = live ? il + A_NEXT : zsrc;
+            const unsigned short *pl0 = live ? il_ : zsrc, *pl1 = live ? il_ + A_NEXT : zsrc;
             const unsigned va = live ? voff_a : 0u;
             WG_LD(st.ah[0], pa0, va);   WG_LD(st.ah[1], pa1, va);
             WG_LD(st.al[0], pl0, va);   WG_LD(st.al[1], pl1, va);
@@ -363,11 +375,13 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
             }
             if (live) {
                 ++gchunk;
-                ++chunk;
-                cur_c += WG16_BK;
-                if (cur_c >= nch) { cur_c = 0; ++cur_seg; }
-                if (chunk == nchunks) {
-                    chunk = 0; cur_seg = 0; cur_c = 0;
+                if (!il) {
+                    ++chunk;
+                    cur_c += WG16_BK;
+                    if (cur_c >= nch) { cur_c = 0; ++cur_seg; }
+                }
+                if (++v == nchunks) {
+                    v = 0; chunk = nil; cur_seg = aa.tap_il; cur_c = 0;
                     tk = min(tk + 1, mine - 1);
                     tile_at(tk, t0, m0, b);
                 }

@@ -105,6 +105,16 @@ struct ConvGemm16sArgs {
     SRef s0;                      // S-plane output (hi == nullptr: none)
     SRef saux;                    // EPI_STORE, convgemm16q only: the accumulate-into input as an S-plane (hi + lo) instead of the fp32 plane aux0
     int ntx, nty, ntz;            // convgemm16w: the tile grid (time tiles, 128-row tiles, plane rows); workgroup w walks tiles w, w + G, ...
+    int tap_il, tap_chunks;       // convgemm16q: the first tap_il K segments are the taps of ONE plane (tap_chunks chunks each): the K loop walks
+                                  // them interleaved -- channel block 0 of every tap, then block 1, ... -- instead of tap after tap, so that a
+                                  // tap's window, which is a neighbouring time tile's centre window, is requested within a few chunks of that
+                                  // neighbour's own request and still sits in the XCD's L2 (tap after tap they are 16 chunks = tens of
+                                  // microseconds apart: the data-gradient conv fetched every window from HBM again, 388 MB for 147 MB)
+    int xcd_items;                // convgemm16q, persistent launches: > 0 = plane rows per XCD (ntz / 8): XCD x (workgroup id & 7) owns the plane
+                                  // rows x, x + 8, ... and walks their tiles row by row -- all time tiles of a row are then in flight on ONE
+                                  // XCD, so a dilation tap's window (another tile's centre window) and the other row tiles' copy of the same
+                                  // columns are hits in that XCD's L2 instead of second and third HBM reads (profiles/r03j: the data-gradient
+                                  // conv fetched 388 MB for 147 MB of operands, the gate conv 145 for 67)
 };
 
 // ------------------------------------------------------------------------------------------------

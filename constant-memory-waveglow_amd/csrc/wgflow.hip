@@ -897,6 +897,15 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
         a16.c = a;
         if (cx.prec == 2) {
             ConvGemm16sArgs as;
+            as.ntx = as.nty = as.ntz = 0; as.xcd_items = 0; as.tap_il = 0; as.tap_chunks = 0;
+#if !defined(WG_OPT_NO_TAP_IL)
+            {   // leading segments that are taps of one plane: walked interleaved (ConvGemm16sArgs::tap_il)
+                int nt = 1;
+                while (nt < nseg && segs[nt].s == segs[0].s && segs[nt].nch == segs[0].nch && segs[nt].sCp == segs[0].sCp &&
+                       segs[nt].sch0 == segs[0].sch0 && segs[nt].per_item == segs[0].per_item) ++nt;
+                if (nt >= 2 && segs[0].s && segs[0].nch % WG16_BK == 0) { as.tap_il = nt; as.tap_chunks = segs[0].nch / WG16_BK; }
+            }
+#endif
             as.img = a16.img; as.img_stride = a16.img_stride; as.c = a; as.s0 = s0; as.saux = saux;
             for (int s = 0; s < nseg; ++s) {
                 as.sseg[s].hi = (const unsigned short *)segs[s].s;
@@ -932,6 +941,13 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
             slots = ntiles;
 #endif
             const dim3 gp = epi == EPI_DGATE ? dim3(as.ntx, as.nty, as.ntz) : dim3(std::min(ntiles, slots));
+            // plane rows dealt to XCDs (ConvGemm16sArgs::xcd_items): full persistent grids whose plane rows divide by the 8 XCDs
+            const bool xcd_rows = epi != EPI_DGATE && as.ntz % 8 == 0 && g.rows == 0
+#if defined(WG_OPT_NO_XCD_ROWS)
+                                  && false
+#endif
+                ;
+            if (xcd_rows && ntiles >= slots && slots % 8 == 0) as.xcd_items = as.ntz / 8;
 #if !defined(WG_OPT_MFMA32)                       // default: the 16x16x32 form of the same kernel (wg_gemm16q.h)
 #if !defined(WG_OPT_NO_HTILE)
             // at most half as many 128 x 64 tiles as CUs (one utterance being synthesised, WaveFlow's row-by-row inverse): such a launch
@@ -974,6 +990,7 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
             if (epi != EPI_DGATE && rup(mrows, WG_TILE) % 256 == 0 && mg2_ok) {
                 as.nty = (int)grid.y / 2;
                 const dim3 g2(std::min(ntiles / 2, cus));
+                if (cus % 8) as.xcd_items = 0;                // (mg2_ok: at least one tile per CU)
                 switch (epi) {
                 case EPI_STORE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE, 2, 2>), g2, dim3(1024), 0, as); break;
                 case EPI_GATE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE, 2, 2>), g2, dim3(1024), 0, as); break;
