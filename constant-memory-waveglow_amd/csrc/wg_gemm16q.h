@@ -47,12 +47,58 @@ __device__ __forceinline__ float *paddr4(const PRef &r, const Geo &g, int b, int
 {
     return r.p + (((size_t)b * (r.Cp >> 2) + ((r.ch0 + ch) >> 2)) * g.P + g.H + t) * 4;
 }
+// S-plane units and the accumulator layout.  A lane of the 16 x 16 MFMA output owns rows 4 rq .. 4 rq + 3 (rq = lane >> 4) of one column:
+// HALF a 16-byte unit; lanes l and l + 16 own the two halves of the same unit.  As 8-byte accesses a wave instruction touches every
+// 64-byte line twice (once from each 16-lane row): the launches bound by these bytes ran at 3-4 TB/s (the residual conv spent 34 of its
+// 38 us on them: tools/experiments/shape_ab.sh).  v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of
+// another, so two column blocks nb0, nb1 pair up: even rows move the WHOLE unit of column block nb0, odd rows that of nb1 -- one 16-byte
+// access per lane instead of two 8-byte ones, 512 contiguous bytes per channel group and instruction.
+// MEASURED AND NOT ADOPTED (-DWG_OPT_UNIT16; parity green): the residual conv went from 38.3 to 40.8 us -- the width of these accesses
+// is not what makes them slow.
+//   store: x = the lane's piece of nb0, y = its piece of nb1  ->  (x', y') = swap(x, y) is the unit the lane stores, in that order;
+//   load:  the lane loads a unit (lo8, hi8)                    ->  (x, y) = swap(lo8, hi8) are its pieces of nb0 and nb1.
+// Must be executed by ALL lanes (no divergence around it); predicate only the memory access.
+__device__ __forceinline__ void swap16_unit(u32x4 &u)      // words (0, 2) and (1, 3) of a unit
+{
+    const u32x2 r0 = __builtin_amdgcn_permlane16_swap(u[0], u[2], false, false);
+    const u32x2 r1 = __builtin_amdgcn_permlane16_swap(u[1], u[3], false, false);
+    u[0] = r0[0]; u[2] = r0[1]; u[1] = r1[0]; u[3] = r1[1];
+}
 template <int EPI, int NB>
 __device__ __forceinline__ void conv_acc_init_q(const ConvGemmArgs &a, const SRef &saux, f32x4 (&acc)[4][NB], int t0, int m0, int b, int wr, int wc,
                                                 int lane)
 {
     const Geo g = a.g;
     const int col = lane & 15, rq = lane >> 4;
+#if defined(WG_OPT_UNIT16)
+    if constexpr (EPI == EPI_STORE && NB >= 2) {
+        if (saux.hi) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const int mu = m0 + wr * 64 + mb * 16 + 8 * (rq >> 1);            // first row of the lane's unit
+#pragma unroll
+                for (int nb = 0; nb < NB; nb += 2) {
+                    const int t = t0 + wc * (16 * NB) + (nb + ((rq & 1))) * 16 + col;   // even rows: column block nb, odd rows: nb + 1
+                    u32x4 uh = {0u, 0u, 0u, 0u}, ul = {0u, 0u, 0u, 0u};
+                    if (t < g.T && mu < a.M) {
+                        const size_t i = s_index(saux, g, b, mu, t);
+                        uh = *reinterpret_cast<const u32x4 *>(saux.hi + i);
+                        ul = *reinterpret_cast<const u32x4 *>(saux.hi + saux.lo_off + i);
+                    }
+                    swap16_unit(uh); swap16_unit(ul);
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {                                 // q = 0: the piece of nb (words 0, 1), q = 1: of nb + 1 (words 2, 3)
+                        acc[mb][nb + q][0] = __uint_as_float(uh[2 * q] << 16) + __uint_as_float(ul[2 * q] << 16);
+                        acc[mb][nb + q][1] = __uint_as_float(uh[2 * q] & 0xffff0000u) + __uint_as_float(ul[2 * q] & 0xffff0000u);
+                        acc[mb][nb + q][2] = __uint_as_float(uh[2 * q + 1] << 16) + __uint_as_float(ul[2 * q + 1] << 16);
+                        acc[mb][nb + q][3] = __uint_as_float(uh[2 * q + 1] & 0xffff0000u) + __uint_as_float(ul[2 * q + 1] & 0xffff0000u);
+                    }
+                }
+            }
+            return;
+        }
+    }
+#endif
     if (EPI == EPI_STORE && saux.hi) {
         // the value to accumulate into comes as an S-plane: a lane's 4 rows of one column are exactly one half unit (8 bytes) of the hi
         // array and one of the lo array; x = hi + lo (the fp32 plane of such a tensor is then never written nor read)
@@ -155,8 +201,13 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
                 split2(gv[4 * mbp], gv[4 * mbp + 1], hh, ll); vh[0] = hh; vl[0] = ll;
                 split2(gv[4 * mbp + 2], gv[4 * mbp + 3], hh, ll); vh[1] = hh; vl[1] = ll;
                 const unsigned so = (unsigned)(2 * mbp + (rq >> 1)) * s_grp + tl * 8u + (unsigned)(4 * (rq & 1));
-                *reinterpret_cast<u32x2 *>(sh + so) = vh;
-                *reinterpret_cast<u32x2 *>(sl + so) = vl;
+                if (WG_OPT_NT_S & 4) {
+                    __builtin_nontemporal_store(vh, reinterpret_cast<u32x2 *>(sh + so));
+                    __builtin_nontemporal_store(vl, reinterpret_cast<u32x2 *>(sl + so));
+                } else {
+                    *reinterpret_cast<u32x2 *>(sh + so) = vh;
+                    *reinterpret_cast<u32x2 *>(sl + so) = vl;
+                }
             }
             __builtin_amdgcn_sched_barrier(0);                   // eight outputs at a time
         }
@@ -220,8 +271,8 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
                             *paddr(a.out0, g, b, a.nsplit + m + e, t) = o2[e];
                         }
                     }
-                    s_store4(s0, g, b, m, t, o);
-                    s_store4(s0, g, b, a.nsplit + m, t, o2);
+                    s_store4<(WG_OPT_NT_S & 2) != 0>(s0, g, b, m, t, o);
+                    s_store4<(WG_OPT_NT_S & 2) != 0>(s0, g, b, a.nsplit + m, t, o2);
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -245,8 +296,34 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
                 o[e] = acc[mb][nb][e];
                 if (base && m + e < a.M) base[(unsigned)(4 * rq + e) * (unsigned)g.P + (unsigned)tl] = o[e];
             }
-            if (res && s0.hi) s_store4(s0, g, b, m, t, o);
+#if defined(WG_OPT_UNIT16)
+            if constexpr (NB >= 2) continue;                 // (the S-plane goes out below, two column blocks at a time)
+#endif
+            if (res && s0.hi) s_store4<(WG_OPT_NT_S & 1) != 0>(s0, g, b, m, t, o);
         }
+#if defined(WG_OPT_UNIT16)
+        if constexpr (NB >= 2) {
+            if (res && s0.hi) {                              // (wave uniform: every lane takes part in the swaps)
+                const int mu = mbase + 8 * (rq >> 1);
+#pragma unroll
+                for (int nb = 0; nb < NB; nb += 2) {
+                    u32x4 uh, ul;
+                    unsigned hh, ll;
+                    split2(acc[mb][nb][0], acc[mb][nb][1], hh, ll); uh[0] = hh; ul[0] = ll;
+                    split2(acc[mb][nb][2], acc[mb][nb][3], hh, ll); uh[1] = hh; ul[1] = ll;
+                    split2(acc[mb][nb + 1][0], acc[mb][nb + 1][1], hh, ll); uh[2] = hh; ul[2] = ll;
+                    split2(acc[mb][nb + 1][2], acc[mb][nb + 1][3], hh, ll); uh[3] = hh; ul[3] = ll;
+                    swap16_unit(uh); swap16_unit(ul);
+                    const int t = t0 + wc * (16 * NB) + (nb + (rq & 1)) * 16 + col;
+                    if (t < g.T && mu < a.M) {
+                        const size_t i = s_index(s0, g, b, mu, t);
+                        *reinterpret_cast<u32x4 *>(s0.hi + i) = uh;
+                        *reinterpret_cast<u32x4 *>(s0.hi + s0.lo_off + i) = ul;
+                    }
+                }
+            }
+        }
+#endif
     }
 }
 

@@ -25,6 +25,12 @@ __device__ __forceinline__ size_t s_index(const SRef &r, const Geo &g, int b, in
     return (((size_t)b * (r.Cp >> 3) + (cc >> 3)) * g.P + g.H + t) * 8 + (cc & 7);
 }
 // 4 consecutive channels (c multiple of 4) of one time step
+// EXPERIMENT -DWG_OPT_NT_S=<mask>: S-plane stores of the conv epilogues with the non-temporal policy (1: store / residual, 2: gate
+// backward, 4: gate conv)
+#if !defined(WG_OPT_NT_S)
+#define WG_OPT_NT_S 0
+#endif
+template <bool NT = false>
 __device__ __forceinline__ void s_store4(const SRef &r, const Geo &g, int b, int c, int t, const float (&v)[4])
 {
     u32x2 h, l;
@@ -32,8 +38,13 @@ __device__ __forceinline__ void s_store4(const SRef &r, const Geo &g, int b, int
     split2(v[0], v[1], hh, ll); h[0] = hh; l[0] = ll;
     split2(v[2], v[3], hh, ll); h[1] = hh; l[1] = ll;
     const size_t i = s_index(r, g, b, c, t);
-    *reinterpret_cast<u32x2 *>(r.hi + i) = h;
-    *reinterpret_cast<u32x2 *>(r.hi + r.lo_off + i) = l;
+    if (NT) {
+        __builtin_nontemporal_store(h, reinterpret_cast<u32x2 *>(r.hi + i));
+        __builtin_nontemporal_store(l, reinterpret_cast<u32x2 *>(r.hi + r.lo_off + i));
+    } else {
+        *reinterpret_cast<u32x2 *>(r.hi + i) = h;
+        *reinterpret_cast<u32x2 *>(r.hi + r.lo_off + i) = l;
+    }
 }
 
 // Two 8-byte half units -> one 16-byte unit per lane.  In the MFMA accumulator layout lanes l and l + 32 own channels 4h .. 4h+3
