@@ -99,7 +99,7 @@ __device__ __forceinline__ void conv_acc_init_q(const ConvGemmArgs &a, const SRe
         }
     }
 #endif
-    if (EPI == EPI_STORE && saux.hi) {
+    if ((EPI == EPI_STORE || EPI == EPI_STORE_SO) && saux.hi) {
         // the value to accumulate into comes as an S-plane: a lane's 4 rows of one column are exactly one half unit (8 bytes) of the hi
         // array and one of the lo array; x = hi + lo (the fp32 plane of such a tensor is then never written nor read)
 #pragma unroll
@@ -120,6 +120,15 @@ __device__ __forceinline__ void conv_acc_init_q(const ConvGemmArgs &a, const SRe
                 acc[mb][nb][3] = __uint_as_float(vh[1] & 0xffff0000u) + __uint_as_float(vl[1] & 0xffff0000u);
             }
         }
+        return;
+    }
+    if (EPI == EPI_STORE_SO) {                                                   // (no fp32 accumulate-into plane in this form: zero)
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[mb][nb][e] = 0.f;
         return;
     }
 #pragma unroll
@@ -143,6 +152,21 @@ __device__ __forceinline__ void conv_acc_init_q(const ConvGemmArgs &a, const SRe
     }
 }
 
+// 8-byte stores of one row block's column blocks: base (scalar) + voff (the lane's constant byte offset) + 256 * nb
+template <int OFF>
+__device__ __forceinline__ void wgq_st8(const unsigned short *base, unsigned voff, const u32x2 &v)
+{
+    asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" ::"v"(voff), "v"(v), "s"(base), "n"(OFF) : "memory");
+}
+template <int NB>
+__device__ __forceinline__ void wgq_store_row(const unsigned short *hb, const unsigned short *lb, unsigned vo, const u32x2 (&ph)[NB],
+                                              const u32x2 (&pl)[NB], int tw0, int T)
+{
+    if (tw0 < T) { wgq_st8<0>(hb, vo, ph[0]); wgq_st8<0>(lb, vo, pl[0]); }
+    if constexpr (NB > 1) if (tw0 + 16 < T) { wgq_st8<256>(hb, vo, ph[1]); wgq_st8<256>(lb, vo, pl[1]); }
+    if constexpr (NB > 2) if (tw0 + 32 < T) { wgq_st8<512>(hb, vo, ph[2]); wgq_st8<512>(lb, vo, pl[2]); }
+    if constexpr (NB > 3) if (tw0 + 48 < T) { wgq_st8<768>(hb, vo, ph[3]); wgq_st8<768>(lb, vo, pl[3]); }
+}
 template <int EPI, int NB>
 __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRef &s0, f32x4 (&acc)[4][NB], int t0, int m0, int b,
                                                 int wr, int wc, int lane)
@@ -279,6 +303,34 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
         return;
     }
     // EPI_STORE / EPI_RESSKIP: the auxiliary values were the accumulators' initial value (conv_acc_init_q): stores only
+#if !defined(WG_OPT_NO_EPI_BATCH) && !defined(WG_OPT_UNIT16)
+    // S-plane only (the residual stream and its gradient, s_only_chain): every store of the tile issued back to back.  On this part a
+    // vector-memory instruction may read its address registers LATE, so the compiler drains vmcnt before anything overwrites a register
+    // of a store in flight: with one address computation per store, each store waited for the previous one to leave -- nine full drains
+    // per tile (the residual conv spent 16 of its 38 us there, tools/experiments/shape_ab.sh).  Here the stores are hand-issued: scalar
+    // base + ONE constant 32-bit lane offset + immediate (column blocks are 256 bytes apart) -- no address register is ever rewritten,
+    // nothing drains, and the tile's stores leave while the next tile is already being multiplied.
+    if (EPI == EPI_STORE_SO) {
+        const unsigned vo = (unsigned)(((rq >> 1) * g.P + col) * 16 + 8 * (rq & 1));       // bytes: unit row, time step, half unit
+        const int tw0 = t0 + wc * (16 * NB) + col;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const int mbase = m0 + wr * 64 + mb * 16;
+            if (mbase >= a.M) continue;
+            const unsigned short *hb = s0.hi + ((size_t)b * (s0.Cp >> 3) + ((s0.ch0 + mbase) >> 3)) * g.P * 8 + (size_t)(g.H + t0 + wc * (16 * NB)) * 8;
+            const unsigned short *lb = hb + s0.lo_off;
+            u32x2 ph[NB], pl[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                unsigned hh, ll;
+                split2(acc[mb][nb][0], acc[mb][nb][1], hh, ll); ph[nb][0] = hh; pl[nb][0] = ll;
+                split2(acc[mb][nb][2], acc[mb][nb][3], hh, ll); ph[nb][1] = hh; pl[nb][1] = ll;
+            }
+            if (mbase + 4 * rq < a.M) wgq_store_row<NB>(hb, lb, vo, ph, pl, tw0, g.T);
+        }
+        return;
+    }
+#endif
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
         const int mbase = m0 + wr * 64 + mb * 16;
@@ -517,7 +569,7 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
             asm volatile("" : "+v"(ln)::"memory");
             WGQ_SB();
         }
-        if (EPI == EPI_STORE || EPI == EPI_RESSKIP) {
+        if (EPI == EPI_STORE || EPI == EPI_STORE_SO || EPI == EPI_RESSKIP) {
             conv_acc_init_q<EPI, NB>(a, aa.saux, acc, t0, m0, b, wr, wc, ln);
         } else {
 #pragma unroll

@@ -970,7 +970,14 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                 return;
             }
 #endif
+            // S-plane-only stores (no fp32 output, no fp32 accumulate-into plane): the instantiation with the hand-issued epilogue (EPI_STORE_SO)
+            const bool so_epi = epi == EPI_STORE && as.s0.hi && !a.out0.p && !a.aux0.p
+#if defined(WG_OPT_NO_EPI_BATCH)
+                                && false
+#endif
+                ;
             if (small) {
+                if (so_epi) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE_SO, 1>), gp, dim3(512), 0, as); return; }
                 switch (epi) {
                 case EPI_STORE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE, 1>), gp, dim3(512), 0, as); break;
                 case EPI_GATE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE, 1>), gp, dim3(512), 0, as); break;
@@ -991,6 +998,7 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                 as.nty = (int)grid.y / 2;
                 const dim3 g2(std::min(ntiles / 2, cus));
                 if (cus % 8) as.xcd_items = 0;                // (mg2_ok: at least one tile per CU)
+                if (so_epi) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE_SO, 2, 2>), g2, dim3(1024), 0, as); return; }
                 switch (epi) {
                 case EPI_STORE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE, 2, 2>), g2, dim3(1024), 0, as); break;
                 case EPI_GATE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE, 2, 2>), g2, dim3(1024), 0, as); break;
@@ -999,6 +1007,7 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                 return;
             }
 #endif
+            if (so_epi) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE_SO, 2>), gp, dim3(512), 0, as); return; }
             switch (epi) {
             case EPI_STORE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE, 2>), gp, dim3(512), 0, as); break;
             case EPI_GATE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE, 2>), gp, dim3(512), 0, as); break;
