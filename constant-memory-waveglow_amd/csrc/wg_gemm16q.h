@@ -158,6 +158,41 @@ __device__ __forceinline__ void wgq_st8(const unsigned short *base, unsigned vof
 {
     asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" ::"v"(voff), "v"(v), "s"(base), "n"(OFF) : "memory");
 }
+template <int OFF>
+__device__ __forceinline__ void wgq_st16nt(const float *base, unsigned voff, const f32x4 &v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt" ::"v"(voff), "v"(v), "s"(base), "n"(OFF) : "memory");
+}
+// EPI_GATE_SO, column block NBI of a wave tile: tanh, sigmoid, gate of the lane's 8 channels; stores at immediate offset 256 * NBI
+template <int NB, int NBI>
+__device__ __forceinline__ void wgq_gate_nb(f32x4 (&acc)[4][NB], bool live, const float *const (&bt)[2], const float *const (&bs)[2],
+                                            const unsigned short *const (&sh)[2], const unsigned short *const (&sl)[2], bool has_ts,
+                                            unsigned vo_t, unsigned vo_s)
+{
+    float tw[8], sf[8], gv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        tw[i] = wg_tanh(acc[i >> 2][NBI][i & 3]);
+        sf[i] = wg_sigmoid(acc[2 + (i >> 2)][NBI][i & 3]);
+        gv[i] = tw[i] * sf[i];
+    }
+#pragma unroll
+    for (int mbp = 0; mbp < 2; ++mbp) {
+        f32x4 vt, vs;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vt[e] = tw[4 * mbp + e]; vs[e] = sf[4 * mbp + e]; }
+        u32x2 vh, vl;
+        unsigned hh, ll;
+        split2(gv[4 * mbp], gv[4 * mbp + 1], hh, ll); vh[0] = hh; vl[0] = ll;
+        split2(gv[4 * mbp + 2], gv[4 * mbp + 3], hh, ll); vh[1] = hh; vl[1] = ll;
+        if (live) {
+            if (has_ts) { wgq_st16nt<256 * NBI>(bt[mbp], vo_t, vt); wgq_st16nt<256 * NBI>(bs[mbp], vo_t, vs); }
+            wgq_st8<256 * NBI>(sh[mbp], vo_s, vh);
+            wgq_st8<256 * NBI>(sl[mbp], vo_s, vl);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);                       // eight outputs at a time
+}
 template <int NB>
 __device__ __forceinline__ void wgq_store_row(const unsigned short *hb, const unsigned short *lb, unsigned vo, const u32x2 (&ph)[NB],
                                               const u32x2 (&pl)[NB], int tw0, int T)
@@ -173,6 +208,30 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
 {
     const Geo g = a.g;
     const int col = lane & 15, rq = lane >> 4;
+    if (EPI == EPI_GATE_SO) {
+        // EPI_GATE with every store hand-issued (see EPI_STORE_SO below): scalar bases per 16-channel block, two constant lane offsets
+        // (the fp32 tanh / sigmoid planes [c / 4][t][4]: 16 bytes per lane; the gate's S-plane: 8 bytes), column blocks as immediates
+        const int chb = (m0 >> 1) + wr * 32;
+        if (2 * chb >= a.M) return;
+        const bool has_ts = a.out1.p != nullptr;
+        const int tl0 = wc * (16 * NB);
+        const float *bt[2], *bs[2];
+        const unsigned short *sh[2], *sl[2];
+#pragma unroll
+        for (int mbp = 0; mbp < 2; ++mbp) {
+            bt[mbp] = has_ts ? paddr4(a.out1, g, b, chb + mbp * 16, t0 + tl0) : nullptr;
+            bs[mbp] = has_ts ? paddr4(a.out2, g, b, chb + mbp * 16, t0 + tl0) : nullptr;
+            sh[mbp] = s0.hi + s_index(s0, g, b, chb + mbp * 16, t0 + tl0);
+            sl[mbp] = sh[mbp] + s0.lo_off;
+        }
+        const unsigned vo_t = (unsigned)((rq * g.P + col) * 16), vo_s = (unsigned)(((rq >> 1) * g.P + col) * 16 + 8 * (rq & 1));
+        const int tw0 = t0 + tl0 + col;
+        wgq_gate_nb<NB, 0>(acc, tw0 < g.T, bt, bs, sh, sl, has_ts, vo_t, vo_s);
+        if constexpr (NB > 1) wgq_gate_nb<NB, 1>(acc, tw0 + 16 < g.T, bt, bs, sh, sl, has_ts, vo_t, vo_s);
+        if constexpr (NB > 2) wgq_gate_nb<NB, 2>(acc, tw0 + 32 < g.T, bt, bs, sh, sl, has_ts, vo_t, vo_s);
+        if constexpr (NB > 3) wgq_gate_nb<NB, 3>(acc, tw0 + 48 < g.T, bt, bs, sh, sl, has_ts, vo_t, vo_s);
+        return;
+    }
     if (EPI == EPI_GATE) {
         // rows 0-31 of the wave tile are the tanh halves, rows 32-63 the sigmoid halves of the same 32 gate channels (pack_kernel's
         // 64-row interleave): channel chb + mbp*16 + 4 rq + e pairs acc[mbp] with acc[mbp + 2]

@@ -976,7 +976,13 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                                 && false
 #endif
                 ;
+            const bool so_gate = epi == EPI_GATE && as.s0.hi && !a.out0.p && WG_TS_INTERLEAVED
+#if defined(WG_OPT_NO_EPI_BATCH)
+                                 && false
+#endif
+                ;
             if (small) {
+                if (so_gate) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE_SO, 1>), gp, dim3(512), 0, as); return; }
                 if (so_epi) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE_SO, 1>), gp, dim3(512), 0, as); return; }
                 switch (epi) {
                 case EPI_STORE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE, 1>), gp, dim3(512), 0, as); break;
@@ -999,6 +1005,7 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                 const dim3 g2(std::min(ntiles / 2, cus));
                 if (cus % 8) as.xcd_items = 0;                // (mg2_ok: at least one tile per CU)
                 if (so_epi) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE_SO, 2, 2>), g2, dim3(1024), 0, as); return; }
+                if (so_gate) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE_SO, 2, 2>), g2, dim3(1024), 0, as); return; }
                 switch (epi) {
                 case EPI_STORE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE, 2, 2>), g2, dim3(1024), 0, as); break;
                 case EPI_GATE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE, 2, 2>), g2, dim3(1024), 0, as); break;
@@ -1008,6 +1015,7 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
             }
 #endif
             if (so_epi) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE_SO, 2>), gp, dim3(512), 0, as); return; }
+            if (so_gate) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE_SO, 2>), gp, dim3(512), 0, as); return; }
             switch (epi) {
             case EPI_STORE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE, 2>), gp, dim3(512), 0, as); break;
             case EPI_GATE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE, 2>), gp, dim3(512), 0, as); break;
