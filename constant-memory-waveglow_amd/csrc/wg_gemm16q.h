@@ -193,6 +193,22 @@ __device__ __forceinline__ void wgq_gate_nb(f32x4 (&acc)[4][NB], bool live, cons
     }
     __builtin_amdgcn_sched_barrier(0);                       // eight outputs at a time
 }
+template <int OFF>
+__device__ __forceinline__ void wgq_ld16nt(f32x4 &v, const float *base, unsigned voff)
+{
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(v) : "v"(voff), "s"(base), "n"(OFF) : "memory");
+}
+// every hand-issued load has landed (names the registers so that nothing that reads them moves above the wait)
+template <int NB>
+__device__ __forceinline__ void wgq_wait_loads(f32x4 (&x)[NB], f32x4 (&y)[NB])
+{
+    if constexpr (NB == 4)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3])::"memory");
+    else if constexpr (NB == 2)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(y[0]), "+v"(y[1])::"memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(y[0])::"memory");
+}
 template <int NB>
 __device__ __forceinline__ void wgq_store_row(const unsigned short *hb, const unsigned short *lb, unsigned vo, const u32x2 (&ph)[NB],
                                               const u32x2 (&pl)[NB], int tw0, int T)
@@ -293,6 +309,48 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
                 }
             }
             __builtin_amdgcn_sched_barrier(0);                   // eight outputs at a time
+        }
+        return;
+    }
+    if (EPI == EPI_DGATE_SO) {
+        // EPI_DGATE with hand-issued memory instructions.  The compiler's form issued a row block's eight 16-byte tanh / sigmoid loads
+        // two at a time, each pair behind a full drain (a fresh 64-bit address pair per load, and this part may read an address register
+        // late): five round trips per block, four blocks per tile -- 49 of the launch's 82 us (tools/experiments/shape_ab.sh).  Here a
+        // block's loads are scalar base + ONE constant lane offset + immediate: issued back to back, one round trip per block; the
+        // S-plane stores likewise (see EPI_STORE_SO).
+        const unsigned vo_t = (unsigned)((rq * g.P + col) * 16), vo_s = (unsigned)(((rq >> 1) * g.P + col) * 16 + 8 * (rq & 1));
+        const int tl0 = wc * (16 * NB), tw0 = t0 + tl0 + col;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const int mbase = m0 + wr * 64 + mb * 16;
+            if (mbase >= a.M) continue;                         // (wave uniform; M is a multiple of 16 on this path)
+            const float *px = paddr4(a.aux0, g, b, mbase, t0 + tl0), *py = paddr4(a.aux1, g, b, mbase, t0 + tl0);
+            f32x4 ax[NB], ay[NB];
+            wgq_ld16nt<0>(ax[0], px, vo_t); wgq_ld16nt<0>(ay[0], py, vo_t);
+            if constexpr (NB > 1) { wgq_ld16nt<256>(ax[1], px, vo_t); wgq_ld16nt<256>(ay[1], py, vo_t); }
+            if constexpr (NB > 2) { wgq_ld16nt<512>(ax[2], px, vo_t); wgq_ld16nt<512>(ay[2], py, vo_t); }
+            if constexpr (NB > 3) { wgq_ld16nt<768>(ax[3], px, vo_t); wgq_ld16nt<768>(ay[3], py, vo_t); }
+            const unsigned short *hb = s0.hi + s_index(s0, g, b, mbase, t0 + tl0), *lb = hb + s0.lo_off;
+            const unsigned short *hb2 = s0.hi + s_index(s0, g, b, a.nsplit + mbase, t0 + tl0), *lb2 = hb2 + s0.lo_off;
+            wgq_wait_loads<NB>(ax, ay);
+            u32x2 ph[NB], pl[NB], qh[NB], ql[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                float o[4], o2[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc[mb][nb][e], tw = ax[nb][e], sf = ay[nb][e];
+                    o[e] = v * sf * (1.0f - tw * tw);
+                    o2[e] = v * tw * sf * (1.0f - sf);
+                }
+                unsigned hh, ll;
+                split2(o[0], o[1], hh, ll); ph[nb][0] = hh; pl[nb][0] = ll;
+                split2(o[2], o[3], hh, ll); ph[nb][1] = hh; pl[nb][1] = ll;
+                split2(o2[0], o2[1], hh, ll); qh[nb][0] = hh; ql[nb][0] = ll;
+                split2(o2[2], o2[3], hh, ll); qh[nb][1] = hh; ql[nb][1] = ll;
+            }
+            wgq_store_row<NB>(hb, lb, vo_s, ph, pl, tw0, g.T);
+            wgq_store_row<NB>(hb2, lb2, vo_s, qh, ql, tw0, g.T);
         }
         return;
     }
@@ -473,7 +531,7 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
     const Geo g = a.g;
     int nchunks = 0;
     for (int s = 0; s < a.nseg; ++s) nchunks += (a.seg[s].nch + WG16_BK - 1) / WG16_BK;
-    constexpr bool PERSIST = EPI != EPI_DGATE;                // (the gate backward keeps one workgroup per tile: see convgemm16w_kernel)
+    constexpr bool PERSIST = EPI != EPI_DGATE && EPI != EPI_DGATE_SO;                // (the gate backward keeps one workgroup per tile: see convgemm16w_kernel)
     const int ntiles = aa.ntx * aa.nty * aa.ntz, G = (int)gridDim.x;
     // (xcd_items: the workgroup's XCD owns ntz / 8 plane rows = xl tiles, dealt to its G / 8 workgroups; see ConvGemm16sArgs)
     const int xper = aa.ntx * aa.nty, xl = aa.xcd_items * xper, xslots = G >> 3, xslot = (int)blockIdx.x >> 3;

@@ -981,7 +981,13 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                                  && false
 #endif
                 ;
+            const bool so_dgate = epi == EPI_DGATE && as.s0.hi && !a.out0.p && WG_TS_INTERLEAVED
+#if defined(WG_OPT_NO_EPI_BATCH)
+                                  && false
+#endif
+                ;
             if (small) {
+                if (so_dgate) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_DGATE_SO, 1>), gp, dim3(512), 0, as); return; }
                 if (so_gate) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE_SO, 1>), gp, dim3(512), 0, as); return; }
                 if (so_epi) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE_SO, 1>), gp, dim3(512), 0, as); return; }
                 switch (epi) {
@@ -1016,6 +1022,7 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
 #endif
             if (so_epi) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE_SO, 2>), gp, dim3(512), 0, as); return; }
             if (so_gate) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE_SO, 2>), gp, dim3(512), 0, as); return; }
+            if (so_dgate) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_DGATE_SO, 2>), gp, dim3(512), 0, as); return; }
             switch (epi) {
             case EPI_STORE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE, 2>), gp, dim3(512), 0, as); break;
             case EPI_GATE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE, 2>), gp, dim3(512), 0, as); break;
