@@ -104,6 +104,7 @@ enum {
     EPI_GATE = 1,     // packed rows come in 64-blocks [32 tanh | 32 sigmoid]; out0 = gate, out1 = tanh, out2 = sigmoid
     EPI_RESSKIP = 2,  // m < nsplit: out0[m] = acc + aux0[m] ; else out1[m-nsplit] (+)= acc
     EPI_DGATE = 3,    // out0[m] = acc*sf*(1-tw^2) ; out0[nsplit+m] = acc*tw*sf*(1-sf)   (aux0 = tw, aux1 = sf)
+    EPI_STORE_FO = 7, // convgemm16q only: EPI_STORE with an fp32 plane as its ONLY output (skip sum, conditioning gradient), hand-issued stores
     EPI_DGATE_SO = 6, // convgemm16q only: EPI_DGATE with S-plane output only; the tanh / sigmoid loads of a row block and its stores hand-issued
     EPI_GATE_SO = 5,  // convgemm16q only: EPI_GATE without the fp32 gate plane (S-plane gate, optional tanh / sigmoid planes), hand-issued stores
     EPI_STORE_SO = 4, // convgemm16q only: EPI_STORE whose output (and accumulate-into input, if any) exist as S-planes ONLY: its own

@@ -135,7 +135,7 @@ __device__ __forceinline__ void conv_acc_init_q(const ConvGemmArgs &a, const SRe
     for (int mb = 0; mb < 4; ++mb) {
         const int mbase = m0 + wr * 64 + mb * 16;                                 // first row of this 16-row block (wave uniform)
         const float *base = nullptr;
-        if (EPI == EPI_STORE) base = a.aux0.p ? paddr(a.aux0, g, b, mbase, t0) : nullptr;
+        if (EPI == EPI_STORE || EPI == EPI_STORE_FO) base = a.aux0.p ? paddr(a.aux0, g, b, mbase, t0) : nullptr;
         else if (EPI == EPI_RESSKIP)                                              // nsplit is a multiple of 32: a block lies on one side
             base = mbase < a.nsplit ? paddr(a.aux0, g, b, mbase, t0) : (a.accumulate ? paddr(a.out1, g, b, mbase - a.nsplit, t0) : nullptr);
 #pragma unroll
@@ -192,6 +192,11 @@ __device__ __forceinline__ void wgq_gate_nb(f32x4 (&acc)[4][NB], bool live, cons
         }
     }
     __builtin_amdgcn_sched_barrier(0);                       // eight outputs at a time
+}
+template <int OFF>
+__device__ __forceinline__ void wgq_st4(const float *base, unsigned voff, float v)
+{
+    asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(voff), "v"(v), "s"(base), "n"(OFF) : "memory");
 }
 template <int OFF>
 __device__ __forceinline__ void wgq_ld16nt(f32x4 &v, const float *base, unsigned voff)
@@ -427,6 +432,27 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
     // per tile (the residual conv spent 16 of its 38 us there, tools/experiments/shape_ab.sh).  Here the stores are hand-issued: scalar
     // base + ONE constant 32-bit lane offset + immediate (column blocks are 256 bytes apart) -- no address register is ever rewritten,
     // nothing drains, and the tile's stores leave while the next tile is already being multiplied.
+    if (EPI == EPI_STORE_FO) {                                  // fp32 plane only: four constant lane offsets (the lane's four rows), column blocks 64 bytes apart
+        unsigned vo[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vo[e] = (unsigned)(((4 * rq + e) * g.P + col) * 4);
+        const int tw0 = t0 + wc * (16 * NB) + col;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const int mbase = m0 + wr * 64 + mb * 16;
+            if (mbase >= a.M) continue;
+            const float *fb = paddr(a.out0, g, b, mbase, t0 + wc * (16 * NB));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (mbase + 4 * rq + e >= a.M) continue;
+                if (tw0 < g.T) wgq_st4<0>(fb, vo[e], acc[mb][0][e]);
+                if constexpr (NB > 1) if (tw0 + 16 < g.T) wgq_st4<64>(fb, vo[e], acc[mb][1][e]);
+                if constexpr (NB > 2) if (tw0 + 32 < g.T) wgq_st4<128>(fb, vo[e], acc[mb][2][e]);
+                if constexpr (NB > 3) if (tw0 + 48 < g.T) wgq_st4<192>(fb, vo[e], acc[mb][3][e]);
+            }
+        }
+        return;
+    }
     if (EPI == EPI_STORE_SO) {
         const unsigned vo = (unsigned)(((rq >> 1) * g.P + col) * 16 + 8 * (rq & 1));       // bytes: unit row, time step, half unit
         const int tw0 = t0 + wc * (16 * NB) + col;
@@ -686,7 +712,7 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
             asm volatile("" : "+v"(ln)::"memory");
             WGQ_SB();
         }
-        if (EPI == EPI_STORE || EPI == EPI_STORE_SO || EPI == EPI_RESSKIP) {
+        if (EPI == EPI_STORE || EPI == EPI_STORE_SO || EPI == EPI_STORE_FO || EPI == EPI_RESSKIP) {
             conv_acc_init_q<EPI, NB>(a, aa.saux, acc, t0, m0, b, wr, wc, ln);
         } else {
 #pragma unroll

@@ -97,7 +97,7 @@ __global__ void to_splane_kernel(PRef src, int nvalid, SRef dst, Geo g)
 #define WG_OPT_2P 0
 #endif
 template <int EPI> struct TwoP {
-    static constexpr bool no_alo = (EPI == EPI_GATE && (WG_OPT_2P & 1)) || ((EPI == EPI_STORE || EPI == EPI_STORE_SO || EPI == EPI_RESSKIP) && (WG_OPT_2P & 4)) ||
+    static constexpr bool no_alo = (EPI == EPI_GATE && (WG_OPT_2P & 1)) || ((EPI == EPI_STORE || EPI == EPI_STORE_SO || EPI == EPI_STORE_FO || EPI == EPI_RESSKIP) && (WG_OPT_2P & 4)) ||
                                    ((EPI == EPI_DGATE || EPI == EPI_DGATE_SO) && (WG_OPT_2P & 8));
     static constexpr bool no_blo = EPI == EPI_GATE && (WG_OPT_2P & 2);
 };

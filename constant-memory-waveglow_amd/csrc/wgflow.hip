@@ -986,7 +986,13 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                                   && false
 #endif
                 ;
+            const bool fo_epi = epi == EPI_STORE && !as.s0.hi && a.out0.p && !as.saux.hi
+#if defined(WG_OPT_NO_EPI_BATCH)
+                                && false
+#endif
+                ;
             if (small) {
+                if (fo_epi) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE_FO, 1>), gp, dim3(512), 0, as); return; }
                 if (so_dgate) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_DGATE_SO, 1>), gp, dim3(512), 0, as); return; }
                 if (so_gate) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE_SO, 1>), gp, dim3(512), 0, as); return; }
                 if (so_epi) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE_SO, 1>), gp, dim3(512), 0, as); return; }
@@ -1012,6 +1018,7 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                 if (cus % 8) as.xcd_items = 0;                // (mg2_ok: at least one tile per CU)
                 if (so_epi) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE_SO, 2, 2>), g2, dim3(1024), 0, as); return; }
                 if (so_gate) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE_SO, 2, 2>), g2, dim3(1024), 0, as); return; }
+                if (fo_epi) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE_FO, 2, 2>), g2, dim3(1024), 0, as); return; }
                 switch (epi) {
                 case EPI_STORE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE, 2, 2>), g2, dim3(1024), 0, as); break;
                 case EPI_GATE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE, 2, 2>), g2, dim3(1024), 0, as); break;
@@ -1023,6 +1030,7 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
             if (so_epi) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE_SO, 2>), gp, dim3(512), 0, as); return; }
             if (so_gate) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE_SO, 2>), gp, dim3(512), 0, as); return; }
             if (so_dgate) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_DGATE_SO, 2>), gp, dim3(512), 0, as); return; }
+            if (fo_epi) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE_FO, 2>), gp, dim3(512), 0, as); return; }
             switch (epi) {
             case EPI_STORE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE, 2>), gp, dim3(512), 0, as); break;
             case EPI_GATE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE, 2>), gp, dim3(512), 0, as); break;

@@ -160,7 +160,7 @@ def test_hand_issued_loads_are_never_touched_before_their_wait():
     # conv: 4 epilogues x 2 tile widths of convgemm16q + its three 256 x 128 (MG = 2) instantiations + 3 x convgemm16h; wgrad16s: 2 tile
     # heights + the paired launch; wgrad16t; the stage interpreter wf_rowsteps_kernel (three convgemm16h bodies inside).  (The superseded
     # 32x32x16 kernels -- A/B builds only -- are checked with --defines WG_OPT_MFMA32.)
-    assert len(lines) == 27 and all(l.rstrip().endswith(" 0 violations") for l in lines), r.stdout
+    assert len(lines) == 30 and all(l.rstrip().endswith(" 0 violations") for l in lines), r.stdout
 
 
 def test_wsrglow_state_dict_layout_matches_reference(golden_dir):
