@@ -161,7 +161,9 @@ __device__ __forceinline__ void wgq_st8(const unsigned short *base, unsigned vof
 template <int OFF>
 __device__ __forceinline__ void wgq_st16nt(const float *base, unsigned voff, const f32x4 &v)
 {
-    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt" ::"v"(voff), "v"(v), "s"(base), "n"(OFF) : "memory");
+    // (s_nop 1: a store of more than 64 bits needs two wait states before its data registers may be written again, and the compiler's
+    // hazard recogniser does not look into asm statements)
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(base), "n"(OFF) : "memory");
 }
 // EPI_GATE_SO, column block NBI of a wave tile: tanh, sigmoid, gate of the lane's 8 channels; stores at immediate offset 256 * NBI
 template <int NB, int NBI>
