@@ -55,6 +55,112 @@ __device__ __forceinline__ const unsigned short *wg_uniform_ptr(const unsigned s
 // The tile `id` of the launch's grid: ntx (64-column tiles) x nty (64-ROW tiles) x ntz, time tile fastest.  A device function so that
 // the stage interpreter (wg_stage.h) runs the same code for one stage of a recorded launch sequence; row_sel1 overrides the argument
 // block's value there (the interpreter walks the height rows of WaveFlow's inverse with ONE recorded program).
+// Accumulator init and epilogue of the 64 x 64-tile kernel with HAND-ISSUED memory instructions (EPI_STORE / EPI_RESSKIP; see the note on
+// drained vmcnt in wg_gemm16q.h: the compiler's form drained 14-15 times per tile, and these launches are chains of latencies --
+// single-utterance synthesis, WaveFlow's row steps).  A wave owns 64 rows x 16 columns: scalar base per 16-row block, the lane's four
+// row offsets (fp32 planes) or its unit offset (S-planes) constant, ONE explicit wait behind all loads.
+template <int OFF>
+__device__ __forceinline__ void wgh_ld4(float &v, const float *base, unsigned voff)
+{
+    asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(base), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void wgh_ld8(u32x2 &v, const unsigned short *base, unsigned voff)
+{
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(base) : "memory");
+}
+template <int EPI, bool IN_MEMORY>
+__device__ __forceinline__ void conv_acc_init_a(const ConvGemmArgs &a, const SRef &saux, const void *safe, f32x4 (&acc)[4][1], int t0, int m0, int b,
+                                                int wc, int lane)
+{
+    // Every load is issued UNCONDITIONALLY (a lane or a block without a value reads `safe`, any readable address, at offset 0) and the
+    // zero is selected behind the wait: a load under a branch lets the compiler merge its destination with the other path's value --
+    // a register copy -- BEFORE the hand-written wait (tools/check_asm_loads.py finds exactly that).
+    const Geo g = a.g;
+    const int col = lane & 15, rq = lane >> 4, tc = t0 + wc * 16, t = tc + col;
+    if (EPI == EPI_STORE && saux.hi) {
+        const unsigned vo_s = (unsigned)(((rq >> 1) * g.P + col) * 16 + 8 * (rq & 1));
+        u32x2 h[4], l[4];
+        bool ok[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const int mbase = m0 + mb * 16;
+            const bool blk = mbase < a.M;                        // (wave uniform)
+            ok[mb] = blk && t < g.T && mbase + 4 * rq < a.M;
+            const unsigned short *hb = blk ? saux.hi + s_index(saux, g, b, mbase, tc) : reinterpret_cast<const unsigned short *>(safe);
+            const unsigned short *lb = blk ? hb + saux.lo_off : hb;
+            const unsigned vo = ok[mb] ? vo_s : 0u;
+            wgh_ld8(h[mb], wg_uniform_ptr<IN_MEMORY>(hb), vo); wgh_ld8(l[mb], wg_uniform_ptr<IN_MEMORY>(lb), vo);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3])::"memory");
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const unsigned h0 = ok[mb] ? h[mb][0] : 0u, h1 = ok[mb] ? h[mb][1] : 0u, l0 = ok[mb] ? l[mb][0] : 0u, l1 = ok[mb] ? l[mb][1] : 0u;
+            acc[mb][0][0] = __uint_as_float(h0 << 16) + __uint_as_float(l0 << 16);
+            acc[mb][0][1] = __uint_as_float(h0 & 0xffff0000u) + __uint_as_float(l0 & 0xffff0000u);
+            acc[mb][0][2] = __uint_as_float(h1 << 16) + __uint_as_float(l1 << 16);
+            acc[mb][0][3] = __uint_as_float(h1 & 0xffff0000u) + __uint_as_float(l1 & 0xffff0000u);
+        }
+        return;
+    }
+    unsigned vo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vo[e] = (unsigned)(((4 * rq + e) * g.P + col) * 4);
+    float x[4][4];
+    bool ok[4][4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const int mbase = m0 + mb * 16;                          // (wave uniform)
+        const float *base = nullptr;
+        if (EPI == EPI_STORE) base = a.aux0.p ? paddr(a.aux0, g, b, mbase, tc) : nullptr;
+        else base = mbase < a.nsplit ? paddr(a.aux0, g, b, mbase, tc) : (a.accumulate ? paddr(a.out1, g, b, mbase - a.nsplit, tc) : nullptr);
+        const bool blk = base != nullptr && mbase < a.M;
+        const float *bp = reinterpret_cast<const float *>(wg_uniform_ptr<IN_MEMORY>(reinterpret_cast<const unsigned short *>(blk ? base : reinterpret_cast<const float *>(safe))));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ok[mb][e] = blk && t < g.T && mbase + 4 * rq + e < a.M;
+            wgh_ld4<0>(x[mb][e], bp, ok[mb][e] ? vo[e] : 0u);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[0][2]), "+v"(x[0][3]), "+v"(x[1][0]), "+v"(x[1][1]), "+v"(x[1][2]), "+v"(x[1][3]),
+                   "+v"(x[2][0]), "+v"(x[2][1]), "+v"(x[2][2]), "+v"(x[2][3]), "+v"(x[3][0]), "+v"(x[3][1]), "+v"(x[3][2]), "+v"(x[3][3])::"memory");
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[mb][0][e] = ok[mb][e] ? x[mb][e] : 0.f;
+}
+template <int EPI, bool IN_MEMORY>
+__device__ __forceinline__ void conv_epilogue_a(const ConvGemmArgs &a, const SRef &s0, f32x4 (&acc)[4][1], int t0, int m0, int b, int wc, int lane)
+{
+    const Geo g = a.g;
+    const int col = lane & 15, rq = lane >> 4, tc = t0 + wc * 16, t = tc + col;
+    const unsigned vo_s = (unsigned)(((rq >> 1) * g.P + col) * 16 + 8 * (rq & 1));
+    unsigned vo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vo[e] = (unsigned)(((4 * rq + e) * g.P + col) * 4);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const int mbase = m0 + mb * 16;
+        if (mbase >= a.M) continue;
+        const bool res = EPI == EPI_STORE || mbase < a.nsplit;
+        const PRef &dst = res ? a.out0 : a.out1;
+        if (dst.p) {
+            const float *base = reinterpret_cast<const float *>(wg_uniform_ptr<IN_MEMORY>(reinterpret_cast<const unsigned short *>(paddr(dst, g, b, res ? mbase : mbase - a.nsplit, tc))));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (t < g.T && mbase + 4 * rq + e < a.M) wgq_st4<0>(base, vo[e], acc[mb][0][e]);
+        }
+        if (res && s0.hi) {
+            u32x2 ph, pl;
+            unsigned hh, ll;
+            split2(acc[mb][0][0], acc[mb][0][1], hh, ll); ph[0] = hh; pl[0] = ll;
+            split2(acc[mb][0][2], acc[mb][0][3], hh, ll); ph[1] = hh; pl[1] = ll;
+            const unsigned short *hb = wg_uniform_ptr<IN_MEMORY>(s0.hi + s_index(s0, g, b, mbase, tc));
+            if (t < g.T && mbase + 4 * rq < a.M) { wgq_st8<0>(hb, vo_s, ph); wgq_st8<0>(wg_uniform_ptr<IN_MEMORY>(hb + s0.lo_off), vo_s, pl); }
+        }
+    }
+}
+
 template <int EPI, bool IN_MEMORY = false>
 __device__ __forceinline__ void convgemm16h_body(const ConvGemm16sArgs &aa, int id, int row_sel1, char *smem)
 {
@@ -162,7 +268,11 @@ __device__ __forceinline__ void convgemm16h_body(const ConvGemm16sArgs &aa, int 
         f.bh = rd(sb + 2 * AIMG + bo); f.bl = rd(sb + 2 * AIMG + BIMG + bo);
     };
     if (EPI == EPI_STORE || EPI == EPI_RESSKIP) {
+#if !defined(WG_OPT_NO_EPI_BATCH)
+        conv_acc_init_a<EPI, IN_MEMORY>(a, aa.saux, aa.img, acc, t0, m0, b, wc, lane);
+#else
         conv_acc_init_q<EPI, 1>(a, aa.saux, acc, t0, m0, b, 0, wc, lane);
+#endif
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -199,7 +309,11 @@ __device__ __forceinline__ void convgemm16h_body(const ConvGemm16sArgs &aa, int 
     if (c < nchunks) step(f0, f1, c);
     for (int c = nchunks; c < nbar; ++c) WG16W_BAR();         // the loaders' spare iterations
     WGH_TRACE(2);
-    conv_epilogue_q<EPI, 1>(a, aa.s0, acc, t0, m0, b, 0, wc, lane);
+#if !defined(WG_OPT_NO_EPI_BATCH)
+    if (EPI == EPI_STORE || EPI == EPI_RESSKIP) conv_epilogue_a<EPI, IN_MEMORY>(a, aa.s0, acc, t0, m0, b, wc, lane);
+    else
+#endif
+        conv_epilogue_q<EPI, 1>(a, aa.s0, acc, t0, m0, b, 0, wc, lane);
     WGH_TRACE(3);
 }
 
