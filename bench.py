@@ -567,8 +567,8 @@ def main(argv=None):
         # bf16x3: every fp32 product costs three bf16 MFMAs; the roofline is the bf16 matrix pipe and only the
         # algorithmic FLOPs are credited (the 3x is overhead, not work) -- SURVEY.md 8d
         peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
-        # template arguments as rocprofv3 prints them: <EPI_GATE = 1, NI = 2 (128 columns), MG = 2 (256-row tile, one workgroup per CU)>
-        targs = {"convgemm_kernel": ["<1>"], "convgemm16_kernel": ["<1, 4>", "<1, 2>"], "convgemm16q_kernel": ["<1, 2, 2>", "<1, 2, 1>"]}[kname]
+        # template arguments as rocprofv3 prints them: <EPI_GATE_SO = 5 (EPI_GATE = 1 where a fp32 gate plane is written), NI = 2 (128 columns), MG = 2 (256-row tile, one workgroup per CU)>
+        targs = {"convgemm_kernel": ["<1>"], "convgemm16_kernel": ["<1, 4>", "<1, 2>"], "convgemm16q_kernel": ["<5, 2, 2>", "<5, 2, 1>", "<1, 2, 2>", "<1, 2, 1>"]}[kname]   # 5 = EPI_GATE_SO: EPI_GATE with hand-issued stores (wg_gemm.h)
         traffic, traffic_src, tsel = None, None, targs[0]
         for ta in targs:
             traffic, traffic_src = _traffic(kname + ta)
