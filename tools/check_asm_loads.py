@@ -11,6 +11,9 @@ convgemm16w kernel along its control-flow graph (every path, every distinct in-f
   * an asm `s_waitcnt vmcnt(N)` retires all but the newest N in-flight loads;
   * any compiler-emitted instruction that names an in-flight register is an error.
 
+A second rule covers every hand-issued vector-memory instruction (loads and the epilogues' stores): its scalar base must not have been
+written by `v_readfirstlane` fewer than five wait states earlier (sgpr_hazards below).
+
     python tools/check_asm_loads.py [--defines WG_X,WG_Y] [--keep out.s]
 Exit code 0 = clean.  Used by tests/test_abi_cpu.py.
 """
@@ -108,6 +111,32 @@ def check_kernel(name, lines):
     return nload, nwait, errors
 
 
+def sgpr_hazards(name, lines):
+    """A hand-issued vector-memory instruction whose scalar base (s[a:b]) was written by v_readfirstlane fewer than five wait states
+    earlier reads a STALE base: the hardware needs the wait states and the compiler's hazard recogniser does not look into asm
+    statements (found the hard way in wf_rowsteps_kernel: memory access faults).  Straight-line check over the listing: the writer
+    must be at least five wait states (instructions; `s_nop N` counts N + 1) in front of the use."""
+    ins, _ = parse(lines)
+    errors = []
+    for n, (no, t, inasm) in enumerate(ins):
+        m = re.match(r"global_(load|store)_\w+ .*?s\[(\d+):(\d+)\]", t)
+        if not (inasm and m):
+            continue
+        lo, hi = int(m.group(2)), int(m.group(3))
+        ws = 0
+        for k in range(n - 1, max(-1, n - 8), -1):
+            p = ins[k][1]
+            d = re.match(r"v_readfirstlane_b32 s(\d+)", p)
+            if d and lo <= int(d.group(1)) <= hi and ws < 5:
+                errors.append("%s:%d: `%s` uses a base written by `%s` %d wait states earlier (needs 5)" % (name, no, t, p, ws))
+                break
+            mm = re.match(r"s_nop (\d+)", p)
+            ws += int(mm.group(1)) + 1 if mm else 1
+            if ws >= 5:
+                break
+    return errors
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--defines", default="")
@@ -127,6 +156,7 @@ def main():
         e = next(i for i in range(s, len(text)) if ".amdhsa_kernel" in text[i] or text[i].startswith(".Lfunc_end"))
         kname = text[s].split(":")[0]
         nload, nwait, errors = check_kernel(kname, text[s:e])
+        errors += sgpr_hazards(kname, text[s:e])
         print("%s: %d asm loads, %d counted waits, %d violations" % (kname, nload, nwait, len(errors)))
         for m in errors[:10]:
             print("   ", m)
