@@ -329,6 +329,9 @@ __global__ __launch_bounds__(256) void packimg_kernel(const PackArgs a)
     for (int tl = blockIdx.x; tl < tk * tm; tl += gridDim.x) {
         const int kc = tl / tm, k0 = kc * 32, m0 = (tl - kc * tm) * 64;
         __syncthreads();
+        // (all eight values of a thread are requested before the first is used: with the load inside the conditional the compiler
+        // issued them one round trip at a time)
+        float sv[8], vv[8];
         if (j.mode == 0) {                                    // consecutive lanes read consecutive k of one source row (see pack_job_plain)
             const int kk = tid & 31, k = k0 + kk;
 #pragma unroll
@@ -340,19 +343,27 @@ __global__ __launch_bounds__(256) void packimg_kernel(const PackArgs a)
                     o = r < 32 ? qq * 32 + r : j.half + qq * 32 + (r - 32);
                     if ((qq * 32 + (r & 31)) >= j.half) o = -1;
                 }
-                float val = 0.f;
-                if (o >= 0 && o < j.no && k < j.ni && m < j.Mp) val = j.scale[o] * j.src[(size_t)o * j.so + (size_t)k * j.si + j.off];
-                tile[kk][mm] = val;
+                const bool ok = o >= 0 && o < j.no && k < j.ni && m < j.Mp;
+                const int oc = ok ? o : 0, kc = ok ? k : 0;                       // (clamped: element 0 always exists)
+                sv[q] = j.scale[oc];
+                vv[q] = j.src[(size_t)oc * j.so + (size_t)kc * j.si + j.off];
+                if (!ok) sv[q] = 0.f;
             }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) tile[kk][(tid >> 5) + 8 * q] = sv[q] * vv[q];
         } else {                                              // mode 1: consecutive lanes read consecutive m of source row k
             const int mm = tid & 63, m = m0 + mm;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int kk = (tid >> 6) + 4 * q, k = k0 + kk;
-                float val = 0.f;
-                if (k < j.no && m < j.ni) val = j.scale[k] * j.src[(size_t)k * j.so + (size_t)m * j.si + j.off];
-                tile[kk][mm] = val;
+                const bool ok = k < j.no && m < j.ni;
+                const int kc = ok ? k : 0, mc = ok ? m : 0;
+                sv[q] = j.scale[kc];
+                vv[q] = j.src[(size_t)kc * j.so + (size_t)mc * j.si + j.off];
+                if (!ok) sv[q] = 0.f;
             }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) tile[(tid >> 6) + 4 * q][mm] = sv[q] * vv[q];
         }
         __syncthreads();
         if (j.dst) {
