@@ -59,13 +59,16 @@ def build_model(dev, seed=0):
     return model.to(dev)
 
 
-def _traffic(kernel):
+def _traffic(kernel, prefix=""):
     """(HBM bytes per launch of the dominant kernel, the file it was read from).  NOT measured in this run: the bytes come from the
     newest committed PMC summary (profiles/*_hbm_traffic.json, produced by tools/profile_summary.py from separate rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); (None, None) if absent."""
     import glob
     best = (None, None)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
+        tag = os.path.basename(f)
+        if (prefix and prefix not in tag) or (not prefix and ("_wf_" in tag or "_wsr_" in tag)):
+            continue
         try:
             k = json.load(open(f))["kernels"]
         except Exception:
@@ -100,8 +103,9 @@ def cpu_baseline():
     """The CPU path timed on the host cores of the GPU box (rank 0, N = 1 only; BASELINE.md section 4's plan): training steps of
     oracle/torch_cpu.py -- the path's algorithm restated on the library the reference itself runs on (ATen's CPU convolutions, a local
     autograd graph per WN, activations rebuilt flow by flow), pinned to the reference's golden vectors by tests/test_oracle_golden.py --
-    at C1 (64ch, 6 flows, B=2, seg 4000) and at the C2 network with B=1 and B=2: 1 warm-up + 3 timed runs each, median reported, all
-    physical cores.  `value` is the C2 B=1 figure.  The plain-C oracle (oracle/wg_oracle.c, OpenMP), which the parity tests use as their
+    `value` = the C2 network on ALL physical cores: physical_cores // 8 worker processes x 8 threads, one 16000-sample segment each
+    (batch items are independent units), 1 warm-up + 3 timed steps per worker.  Next to it one process alone (`single_process`, C2 B=1,
+    its fastest thread count) and C1 (64ch, 6 flows, B=2, seg 4000).  The plain-C oracle (oracle/wg_oracle.c, OpenMP), which the parity tests use as their
     checker, is timed next to it on C2 B=1 as `c_port`."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import fill
@@ -136,27 +140,35 @@ def cpu_baseline():
         probe[n] = timed(lambda: torch_cpu.train_step(c1, tab, audio, h, SIGMA), 2, 4000, runs=2)["median_s"]
     cores = torch_cpu.set_threads(min(probe, key=probe.get))
     res["c1_b2"] = timed(lambda: torch_cpu.train_step(c1, tab, audio, h, SIGMA), 2, 4000)
-    for B in (1, 2):
-        _, tab, audio, h = case("c2", C2, B, SEG, FRAMES)
-        res["c2_b%d" % B] = timed(lambda: torch_cpu.train_step(C2, tab, audio, h, SIGMA), B, SEG)
-    total = sum(r["median_s"] * (r["runs"] + 1) for r in res.values())
-    # the C port: capped at 64 OpenMP threads (its loops expose 64-128 independent row blocks; more threads measured slower)
     _, tab, audio, h = case("c2", C2, 1, SEG, FRAMES)
+    res["c2_b1"] = timed(lambda: torch_cpu.train_step(C2, tab, audio, h, SIGMA), 1, SEG)
+    # ALL cores: batch items are independent units, so the honest all-core figure is one segment per worker PROCESS, physical_cores // 8
+    # processes x 8 threads (where ATen's pool still scales), all released together after a warm-up step, 3 timed steps each
+    # (oracle/torch_cpu.py: time_parallel).  (A B = 2 step in ONE process ran 2.3x slower per sample than B = 1 in round 3 -- the thread
+    # pool, not the algorithm -- and is no longer quoted.)
+    workers = max(1, phys // 8)
+    allcore = torch_cpu.time_parallel(C2, tab, audio, h, SIGMA, workers=workers, threads=min(8, phys), runs=3)
+    total = sum(r["median_s"] * (r["runs"] + 1) for r in res.values()) + allcore["wall_s"] * 4.0 / 3.0
+    # the C port: capped at 64 OpenMP threads (its loops expose 64-128 independent row blocks; more threads measured slower)
     oc = orc.make_config(**C2)
     cthreads = orc.set_threads(min(int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)), 64))
     cport = timed(lambda: orc.train_step(oc, tab, audio, h, SIGMA), 1, SEG, runs=2)
     cport.update({"unit": "samples/s", "cores": cthreads, "what": "oracle/wg_oracle.c (plain C + OpenMP), C2 B=1: 1 warm-up + 2 runs, median"})
-    return {"value": res["c2_b1"]["samples_per_s"], "unit": "samples/s", "cores": cores, "kind": "port",
+    single = dict(res["c2_b1"], cores=cores, what="ONE process, its fastest thread count (probed on C1): C2 B=1, median of 3 runs after 1 warm-up")
+    return {"value": allcore["samples_per_s"], "unit": "samples/s", "cores": allcore["workers"] * allcore["threads_per_worker"], "kind": "port",
             "implementation": "torch-cpu: oracle/torch_cpu.py, the step restated on ATen's CPU kernels (F.conv1d / MKLDNN), "
                               "constant-memory backward with a local autograd graph per WN; torch %s" % torch.__version__,
             "cpu_model": _cpu_model(),
-            "sample": "WaveGlow-256ch 12 flows fwd+NLL+bwd on 1 segment of 16000 samples (B=1): median of 3 runs after 1 warm-up; also C2 at "
-                      "B=2 and C1 (64ch, 6 flows, B=2, seg 4000), 3 runs each; %.0f s of CPU work in all" % (total + cport["median_s"] * 3),
-            "configs": res, "c_port": cport, "thread_probe_c1_s": {str(k): v for k, v in probe.items()}, "physical_cores": phys,
+            "sample": "WaveGlow-256ch 12 flows fwd+NLL+bwd, one 16000-sample segment per worker process: %d processes x %d threads, 1 warm-up + 3 "
+                      "timed steps each, released together; value = processes x 3 x 16000 / (last end - first start).  Beside it: one "
+                      "process alone (`single_process`), C1 (64ch, 6 flows, B=2, seg 4000) and the plain-C oracle; about %.0f s of CPU work in all"
+                      % (allcore["workers"], allcore["threads_per_worker"], total + cport["median_s"] * 3),
+            "all_core": allcore, "single_process": single, "configs": res, "c_port": cport,
+            "thread_probe_c1_s": {str(k): v for k, v in probe.items()}, "physical_cores": phys,
             "build_container_reference": {
                 "note": "measured in the BUILD container (8 cores of a Xeon, not this host), where the reference can be imported: the "
                         "reference's own torch-CPU path 7 980 samples/s (BASELINE.md section 2), oracle/torch_cpu.py 9 590, the C port "
-                        "2 300, all on the C2 B=1 step -- context for how close `value` is to the reference's speed, not an extrapolation",
+                        "2 300, all on the C2 B=1 step -- context for how close the figures are to the reference's speed, not an extrapolation",
                 "reference_samples_per_s": 7980.0, "torch_cpu_samples_per_s": 9590.0, "c_port_samples_per_s": 2300.0}}
 
 
@@ -344,7 +356,7 @@ def kernel_rooflines(trainer, x, h, split, steps=2, top=8):
 
 def f32_mode(dev, x, h):
     """The same step with the contractions on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32; WG_PRECISION=f32): the number that needs no
-    argument about operand splitting, next to the bf16x3 headline.  1 warm-up + 2 timed steps; the gate kernel against the fp32 roof."""
+    argument about operand splitting, next to the bf16x3 headline.  1 warm-up + 5 timed steps; the gate kernel against the fp32 roof."""
     from constant_memory_waveglow_amd import _lib
     from constant_memory_waveglow_amd.parallel import FlowTrainer
     old = os.environ.get("WG_PRECISION")
@@ -355,7 +367,7 @@ def f32_mode(dev, x, h):
         L = _lib.lib()
         tr.step(x, h)
         torch.cuda.synchronize()
-        steps = 2
+        steps = 5
         timer = L.wg_timer_create(_lib.K_CONV_GATE, 2 * C2["flows"] * C2["depth"] * steps)
         L.wg_timer_attach(timer)
         t0 = time.perf_counter()
@@ -384,12 +396,130 @@ def f32_mode(dev, x, h):
         torch.cuda.empty_cache()
 
 
+
+def make_workload(name, dev, batch, rank):
+    """The three benchmarked training steps behind one interface (BASELINE.json configs[1..4]):
+      waveglow  configs/waveglow_LJ_speech.json   batch 24 x 16000, sigma 0.7   FlowTrainer (wg_train_step, per-flow gradient buckets)
+      waveflow  configs/waveflow_LJ_speech.json   batch 12 x 16000, sigma 0.7   autograd (_WaveFlowFn) + ONE 24 MB gradient collective
+      wsrglow   configs/wsrglow_vctk_2x.json      batch 12 x 8192,  sigma 1.0   FlowTrainer (+ the embedding-table bucket)
+    step() = forward + NLL + backward to every parameter gradient (+ the mean all-reduce when the process group has > 1 rank or the
+    collectives are forced); weights re-packed every step, inputs resident in HBM."""
+    import constant_memory_waveglow_amd as cm
+    from constant_memory_waveglow_amd.parallel import FlowTrainer, GradSync
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    if name == "waveglow":
+        B = batch or 24
+        model = build_model(dev)
+        trainer = FlowTrainer(model, SIGMA)
+        x = torch.rand(B, SEG, device=dev, generator=g) * 2 - 1          # as tests/test_fwd_bwd.py:28 upstream
+        h = torch.randn(B, C2["n_mels"], FRAMES, device=dev, generator=g)
+        kcat = C2["radix"] * C2["residual_channels"] + C2["n_mels"]
+        return dict(model=model, trainer=trainer, sync=trainer.sync, batch=B, segment=SEG, x=x, h=h, generator=g,
+                    step=lambda: trainer.step(x, h)[0], metric="audio samples/sec (fwd+bwd) WaveGlow-256ch seg=16000",
+                    workload="WaveGlow 256ch, 12 flows, seg=16000, batch=%d per GPU (waveglow_LJ_speech.json), forward + NLL + "
+                             "constant-memory backward" % B,
+                    step_flop_per_sample=STEP_FLOP_PER_SAMPLE, gate_launches_per_step=2 * C2["flows"] * C2["depth"],
+                    gate_flop_per_launch=2.0 * kcat * 2 * C2["dilation_channels"] * B * (SEG // C2["n_group"]),
+                    gate_what="dilated k=3 conv + mel conditioning + gate", profile_prefix="")
+    if name == "wsrglow":
+        B = batch or 12
+        torch.manual_seed(0)
+        model = cm.WSRGlow(upsample_rate=2, memory_efficient=True, bias=False)
+        with torch.no_grad():
+            for blk in model.WNs:
+                blk.F.end.weight.normal_(0.0, 0.02)
+        model = model.to(dev)
+        trainer = FlowTrainer(model, 1.0)
+        seg = 8192
+        x = torch.rand(B, seg, device=dev, generator=g) * 2 - 1
+        c = (torch.rand(B, seg // 2, device=dev, generator=g) * 2 - 1) * 0.9
+        # per time step of 16 samples and flow: 8 layers x 2 x (3 x 256 + 3659) x 512 (conv + conditioning) + W_o + start / end
+        kcat = 3 * 256 + 3659
+        fwd = (8 * (2 * kcat * 512 + 2 * 256 * 512) - 2 * 256 * 256 + 2 * 256 * 16) * 12 / 16.0
+        return dict(model=model, trainer=trainer, sync=trainer.sync, batch=B, segment=seg, x=x, h=c, generator=g,
+                    step=lambda: trainer.step(x, c.clone())[0], metric="audio samples/sec (fwd+bwd) WSRGlow 2x seg=8192",
+                    workload="WSRGlow 2x (wsrglow_vctk_2x.json: 12 flows, n_group 16, 3659 conditioning channels, 229.7 M parameters), "
+                             "seg=8192, batch=%d per GPU, conditioning front-end + forward + NLL + constant-memory backward" % B,
+                    step_flop_per_sample=3.0 * fwd, gate_launches_per_step=2 * 12 * 8,
+                    gate_flop_per_launch=2.0 * kcat * 512 * B * (seg // 16), gate_what="dilated k=3 conv + 3659-channel conditioning + gate",
+                    profile_prefix="_wsr_")
+    B = batch or 12
+    torch.manual_seed(0)
+    model = cm.WaveFlow(flows=8, n_group=64, n_mels=80, use_conv1x1=False, memory_efficient=False, dilation_channels=64,
+                        residual_channels=64, skip_channels=64, bias=False)
+    with torch.no_grad():
+        for wn in model.WNs:
+            wn.end.weight.normal_(0.0, 0.02)
+    model = model.to(dev)
+    crit = cm.WaveGlowLoss(SIGMA)
+    sync = GradSync()
+    params = list(model.parameters())
+    sync.broadcast_params(params)
+    x = torch.rand(B, SEG, device=dev, generator=g) * 2 - 1
+    h = torch.randn(B, 80, FRAMES, device=dev, generator=g)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        model._engine.packed.key = None            # as in training, where the weights change: re-pack every step
+        z, ld = model(x, h)
+        loss = crit(z, ld)
+        loss.backward()
+        sync.all_reduce_params(params)
+        return loss
+    # per (height row, time) position and layer: 3x3 conv 2 x 64 x 128 x 9, conditioning 2 x 80 x 128, W_o 2 x 64 x 128; 8 flows x 8 layers;
+    # 63 of an item's 64 rows are WN2D inputs (waveflow.py:196-206)
+    fwd = 8 * 8 * (2 * 64 * 128 * 9 + 2 * 80 * 128 + 2 * 64 * 128) * 63 / 64.0
+    return dict(model=model, trainer=None, sync=sync, batch=B, segment=SEG, x=x, h=h, generator=g, step=step, n_param_bytes=4 * sum(p.numel() for p in params),
+                metric="audio samples/sec (fwd+bwd) WaveFlow-64ch seg=16000",
+                workload="WaveFlow 64ch, 8 flows, n_group 64 (waveflow_LJ_speech.json), seg=16000, batch=%d per GPU, forward + NLL + backward" % B,
+                step_flop_per_sample=3.0 * fwd, gate_launches_per_step=2 * 8 * 8,
+                gate_flop_per_launch=2.0 * (9 * 64 + 80) * 128 * B * 64 * (SEG // 64), gate_what="3x3 dilated conv + mel conditioning + gate",
+                profile_prefix="_wf_")
+
+
+def comm_report(wl, args, use_dist, world, rank, dev, dt_own, ms_per_step, barrier):
+    """What the N > 1 line needs for a first real multi-GPU run to be diagnosed: bytes and buckets of the gradient exchange, every
+    rank's own step time, and `exposed_ms` = the step minus the SAME step with the collectives skipped (all ranks skip together, so
+    nothing waits), i.e. the communication time the backward did not hide."""
+    sync, tr = wl["sync"], wl["trainer"]
+    if tr is not None:
+        buckets = [4 * tr.fg.comm_slice(b).numel() for b in range(tr.n_buckets)]
+    else:
+        buckets = [wl["n_param_bytes"]]
+    per_rank = torch.zeros(world, device=dev, dtype=torch.float64)
+    per_rank[rank] = dt_own / args.steps * 1e3
+    dist.all_reduce(per_rank)
+    k = max(1, min(args.steps, 5))
+    sync.skip = True
+    try:
+        wl["step"]()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            wl["step"]()
+        barrier()
+        t_nc = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    finally:
+        sync.skip = False
+    dist.all_reduce(t_nc, op=dist.ReduceOp.MAX)
+    nocomm_ms = float(t_nc.item()) / k * 1e3
+    # a ring all-reduce moves 2 (N - 1) / N of the buffer per rank over its xGMI links
+    return {"backend": dist.get_backend(), "bytes_per_step": int(sum(buckets)), "buckets": len(buckets),
+            "bucket_mb": [round(b / 1e6, 2) for b in buckets], "order": "backward order: last flow first, then the upsampler" if tr is not None else "one collective behind the backward",
+            "per_rank_ms": [round(float(v), 3) for v in per_rank.tolist()], "ms_per_step": ms_per_step,
+            "ms_per_step_collectives_skipped": nocomm_ms, "exposed_ms": ms_per_step - nocomm_ms, "steps_skipped_run": k,
+            "wire_bytes_per_rank_ring": int(2.0 * (world - 1) / max(world, 1) * sum(buckets))}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=24, help="per-GPU batch (configs[1]: 24)")
+    ap.add_argument("--model", choices=("waveglow", "waveflow", "wsrglow"), default="waveglow",
+                    help="waveglow: BASELINE.json configs[1] / [2] (the headline); waveflow: configs[3] (waveflow_LJ_speech.json); "
+                         "wsrglow: configs[4] (wsrglow_vctk_2x.json) -- same launcher, same JSON contract")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the model's config -- 24 / 12 / 12)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-inverse", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the WSRGlow / WaveFlow step timings (SURVEY.md 8f rows)")
@@ -473,7 +603,7 @@ def selftest_rank(args, world, rank):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.barrier()
     if rank == 0:
-        print(json.dumps({"metric": "selftest", "value": float(t.item()), "n_gpus": world, "rccl_ranks": world,
+        print(json.dumps({"metric": "selftest", "model": args.model, "value": float(t.item()), "n_gpus": world, "rccl_ranks": world,
                           "steps": args.steps, "warmup": args.warmup, "launched": os.environ.get("WG_BENCH_LAUNCHED") == "1"}), flush=True)
     dist.destroy_process_group()
     return 0
@@ -515,14 +645,16 @@ def main(argv=None):
     torch.cuda.set_device(dev)
 
     from constant_memory_waveglow_amd import _lib
-    from constant_memory_waveglow_amd.parallel import FlowTrainer
 
-    model = build_model(dev)
-    trainer = FlowTrainer(model, SIGMA)
-    B = args.batch
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    x = torch.rand(B, SEG, device=dev, generator=g) * 2 - 1              # as tests/test_fwd_bwd.py:28 upstream
-    h = torch.randn(B, C2["n_mels"], FRAMES, device=dev, generator=g)
+    if args.gpus > 1 and not args.oversubscribe and not (use_dist and dist.get_backend() == "nccl" and dist.get_world_size() == args.gpus):
+        print("bench.py: --gpus %d needs %d RCCL ranks (got backend %s, %d ranks)"
+              % (args.gpus, args.gpus, dist.get_backend() if use_dist else None, dist.get_world_size() if use_dist else 0), file=sys.stderr)
+        return 2
+    wl = make_workload(args.model, dev, args.batch, rank)
+    model, trainer, B, SEGW = wl["model"], wl["trainer"], wl["batch"], wl["segment"]
+    x, h = wl["x"], wl["h"]
+    g = wl["generator"]
+    step = wl["step"]
 
     def barrier():
         if use_dist:
@@ -530,26 +662,27 @@ def main(argv=None):
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        trainer.step(x, h)
+        step()
     L = _lib.lib()
-    per_step_gate = 2 * C2["flows"] * C2["depth"]                        # forward + recompute
+    per_step_gate = wl["gate_launches_per_step"]
     timer = L.wg_timer_create(_lib.K_CONV_GATE, per_step_gate * args.steps) if rank == 0 else None
     barrier()
     if timer:
         L.wg_timer_attach(timer)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, z, logdet = trainer.step(x, h)
+        loss = step()
     barrier()
-    dt = time.perf_counter() - t0
+    dt_own = time.perf_counter() - t0
     if timer:
         L.wg_timer_attach(None)
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    tmax = torch.tensor([dt_own], device=dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
-    value = world * B * SEG * args.steps / dt
+    value = world * B * SEGW * args.steps / dt
+    comm = comm_report(wl, args, use_dist, world, rank, dev, dt_own, ms_per_step, barrier) if use_dist else None
 
     out = None
     if rank == 0:
@@ -558,9 +691,7 @@ def main(argv=None):
         L.wg_timer_read(timer, buf, n)
         L.wg_timer_destroy(timer)
         gate_ms = float(np.mean(np.frombuffer(buf, dtype=np.float32))) if n else float("nan")
-        T = SEG // C2["n_group"]
-        kcat = C2["radix"] * C2["residual_channels"] + C2["n_mels"]
-        gate_flop = 2.0 * kcat * 2 * C2["dilation_channels"] * B * T     # algorithmic FLOPs of one launch
+        gate_flop = wl["gate_flop_per_launch"]                           # algorithmic FLOPs of one launch
         achieved = gate_flop / (gate_ms * 1e-3) / 1e12
         split = _lib.default_precision() != _lib.PREC_F32
         kname = {0: 'convgemm_kernel', 1: 'convgemm16_kernel', 2: 'convgemm16q_kernel'}[_lib.default_precision()]
@@ -571,14 +702,15 @@ def main(argv=None):
         targs = {"convgemm_kernel": ["<1>"], "convgemm16_kernel": ["<1, 4>", "<1, 2>"], "convgemm16q_kernel": ["<5, 2, 2>", "<5, 2, 1>", "<1, 2, 2>", "<1, 2, 1>"]}[kname]   # 5 = EPI_GATE_SO: EPI_GATE with hand-issued stores (wg_gemm.h)
         traffic, traffic_src, tsel = None, None, targs[0]
         for ta in targs:
-            traffic, traffic_src = _traffic(kname + ta)
+            traffic, traffic_src = _traffic(kname + ta, wl["profile_prefix"])
             if traffic is not None:
                 tsel = ta
                 break
         if traffic_src:
             traffic_src += " (committed rocprofv3 --pmc summary of this command; not re-measured in this run)"
+        STEP_FLOP = wl["step_flop_per_sample"]
         out = {
-            "metric": "audio samples/sec (fwd+bwd) WaveGlow-256ch seg=16000",
+            "metric": wl["metric"],
             "value": value, "unit": "samples/s", "n_gpus": world,
             "rccl_ranks": dist.get_world_size() if use_dist and not args.oversubscribe else 0,
             **({"oversubscribed": "HARNESS TEST: %d gloo ranks share %d GPU(s); not a scaling number" % (world, torch.cuda.device_count())}
@@ -586,20 +718,41 @@ def main(argv=None):
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (contractions as split bf16x3 MFMA, fp32 accumulate)" if split else "f32", "data": "synthetic",
-            "config": {"workload": "WaveGlow 256ch, 12 flows, seg=16000, batch=%d per GPU (waveglow_LJ_speech.json), "
-                                   "forward + NLL + constant-memory backward%s" % (B, " + RCCL grad all-reduce" if world > 1 else ""),
-                       "global_batch": B * world, "segment": SEG, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "%s%s (EPI_GATE: dilated k=3 conv + mel conditioning + gate)" % (kname, tsel),
+            "config": {"workload": wl["workload"] + (" + RCCL grad all-reduce" if world > 1 else ""),
+                       "global_batch": B * world, "segment": SEGW, "parallelism": "dp%d" % world},
+            "roofline": {"bound": "mfma", "kernel": "%s%s (EPI_GATE: %s)" % (kname, tsel, wl["gate_what"]),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": gate_ms, "launches_timed": n, "flop_per_launch": gate_flop,
                          "mfma_tflops_issued": achieved * (3 if split else 1),
                          "x_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS},
-            "step_tflops_algorithmic": value * STEP_FLOP_PER_SAMPLE / 1e12 / world,
-            "step_frac_of_fp32_mfma_peak": value * STEP_FLOP_PER_SAMPLE / 1e12 / world / FP32_MFMA_PEAK_TFLOPS,
+            "step_flop_per_sample": STEP_FLOP,
+            "step_tflops_algorithmic": value * STEP_FLOP / 1e12 / world,
+            "step_frac_of_fp32_mfma_peak": value * STEP_FLOP / 1e12 / world / FP32_MFMA_PEAK_TFLOPS,
+            "step_frac_of_bf16_mfma_peak": value * STEP_FLOP / 1e12 / world / BF16_MFMA_PEAK_TFLOPS,
             "loss": float(loss),
-            "logged": trainer.metrics_dict(),          # the scalars LightModel.training_step logs (lightning.py:58-64), rank-mean
         }
+        if trainer is not None:
+            out["logged"] = trainer.metrics_dict()     # the scalars LightModel.training_step logs (lightning.py:58-64), rank-mean
+        if comm is not None:
+            out["comm"] = comm
+        if args.model != "waveglow":
+            args.no_inverse = args.no_extra = args.no_cpu = True         # the secondary legs belong to the headline workload
+            if world == 1 and trainer is not None:
+                try:
+                    out["roofline"]["kernels"] = kernel_rooflines(trainer, x, h, split)
+                except Exception as e:                                    # noqa: BLE001
+                    out["roofline"]["kernels"] = {"error": repr(e)}
+            if args.model == "waveflow" and world == 1 and not wl.get("no_inverse"):
+                with torch.no_grad():                                     # synthesis (row-by-row inverse), as inference.py:50-56
+                    for frames in (63, 862):
+                        hc = torch.randn(1, 80, frames, device=dev)
+                        model.infer(hc, 0.6)
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        xs = model.infer(hc, 0.6)
+                        torch.cuda.synchronize()
+                        out["inverse_khz_%d" % xs.numel()] = xs.numel() / (time.perf_counter() - t1) / 1000.0
         if not args.no_inverse:
             with torch.no_grad():
                 for frames in (63, 862):                                  # 16 128 samples and ~10 s of audio
@@ -627,7 +780,7 @@ def main(argv=None):
                                     "frac": out["inverse_khz_%d" % nn] * 1e3 * FWD_FLOP_PER_SAMPLE / 1e12 / peak} for nn in (63 * 256, 862 * 256)},
                 "note": "one call between two synchronisations as inference.py:50-56; a 16 128-sample utterance is a chain of ~250 small "
                         "launches (64 x 64 tiles on every CU, DESIGN.md section 4a iii), the 10 s utterance fills the chip"}
-        if world == 1:
+        if world == 1 and args.model == "waveglow":
             # outside the metric (SURVEY.md 8d excludes the optimizer): one Adam step over all 53.66 M parameters on the flat buffers
             from constant_memory_waveglow_amd.parallel import FlatAdam
             opt = FlatAdam(trainer, lr=1e-4)
@@ -639,7 +792,7 @@ def main(argv=None):
                 opt.step()
             torch.cuda.synchronize()
             out["adam_step_ms"] = (time.perf_counter() - t1) / 5 * 1e3
-        if world == 1:                                                # (extra steps on one rank only would wait for collectives forever)
+        if world == 1 and args.model == "waveglow":                   # (extra steps on one rank only would wait for collectives forever)
             try:
                 out["roofline"]["kernels"] = kernel_rooflines(trainer, x, h, split)
             except Exception as e:                                    # noqa: BLE001 -- diagnostics never touch the headline line

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WGFLOW_LIB") or os.path.join(_HERE, "csrc", "libwgflow.so")   # WGFLOW_LIB: developer A/B builds
 _LIB = None
 
-ABI_VERSION = 5          # include/wgflow.h WG_ABI_VERSION (5: wg_config / wg_wn_dims gained bias)
+ABI_VERSION = 6          # include/wgflow.h WG_ABI_VERSION (6: wg_stat_layer_launches; workspaces carry the one-launch layer's counters)
 ABI_SYMBOLS = [
     "wg_strerror", "wg_abi_version", "wg_param_count", "wg_packed_bytes", "wg_workspace_bytes",
     "wg_wn_param_count", "wg_wn_packed_bytes", "wg_coupling_workspace_bytes", "wg_invconv_workspace_bytes",
@@ -21,6 +21,7 @@ ABI_SYMBOLS = [
     "wg_wf_inverse", "wg_wf_backward", "wg_melspec_frames", "wg_melspec", "wg_lowpass_workspace_bytes", "wg_lowpass", "wg_train_step",
     "wg_nll_scratch_floats", "wg_train_scratch_floats",
     "wg_timer_create", "wg_timer_attach", "wg_timer_count", "wg_timer_read", "wg_timer_read_info", "wg_timer_destroy", "wg_stat_wgrad16t_launches",
+    "wg_stat_layer_launches",
 ]
 K_CONV_STORE, K_CONV_GATE, K_CONV_RESSKIP, K_CONV_DGATE, K_WGRAD = range(5)
 
@@ -136,6 +137,8 @@ def lib():
     L.wg_timer_read_info.argtypes = [vp, vp, i]
     L.wg_stat_wgrad16t_launches.restype = C.c_longlong
     L.wg_stat_wgrad16t_launches.argtypes = []
+    L.wg_stat_layer_launches.restype = C.c_longlong
+    L.wg_stat_layer_launches.argtypes = []
     L.wg_timer_destroy.argtypes = [vp]
     L.wg_timer_destroy.restype = None
     _LIB = L

@@ -12,6 +12,7 @@
 #include "wg_wf.h"
 #include "wg_mel.h"
 #include "wg_stage.h"
+#include "wg_layer16h.h"
 #include "wg_thin.h"
 
 #include <algorithm>
@@ -80,7 +81,7 @@ struct TimerScope {
     TimerScope(int id, hipStream_t s, long long M = 0, long long K = 0, long long cols = 0, long long bytes = 0)
         : t(g_timer.load(std::memory_order_relaxed)), st(s), slot(-1)
     {
-        if (t && (t->kernel_id == id || t->kernel_id < 0) && t->count < t->capacity) {
+        if (t && id > -1000 && (t->kernel_id == id || t->kernel_id < 0) && t->count < t->capacity) {
             slot = t->count++;
             long long *q = t->info + 5 * (size_t)slot;
             q[0] = id; q[1] = M; q[2] = K; q[3] = cols; q[4] = bytes;
@@ -659,9 +660,11 @@ struct WnWs {               // plane bases (float offsets) of one WN's activatio
     size_t dxy_step = 0, dxyS_step = 0;                  // fused_dy: layer i's dxy at dxy + i * step (0: one buffer for all layers)
     size_t dHS_step = 0;                                 // grouped_wgrad: dh_i at dHS + i * step (0: accumulated in place in one plane)
     size_t ones = 0, onesS = 0;                          // WnD::bias: 32 channels of ones on [0, T) (fp32 plane, S-plane), filled by every WN pass
+    size_t lsync = 0;                                    // precision 2: the one-launch layer's hand-off counters (wg_layer16h.h), WGL_SYNC_WORDS words, zero between launches
     int nH;                 // 2 (ping-pong) or depth
     size_t slab_floats;
 };
+#define WGL_SYNC_WORDS 16384     // hand-off counters of the one-launch layer (wg_layer16h.h): one 128-byte line per column tile
 struct Bump {
     size_t off = 0;
     size_t take(size_t n) { size_t o = off; off += rupz(n, 64); return o; }
@@ -675,6 +678,7 @@ void wn_ws_layout(Bump &bp, const WnD &d, int ic_max, const Geo &g, int mode, in
         for (int i = 0; i < nHS; ++i) w.HS[i] = bp.take(pC);
         for (int i = 0; i < d.depth; ++i) w.gateS[i] = (mode || i == 0 || fused_skip(d)) ? bp.take(pD) : w.gateS[0];
         w.XaS = bp.take((size_t)g.B * rup(ic_max, WG_BK) * g.P);
+        w.lsync = bp.take(WGL_SYNC_WORDS);
         if (mode) {
             w.GS = bp.take((size_t)g.B * rup(2 * ic_max, WG_BK) * g.P);
             w.dSS = bp.take(pS);
@@ -887,7 +891,7 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
     else if (epi == EPI_RESSKIP) out_ch = (long long)nsplit * (1 + (out0.p ? 1 : 0) + (s0.hi ? 1 : 0)) + (long long)(M - nsplit) * (1 + accumulate);
     else out_ch = (long long)M * ((out0.p ? 1 : 0) + (s0.hi ? 1 : 0) + (aux0.p ? 1 : 0) + (saux.hi ? 1 : 0));
     const long long alg_bytes = 4 * cols * (in_ch + out_ch) + 4LL * M * Ksum;
-    TimerScope ts(WG_K_CONV_STORE + epi, cx.st, M, Ksum, cols, alg_bytes);
+    TimerScope ts(cx.rec ? -1000 : WG_K_CONV_STORE + epi, cx.st, M, Ksum, cols, alg_bytes);      // (nothing is launched while recording)
     if (cx.prec) {
         ConvGemm16Args a16;
         int K = 0, nc = 0;
@@ -1458,6 +1462,61 @@ SegSpec ones_seg(Ctx &cx, const WnRun &r, bool fill)
     return s;
 }
 
+// ------------------------------------------------------------------------------------------------
+// One launch per WN layer (wg_layer16h.h) where both of the layer's products would take the 64 x 64-tile kernel: the two launches are
+// RECORDED (the recorder of the stage interpreter: run_convgemm fills its argument block instead of launching), checked to be the
+// gate conv and the residual / skip conv over the same column tiles, and issued as ONE convlayer16h_kernel.  Returns false when the
+// shape does not qualify (nothing was launched: the caller then issues the two launches the ordinary way).
+// ------------------------------------------------------------------------------------------------
+std::atomic<long long> g_layer_launches{0};                   // diagnostics: launches of convlayer16h_kernel by this process (wg_stat_layer_launches)
+template <class FA, class FB>
+bool run_convlayer(Ctx &cx, float *ws, size_t lsync, FA &&gate_call, FB &&wo_call)
+{
+#if defined(WG_OPT_NO_LAYER)
+    return false;
+#else
+    if (cx.prec != 2 || cx.rec || cx.err) return false;
+    {   // OPT-IN (WG_LAYER_FUSION=1 in the environment).  Measured on MI355X (gpurun_out/r04e_stress.txt): parity
+        // identical, and no faster than the two launches it replaces -- 2.72 against 2.65-2.76 ms per 0.7 s utterance, 95.7 against 95.8 ms
+        // for WaveFlow's row-by-row synthesis: the in-launch hand-off (write-through drain, arrival, poll, first sc1 loads) costs what
+        // the kernel boundary did.  Kept for the test that pins it and as the starting point should the hand-off get cheaper.
+        const char *e = getenv("WG_LAYER_FUSION");
+        if (!e || e[0] != '1') return false;
+    }
+    StageRec rec;
+    cx.rec = &rec;
+    gate_call();
+    wo_call();
+    cx.rec = nullptr;
+    if (!rec.ok || rec.st.size() != 2 || rec.st[0].kind != WGS_CONV_GATE || rec.st[1].kind != WGS_CONV_RESSKIP) return false;
+    ConvLayer16hArgs la;
+    la.gate = rec.st[0].u.conv;
+    la.wo = rec.st[1].u.conv;
+    const ConvGemm16sArgs &A = la.gate, &B = la.wo;
+    if (A.ntx != B.ntx || A.ntz != B.ntz || A.c.row_sel1 != B.c.row_sel1 || A.c.out0.p || A.c.out1.p || !A.s0.hi) return false;
+    if (B.c.nseg != 1 || B.sseg[0].hi != A.s0.hi || B.sseg[0].row_off || B.sseg[0].per_item) return false;      // W_o's operand IS the gate this launch writes
+    la.ncol = A.ntx * A.ntz; la.ntx = A.ntx; la.nty = std::max(A.nty, B.nty);
+    if (la.ncol * WGL_SYNC_STRIDE > WGL_SYNC_WORDS || la.nty < 1) return false;
+    const int grid = 8 * ((la.ncol + 7) / 8) * la.nty;
+    if (grid > 2 * device_cus()) return false;               // every workgroup resident: a set never waits for an undispatched member
+    la.sync = reinterpret_cast<unsigned *>(ws + lsync);
+    la.wo_epi = EPI_RESSKIP;
+    long long KA = 0;
+    for (int q = 0; q < A.c.nseg; ++q) KA += A.c.seg[q].nch;
+    const long long cols = (long long)A.ntz * A.c.g.T;
+    TimerScope ts(WG_K_CONV_STORE + EPI_GATE, cx.st, A.c.M, KA, cols, 4 * cols * (KA + A.c.M / 2 + 2 * B.c.M) + 4LL * A.c.M * KA);
+    WG_LAUNCH(cx, convlayer16h_kernel<EPI_RESSKIP>, dim3(grid), dim3(512), 0, la);
+    g_layer_launches.fetch_add(1, std::memory_order_relaxed);
+    return true;
+#endif
+}
+// (the counters are left at zero by every launch; a call that was cut short -- an error half way -- is the reason they are cleared
+// once at the start of every entry point that may use them)
+void layer_sync_clear(Ctx &cx, float *ws, size_t lsync)
+{
+    if (cx.prec == 2 && !cx.err && hipMemsetAsync(ws + lsync, 0, WGL_SYNC_WORDS * sizeof(unsigned), cx.st) != hipSuccess) cx.err = WG_ELAUNCH;
+}
+
 void wn_forward(Ctx &cx, const WnRun &r)
 {
     const WnD &d = r.d;
@@ -1491,11 +1550,21 @@ void wn_forward(Ctx &cx, const WnRun &r)
         sg[ns++] = {r.Y, d.auxp(), 0, d.auxp(), 0, r.YS, d.auxp(), 0, 0, d.mode2d};
         if (nb) sg[ns++] = sone;
         // fp32 gate plane: only the on-the-fly weight-gradient kernel still reads it (backward); the S-plane feeds W_o
-        run_convgemm(cx, g, r.pk + r.L.Acat[i], r.L.ld_Acat, 2 * d.Cd, sg, ns, EPI_GATE, sp ? pnull() : pref(gate, d.Cd),
-                     r.save ? pref(ws + r.w.tw[i], d.Cd) : pnull(), r.save ? pref(ws + r.w.sf[i], d.Cd) : pnull(),
-                     pnull(), pnull(), 0, 0, sp ? sref(g, gateS, d.Cd) : snull());                 // waveglow.py:42-44
+        auto gate_call = [&]() {
+            run_convgemm(cx, g, r.pk + r.L.Acat[i], r.L.ld_Acat, 2 * d.Cd, sg, ns, EPI_GATE, sp ? pnull() : pref(gate, d.Cd),
+                         r.save ? pref(ws + r.w.tw[i], d.Cd) : pnull(), r.save ? pref(ws + r.w.sf[i], d.Cd) : pnull(),
+                         pnull(), pnull(), 0, 0, sp ? sref(g, gateS, d.Cd) : snull());             // waveglow.py:42-44
+        };
         SegSpec sgt[2] = {{gate, d.Cd, 0, d.Cd, 0, gateS, d.Cd, 0}, sone};
         const int last = i == d.depth - 1;
+        auto wo_call = [&]() {
+            run_convgemm(cx, g, r.pk + r.L.WoT[i], r.L.ld_WoT[i], d.wo_rows(i), sgt, 1 + nb, EPI_RESSKIP, pref(Hout, d.C),
+                         pref(ws + r.w.skip, d.Cs), pnull(), pref(Hin, d.C), pnull(), last ? 0 : d.C, i > 0,
+                         (sp && !last) ? sref(g, ws + r.w.HS[hout], d.C) : snull());               // :45-46,104
+        };
+        // the whole layer as ONE launch where both products are small-grid launches (single-utterance synthesis, WaveFlow's row steps)
+        if (!fs && !r.save && !nb && run_convlayer(cx, ws, r.w.lsync, gate_call, wo_call)) continue;
+        gate_call();
         if (fs) {
             // residual rows only: h_{i+1} = h_i + Wres_i gate_i (the first C rows of W_o); the skip rows of all layers follow in one product
             if (!last)
@@ -1504,9 +1573,7 @@ void wn_forward(Ctx &cx, const WnRun &r)
                              so ? sref(g, ws + r.w.HS[hin], d.C) : snull());                                   // :45-46
             continue;
         }
-        run_convgemm(cx, g, r.pk + r.L.WoT[i], r.L.ld_WoT[i], d.wo_rows(i), sgt, 1 + nb, EPI_RESSKIP, pref(Hout, d.C),
-                     pref(ws + r.w.skip, d.Cs), pnull(), pref(Hin, d.C), pnull(), last ? 0 : d.C, i > 0,
-                     (sp && !last) ? sref(g, ws + r.w.HS[hout], d.C) : snull());                   // :45-46,104
+        wo_call();
     }
     if (fs) {                                                 // cum_skip = sum_i skip_i (waveglow.py:104) = [Wskip_0 .. Wskip_{d-1}] [gate_0; ..; gate_{d-1}]
         SegSpec sk[WG_MAX_SEG];
@@ -1536,13 +1603,20 @@ void run_end_affine(Ctx &cx, const WnRun &r, int mode, PRef dX, float *log_s_out
 }
 
 // The thin products of WN's backward (wg_thin.h): precision 2, inside a FinQueue (the partials come from its arena).
+// Dynamic LDS of the two kernels (floats -> bytes): the [channels][65] tile, the thin operand's tile, the per-wave shares and the weights.
+static int thin_icp(const WnD &d) { return d.ic <= 4 ? 4 : d.ic <= 8 ? 8 : 16; }
+static int thin_k2p(const WnD &d) { return 2 * d.ic <= 8 ? 8 : 2 * d.ic <= 16 ? 16 : 32; }
+static size_t thin_start_lds(const WnD &d) { const int icp = thin_icp(d); return ((size_t)d.C * WGTH_LDT + WGTH_TB * icp + 4 * icp * 64 + (size_t)d.C * icp) * sizeof(float); }
+static size_t thin_end_lds(const WnD &d) { const int k2p = thin_k2p(d); return ((size_t)d.Cs * WGTH_LDT + WGTH_TB * k2p + (size_t)k2p * d.Cs) * sizeof(float); }
+#define WG_LDS_BYTES (160 * 1024)      // gfx950: LDS per CU = the most one workgroup can ask for
 bool thin_ok(const Ctx &cx, const WnD &d)
 {
 #if defined(WG_OPT_NO_THIN)
     return false;
 #else
+    // (shapes whose tiles do not fit the LDS -- 512 channels with more than 8 thin rows -- keep the split-K MFMA products + convs)
     return cx.prec == 2 && cx.fq && !cx.rec && !d.bias && d.ic <= 16 && d.C % 8 == 0 && d.Cs % 8 == 0 && d.C <= WGTH_MAXROWS * WGTH_THREADS &&
-           d.Cs <= WGTH_MAXROWS * WGTH_THREADS;
+           d.Cs <= WGTH_MAXROWS * WGTH_THREADS && thin_start_lds(d) <= WG_LDS_BYTES && thin_end_lds(d) <= WG_LDS_BYTES;
 #endif
 }
 static int thin_grid(int tiles)
@@ -1555,7 +1629,7 @@ void run_thin_start(Ctx &cx, const WnRun &r, const float *dhS, PRef dX, const fl
 {
     const WnD &d = r.d;
     const Geo &g = r.g;
-    const int icp = d.ic <= 4 ? 4 : d.ic <= 8 ? 8 : 16;
+    const int icp = thin_icp(d);
     ThinStartArgs a;
     memset(&a, 0, sizeof(a));
     a.dh = sref(g, const_cast<float *>(dhS), d.C);
@@ -1565,7 +1639,7 @@ void run_thin_start(Ctx &cx, const WnRun &r, const float *dhS, PRef dX, const fl
     const int grid = thin_grid(a.tiles), n = d.C * icp;
     a.part = cx.fq->reserve(wgth_part_floats(grid, n));
     float *out = a.part + (size_t)grid * n;
-    const size_t lds = ((size_t)d.C * WGTH_LDT + WGTH_TB * icp + 4 * icp * 64 + (size_t)d.C * icp) * sizeof(float);
+    const size_t lds = thin_start_lds(d);
     if (cx.err) return;
     switch (icp) {
 #define WG_THIN_CASE(P, SLOT)                                                                                         \
@@ -1586,7 +1660,7 @@ void run_thin_end(Ctx &cx, const WnRun &r, float *G, int Gc, float *skip, float 
 {
     const WnD &d = r.d;
     const Geo &g = r.g;
-    const int k2 = 2 * d.ic, k2p = k2 <= 8 ? 8 : k2 <= 16 ? 16 : 32;
+    const int k2 = 2 * d.ic, k2p = thin_k2p(d);
     ThinEndArgs a;
     memset(&a, 0, sizeof(a));
     a.G = pref(G, Gc); a.skip = pref(skip, d.Cs); a.dS = sref(g, dSS, d.Cs);
@@ -1595,7 +1669,7 @@ void run_thin_end(Ctx &cx, const WnRun &r, float *G, int Gc, float *skip, float 
     const int grid = thin_grid(a.tiles), n = k2p * d.Cs;
     a.part = cx.fq->reserve(wgth_part_floats(grid, n));
     float *out = a.part + (size_t)grid * n;
-    const size_t lds = ((size_t)d.Cs * WGTH_LDT + WGTH_TB * k2p + (size_t)k2p * d.Cs) * sizeof(float);
+    const size_t lds = thin_end_lds(d);
     if (cx.err) return;
     switch (k2p) {
 #define WG_THIN_CASE(P, SLOT)                                                                                         \
@@ -1976,6 +2050,7 @@ int wg_dbg_trace_read_cycles(unsigned long long *out, int n)
 }
 #endif
 long long wg_stat_wgrad16t_launches(void) { return g_wgrad16t_launches.load(std::memory_order_relaxed); }
+long long wg_stat_layer_launches(void) { return g_layer_launches.load(std::memory_order_relaxed); }
 void *wg_timer_create(int kernel_id, int capacity)
 {
     if (capacity < 1) return nullptr;
@@ -2137,6 +2212,7 @@ static int model_run_fwd_or_inv(const wg_config *cf, const void *packed, const f
     const int G = cf->n_group;
     const int last_k = (cf->reverse_mode != 0) == (inverse != 0) ? cf->n_flows - 1 : 0;     // the flow this direction processes last
     PRef X = pref(ws + W.X, W.Gp);
+    layer_sync_clear(cx, ws, W.wn.lsync);
     WG_LAUNCH(cx, squeeze_kernel, dim3((T + 255) / 256, B), dim3(256), 0, in, X, g, G, N);           // waveglow.py:153 / :184
     run_upsample(cx, cf, pk + M.up_w, pk + M.up_bias, h, F, g, pref(ws + W.Y, W.auxp), nullptr);                // :151,157
     if (cx.prec == 2) run_to_splane(cx, g, pref(ws + W.Y, W.auxp), cf->n_mels, ws + W.YS, W.auxp);
@@ -2506,6 +2582,7 @@ int wg_wf_forward(const wg_wf_config *cf, const void *const *params, const void 
     const Geo g = W.g;
     const size_t xplane = (size_t)g.B * g.P;
     auto xk = [&](int k) { return tape ? (float *)tape + (size_t)k * xplane : ws + W.X[k & 1]; };
+    layer_sync_clear(cx, ws, W.wn.lsync);
     WG_LAUNCH(cx, wf_squeeze_kernel, dim3((g.T + 255) / 256, g.B), dim3(256), 0, audio, pref(xk(0), 1), g, N);        // waveflow.py:186
     wf_upsample(cx, cf, p, pk, L, mel, F, W, ws);                                                                    // :183,187
     WnRun r;
@@ -2547,6 +2624,7 @@ int wg_wf_inverse(const wg_wf_config *cf, const void *const *params, const void 
     const int H = g.rows;
     const dim3 rgrid((g.T + 255) / 256, g.B), igrid((g.T + 255) / 256, B);
     float *Z = ws + W.X[0], *Zf = ws + W.X[1], *Xb = ws + W.dX[0];
+    layer_sync_clear(cx, ws, W.wn.lsync);
     WG_LAUNCH(cx, wf_squeeze_kernel, rgrid, dim3(256), 0, z, pref(Z, 1), g, N);
     wf_upsample(cx, cf, p, pk, L, mel, F, W, ws);
     WnRun r;
@@ -2631,7 +2709,13 @@ int wg_wf_inverse(const wg_wf_config *cf, const void *const *params, const void 
         std::swap(Z, Xb);
     }
     // rowsum rows H-1 are never written by mode 2: they were zeroed with the workspace
+    // (the row walk's failure word is only ever written by the -DWG_OPT_ROWWALK build: the default build must not read a workspace
+    // region nothing initialises -- a workspace that served another layout could turn every logdet into NaN)
+#if defined(WG_OPT_ROWWALK)
     const int *walk_fail = reinterpret_cast<const int *>(reinterpret_cast<const char *>(ws + W.prog) + WF_PROG_STAGES * sizeof(WgStage)) + 8;
+#else
+    const int *walk_fail = nullptr;
+#endif
     WG_LAUNCH(cx, wf_logdet_kernel, dim3((B + 63) / 64), dim3(64), 0, ws + W.rowsum, cf->flows, B, H, logdet,
               cf->use_conv1x1 ? pk + L.mix : (const float *)nullptr, L.mix_stride, -(float)g.T, walk_fail);          // :227-229
     WG_LAUNCH(cx, wf_unsqueeze_kernel, rgrid, dim3(256), 0, pref(Z, 1), g, N, x);
@@ -2908,6 +2992,7 @@ int wg_coupling_apply(const wg_wn_dims *dd, const void *packed, const float *x, 
     float *ws = (float *)wsv;
     const Geo g = W.g;
     PRef X = pref(ws + W.X, W.Xp);
+    layer_sync_clear(cx, ws, W.wn.lsync);
     WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, 2 * d.ic, B), dim3(256), 0, x, X, g, 2 * d.ic);
     WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, d.aux, B), dim3(256), 0, y, pref(ws + W.Y, W.auxp), g, d.aux);
     if (cx.prec == 2) run_to_splane(cx, g, pref(ws + W.Y, W.auxp), d.aux, ws + W.YS, W.auxp);
@@ -2933,6 +3018,7 @@ int wg_wn_apply(const wg_wn_dims *dd, const void *packed, const float *x, const 
     float *ws = (float *)wsv;
     const Geo g = W.g;
     PRef X = pref(ws + W.X, W.Xp);
+    layer_sync_clear(cx, ws, W.wn.lsync);
     WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, d.ic, B), dim3(256), 0, x, X, g, d.ic);
     WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, d.aux, B), dim3(256), 0, y, pref(ws + W.Y, W.auxp), g, d.aux);
     if (cx.prec == 2) run_to_splane(cx, g, pref(ws + W.Y, W.auxp), d.aux, ws + W.YS, W.auxp);

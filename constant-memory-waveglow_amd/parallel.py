@@ -79,6 +79,7 @@ class GradSync:
         if force_collectives is None:
             force_collectives = os.environ.get("WG_BENCH_FORCE_DIST") == "1"
         self._force = dist.is_initialized() and bool(force_collectives)
+        self.skip = False                      # diagnostics (bench.py's `exposed_ms`): run the step WITHOUT its collectives, all ranks alike
 
     def all_reduce(self, fg: FlatGrads, order: Sequence[int] = None, events=None, after_bucket=None):
         """events[b] (torch.cuda.Event, optional): bucket b's gradients are final once the event has fired; its all-reduce is
@@ -86,7 +87,7 @@ class GradSync:
         after_bucket(b) (optional) runs right behind bucket b's reduction -- on the side stream when there is one -- which is
         where FlatAdam puts the optimizer step of that bucket."""
         order = list(order) if order is not None else list(range(len(fg.bucket_ranges) - 1, -1, -1))
-        if self.world == 1 and not self._force:
+        if (self.world == 1 and not self._force) or self.skip:
             if after_bucket is not None:
                 for b in order:
                     after_bucket(b)
@@ -134,7 +135,7 @@ class GradSync:
         24 MB, i.e. 2 * 7/8 * 24 MB = 42 MB per GPU through >= 153 GB/s of xGMI = about 0.3 ms behind a 51 ms step (0.6 %), and its
         autograd node (`_WaveFlowFn`) hands over all gradients at once when the backward call returns, so there is no earlier point
         at which a bucket would be final.  (WaveGlow / WSRGlow, 215 / 919 MB, go through FlowTrainer's per-flow buckets.)"""
-        if self.world == 1 and not self._force:
+        if (self.world == 1 and not self._force) or self.skip:
             return
         grads = [p.grad for p in params if p.grad is not None]
         if not grads:
@@ -149,7 +150,7 @@ class GradSync:
             off += g.numel()
 
     def broadcast_params(self, params: Sequence[torch.Tensor], src: int = 0):
-        """Replicas start identical (what DDP does when it wraps the module): ONE broadcast of all parameters as a flat buffer
+        """src: the GLOBAL rank whose weights every replica takes (it must belong to the group).  Replicas start identical (what DDP does when it wraps the module): ONE broadcast of all parameters as a flat buffer
         (WaveGlow-256ch: 459 tensors, 214.6 MB -- 459 separate collectives would each pay RCCL's launch latency), copied back into
         the parameters on the receiving ranks."""
         if self.world == 1 and not self._force:
@@ -157,10 +158,12 @@ class GradSync:
         params = [p for p in params if p is not None]
         if not params:
             return
+        if len({(p.dtype, p.device) for p in params}) != 1:
+            raise ValueError("broadcast_params: the parameters must share one dtype and one device (torch.cat would promote silently)")
         with torch.no_grad():
             flat = torch.cat([p.detach().reshape(-1) for p in params])
-            dist.broadcast(flat, src=src, group=self.pg)
-            if dist.get_rank(self.pg) != src or self._force:
+            dist.broadcast(flat, src=src, group=self.pg)          # `src` is a GLOBAL rank (torch.distributed's convention)
+            if dist.get_rank() != src or self._force:             # ... so it is compared with this process's global rank
                 off = 0
                 for p in params:
                     n = p.numel()

@@ -42,34 +42,42 @@ class SlotTable:
 
     The cache is only as good as the tree it was resolved from, so every call re-checks it cheaply: the table belongs to ONE owner
     module (a shallow copy of the owner -- an nn.DataParallel-style replica -- shares this object through its __dict__ and gets its
-    own resolution), every parent -> child edge of the owner's tree must still hold the same child object (`model.WNs[k] = block`,
+    own resolution whenever it calls; the resolution is kept as one tuple, replaced as a unit), every parent -> child edge of the owner's tree must still hold the same child object (`model.WNs[k] = block`,
     `model.upsampler = ...` re-resolve; ~400 dict lookups, 30 us), and a KeyError from a slot (weight norm added or removed) re-resolves
     as before."""
 
     def __init__(self, method: str):
-        self._method, self._slots, self._edges, self._owner = method, None, (), None
+        # ONE attribute holds the whole resolution (weak owner reference, slots, edges): it is replaced as a unit, so a replica that
+        # resolves on another thread can never leave this object with one owner's slots next to another owner's edges, and the table
+        # does not keep its module alive (no module <-> table reference cycle).
+        self._method, self._state = method, None
 
     def _resolve(self, owner):
-        self._slots = getattr(owner, self._method)()
-        self._edges = [(m._modules, name, child) for m in owner.modules() for name, child in m._modules.items()]
-        self._owner = owner
+        import weakref
+        slots = getattr(owner, self._method)()
+        edges = [(m._modules, name, child) for m in owner.modules() for name, child in m._modules.items()]
+        state = (weakref.ref(owner), slots, edges)
+        self._state = state
+        return state
 
-    def _valid(self, owner):
-        if self._slots is None or self._owner is not owner:
+    @staticmethod
+    def _valid(state, owner):
+        if state is None or state[0]() is not owner:
             return False
-        for d, k, c in self._edges:
+        for d, k, c in state[2]:
             if d.get(k) is not c:
                 return False
         return True
 
     def __call__(self, owner):
-        if self._valid(owner):
+        state = self._state                 # read once: everything below works on this snapshot
+        if self._valid(state, owner):
             try:
-                return [None if s is None else s[0][s[1]] for s in self._slots]
+                return [None if s is None else s[0][s[1]] for s in state[1]]
             except KeyError:                # weight norm was added or removed somewhere: resolve the tree again
                 pass
-        self._resolve(owner)
-        return [None if s is None else s[0][s[1]] for s in self._slots]
+        state = self._resolve(owner)
+        return [None if s is None else s[0][s[1]] for s in state[1]]
 
 
 def conv_gv(m):

@@ -80,9 +80,10 @@ const char *wg_strerror(int code);
 /* ABI revision of this header (2: wg_config gained keep_activations; 3: wg_nll_loss / wg_train_step produce the logged
  * training scalars and take their scratch from the caller, wg_melspec returns the power spectrogram on request, wg_wf_config gained
  * use_conv1x1, wg_wf_upsample; 4: wg_timer_create(-1, ..) times every kernel class, wg_timer_read_info, wg_stat_wgrad16t_launches,
- * wg_wf_* accept every WG_PREC_*; 5: wg_config and wg_wn_dims gained bias).  A binding built against another revision must not pass its
+ * wg_wf_* accept every WG_PREC_*; 5: wg_config and wg_wn_dims gained bias; 6: wg_stat_layer_launches, the workspaces carry the one-launch
+ * layer's hand-off counters).  A binding built against another revision must not pass its
  * structs: the Python loader compares this with its own ABI_VERSION and refuses the library otherwise. */
-#define WG_ABI_VERSION 5
+#define WG_ABI_VERSION 6
 int wg_abi_version(void);
 
 /* Diagnostics (no counterpart upstream; the reference times with wall-clock time(), inference.py:39-53): while a
@@ -106,6 +107,9 @@ void  wg_timer_destroy(void *timer);
 /* diagnostics: how many times this process has launched wgrad16t_kernel (the one-workgroup-per-CU weight-gradient kernel; shapes
  * without a plan take wgrad16s_pair_kernel) -- lets a test assert which kernel a shape ran on */
 long long wg_stat_wgrad16t_launches(void);
+/* diagnostics: launches of convlayer16h_kernel (ONE launch per WN layer: gate conv -> gate -> W_o -> residual / skip, wg_layer16h.h; small grids
+ * only -- single-utterance synthesis, WaveFlow's row steps); larger shapes take two launches per layer */
+long long wg_stat_layer_launches(void);
 
 /* ---- sizes -------------------------------------------------------------------------------- */
 int    wg_param_count(const wg_config *cfg);                 /* entries of the parameter table */
@@ -221,7 +225,7 @@ int wg_train_step(const wg_config *cfg, const void *const *params, const void *p
  * affine coupling along the height axis, flip between flows.  Parameter table = named_parameters() order (3 + 37 per flow):
  *   upsampler.1.{bias, weight_g, weight_v}; WNs.k.{V.g, V.v, start.g, start.v, layers.i.{W.g, W.v, W_o.g, W_o.v} x 8, end.weight};
  *   with use_conv1x1 followed by invconv1x1.k.weight for every flow (3 + 38 per flow).
- * Only WG_PREC_BF16X3_PLANES is built for this model.  The hop length is 256 (waveflow.py:160). */
+ * Every WG_PREC_* arithmetic mode is built for this model (ABI 4).  The hop length is 256 (waveflow.py:160). */
 typedef struct wg_wf_config {
     int32_t flows, n_group, n_mels;
     int32_t res_ch, dil_ch, skip_ch;

@@ -67,12 +67,15 @@ def set_threads(n):
 
 
 @torch.no_grad()
-def train_step(cfg, params, audio, h, sigma, need_dh=False):
-    """cfg: dict of the reference's WaveGlow ctor keywords.  Returns dict(z, logdet, loss, grads [list like params], dh)."""
+def train_step(cfg, params, audio, h, sigma, need_dh=False, double=False):
+    """cfg: dict of the reference's WaveGlow ctor keywords.  Returns dict(z, logdet, loss, grads [list like params], dh).
+    double: float64 arithmetic on the same float32 inputs (the checker for the headline shape; ATen's plain convolution path)."""
     flows, G, depth, radix = cfg["flows"], cfg["n_group"], cfg.get("depth", 8), cfg.get("radix", 3)
     C = cfg.get("residual_channels", 256)
-    P = [None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)) for a in params]
-    x_in, hm = torch.from_numpy(np.ascontiguousarray(audio, np.float32)), torch.from_numpy(np.ascontiguousarray(h, np.float32))
+    dt = torch.float64 if double else torch.float32
+    P = [None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dt) for a in params]
+    x_in = torch.from_numpy(np.ascontiguousarray(audio, np.float32)).to(dt)
+    hm = torch.from_numpy(np.ascontiguousarray(h, np.float32)).to(dt)
     B, N = x_in.shape
     T = N // G
     up = cfg["hop_size"] // G
@@ -86,7 +89,7 @@ def train_step(cfg, params, audio, h, sigma, need_dh=False):
 
     y = upsample(P[0], P[1], P[2], hm)
     x = x_in.view(B, T, G).transpose(1, 2).contiguous()
-    logdet = torch.zeros(B)
+    logdet = torch.zeros(B, dtype=dt)
     early, outs = [], []                                   # emitted channels; per-flow outputs (only views of what the backward needs)
     for k in range(flows):
         if k and k % cfg["n_early_every"] == 0:
@@ -158,3 +161,202 @@ def train_step(cfg, params, audio, h, sigma, need_dh=False):
             grads[j] = next(it)
     dh = next(it).numpy() if need_dh else None
     return dict(z=z.numpy(), logdet=logdet.numpy(), loss=float(loss), grads=[None if g is None else g.numpy() for g in grads], dh=dh)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Batch items are independent units, so a step over B segments is W worker PROCESSES with a share of the batch each:
+# ATen's intra-op pool does not scale on these shapes (T = 2000 columns per convolution), W processes x a few threads do.  Used by
+#   * tests/test_gpu_parity.py::test_c2_full_batch_vs_oracle -- the B = 24 x 16000 headline shape against this oracle;
+#   * bench.py's cpu_baseline -- the all-core CPU figure (`time_parallel`).
+# A worker is `python -m oracle.torch_cpu --worker <dir> <index>`: inputs and outputs travel as .npy / .npz files in a scratch directory.
+# Combination: with the loss normalised by B N, the full-batch gradient is sum_w (B_w / B) grad_w -- including the 1x1 convs'
+# W^-T (sum_b dlogdet_b) T term, which is -T / N in every share -- and the loss the same weighted mean.
+# ------------------------------------------------------------------------------------------------------------------------------
+def _scratch():
+    import tempfile
+    base = "/dev/shm" if __import__("os").path.isdir("/dev/shm") else None
+    return tempfile.mkdtemp(prefix="wg_torch_cpu_", dir=base)
+
+
+def host_cpu_budget():
+    """What this process may really use: (logical CPUs in its affinity mask, CPUs' worth of cgroup quota or None, physical cores among the
+    allowed CPUs as a list of one logical CPU per core).  A container may show 128 cores and grant a fraction of them."""
+    import os
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:                                            # noqa: BLE001
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:                                        # noqa: BLE001
+            pass
+    firsts, seen = [], set()
+    for c in allowed:
+        try:
+            sib = open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read().strip()
+        except Exception:                                        # noqa: BLE001
+            sib = str(c)
+        if sib not in seen:
+            seen.add(sib)
+            firsts.append(c)
+    return len(allowed), quota, firsts
+
+
+def _spawn(workdir, n):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="", MKL_NUM_THREADS="")
+    env.pop("OMP_NUM_THREADS"); env.pop("MKL_NUM_THREADS")
+    return [subprocess.Popen([sys.executable, "-m", "oracle.torch_cpu", "--worker", workdir, str(i)], env=env, cwd=root) for i in range(n)]
+
+
+def _write_job(workdir, cfg, params, audio, h, sigma, shares, threads, double, need_dh, runs):
+    import json
+    import os
+    np.savez(os.path.join(workdir, "params.npz"), **{"p%d" % i: a for i, a in enumerate(params) if a is not None})
+    np.save(os.path.join(workdir, "audio.npy"), np.ascontiguousarray(audio, np.float32))
+    np.save(os.path.join(workdir, "h.npy"), np.ascontiguousarray(h, np.float32))
+    with open(os.path.join(workdir, "job.json"), "w") as f:
+        # every worker gets physical cores of its own (one logical CPU per core, consecutive cores): without it the workers' thread
+        # pools were free to pile onto the same cores
+        _, _, firsts = host_cpu_budget()
+        cpus = [firsts[i * int(threads):(i + 1) * int(threads)] for i in range(len(shares))]
+        if any(len(c) < int(threads) for c in cpus):
+            cpus = None
+        json.dump(dict(cfg=cfg, n_params=len(params), none=[i for i, a in enumerate(params) if a is None], sigma=float(sigma),
+                       shares=shares, threads=int(threads), double=bool(double), need_dh=bool(need_dh), runs=int(runs), cpus=cpus), f)
+
+
+def _wait(procs, what):
+    for p in procs:
+        if p.wait() != 0:
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()
+            raise RuntimeError("oracle/torch_cpu.py: a worker process of %s failed (exit code %s)" % (what, p.returncode))
+
+
+def _shares(B, workers):
+    workers = max(1, min(int(workers), B))
+    cut = [round(i * B / workers) for i in range(workers + 1)]
+    return [(cut[i], cut[i + 1]) for i in range(workers) if cut[i + 1] > cut[i]]
+
+
+def train_step_parallel(cfg, params, audio, h, sigma, workers, threads=8, need_dh=False, double=False):
+    """train_step over the batch cut into `workers` shares, one process each (see above).  Same return value as train_step
+    (arrays in float64 when double)."""
+    import os
+    import shutil
+    B, N = audio.shape
+    shares = _shares(B, workers)
+    workdir = _scratch()
+    try:
+        _write_job(workdir, cfg, params, audio, h, sigma, shares, threads, double, need_dh, 0)
+        _wait(_spawn(workdir, len(shares)), "train_step_parallel")
+        out = None
+        for i, (b0, b1) in enumerate(shares):
+            r = np.load(os.path.join(workdir, "out%d.npz" % i))
+            w = (b1 - b0) / B
+            if out is None:
+                out = dict(z=np.empty((B, N), r["z"].dtype), logdet=np.empty(B, r["logdet"].dtype), loss=0.0,
+                           grads=[None if ("g%d" % j) not in r else np.zeros(r["g%d" % j].shape, np.float64) for j in range(len(params))],
+                           dh=np.empty(h.shape, r["dh"].dtype) if need_dh else None)
+            out["z"][b0:b1], out["logdet"][b0:b1] = r["z"], r["logdet"]
+            out["loss"] += w * float(r["loss"])
+            for j, g in enumerate(out["grads"]):
+                if g is not None:
+                    g += w * r["g%d" % j]
+            if need_dh:
+                out["dh"][b0:b1] = w * r["dh"]                  # d loss / d h_b carries the 1 / (B N) of ITS share's loss
+        if not double:
+            out["grads"] = [None if g is None else g.astype(np.float32) for g in out["grads"]]
+        return out
+    finally:
+        shutil.rmtree(workdir, ignore_errors=True)
+
+
+def time_parallel(cfg, params, audio, h, sigma, workers, threads=8, runs=3):
+    """All-core throughput: `workers` processes, each with ONE segment (row i % B of `audio`), 1 warm-up step, then -- all released
+    together -- `runs` timed steps.  Returns dict(samples_per_s = workers * runs * N / (last end - first start), per-worker medians)."""
+    import json
+    import os
+    import shutil
+    import time
+    B, N = audio.shape
+    shares = [(i % B, i % B + 1) for i in range(int(workers))]
+    workdir = _scratch()
+    try:
+        _write_job(workdir, cfg, params, audio, h, sigma, shares, threads, False, False, runs)
+        procs = _spawn(workdir, len(shares))
+        t_wait = time.time()
+        while sum(os.path.exists(os.path.join(workdir, "ready%d" % i)) for i in range(len(shares))) < len(shares):
+            if any(p.poll() not in (None, 0) for p in procs) or time.time() - t_wait > 900:
+                for q in procs:
+                    if q.poll() is None:
+                        q.kill()
+                raise RuntimeError("oracle/torch_cpu.py: a timing worker failed or did not come up")
+            time.sleep(0.05)
+        open(os.path.join(workdir, "go"), "w").close()
+        _wait(procs, "time_parallel")
+        t = [json.load(open(os.path.join(workdir, "time%d.json" % i))) for i in range(len(shares))]
+        start, end = min(x["start"] for x in t), max(x["end"] for x in t)
+        med = sorted(sorted(x["steps"])[len(x["steps"]) // 2] for x in t)
+        return {"samples_per_s": len(shares) * runs * N / (end - start), "wall_s": end - start, "workers": len(shares), "threads_per_worker": int(threads),
+                "runs": int(runs), "step_s_median_fastest_worker": med[0], "step_s_median_slowest_worker": med[-1]}
+    finally:
+        shutil.rmtree(workdir, ignore_errors=True)
+
+
+def _worker_main(workdir, index):
+    import json
+    import os
+    import time
+    job = json.load(open(os.path.join(workdir, "job.json")))
+    if job.get("cpus"):
+        try:
+            os.sched_setaffinity(0, job["cpus"][index])
+        except Exception:                                        # noqa: BLE001 -- a refused mask only costs speed
+            pass
+    set_threads(job["threads"])
+    pz = np.load(os.path.join(workdir, "params.npz"))
+    params = [None if i in set(job["none"]) else pz["p%d" % i] for i in range(job["n_params"])]
+    b0, b1 = job["shares"][index]
+    audio = np.array(np.load(os.path.join(workdir, "audio.npy"), mmap_mode="r")[b0:b1])      # (copies: torch wants writable arrays)
+    h = np.array(np.load(os.path.join(workdir, "h.npy"), mmap_mode="r")[b0:b1])
+    if job["runs"]:                                          # timing worker
+        train_step(job["cfg"], params, audio, h, job["sigma"])
+        open(os.path.join(workdir, "ready%d" % index), "w").close()
+        while not os.path.exists(os.path.join(workdir, "go")):
+            time.sleep(0.005)
+        steps, start = [], time.time()
+        for _ in range(job["runs"]):
+            t0 = time.time()
+            train_step(job["cfg"], params, audio, h, job["sigma"])
+            steps.append(time.time() - t0)
+        with open(os.path.join(workdir, "time%d.json" % index), "w") as f:
+            json.dump({"start": start, "end": time.time(), "steps": steps}, f)
+        return
+    r = train_step(job["cfg"], params, audio, h, job["sigma"], need_dh=job["need_dh"], double=job["double"])
+    out = {"z": r["z"], "logdet": r["logdet"], "loss": np.float64(r["loss"])}
+    for j, g in enumerate(r["grads"]):
+        if g is not None:
+            out["g%d" % j] = g
+    if job["need_dh"]:
+        out["dh"] = r["dh"]
+    np.savez(os.path.join(workdir, "out%d.npz" % index), **out)
+
+
+if __name__ == "__main__":
+    import sys
+    if len(sys.argv) == 4 and sys.argv[1] == "--worker":
+        _worker_main(sys.argv[2], int(sys.argv[3]))
+    else:
+        raise SystemExit("usage: python -m oracle.torch_cpu --worker <scratch dir> <index>   (started by train_step_parallel / time_parallel)")

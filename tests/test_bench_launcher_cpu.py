@@ -69,3 +69,21 @@ def test_failing_rank_fails_the_bench():
 def test_world_size_must_match_gpus():
     r = _run("--gpus", "4", "--selftest", "ok", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr
+
+
+@pytest.mark.parametrize("model", ["waveflow", "wsrglow"])
+def test_model_flag_reaches_every_rank(model):
+    """BASELINE.json configs[3] / [4] (`train.py:51-53,73-78` trains any config on N GPUs): `--model` goes through the same launcher."""
+    r = _run("--model", model, "--gpus", "4", "--dry-run")
+    assert r.returncode == 0, r.stderr
+    cmd = json.loads(r.stdout.strip().splitlines()[-1])["cmd"]
+    assert cmd[cmd.index(BENCH) + 1:] == ["--model", model, "--gpus", "4"]
+    r = _run("--model", model, "--gpus", "2", "--selftest", "ok")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["model"] == model and line["n_gpus"] == 2
+
+
+def test_unknown_model_is_refused():
+    r = _run("--model", "melglow", "--dry-run")
+    assert r.returncode != 0

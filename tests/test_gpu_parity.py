@@ -261,6 +261,91 @@ def test_full_size_properties(dev):
         assert float((a - b).abs().max()) <= GRAD_RTOL * float(b.abs().max()) + 1e-12, n
 
 
+@pytest.mark.parametrize("name", ["micro", "c1", "c2"])
+def test_one_launch_layer_vs_two_launches(dev, precision, monkeypatch, name):
+    """convlayer16h_kernel (wg_layer16h.h): one launch per WN layer -- gate conv -> gate -> W_o -> residual / skip, model/waveglow.py:41-46 --
+    wherever both products are small-grid launches (single-utterance synthesis).  The gate crosses workgroups inside the launch (sc1
+    stores, an arrival counter per column tile, sc1 loads); the arithmetic is the two launches' own, so forward and inverse must agree with
+    the two-launch path (WG_LAYER_FUSION=0) to rounding, repeat bit for bit, and the launch counter must show that the fused kernel ran."""
+    if precision != "bf16x3p":
+        pytest.skip("the one-launch layer exists in the S-plane mode only")
+    from constant_memory_waveglow_amd import _lib
+    m, cfg, specs, P = build(name, dev)
+    _, N, F = fill.SHAPES[name]
+    audio, h = fill.inputs(name, 1, N, F, cfg["n_mels"])
+    x, ht = T(audio, dev), T(h, dev)
+    depth = cfg.get("depth", 8)
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("WG_LAYER_FUSION", fused)
+        before = _lib.lib().wg_stat_layer_launches()
+        runs = []
+        with torch.no_grad():
+            for rep in range(4):                                  # repeated: the counters of a launch must be clean for the next one
+                z, ld = m(x.clone(), ht)
+                xr, ldr = m.reverse(z, ht)
+                runs.append((z, ld, xr, ldr))
+        torch.cuda.synchronize()
+        n = _lib.lib().wg_stat_layer_launches() - before
+        assert n == (4 * 2 * cfg["flows"] * depth if fused == "1" else 0), n
+        for later in runs[1:]:                                    # a hand-off that read stale bytes would not repeat bit for bit
+            for a, b in zip(runs[0], later):
+                assert torch.equal(a, b)
+        res[fused] = runs[0]
+    # the two forms run the same MFMA sequences; the compiler contracts the gate's tanh * sigmoid arithmetic differently in the two
+    # kernels, so they agree to rounding, not bit for bit
+    z1, ld1, x1, lr1 = res["1"]
+    z0, ld0, x0, lr0 = res["0"]
+    assert float((z1 - z0).abs().max()) < 1e-5 * max(1.0, float(z0.abs().max())) and float((x1 - x0).abs().max()) < 1e-5
+    assert float((ld1 - ld0).abs().max()) < 1e-6 * float(ld0.abs().max()) + 1e-5
+    assert float((x1 - x).abs().max()) < Z_ATOL
+
+
+def test_c2_full_batch_vs_oracle(dev, precision):
+    """The HEADLINE shape itself -- BASELINE.json configs[1]: 256 channels, 12 flows, batch 24 x 16000 samples
+    (configs/waveglow_LJ_speech.json:6-29), 48 000 columns per launch: wgrad16t's two-phase plan at K = 48 000, the 750-tile persistent
+    walks, XCD rows, the one-product skip / conditioning gradient -- through FlowTrainer.step (wg_train_step, what bench.py times)
+    against the float64 torch-CPU oracle (oracle/torch_cpu.py, pinned to the reference's goldens by tests/test_oracle_golden.py).
+    Batch items are independent, so the oracle runs as one worker process per share of the batch (train_step_parallel).
+    Bars: z 1e-4, logdet rtol 1e-4, loss 1e-6, every one of the 459 gradients and dh within 1e-4 of its tensor's max."""
+    if precision != "bf16x3p":
+        pytest.skip("the headline shape is checked in the default arithmetic (CPU oracle time)")
+    from oracle import torch_cpu
+    from constant_memory_waveglow_amd.parallel import FlowTrainer
+    m, cfg, specs, P = build("c2", dev)
+    B, N, F = 24, 16000, 63
+    audio, h = fill.inputs("c2full", B, N, F, cfg["n_mels"])
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or os.cpu_count() or 8
+    except Exception:                                            # noqa: BLE001
+        cores = os.cpu_count() or 8
+    workers = max(1, min(B, cores // 8))
+    ref = torch_cpu.train_step_parallel(cfg, fill.table(specs, P), audio, h, fill.SIGMA, workers=workers, threads=max(1, min(8, cores // workers)),
+                                        need_dh=True, double=True)
+    tr = FlowTrainer(m, fill.SIGMA)
+    x, ht = T(audio, dev), T(h, dev)
+    loss, z, logdet = tr.step(x, ht)
+    assert np.abs(npy(z) - ref["z"]).max() < Z_ATOL
+    assert logdet_close(npy(logdet), ref["logdet"], N)
+    assert abs(float(loss) - ref["loss"]) < LOSS_ATOL
+    named = dict(m.named_parameters())
+    worst = 0.0
+    for i, (n, _, _) in enumerate(specs):
+        e = relmax(npy(named[n].grad).astype(np.float64), ref["grads"][i])
+        worst = max(worst, e)
+        assert e < GRAD_RTOL, n
+    # dh through the autograd path of the same model (FlowTrainer does not return it for WaveGlow): same kernels, need_dh on
+    m.zero_grad(set_to_none=True)
+    hg = T(h, dev).requires_grad_(True)
+    z2, ld2 = m(T(audio, dev), hg)
+    cm.WaveGlowLoss(fill.SIGMA)(z2, ld2).backward()
+    assert torch.equal(z2.detach(), z) or float((z2.detach() - z).abs().max()) < 1e-6
+    assert relmax(npy(hg.grad).astype(np.float64), ref["dh"]) < GRAD_RTOL
+    print("headline shape vs float64 oracle: |dz| %.2e, worst gradient %.2e of its tensor's max (%d oracle workers)"
+          % (float(np.abs(npy(z) - ref["z"]).max()), worst, workers))
+
+
 @pytest.mark.parametrize("c", [2, 4, 8])
 @pytest.mark.parametrize("batch", [1, 3])
 @pytest.mark.parametrize("rev", [False, True])
@@ -1140,12 +1225,12 @@ def test_waveflow_after_remove_weight_norms(dev, precision):
 @pytest.mark.parametrize("B,Tn,depth,aux,ch,planned", [(3, 1000, 8, 80, 256, True), (5, 130, 8, 80, 256, True), (2, 2000, 4, 80, 256, True),
                                                        (4, 2000, 2, 80, 256, True), (1, 300, 8, 80, 256, True), (2, 700, 2, 80, 256, True),
                                                        (1, 64, 8, 80, 256, True), (2, 500, 3, 80, 256, True), (2, 512, 8, 1500, 256, True),
-                                                       (3, 700, 5, 3659, 256, True), (2, 500, 3, 80, 64, False)])
+                                                       (3, 700, 5, 3659, 256, True), (2, 500, 3, 80, 64, False), (24, 2000, 8, 80, 256, True)])
 def test_weight_gradient_kernel_plans_vs_oracle(dev, precision, B, Tn, depth, aux, ch, planned):
     """wgrad16t_kernel (one workgroup per CU, planned phases, wg_wgrad16t.h) at the shipped WN width over several (batch, length, depth,
     conditioning width) combinations: different K ranges, part counts and phase shapes of the two planners -- the two-phase plan of the
     headline shape; the ROUNDS plan for a layer count that does not divide the 8 XCDs and for rows of tiles wider than an XCD (WSRGlow's
-    3 659 conditioning channels: 35 column tiles in sub-sets of 7) -- against the oracle, and a case WITHOUT a plan (a 64-channel WN: its
+    3 659 conditioning channels: 35 column tiles in sub-sets of 7); the headline shape's own K = 24 x 2000 columns -- against the oracle, and a case WITHOUT a plan (a 64-channel WN: its
     products have 128 rows, the kernel's tiles 256), which must take the two-workgroup kernel and agree as well."""
     if precision != "bf16x3p":
         pytest.skip("the grouped weight-gradient launches exist in the S-plane mode only")

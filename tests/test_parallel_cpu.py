@@ -82,6 +82,16 @@ def _worker(rank, world, port, q):
     sync.all_reduce_params(ps)
     assert torch.allclose(ps[0].grad, torch.full((5,), 1.5)) and torch.allclose(ps[1].grad, torch.arange(6, dtype=torch.float32).view(2, 3) * 1.5)
     assert ps[2].grad is None
+    # GradSync.skip (bench.py's `exposed_ms` run: the same step WITHOUT its collectives, every rank alike): nothing is exchanged, the
+    # per-bucket callbacks still run in order
+    sync.skip = True
+    ps[0].grad = torch.full((5,), float(rank + 1))
+    sync.all_reduce_params(ps)
+    assert torch.equal(ps[0].grad, torch.full((5,), float(rank + 1)))
+    before, seen2 = fg.flat.clone(), []
+    sync.all_reduce(fg, order=order, after_bucket=lambda b: seen2.append(b))
+    assert seen2 == order and torch.equal(fg.flat, before)
+    sync.skip = False
     # replicas start identical
     probe = [torch.full((3,), float(rank)), None, torch.nn.Parameter(torch.full((2, 4), 7.0 + rank)), torch.full((1,), 5.0 * rank)]
     sync.broadcast_params(probe)                                      # ONE flat collective over all of them, copied back per tensor
