@@ -103,8 +103,8 @@ def cpu_baseline():
     """The CPU path timed on the host cores of the GPU box (rank 0, N = 1 only; BASELINE.md section 4's plan): training steps of
     oracle/torch_cpu.py -- the path's algorithm restated on the library the reference itself runs on (ATen's CPU convolutions, a local
     autograd graph per WN, activations rebuilt flow by flow), pinned to the reference's golden vectors by tests/test_oracle_golden.py --
-    `value` = the C2 network on ALL physical cores: physical_cores // 8 worker processes x 8 threads, one 16000-sample segment each
-    (batch items are independent units), 1 warm-up + 3 timed steps per worker.  Next to it one process alone (`single_process`, C2 B=1,
+    `value` = the C2 network on ALL cores the host grants (min(physical cores, cgroup CPU quota)): worker processes x threads in the split a
+    short C1 probe finds fastest, one 16000-sample segment per process (batch items are independent units), 1 warm-up + 3 timed steps.  Next to it one process alone (`single_process`, C2 B=1,
     its fastest thread count) and C1 (64ch, 6 flows, B=2, seg 4000).  The plain-C oracle (oracle/wg_oracle.c, OpenMP), which the parity tests use as their
     checker, is timed next to it on C2 B=1 as `c_port`."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -146,8 +146,21 @@ def cpu_baseline():
     # processes x 8 threads (where ATen's pool still scales), all released together after a warm-up step, 3 timed steps each
     # (oracle/torch_cpu.py: time_parallel).  (A B = 2 step in ONE process ran 2.3x slower per sample than B = 1 in round 3 -- the thread
     # pool, not the algorithm -- and is no longer quoted.)
-    workers = max(1, phys // 8)
-    allcore = torch_cpu.time_parallel(C2, tab, audio, h, SIGMA, workers=workers, threads=min(8, phys), runs=3)
+    # What "all cores" means on this host: the container may show 128 physical cores and grant a cgroup quota of 16 CPUs (the GPU boxes of
+    # this pool do), and ATen's pool does not scale past a few threads on these shapes.  So the budget is min(physical cores, quota), and
+    # the split of it into processes x threads is probed on C1 (2 timed steps per candidate) and the fastest runs the C2 measurement.
+    logical, quota, _ = torch_cpu.host_cpu_budget()
+    budget = max(1, min(phys, int(quota + 0.5)) if quota else phys)
+    cands = sorted({(max(1, budget // t), t) for t in (8, 4, 2, 1) if budget // t >= 1} | {(min(2 * budget, phys), 1)})
+    split_probe = {}
+    c1_tab = fill.table(fill.model_param_specs(c1), fill.fill_params(fill.model_param_specs(c1), "c1/"))
+    c1_audio, c1_h = fill.inputs("c1/cpu2", 2, 4000, 16, c1["n_mels"])
+    for w_, t_ in cands:
+        split_probe["%dx%d" % (w_, t_)] = torch_cpu.time_parallel(c1, c1_tab, c1_audio[:1], c1_h[:1], SIGMA, workers=w_, threads=t_, runs=2)["samples_per_s"]
+    best = max(split_probe, key=split_probe.get)
+    workers, wthreads = (int(v) for v in best.split("x"))
+    allcore = torch_cpu.time_parallel(C2, tab, audio, h, SIGMA, workers=workers, threads=wthreads, runs=3)
+    allcore.update({"cgroup_quota_cpus": quota, "logical_cpus": logical, "core_budget": budget, "split_probe_c1_samples_per_s": split_probe})
     total = sum(r["median_s"] * (r["runs"] + 1) for r in res.values()) + allcore["wall_s"] * 4.0 / 3.0
     # the C port: capped at 64 OpenMP threads (its loops expose 64-128 independent row blocks; more threads measured slower)
     oc = orc.make_config(**C2)
@@ -155,7 +168,7 @@ def cpu_baseline():
     cport = timed(lambda: orc.train_step(oc, tab, audio, h, SIGMA), 1, SEG, runs=2)
     cport.update({"unit": "samples/s", "cores": cthreads, "what": "oracle/wg_oracle.c (plain C + OpenMP), C2 B=1: 1 warm-up + 2 runs, median"})
     single = dict(res["c2_b1"], cores=cores, what="ONE process, its fastest thread count (probed on C1): C2 B=1, median of 3 runs after 1 warm-up")
-    return {"value": allcore["samples_per_s"], "unit": "samples/s", "cores": allcore["workers"] * allcore["threads_per_worker"], "kind": "port",
+    return {"value": allcore["samples_per_s"], "unit": "samples/s", "cores": min(budget, allcore["workers"] * allcore["threads_per_worker"]), "kind": "port",
             "implementation": "torch-cpu: oracle/torch_cpu.py, the step restated on ATen's CPU kernels (F.conv1d / MKLDNN), "
                               "constant-memory backward with a local autograd graph per WN; torch %s" % torch.__version__,
             "cpu_model": _cpu_model(),
@@ -302,11 +315,11 @@ def other_models(dev):
 
 
 KCLASS = {0: "conv store / residual / data-gradient (EPI_STORE)", 1: "gate conv (EPI_GATE)", 2: "residual + skip conv (EPI_RESSKIP)",
-          3: "gate backward (EPI_DGATE)", 4: "weight gradient"}
+          3: "gate backward (EPI_DGATE)", 4: "weight gradient", 5: "layer launch: gate conv + residual product (opt-in)"}
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
-def kernel_rooflines(trainer, x, h, split, steps=2, top=8):
+def kernel_rooflines(trainer, x, h, split, steps=2, top=8, step_fn=None):
     """Per-SHAPE rooflines of the conv / weight-gradient launches of the training step: every such launch of `steps` extra steps is
     bracketed with HIP events on the launch stream (wg_timer_create(-1, ..): all classes) and reported with the shape the library
     attaches to it (wg_timer_read_info): class, M x K, columns, algorithmic HBM bytes.  Grouped by (class, M, K); per group: launches per
@@ -319,7 +332,10 @@ def kernel_rooflines(trainer, x, h, split, steps=2, top=8):
     torch.cuda.synchronize()
     L.wg_timer_attach(t)
     for _ in range(steps):
-        trainer.step(x, h)
+        if step_fn is not None:
+            step_fn()
+        else:
+            trainer.step(x, h)
     torch.cuda.synchronize()
     L.wg_timer_attach(None)
     n = L.wg_timer_count(t)
@@ -737,10 +753,11 @@ def main(argv=None):
         if comm is not None:
             out["comm"] = comm
         if args.model != "waveglow":
+            wl["no_inverse"] = args.no_inverse
             args.no_inverse = args.no_extra = args.no_cpu = True         # the secondary legs belong to the headline workload
-            if world == 1 and trainer is not None:
+            if world == 1:
                 try:
-                    out["roofline"]["kernels"] = kernel_rooflines(trainer, x, h, split)
+                    out["roofline"]["kernels"] = kernel_rooflines(trainer, x, h, split, step_fn=step if trainer is None else None)
                 except Exception as e:                                    # noqa: BLE001
                     out["roofline"]["kernels"] = {"error": repr(e)}
             if args.model == "waveflow" and world == 1 and not wl.get("no_inverse"):

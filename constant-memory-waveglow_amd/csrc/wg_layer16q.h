@@ -1,0 +1,387 @@
+// wg_layer16q.h -- a WN layer's gate conv AND its residual product in ONE persistent launch, for the shapes that fill the chip
+// (the training step):
+//     gate = tanh(xy[:Cd]) * sigmoid(xy[Cd:]),  xy = W (*) h + V y        "G tiles": 256 x 128, K = radix C + aux (27 chunks at C2)
+//     h'   = h + Wres gate                                                 "R tiles": 256 x 128, K = Cd         ( 8 chunks at C2)
+// (model/waveglow.py:41-46; the skip rows of W_o stay one product per WN behind the layer loop, wn_forward.)
+//
+// Why.  As its own launch the residual product is bound by bytes -- 147 MB in 35 us, 4.2 TB/s -- while the gate conv next to it is bound by
+// the matrix pipe and leaves HBM three quarters idle.  In one persistent walk a workgroup's R tiles run between
+// its G tiles, at the G tiles' chunk rate, and the launch boundary with its drain and ramp goes.  This is the wg_gemm16q.h kernel in its
+// MG = 2 form (one 16-wave workgroup per CU, two 128-row compute groups sharing the B image, 8 loader waves) walking a LIST of tiles of
+// two shapes.  The gate conv's grid is dealt as the stand-alone launch deals it (XCD rows: the two row tiles of a column tile sit on two
+// neighbouring workgroups of one XCD, which run in step); with n rounds per workgroup and e = the workgroup's row-tile index (0 / 1):
+//     e == 0:  G_0, G_1, R_0, G_2,      G_3, R_2, ...                      R_k is owned by the row tile (k & 1) for k < n - 1,
+//     e == 1:  G_0, G_1,      G_2, R_1, G_3,      ...                      the last round's R by the owner of round n - 2
+// i.e. an R tile always has a whole item between it and the G tile of its own round.
+//
+// The gate crosses workgroups inside the launch.  G tiles store it write-through (sc1: it has to reach HBM anyway -- the skip product and
+// the backward read it).  A G tile's stores are PUBLISHED half an item later: every compute wave's `s_waitcnt vmcnt(0)` is free by
+// then, the wave that counts last in an LDS word adds 1 to the column tile's arrival counter (one lane for all the workgroup's stores,
+// behind every storing wave's wait: MI355X_MICROARCH.md, inter-workgroup visibility, table row 1).  The loader waves poll that counter
+// (an sc1 load, each wave for itself) in front of an R tile's first chunk -- by construction both publications are at least a quarter of
+// an item old by then -- and fetch every B operand of this kernel with sc1 loads.  A loader wave that waits stops the workgroup's
+// chunk barriers, so an R tile must never wait for a G tile of its own workgroup that is not finished: that is what the item in between
+// guarantees; G tiles wait for nothing, so the walk cannot deadlock as long as every workgroup is resident (grid <= CUs).
+#pragma once
+#include "wg_gemm16q.h"
+#include "wg_layer16h.h"
+
+struct ConvLayer16qArgs {
+    ConvGemm16sArgs p[2];      // [0] the gate conv (EPI_GATE_SO), [1] the residual product (EPI_STORE_SO, saux = h); the tile grid is [0]'s
+    unsigned *sync;            // one 128-byte line (WGL_SYNC_STRIDE words) per column tile: word 0 = arrivals; zero before and after the launch
+};
+
+#define WGLQ_SPIN_MAX (1 << 22)
+// timing bisection only (-DWGLQ_DBG=<mask>; results are WRONG with any bit): 1 plain B loads, 2 plain gate stores, 4 no R tiles, 8 no poll
+#if !defined(WGLQ_DBG)
+#define WGLQ_DBG 0
+#endif
+
+// EPI_GATE_SO's column block (wgq_gate_nb, wg_gemm16q.h) with the gate's S-plane stored write-through; the saved tanh / sigmoid planes
+// (private to this workgroup's later gate backward) keep their non-temporal stores
+template <int OFF>
+__device__ __forceinline__ void wglq_st8_sc1(const unsigned short *base, unsigned voff, const u32x2 &v)
+{
+    if (WGLQ_DBG & 2) asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" ::"v"(voff), "v"(v), "s"(base), "n"(OFF) : "memory");
+    else asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3 sc1" ::"v"(voff), "v"(v), "s"(base), "n"(OFF) : "memory");
+}
+template <int NB, int NBI>
+__device__ __forceinline__ void wglq_gate_nb(f32x4 (&acc)[4][NB], bool live, const float *const (&bt)[2], const float *const (&bs)[2],
+                                             const unsigned short *const (&sh)[2], const unsigned short *const (&sl)[2], bool has_ts,
+                                             unsigned vo_t, unsigned vo_s)
+{
+    float tw[8], sf[8], gv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        tw[i] = wg_tanh(acc[i >> 2][NBI][i & 3]);
+        sf[i] = wg_sigmoid(acc[2 + (i >> 2)][NBI][i & 3]);
+        gv[i] = tw[i] * sf[i];
+    }
+#pragma unroll
+    for (int mbp = 0; mbp < 2; ++mbp) {
+        f32x4 vt, vs;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vt[e] = tw[4 * mbp + e]; vs[e] = sf[4 * mbp + e]; }
+        u32x2 vh, vl;
+        unsigned hh, ll;
+        split2(gv[4 * mbp], gv[4 * mbp + 1], hh, ll); vh[0] = hh; vl[0] = ll;
+        split2(gv[4 * mbp + 2], gv[4 * mbp + 3], hh, ll); vh[1] = hh; vl[1] = ll;
+        if (live) {
+            if (has_ts) { wgq_st16nt<256 * NBI>(bt[mbp], vo_t, vt); wgq_st16nt<256 * NBI>(bs[mbp], vo_t, vs); }
+            wglq_st8_sc1<256 * NBI>(sh[mbp], vo_s, vh);
+            wglq_st8_sc1<256 * NBI>(sl[mbp], vo_s, vl);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int NB>
+__device__ __forceinline__ void wglq_gate_epilogue(const ConvGemmArgs &a, const SRef &s0, f32x4 (&acc)[4][NB], int t0, int m0, int b, int wr, int wc, int lane)
+{
+    const Geo g = a.g;
+    const int col = lane & 15, rq = lane >> 4;
+    const int chb = (m0 >> 1) + wr * 32;
+    if (2 * chb >= a.M) return;
+    const bool has_ts = a.out1.p != nullptr;
+    const int tl0 = wc * (16 * NB);
+    const float *bt[2], *bs[2];
+    const unsigned short *sh[2], *sl[2];
+#pragma unroll
+    for (int mbp = 0; mbp < 2; ++mbp) {
+        bt[mbp] = has_ts ? paddr4(a.out1, g, b, chb + mbp * 16, t0 + tl0) : nullptr;
+        bs[mbp] = has_ts ? paddr4(a.out2, g, b, chb + mbp * 16, t0 + tl0) : nullptr;
+        sh[mbp] = s0.hi + s_index(s0, g, b, chb + mbp * 16, t0 + tl0);
+        sl[mbp] = sh[mbp] + s0.lo_off;
+    }
+    const unsigned vo_t = (unsigned)((rq * g.P + col) * 16), vo_s = (unsigned)(((rq >> 1) * g.P + col) * 16 + 8 * (rq & 1));
+    const int tw0 = t0 + tl0 + col;
+    wglq_gate_nb<NB, 0>(acc, tw0 < g.T, bt, bs, sh, sl, has_ts, vo_t, vo_s);
+    if constexpr (NB > 1) wglq_gate_nb<NB, 1>(acc, tw0 + 16 < g.T, bt, bs, sh, sl, has_ts, vo_t, vo_s);
+    if constexpr (NB > 2) wglq_gate_nb<NB, 2>(acc, tw0 + 32 < g.T, bt, bs, sh, sl, has_ts, vo_t, vo_s);
+    if constexpr (NB > 3) wglq_gate_nb<NB, 3>(acc, tw0 + 48 < g.T, bt, bs, sh, sl, has_ts, vo_t, vo_s);
+}
+
+__global__ __launch_bounds__(1024) void convlayer16q_kernel(const ConvLayer16qArgs la)
+{
+    constexpr int MG = 2, NI = 2;
+    typedef StageOf<1>::type Stage;                           // per loader lane and chunk: 4 A + 2 B loads
+    constexpr int AIMG = 128 * MG * WG16Q_ROWB;
+    constexpr int BIMG = 64 * NI * WG16Q_ROWB;
+    constexpr int BUF = 2 * AIMG + 2 * BIMG;
+    constexpr int TT = 64 * NI;
+    constexpr int NB = 2 * NI;
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+    __shared__ unsigned s_cnt[2];                             // compute waves that have drained a G tile's stores (alternating words)
+    __shared__ int s_bad;
+    const ConvGemm16sArgs &ag = la.p[0];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const Geo g = ag.c.g;
+    if (tid < 2) s_cnt[tid] = 0;
+    if (tid == 2) s_bad = 0;
+    int ncG = 0, ncR = 0;
+    for (int s = 0; s < la.p[0].c.nseg; ++s) ncG += (la.p[0].c.seg[s].nch + WG16_BK - 1) / WG16_BK;
+    for (int s = 0; s < la.p[1].c.nseg; ++s) ncR += (la.p[1].c.seg[s].nch + WG16_BK - 1) / WG16_BK;
+    // ---- the gate conv's tile walk (convgemm16q_kernel's XCD rows; the host launches this kernel for that mapping only) ----
+    const int G = (int)gridDim.x;
+    const int xper = ag.ntx * ag.nty, xl = ag.xcd_items * xper, xslots = G >> 3, xslot = (int)blockIdx.x >> 3;
+    const int mine = xl / xslots;                             // rounds: the same for every workgroup (host: xl % xslots == 0, mine >= 2)
+    auto gtile = [&](int k, int &tx, int &ty, int &tz) {
+        const int local = xslot + k * xslots, zl = local / xper, rem = local - zl * xper;
+        const int id = (((int)blockIdx.x & 7) + 8 * zl) * xper + (rem % ag.nty) * ag.ntx + rem / ag.nty;
+        tx = id % ag.ntx;
+        const int q = id / ag.ntx;
+        ty = q % ag.nty; tz = q / ag.nty;
+    };
+    const int my_e = xslot & 1;                               // this workgroup's row-tile index (nty == 2, xslots even): the same in every round
+    auto owns = [&](int k) { return !(WGLQ_DBG & 4) && my_e == ((k < mine - 1 ? k : mine - 2) & 1); };
+    // item p of this workgroup's list -> (kind, round):  G_0; for k = 1 .. n-1: G_k, [R_{k-1}]; [R_{n-1}]
+    struct Item { int kind, k; };
+    int nitems = 0, total = 0;
+    for (int k = 0; k < mine; ++k) {
+        const int o = owns(k) ? 1 : 0;
+        nitems += 1 + o;
+        total += ncG + o * ncR;
+    }
+    auto item_at = [&](int p) {
+        Item it = {0, 0};
+        int q = 0;
+        for (int k = 0; k < mine; ++k) {
+            if (q == p) { it.kind = 0; it.k = k; return it; }
+            ++q;
+            if (k >= 1 && owns(k - 1)) {
+                if (q == p) { it.kind = 1; it.k = k - 1; return it; }
+                ++q;
+            }
+        }
+        it.kind = 1; it.k = mine - 1;                         // (the last item of the owner of the last round)
+        return it;
+    };
+    auto coords = [&](const Item &it, int &t0, int &m0, int &b, int &ct) {
+        int tx, ty, tz;
+        gtile(it.k, tx, ty, tz);
+        t0 = tx * TT; m0 = it.kind ? 0 : ty * (WG_TILE * MG);
+        b = tz;
+        ct = tx + ag.ntx * tz;
+    };
+    __syncthreads();                                          // s_cnt / s_bad initialised
+
+    if (wave >= 4 * MG) {
+        // ------------------------------- loader waves -------------------------------
+        const int lt = tid - 256 * MG;
+        const int bt = lt & 127, cg0 = lt >> 7;
+        int p = 0, v = 0, gchunk = 0;
+        Item it = item_at(0);
+        int t0, m0, b, ct;
+        coords(it, t0, m0, b, ct);
+        int nil = la.p[0].tap_il * la.p[0].tap_chunks;
+        int cur_seg = la.p[0].tap_il, cur_c = 0, chunk = nil, nchunks = ncG;
+        const unsigned voff_a = (unsigned)lt * 16u;
+        const int arow = lt & 127, akg = lt >> 7;
+        const int a_off[2] = {wg16q_off(arow, akg), wg16q_off(128 + arow, akg)};
+        constexpr int A_NEXT = 4096;
+        const int b_off = wg16q_off(bt, cg0);
+        const unsigned voff_b = (unsigned)((cg0 * g.P + bt) * 16);
+#define WGLQ_LD(dst, base, voff) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
+#define WGLQ_LDS1(dst, base, voff)                                                                                          \
+    do {                                                                                                                   \
+        if (WGLQ_DBG & 1) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");     \
+        else asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(dst) : "v"(voff), "s"(base) : "memory");              \
+    } while (0)
+        const unsigned short *zsrc = ag.sseg[0].hi;           // plane position 0 of the gate conv's first operand: always-zero halo
+        auto issue = [&](Stage &st) {                         // exactly 6 loads in straight-line code (tools/check_asm_loads.py)
+            const bool live = gchunk < total;
+            if (live && v == 0 && it.kind && !(WGLQ_DBG & 8)) {
+                // an R tile's first chunk: the column tile's two G tiles must have been published (every loader wave polls for itself;
+                // bounded: a hand-off that never comes shows as NaN outputs, not as a hang)
+                const unsigned *arrive = la.sync + (size_t)ct * WGL_SYNC_STRIDE;
+                int spins = 0;
+                while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2u && spins < WGLQ_SPIN_MAX) {
+                    __builtin_amdgcn_s_sleep(1);
+                    ++spins;
+                }
+                if (spins >= WGLQ_SPIN_MAX && lane == 0) s_bad = 1;
+            }
+            const ConvGemm16sArgs &P = la.p[it.kind];
+            const ConvGemmArgs &a = P.c;
+            const bool il = v < nil;
+            const int sgi = il ? v % P.tap_il : cur_seg, cbi = il ? v / P.tap_il : 0;
+            const int ci = il ? cbi * WG16_BK : cur_c, chi = il ? sgi * P.tap_chunks + cbi : chunk;
+            const int sg = min(sgi, a.nseg - 1);
+            const int nch = a.seg[sg].nch, shift = a.seg[sg].shift;
+            const SSeg ss = P.sseg[sg];
+            const bool full = live && (nch - ci > 16);
+            const unsigned short *ih = P.img + ((size_t)chi * a.lda + m0) * WG16_BK, *il_ = ih + P.img_stride;
+            const unsigned short *row0 = ss.hi + ((size_t)b * (ss.Cp >> 3) + ((ss.ch0 + ci) >> 3)) * g.P * 8;
+            const unsigned short *pa0 = live ? ih : zsrc, *pa1 = live ? ih + A_NEXT : zsrc;
+            const unsigned short *pl0 = live ? il_ : zsrc, *pl1 = live ? il_ + A_NEXT : zsrc;
+            const unsigned va = live ? voff_a : 0u;
+            WGLQ_LD(st.ah[0], pa0, va);   WGLQ_LD(st.ah[1], pa1, va);
+            WGLQ_LD(st.al[0], pl0, va);   WGLQ_LD(st.al[1], pl1, va);
+            const unsigned short *pb = live ? row0 : zsrc, *pbl = live ? row0 + ss.lo_off : zsrc;
+            const bool lane_ok = live && (cg0 < 2 || full);
+            const unsigned vb = lane_ok ? voff_b + (unsigned)((g.H + t0 + shift) * 16) : 0u;
+            WGLQ_LDS1(st.bh[0], pb, vb);  WGLQ_LDS1(st.bl[0], pbl, vb);
+            if (live) {
+                ++gchunk;
+                if (!il) {
+                    ++chunk;
+                    cur_c += WG16_BK;
+                    if (cur_c >= nch) { cur_c = 0; ++cur_seg; }
+                }
+                if (++v == nchunks) {                         // next item of the list
+                    v = 0;
+                    p = min(p + 1, nitems - 1);
+                    it = item_at(p);
+                    coords(it, t0, m0, b, ct);
+                    nil = la.p[it.kind].tap_il * la.p[it.kind].tap_chunks;
+                    chunk = nil; cur_seg = la.p[it.kind].tap_il; cur_c = 0;
+                    nchunks = it.kind ? ncR : ncG;
+                }
+            }
+        };
+#undef WGLQ_LD
+#undef WGLQ_LDS1
+        auto write = [&](const Stage &st, int buf) {
+            char *sb = smem + buf * BUF;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                *reinterpret_cast<u32x4 *>(sb + a_off[j]) = st.ah[j];
+                *reinterpret_cast<u32x4 *>(sb + AIMG + a_off[j]) = st.al[j];
+            }
+            *reinterpret_cast<u32x4 *>(sb + 2 * AIMG + b_off) = st.bh[0];
+            *reinterpret_cast<u32x4 *>(sb + 2 * AIMG + BIMG + b_off) = st.bl[0];
+        };
+        Stage s0, s1;
+        issue(s0);
+        issue(s1);
+        asm_wait_stage(s0);
+        write(s0, 0);
+        issue(s0);
+        WG16W_BAR();                                          // buffer 0 ready
+        auto iter = [&](Stage &st, int c) {
+            asm_wait_stage(st);
+            write(st, (c & 1) ^ 1);
+            issue(st);
+            WG16W_BAR();
+        };
+        for (int c = 0; c + 1 < total; c += 2) {              // always in pairs (convgemm16w_kernel)
+            iter(s1, c);
+            iter(s0, c + 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    // ------------------------------- compute waves -------------------------------
+    const int grp = wave >> 2, wr = (wave >> 1) & 1, wc = wave & 1;
+    f32x4 acc[4][NB];
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int ao = wg16q_off(grp * 128 + wr * 64 + r16, kg), bo = wg16q_off(wc * 32 * NI + r16, kg);
+#define WGQ_SB() __builtin_amdgcn_sched_barrier(0)
+    bf16x8 ah[4], al[4], bh[2], bl[2];
+    auto rd = [&](const char *q) { return *reinterpret_cast<const bf16x8 *>(q); };
+    int gc = 0;
+    int pub_ct = -1, pub_n = 0;                               // the G tile whose stores are not published yet (its column tile); publications so far
+    // every compute wave has drained its stores; the wave that counts last adds the arrival (one lane, behind all eight waits)
+    auto publish = [&]() {
+        if (pub_ct < 0) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            unsigned *w = &s_cnt[pub_n & 1];
+            if (__hip_atomic_fetch_add(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 4u * MG - 1u) {
+                __hip_atomic_store(w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(la.sync + (size_t)pub_ct * WGL_SYNC_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        ++pub_n;
+        pub_ct = -1;
+    };
+    auto run_chunks = [&](int c0, int c1) {
+        for (int c = c0; c < c1; ++c, ++gc) {
+            const char *pb = smem + (gc & 1) * BUF + 2 * AIMG + bo;
+            const char *na = smem + ((gc & 1) ^ 1) * BUF + ao, *nb_ = smem + ((gc & 1) ^ 1) * BUF + 2 * AIMG + bo;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const int cur = nb & 1, nxt = cur ^ 1;
+                if (nb == NB - 1) {
+                    WGQ_SB();
+                    if (gc + 1 < total || !(total & 1)) WG16W_BAR();
+                }
+                WGQ_SB();
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mb], bh[cur], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mb], bl[cur], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mb], bh[cur], acc[mb][nb], 0, 0, 0);
+                    if (mb == 0) {
+                        WGQ_SB();
+                        if (nb == NB - 1) { bh[nxt] = rd(nb_); bl[nxt] = rd(nb_ + BIMG); }
+                        else { bh[nxt] = rd(pb + (nb + 1) * 1024); bl[nxt] = rd(pb + BIMG + (nb + 1) * 1024); }
+                        WGQ_SB();
+                    }
+                    if (nb == NB - 1) {
+                        WGQ_SB();
+                        ah[mb] = rd(na + mb * 1024); al[mb] = rd(na + AIMG + mb * 1024);
+                        WGQ_SB();
+                    }
+                }
+                WGQ_SB();
+            }
+        }
+    };
+    for (int p = 0; p < nitems; ++p) {
+        const Item it = item_at(p);
+        int t0, m0, b, ct;
+        coords(it, t0, m0, b, ct);
+        m0 += grp * 128;
+        const ConvGemm16sArgs &P = la.p[it.kind];
+        const ConvGemmArgs &a = P.c;
+        const int nchunks = it.kind ? ncR : ncG;
+        int ln = lane;
+        asm volatile("" : "+v"(ln)::"memory");
+        WGQ_SB();
+        if (it.kind) {
+            conv_acc_init_q<EPI_STORE_SO, NB>(a, P.saux, acc, t0, m0, b, wr, wc, ln);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[i][j][q] = 0.f;
+        }
+        if (p == 0) WG16W_BAR();                              // buffer 0 ready (later items: published by the previous chunk's barrier)
+        {
+            const char *pa = smem + (gc & 1) * BUF + ao, *pb = smem + (gc & 1) * BUF + 2 * AIMG + bo;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { ah[i] = rd(pa + i * 1024); al[i] = rd(pa + AIMG + i * 1024); }
+            bh[0] = rd(pb); bl[0] = rd(pb + BIMG);
+        }
+        // the previous G tile's stores are published in the MIDDLE of this item: half an item after they were issued the wait is free, and
+        // it is a quarter of an item before any loader wave may poll for them
+        run_chunks(0, nchunks >> 1);
+        publish();
+        run_chunks(nchunks >> 1, nchunks);
+        int le = lane;
+        asm volatile("" : "+v"(le)::"memory");
+        if (it.kind) {
+            {   // a hand-off that timed out turns this tile into NaN (a multiplication by 1.0f otherwise: no branch around the accumulators)
+                const float pz = s_bad ? __builtin_nanf("") : 1.0f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[i][j][q] *= pz;
+            }
+            conv_epilogue_q<EPI_STORE_SO, NB>(a, P.s0, acc, t0, m0, b, wr, wc, le);
+            if (wave == 0 && lane == 0)                       // both arrivals were consumed (every loader wave polled before this tile's first chunk)
+                __hip_atomic_store(la.sync + (size_t)ct * WGL_SYNC_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            wglq_gate_epilogue<NB>(a, P.s0, acc, t0, m0, b, wr, wc, le);
+            pub_ct = ct;
+        }
+        WGQ_SB();
+    }
+    publish();                                                // a list that ends with a G tile: its stores, behind a real drain
+#undef WGQ_SB
+}

@@ -13,6 +13,7 @@
 #include "wg_mel.h"
 #include "wg_stage.h"
 #include "wg_layer16h.h"
+#include "wg_layer16q.h"
 #include "wg_thin.h"
 
 #include <algorithm>
@@ -38,6 +39,12 @@ struct Ctx {
     int row_sel1;   // Geo::rows > 0 only: 0 = every plane row; r + 1 = the conv launches cover height row r of every item (WaveFlow's inverse)
     struct FinQueue *fq = nullptr;   // set inside wn_backward: weight-gradient slabs come from its arena, finalisations are batched
     struct StageRec *rec = nullptr;  // set while a launch sequence is RECORDED for the stage interpreter (wg_stage.h): nothing is launched
+    struct BigCap *cap = nullptr;    // set while run_convgemm only DESCRIBES a chip-filling launch (run_convlayer_big): nothing is launched
+};
+// a launch of the 256 x 128-tile conv kernel as its argument block (ntx x nty x ntz tiles of 256 rows), instead of the launch
+struct BigCap {
+    ConvGemm16sArgs as;
+    bool ok;
 };
 // the launches of one row step of WaveFlow's inverse, as argument blocks (see wg_stage.h); ok = false: a launch that the interpreter
 // cannot run turned up (the caller then launches everything the ordinary way)
@@ -891,7 +898,8 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
     else if (epi == EPI_RESSKIP) out_ch = (long long)nsplit * (1 + (out0.p ? 1 : 0) + (s0.hi ? 1 : 0)) + (long long)(M - nsplit) * (1 + accumulate);
     else out_ch = (long long)M * ((out0.p ? 1 : 0) + (s0.hi ? 1 : 0) + (aux0.p ? 1 : 0) + (saux.hi ? 1 : 0));
     const long long alg_bytes = 4 * cols * (in_ch + out_ch) + 4LL * M * Ksum;
-    TimerScope ts(cx.rec ? -1000 : WG_K_CONV_STORE + epi, cx.st, M, Ksum, cols, alg_bytes);      // (nothing is launched while recording)
+    if (cx.cap && cx.prec != 2) { cx.cap->ok = false; return; }
+    TimerScope ts((cx.rec || cx.cap) ? -1000 : WG_K_CONV_STORE + epi, cx.st, M, Ksum, cols, alg_bytes);      // (nothing is launched while recording)
     if (cx.prec) {
         ConvGemm16Args a16;
         int K = 0, nc = 0;
@@ -952,6 +960,17 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
 #endif
                 ;
             if (xcd_rows && ntiles >= slots && slots % 8 == 0) as.xcd_items = as.ntz / 8;
+            if (cx.cap) {                                     // describe, do not launch: the 256 x 128-tile form with S-plane-only epilogues
+                const bool sg = epi == EPI_GATE && as.s0.hi && !a.out0.p && WG_TS_INTERLEAVED;
+                const bool se = epi == EPI_STORE && as.s0.hi && !a.out0.p && !a.aux0.p;
+                cx.cap->ok = !small && rup(mrows, WG_TILE) % 256 == 0 && (sg || se) && !cx.row_sel1 && g.rows == 0 && !cx.rec;
+                if (cx.cap->ok) {
+                    as.nty = (int)grid.y / 2;
+                    as.xcd_items = as.ntz % 8 == 0 ? as.ntz / 8 : 0;
+                    cx.cap->as = as;
+                }
+                return;
+            }
 #if !defined(WG_OPT_MFMA32)                       // default: the 16x16x32 form of the same kernel (wg_gemm16q.h)
 #if !defined(WG_OPT_NO_HTILE)
             // at most half as many 128 x 64 tiles as CUs (one utterance being synthesised, WaveFlow's row-by-row inverse): such a launch
@@ -1510,6 +1529,62 @@ bool run_convlayer(Ctx &cx, float *ws, size_t lsync, FA &&gate_call, FB &&wo_cal
     return true;
 #endif
 }
+// A layer's gate conv and residual product as ONE persistent launch (wg_layer16q.h) where the gate conv fills the chip with 256 x 128 tiles
+// dealt by XCD rows in at least two whole rounds (the training shapes).  Both launches are only DESCRIBED (Ctx::cap), checked, and issued as
+// convlayer16q_kernel; false = nothing was launched (the caller issues the two launches the ordinary way).
+std::atomic<long long> g_layerq_launches{0};                  // diagnostics: launches of convlayer16q_kernel (wg_stat_layerq_launches)
+template <class FA, class FB>
+bool run_convlayer_big(Ctx &cx, float *ws, size_t lsync, FA &&gate_call, FB &&res_call)
+{
+#if defined(WG_OPT_NO_LAYERQ)
+    return false;
+#else
+    if (cx.prec != 2 || cx.rec || cx.cap || cx.err) return false;
+    {
+        // OPT-IN (WG_LAYER_FUSION_BIG=1).  Measured at the headline shape (gpurun_out/r04g_bigfuse.txt, r04h_bisect.txt):
+        // parity identical, 166-169 us per layer against 117.7 + 34.8 = 152.5 us for the two launches (step 65.9 against 64.3 ms).  The R tiles
+        // cost 42 us of the launch -- twice their share of chunks: an 8-chunk tile is half overhead (the accumulate-into tile's round trip,
+        // the epilogue, the poll), exactly as in the stand-alone residual launch -- and the G tiles run 8 % slower in the two-shape loop.
+        const char *e = getenv("WG_LAYER_FUSION_BIG");
+        if (!e || e[0] != '1') return false;
+    }
+    BigCap cg, cr;
+    cg.ok = cr.ok = false;
+    cx.cap = &cg;
+    gate_call();
+    cx.cap = &cr;
+    res_call();
+    cx.cap = nullptr;
+    if (!cg.ok || !cr.ok || cx.err) return false;
+    const ConvGemm16sArgs &A = cg.as, &R = cr.as;
+    const int cus = device_cus();
+    if (cus % 16 || A.nty != 2 || R.nty != 1 || A.ntx != R.ntx || A.ntz != R.ntz || A.xcd_items <= 0) return false;
+    if (R.c.nseg != 1 || R.sseg[0].hi != A.s0.hi || R.c.seg[0].shift || !R.saux.hi || R.c.M > 256) return false;     // the residual's operand IS the gate
+    const int xper = A.ntx * A.nty, xl = A.xcd_items * xper, xslots = cus / 8;
+    if (xl % xslots || xl / xslots < 2) return false;        // whole rounds, at least two (an R tile needs an item between it and its own G tile)
+    const int ncol = A.ntx * A.ntz;
+    if ((size_t)ncol * WGL_SYNC_STRIDE > WGL_SYNC_WORDS) return false;
+    ConvLayer16qArgs la;
+    la.p[0] = A; la.p[1] = R;
+    la.sync = reinterpret_cast<unsigned *>(ws + lsync);
+    long long KA = 0, in_ch = 0;
+    for (int q = 0; q < A.c.nseg; ++q) {
+        KA += A.c.seg[q].nch;
+        bool seen = false;
+        for (int u = 0; u < q; ++u) seen = seen || A.sseg[u].hi == A.sseg[q].hi;
+        if (!seen) in_ch += A.c.seg[q].nch;
+    }
+    const long long KR = R.c.seg[0].nch, cols = (long long)A.ntz * A.c.g.T;
+    const long long Keff = KA + KR * R.c.M / std::max(1, A.c.M);
+    // every operand plane once (h, y, the gate written and read back, tanh / sigmoid where saved, h in and out of the residual) + the weights
+    const long long bytes = 4 * cols * (in_ch + (long long)A.c.M / 2 * (A.c.out1.p ? 4 : 2) + 2LL * R.c.M) + 4LL * A.c.M * KA + 4LL * R.c.M * KR;
+    TimerScope ts(WG_K_LAYER, cx.st, A.c.M, Keff, cols, bytes);
+    WG_LAUNCH(cx, convlayer16q_kernel, dim3(cus), dim3(1024), 0, la);
+    g_layerq_launches.fetch_add(1, std::memory_order_relaxed);
+    return true;
+#endif
+}
+
 // (the counters are left at zero by every launch; a call that was cut short -- an error half way -- is the reason they are cleared
 // once at the start of every entry point that may use them)
 void layer_sync_clear(Ctx &cx, float *ws, size_t lsync)
@@ -1564,15 +1639,20 @@ void wn_forward(Ctx &cx, const WnRun &r)
         };
         // the whole layer as ONE launch where both products are small-grid launches (single-utterance synthesis, WaveFlow's row steps)
         if (!fs && !r.save && !nb && run_convlayer(cx, ws, r.w.lsync, gate_call, wo_call)) continue;
-        gate_call();
         if (fs) {
             // residual rows only: h_{i+1} = h_i + Wres_i gate_i (the first C rows of W_o); the skip rows of all layers follow in one product
-            if (!last)
+            auto res_call = [&]() {
                 run_convgemm(cx, g, r.pk + r.L.WoT[i], r.L.ld_WoT[i], d.C, sgt, 1 + nb, EPI_STORE, so ? pnull() : pref(Hout, d.C), pnull(), pnull(),
                              so ? pnull() : pref(Hin, d.C), pnull(), 0, 0, sp ? sref(g, ws + r.w.HS[hout], d.C) : snull(),
                              so ? sref(g, ws + r.w.HS[hin], d.C) : snull());                                   // :45-46
+            };
+            // gate conv + residual product as ONE persistent launch where the gate conv fills the chip in whole rounds (wg_layer16q.h)
+            if (!last && so && !nb && run_convlayer_big(cx, ws, r.w.lsync, gate_call, res_call)) continue;
+            gate_call();
+            if (!last) res_call();
             continue;
         }
+        gate_call();
         wo_call();
     }
     if (fs) {                                                 // cum_skip = sum_i skip_i (waveglow.py:104) = [Wskip_0 .. Wskip_{d-1}] [gate_0; ..; gate_{d-1}]
@@ -2050,7 +2130,7 @@ int wg_dbg_trace_read_cycles(unsigned long long *out, int n)
 }
 #endif
 long long wg_stat_wgrad16t_launches(void) { return g_wgrad16t_launches.load(std::memory_order_relaxed); }
-long long wg_stat_layer_launches(void) { return g_layer_launches.load(std::memory_order_relaxed); }
+long long wg_stat_layer_launches(void) { return g_layer_launches.load(std::memory_order_relaxed) + g_layerq_launches.load(std::memory_order_relaxed); }
 void *wg_timer_create(int kernel_id, int capacity)
 {
     if (capacity < 1) return nullptr;

@@ -95,6 +95,8 @@ int wg_abi_version(void);
 #define WG_K_CONV_RESSKIP 2  /* convgemm, W_o + residual/skip epilogue */
 #define WG_K_CONV_DGATE 3    /* convgemm, W_o^T + gate backward */
 #define WG_K_WGRAD 4         /* weight-gradient kernel */
+#define WG_K_LAYER 5         /* convlayer16q_kernel: a layer's gate conv + residual product in one persistent launch (reported as M = gate rows,
+                              * K = gate K + residual K * residual rows / gate rows, so that 2 M K columns = the launch's FLOPs) */
 void *wg_timer_create(int kernel_id, int capacity);   /* kernel_id < 0: every class above */
 void  wg_timer_attach(void *timer);
 int   wg_timer_count(void *timer);

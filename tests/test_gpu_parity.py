@@ -301,6 +301,46 @@ def test_one_launch_layer_vs_two_launches(dev, precision, monkeypatch, name):
     assert float((x1 - x).abs().max()) < Z_ATOL
 
 
+@pytest.mark.parametrize("B", [16, 24])
+def test_layer_launch_of_the_training_shapes_vs_two_launches(dev, precision, monkeypatch, B):
+    """convlayer16q_kernel (wg_layer16q.h): a layer's gate conv and residual product as ONE persistent launch where the gate conv fills the
+    chip in whole rounds of 256 x 128 tiles (batch 16: two rounds, batch 24: three -- the headline shape).  The gate crosses workgroups
+    inside the launch (write-through stores, an arrival counter per column tile published half a tile late, sc1 loads).  A whole training
+    step -- forward, recompute, backward -- must agree with the two-launch path (WG_LAYER_FUSION_BIG=0) to rounding, repeat bit for bit,
+    and the launch counter must show the fused kernel ran in the forward and in the recompute pass of every flow."""
+    if precision != "bf16x3p":
+        pytest.skip("the one-launch layer exists in the S-plane mode only")
+    from constant_memory_waveglow_amd import _lib
+    from constant_memory_waveglow_amd.parallel import FlowTrainer
+    m, cfg, specs, P = build("c2", dev)
+    N, F = 16000, 63
+    audio, h = fill.inputs("c2fused%d" % B, B, N, F, cfg["n_mels"])
+    x, ht = T(audio, dev), T(h, dev)
+    tr = FlowTrainer(m, fill.SIGMA)
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("WG_LAYER_FUSION_BIG", fused)
+        before = _lib.lib().wg_stat_layer_launches()
+        runs = []
+        for rep in range(3):
+            loss, z, logdet = tr.step(x, ht)
+            runs.append((loss.clone(), z.clone(), logdet.clone(), tr.fg.flat.clone()))
+        torch.cuda.synchronize()
+        n = _lib.lib().wg_stat_layer_launches() - before
+        # per step: 7 of 8 layers of every flow in the forward, and in the recompute of every flow but the one the forward kept
+        assert n == (3 * (cfg["flows"] * 7 + (cfg["flows"] - 1) * 7) if fused == "1" else 0), n
+        for later in runs[1:]:
+            for a, b in zip(runs[0], later):
+                assert torch.equal(a, b)
+        res[fused] = runs[0]
+    (l1, z1, d1, g1), (l0, z0, d0, g0) = res["1"], res["0"]
+    assert abs(float(l1) - float(l0)) < 1e-7
+    assert float((z1 - z0).abs().max()) < 1e-5 and float((d1 - d0).abs().max()) < 1e-5 * float(d0.abs().max()) + 1e-4
+    for b in range(tr.n_buckets):                                 # every gradient bucket (one per flow, the upsampler's) to 1e-5 of its max
+        s, e = tr.fg.bucket_ranges[b]
+        assert float((g1[s:e] - g0[s:e]).abs().max()) <= 1e-5 * float(g0[s:e].abs().max()), b
+
+
 def test_c2_full_batch_vs_oracle(dev, precision):
     """The HEADLINE shape itself -- BASELINE.json configs[1]: 256 channels, 12 flows, batch 24 x 16000 samples
     (configs/waveglow_LJ_speech.json:6-29), 48 000 columns per launch: wgrad16t's two-phase plan at K = 48 000, the 750-tile persistent

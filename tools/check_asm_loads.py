@@ -147,7 +147,7 @@ def main():
     cmd += ["-D" + d for d in a.defines.split(",") if d]
     subprocess.run(cmd, check=True)
     text = open(out).read().split("\n")
-    starts = [i for i, l in enumerate(text) if re.match(r"^_Z\d+(convgemm16[wxqh]_kernel|convlayer16h_kernel|wgrad16s_kernel|wgrad16s_pair_kernel|wgrad16t_kernel|wf_rowsteps_kernel)\w*:", l)]
+    starts = [i for i, l in enumerate(text) if re.match(r"^_Z\d+(convgemm16[wxqh]_kernel|convlayer16[hq]_kernel|wgrad16s_kernel|wgrad16s_pair_kernel|wgrad16t_kernel|wf_rowsteps_kernel)\w*:", l)]
     if not starts:
         print("no convgemm16w_kernel instantiation in the ISA")
         return 1
