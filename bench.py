@@ -319,7 +319,7 @@ KCLASS = {0: "conv store / residual / data-gradient (EPI_STORE)", 1: "gate conv 
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
-def kernel_rooflines(trainer, x, h, split, steps=2, top=8, step_fn=None):
+def kernel_rooflines(trainer, x, h, split, steps=2, top=12, step_fn=None):
     """Per-SHAPE rooflines of the conv / weight-gradient launches of the training step: every such launch of `steps` extra steps is
     bracketed with HIP events on the launch stream (wg_timer_create(-1, ..): all classes) and reported with the shape the library
     attaches to it (wg_timer_read_info): class, M x K, columns, algorithmic HBM bytes.  Grouped by (class, M, K); per group: launches per

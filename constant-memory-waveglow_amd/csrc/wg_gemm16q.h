@@ -23,6 +23,7 @@
 //     (8 bytes per lane, 2 x 256 contiguous bytes per wave instruction).
 #pragma once
 #include "wg_gemm16s.h"
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -542,16 +543,21 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
 // MG = 2 (NI = 2 only): 16 waves, ONE workgroup per CU, 256 x 128 tile: the two compute groups share the B image of every chunk,
 // i.e. the L2 -> LDS stream carries 48 KB per chunk for two 128 x 128 tiles instead of 64 KB, and there is no second, slower
 // co-resident workgroup whose last tiles run alone.
-template <int EPI, int NI, int MG = 1>
+// M64 (NI = 2, MG = 1 only): products with at most 64 rows (WaveFlow's 64-channel WN2D: data-gradient conv, residual / skip products, gate
+// backward).  On the 128-row tile half of every MFMA multiplied padding rows: the data-gradient conv ran at 181 TF where the full-height gate
+// conv reaches 314 (profiles/r04_wf_*).  The tile becomes 64 rows x 128 columns: the four compute waves sit side by side (64 rows x 32
+// columns each: NB = 2), the loader waves fetch ONE A unit per lane, image and chunk instead of two, the A images take half the LDS.
+template <int EPI, int NI, int MG = 1, bool M64 = false>
 __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16sArgs aa)
 {
     static_assert(MG == 1 || NI == 2, "the two-group workgroup is built for the 128-column tile");
-    typedef typename StageOf<MG == 2 ? 1 : NI>::type Stage;   // loads per loader lane and chunk: MG = 1: 4 A + 2 NI B; MG = 2: 4 A + 2 B
-    constexpr int AIMG = 128 * MG * WG16Q_ROWB;               // 128 MG rows x 64 B
+    static_assert(!M64 || (MG == 1 && NI == 2), "the 64-row tile is built for the 128-column tile of one compute group");
+    typedef typename std::conditional<M64, Stage6a, typename StageOf<MG == 2 ? 1 : NI>::type>::type Stage;   // loads per loader lane and chunk: MG = 1: 4 A + 2 NI B; MG = 2: 4 A + 2 B; M64: 2 A + 4 B
+    constexpr int AIMG = (M64 ? 64 : 128 * MG) * WG16Q_ROWB;  // 128 MG rows x 64 B (M64: 64 rows)
     constexpr int BIMG = 64 * NI * WG16Q_ROWB;
     constexpr int BUF = 2 * AIMG + 2 * BIMG;
     constexpr int TT = 64 * NI;                               // columns per tile
-    constexpr int NB = 2 * NI;                                // 16-column blocks per wave
+    constexpr int NB = M64 ? NI : 2 * NI;                     // 16-column blocks per wave
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
     const ConvGemmArgs &a = aa.c;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -573,10 +579,10 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
                 id = (((int)blockIdx.x & 7) + 8 * zl) * xper + (rem % aa.nty) * aa.ntx + rem / aa.nty;
             }
             const int tx = id % aa.ntx, q = id / aa.ntx, ty = q % aa.nty, tz = q / aa.nty;
-            t0 = tx * TT; m0 = ty * (WG_TILE * MG);
+            t0 = tx * TT; m0 = ty * (M64 ? 64 : WG_TILE * MG);
             b = a.row_sel1 ? tz * g.rows + a.row_sel1 - 1 : tz;
         } else {
-            t0 = blockIdx.x * TT; m0 = blockIdx.y * (WG_TILE * MG);
+            t0 = blockIdx.x * TT; m0 = blockIdx.y * (M64 ? 64 : WG_TILE * MG);
             b = a.row_sel1 ? (int)blockIdx.z * g.rows + a.row_sel1 - 1 : (int)blockIdx.z;
         }
     };
@@ -592,10 +598,11 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
         int cur_seg = aa.tap_il, cur_c = 0, chunk = nil, v = 0; // v: position in the tile's walk; (cur_seg, cur_c, chunk): the sequential part behind
         int gchunk = 0, tk = 0, t0, m0, b;
         tile_at(0, t0, m0, b);
-        const unsigned voff_a = (unsigned)lt * 16u;
+        const unsigned voff_a = M64 ? (unsigned)(((lt >> 6) * 128 + (lt & 63)) * 16) : (unsigned)lt * 16u;
         // A pieces of a lane.  MG = 1: pieces lt and lt + 256 of the 128-row block: row lt & 127, k-groups (lt >> 7) and (lt >> 7) + 2.
         // MG = 2 (512 loader lanes): piece lt (row lt & 127, k-group lt >> 7) of BOTH 128-row blocks of the tile.
-        const int arow = lt & 127, akg = lt >> 7;
+        // M64: ONE piece per lane: row lt & 63, k-group lt >> 6 of the 64 live rows of the (128-row) image block.
+        const int arow = M64 ? (lt & 63) : (lt & 127), akg = M64 ? (lt >> 6) : (lt >> 7);
         const int a_off[2] = {wg16q_off(arow, akg), MG == 2 ? wg16q_off(128 + arow, akg) : wg16q_off(arow, akg + 2)};
         constexpr int A_NEXT = MG == 2 ? 4096 : 2048;         // elements from a lane's first A piece to its second
         const int b_off[2] = {wg16q_off(bt, cg0), wg16q_off(bt, (cg0 + 2) & 3)};
@@ -631,8 +638,13 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
             const unsigned short *pa0 = live ? ih : zsrc, *pa1 = live ? ih + A_NEXT : zsrc;
             const unsigned short *pl0 = live ? il_ : zsrc, *pl1 = live ? il_ + A_NEXT : zsrc;
             const unsigned va = live ? voff_a : 0u;
-            WG_LD(st.ah[0], pa0, va);   WG_LD(st.ah[1], pa1, va);
-            WG_LD(st.al[0], pl0, va);   WG_LD(st.al[1], pl1, va);
+            if constexpr (M64) {
+                WG_LD(st.ah[0], pa0, va);   WG_LD(st.al[0], pl0, va);
+                (void)pa1; (void)pl1;
+            } else {
+                WG_LD(st.ah[0], pa0, va);   WG_LD(st.ah[1], pa1, va);
+                WG_LD(st.al[0], pl0, va);   WG_LD(st.al[1], pl1, va);
+            }
             if constexpr (NI == 2 && MG == 1) {
                 const unsigned short *b0 = row0 + (size_t)(g.H + t0 + shift) * 8, *b0l = b0 + ss.lo_off;
                 const unsigned short *b1 = b0 + (size_t)2 * g.P * 8, *b1l = b1 + ss.lo_off;
@@ -665,7 +677,7 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
         auto write = [&](const Stage &st, int buf) {
             char *sb = smem + buf * BUF;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < (M64 ? 1 : 2); ++j) {
                 *reinterpret_cast<u32x4 *>(sb + a_off[j]) = st.ah[j];
                 *reinterpret_cast<u32x4 *>(sb + AIMG + a_off[j]) = st.al[j];
             }
@@ -696,10 +708,11 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
         return;
     }
     // ------------------------------- compute waves -------------------------------
-    const int grp = wave >> 2, wr = (wave >> 1) & 1, wc = wave & 1;       // grp: which 128-row half of the tile (MG = 2)
+    // M64: the four waves side by side, 64 rows x 32 columns each
+    const int grp = wave >> 2, wr = M64 ? 0 : (wave >> 1) & 1, wc = M64 ? (wave & 3) : (wave & 1);       // grp: which 128-row half of the tile (MG = 2)
     f32x4 acc[4][NB];
     const int r16 = lane & 15, kg = lane >> 4;
-    const int ao = wg16q_off(grp * 128 + wr * 64 + r16, kg), bo = wg16q_off(wc * 32 * NI + r16, kg);      // + 16-row block * 1024
+    const int ao = wg16q_off(grp * 128 + wr * 64 + r16, kg), bo = wg16q_off(wc * (16 * NB) + r16, kg);      // + 16-row block * 1024
 #define WGQ_SB() __builtin_amdgcn_sched_barrier(0)
     bf16x8 ah[4], al[4], bh[2], bl[2];
     auto rd = [&](const char *q) { return *reinterpret_cast<const bf16x8 *>(q); };

@@ -168,11 +168,18 @@ struct Stage8 {
 struct Stage6 {                      // the 64-column tile: one B unit per lane and image
     u32x4 ah[2], al[2], bh[1], bl[1];
 };
+struct Stage6a {                     // the 64-ROW tile (convgemm16q_kernel<.., M64>): one A unit per lane and image, two B units
+    u32x4 ah[1], al[1], bh[2], bl[2];
+};
 template <int NI> struct StageOf { typedef Stage8 type; };
 template <> struct StageOf<1> { typedef Stage6 type; };
 #define WG_STAGE_REGS(s) "+v"(s.ah[0]), "+v"(s.ah[1]), "+v"(s.al[0]), "+v"(s.al[1]), "+v"(s.bh[0]), "+v"(s.bh[1]), "+v"(s.bl[0]), "+v"(s.bl[1])
 __device__ __forceinline__ void asm_wait_keep8(Stage8 &s) { asm volatile("s_waitcnt vmcnt(8)" : WG_STAGE_REGS(s)::"memory"); }
 __device__ __forceinline__ void asm_wait_stage(Stage8 &s) { asm_wait_keep8(s); }
+__device__ __forceinline__ void asm_wait_stage(Stage6a &s)
+{
+    asm volatile("s_waitcnt vmcnt(6)" : "+v"(s.ah[0]), "+v"(s.al[0]), "+v"(s.bh[0]), "+v"(s.bh[1]), "+v"(s.bl[0]), "+v"(s.bl[1])::"memory");
+}
 __device__ __forceinline__ void asm_wait_stage(Stage6 &s)
 {
     asm volatile("s_waitcnt vmcnt(6)" : "+v"(s.ah[0]), "+v"(s.ah[1]), "+v"(s.al[0]), "+v"(s.al[1]), "+v"(s.bh[0]), "+v"(s.bl[0])::"memory");

@@ -85,8 +85,10 @@ struct WfUpBwdArgs {
 };
 __global__ __launch_bounds__(256) void wf_upsample_bwd_kernel(const WfUpBwdArgs a)
 {
-    const int c = blockIdx.x, tid = threadIdx.x;
-    for (int e = tid; e < a.M * a.K; e += 256) {
+    // grid (M, S): block (c, y) takes every S-th 256-element slice of channel c's work (80 blocks of 256 threads walking 720 weight
+    // gradients x batch x frames one after the other took 0.9 ms of a WaveFlow step: a chain of load latencies on a third of the CUs)
+    const int c = blockIdx.x, tid = threadIdx.x + 256 * blockIdx.y, nth = 256 * gridDim.y;
+    for (int e = tid; e < a.M * a.K; e += nth) {
         const int o = e / a.K, k = e - o * a.K;
         float acc = 0.f;
         for (int b = 0; b < a.B; ++b) {
@@ -99,14 +101,14 @@ __global__ __launch_bounds__(256) void wf_upsample_bwd_kernel(const WfUpBwdArgs 
         a.dw[(size_t)c * a.M * a.K + e] = acc;
     }
     if (c == 0 && a.dbias)
-        for (int o = tid; o < a.M; o += 256) {
+        for (int o = tid; o < a.M; o += nth) {
             float acc = 0.f;
             for (int b = 0; b < a.B; ++b)
                 for (int j = 0; j < a.W; ++j) acc += a.gp[((size_t)b * a.M + o) * a.W + j];
             a.dbias[o] = acc;
         }
     if (a.dmel)
-        for (int e = tid; e < a.B * a.F; e += 256) {
+        for (int e = tid; e < a.B * a.F; e += nth) {
             const int b = e / a.F, i = e - b * a.F;
             float acc = 0.f;
             for (int ii = i; ii <= (i == a.F - 1 ? a.F : i); ++ii)         // the last frame also feeds the replicated one
@@ -200,6 +202,49 @@ __global__ __launch_bounds__(256) void wf_couple_kernel(const WfCoupleArgs a)
 {
     __shared__ float red[256];
     wf_couple_body<256>(a, (int)blockIdx.x, a.row_sel, red);
+}
+// Mode 2 (one row of the inverse, model/waveflow.py:246-253) as its own launch: ONE block per item -- the sum of log_s over the row stays
+// one fixed-order reduction -- of 1024 threads = 256 time steps x 4 quarters of the skip channels, so a thread has Cs / 4 independent loads
+// in flight instead of walking all Cs channels one after the other (17.7 us per row step for a 0.7 s utterance, 9 % of the synthesis call).
+__global__ __launch_bounds__(1024) void wf_couple_row_kernel(const WfCoupleArgs a)
+{
+    __shared__ float part[3][256][2];
+    __shared__ float red[256];
+    const Geo g = a.g;
+    const int H = g.rows, tid = threadIdx.x, tq = tid & 255, cq = tid >> 8;
+    const int row = (int)blockIdx.x * H + a.row_sel, b = row / H;
+    const int c0 = cq * (a.Cs >> 2), c1 = cq == 3 ? a.Cs : c0 + (a.Cs >> 2);
+    (void)b;
+    float lsum = 0.f;
+    for (int t0 = 0; t0 < g.T; t0 += 256) {                    // (every thread takes part in every barrier)
+        const int t = t0 + tq;
+        float ls = 0.f, tt = 0.f;
+        if (t < g.T) {
+#pragma unroll 8
+            for (int c = c0; c < c1; ++c) {
+                const float s = *paddr(a.S, g, row, c, t);
+                ls = fmaf(a.endw[c], s, ls);
+                tt = fmaf(a.endw[a.Cs + c], s, tt);
+            }
+        }
+        if (cq) { part[cq - 1][tq][0] = ls; part[cq - 1][tq][1] = tt; }
+        __syncthreads();
+        if (!cq && t < g.T) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { ls += part[q][tq][0]; tt += part[q][tq][1]; }
+            *paddr(a.Xn, g, row + 1, 0, t) = (*paddr(a.X, g, row + 1, 0, t) - tt) / expf(ls);
+            lsum -= ls;
+        }
+        __syncthreads();
+    }
+    if (!a.rowsum) return;
+    if (!cq) red[tq] = lsum;
+    __syncthreads();
+    for (int q = 128; q > 0; q >>= 1) {
+        if (tid < q) red[tid] += red[tid + q];
+        __syncthreads();
+    }
+    if (tid == 0) a.rowsum[row] = red[0];
 }
 // exact-fp32 mode: out[item][c][t] = sum over the item's height rows of src[item * H + h][c][t] (the conditioning gradient: the conditioning is
 // broadcast over the height axis); the S-plane modes use wf_rowsum_s_kernel
@@ -371,20 +416,46 @@ __global__ __launch_bounds__(256) void wf_hgram_reduce_kernel(const float *__res
 
 // S-plane row sum over the height axis: out[b][c][t] = sum_h in[b*H + h][c][t] (hi + lo summed in fp32, re-split).  Used for the
 // conditioning gradient, which is broadcast over the height axis: V^T (sum_h dxy[h]) instead of sum_h V^T dxy[h].
-__global__ void wf_rowsum_s_kernel(SRef in, Geo g, SRef out, Geo gi)
+// Block = 64 time steps x 4 groups of height rows (256 threads): a thread sums its share of the rows with eight rows' loads in flight, the
+// four partial sums meet in LDS.  (One thread per time step walking all 64 rows -- a chain of 64 dependent round trips, 188 blocks --
+// read its 98 MB at 2.3 TB/s: 42 us per launch, 64 launches per WaveFlow step.)
+__global__ __launch_bounds__(256) void wf_rowsum_s_kernel(SRef in, Geo g, SRef out, Geo gi)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x, cg = blockIdx.y, b = blockIdx.z;
-    if (t >= g.T) return;
+    __shared__ float part[3][64][9];
+    const int tl = threadIdx.x & 63, hq = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + tl, cg = blockIdx.y, b = blockIdx.z;
+    const bool live = t < g.T;
+    const int per = (g.rows + 3) >> 2, h0 = hq * per, h1 = min(g.rows, h0 + per);
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int h = 0; h < g.rows; ++h) {
-        const size_t i = s_index(in, g, b * g.rows + h, cg * 8, t);
-        const u32x4 hi = *reinterpret_cast<const u32x4 *>(in.hi + i), lo = *reinterpret_cast<const u32x4 *>(in.hi + in.lo_off + i);
+    for (int hb = h0; hb < h1; hb += 8) {
+        u32x4 hi[8], lo[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            acc[2 * e] += __uint_as_float(hi[e] << 16) + __uint_as_float(lo[e] << 16);
-            acc[2 * e + 1] += __uint_as_float(hi[e] & 0xffff0000u) + __uint_as_float(lo[e] & 0xffff0000u);
+        for (int q = 0; q < 8; ++q) {
+            hi[q] = u32x4{0u, 0u, 0u, 0u}; lo[q] = u32x4{0u, 0u, 0u, 0u};
+            if (live && hb + q < h1) {
+                const size_t i = s_index(in, g, b * g.rows + hb + q, cg * 8, t);
+                hi[q] = *reinterpret_cast<const u32x4 *>(in.hi + i);
+                lo[q] = *reinterpret_cast<const u32x4 *>(in.hi + in.lo_off + i);
+            }
         }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)                            // (a fixed order: four partial sums of 16 rows each, then their sum)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[2 * e] += __uint_as_float(hi[q][e] << 16) + __uint_as_float(lo[q][e] << 16);
+                acc[2 * e + 1] += __uint_as_float(hi[q][e] & 0xffff0000u) + __uint_as_float(lo[q][e] & 0xffff0000u);
+            }
     }
+    if (hq) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[hq - 1][tl][e] = acc[e];
+    }
+    __syncthreads();
+    if (hq || !live) return;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += part[q][tl][e];
     u32x4 oh, ol;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {

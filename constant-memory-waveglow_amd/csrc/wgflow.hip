@@ -1014,6 +1014,17 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                                 && false
 #endif
                 ;
+#if !defined(WG_OPT_NO_M64)
+            // products with at most 64 rows on 64 x 128 tiles (convgemm16q_kernel<.., M64>): WaveFlow's 64-channel WN2D -- on 128-row tiles
+            // half of every MFMA multiplied padding (the data-gradient conv: 181 TF against 314 for the full-height gate conv)
+            if (!small && M <= 64 && epi != EPI_GATE && epi != EPI_RESSKIP) {
+                if (fo_epi) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE_FO, 2, 1, true>), gp, dim3(512), 0, as); return; }
+                if (so_dgate) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_DGATE_SO, 2, 1, true>), gp, dim3(512), 0, as); return; }
+                if (so_epi) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE_SO, 2, 1, true>), gp, dim3(512), 0, as); return; }
+                if (epi == EPI_STORE) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE, 2, 1, true>), gp, dim3(512), 0, as); return; }
+                if (epi == EPI_DGATE) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_DGATE, 2, 1, true>), gp, dim3(512), 0, as); return; }
+            }
+#endif
             if (small) {
                 if (fo_epi) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE_FO, 1>), gp, dim3(512), 0, as); return; }
                 if (so_dgate) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_DGATE_SO, 1>), gp, dim3(512), 0, as); return; }
@@ -1879,7 +1890,7 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
             // the conditioning is broadcast over the height axis: sum dxy over the rows of an item first (64x fewer columns for
             // the product, no per-row gradient plane), then dy[item] += V_i^T rowsum
             if (sp)
-                WG_LAUNCH(cx, wf_rowsum_s_kernel, dim3((g.T + 255) / 256, 2 * d.Cd / 8, r.gi.B), dim3(256), 0, sref(g, dxyS, 2 * d.Cd), g,
+                WG_LAUNCH(cx, wf_rowsum_s_kernel, dim3((g.T + 63) / 64, 2 * d.Cd / 8, r.gi.B), dim3(256), 0, sref(g, dxyS, 2 * d.Cd), g,
                           sref(r.gi, r.rs, 2 * d.Cd), r.gi);
             else                                              // exact-fp32 mode: the same sum on the fp32 plane (r.rs holds 2 Cd fp32 channels then)
                 WG_LAUNCH(cx, wf_rowsum_kernel, dim3((g.T + 255) / 256, 2 * d.Cd, r.gi.B), dim3(256), 0, pref(dxy, 2 * d.Cd), g,
@@ -2096,6 +2107,7 @@ void wf_couple(Ctx &cx, const WnRun &r, const float *endw, int mode, PRef X, PRe
     a.G = pref(r.ws + r.w.G, r.L.kp_end);
     a.dld = dld; a.rowsum = rowsum; a.row_sel = row_sel; a.g = r.g; a.mode = mode; a.noflip = noflip;
     if (cx.rec && mode == 2) { cx.rec->add(WGS_WFCOUPLE, r.g.B / r.g.rows).u.cpl = a; return; }
+    if (mode == 2 && a.Cs % 4 == 0) { WG_LAUNCH(cx, wf_couple_row_kernel, dim3(r.g.B / r.g.rows), dim3(1024), 0, a); return; }
     WG_LAUNCH(cx, wf_couple_kernel, dim3(mode == 2 ? r.g.B / r.g.rows : r.g.B), dim3(256), 0, a);
 }
 }  // namespace
@@ -2871,7 +2883,7 @@ int wg_wf_backward(const wg_wf_config *cf, const void *const *params, const void
     a.mel = mel; a.v = p[2]; a.scale = pk + L.up_scale; a.gp = ws + W.gp;
     a.B = B; a.M = M; a.F = F; a.K = K; a.s = s; a.pad = s / 2; a.W = Wd;
     a.dw = ws + W.dwup; a.dbias = gr[0]; a.dmel = dmel;
-    WG_LAUNCH(cx, wf_upsample_bwd_kernel, dim3(M), dim3(256), 0, a);
+    WG_LAUNCH(cx, wf_upsample_bwd_kernel, dim3(M, 8), dim3(256), 0, a);
     WgradOut wo;
     wo.nsplit = 1; wo.Mp = M; wo.Np = M * K;
     run_finalize(cx, ws + W.dwup, wo, 0, M, M * K, 1, 0, 1, 0, p[1], p[2], gr[1], gr[2]);

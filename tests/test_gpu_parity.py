@@ -589,6 +589,19 @@ def test_inverse_graph_replay_matches_eager(dev, monkeypatch):
         monkeypatch.setenv("WG_GRAPHS", "1")
         got = [m.reverse(z, T(h, dev))[0].clone() for z in (z1, z2, z1)]      # capture, replay, replay
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and torch.equal(got[2], want[0])
+    # the default (auto): a small call is captured on its third occurrence and replayed from then on
+    m2, _, _, _ = build("micro", dev)
+    monkeypatch.delenv("WG_GRAPHS", raising=False)
+    with torch.no_grad():
+        auto = [m2.reverse(z, T(h, dev))[0].clone() for z in (z1, z2, z1, z2, z1)]
+    assert len(m2._engine._graphs) == 1
+    assert all(torch.equal(a, want[i % 2]) for i, a in enumerate(auto))
+    monkeypatch.setenv("WG_GRAPHS", "0")
+    m3, _, _, _ = build("micro", dev)
+    with torch.no_grad():
+        for z in (z1, z2, z1, z2):
+            m3.reverse(z, T(h, dev))
+    assert len(m3._engine._graphs) == 0
 
 
 def test_loss_kernel(dev):
