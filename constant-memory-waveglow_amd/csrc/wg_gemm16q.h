@@ -547,16 +547,21 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
 // backward).  On the 128-row tile half of every MFMA multiplied padding rows: the data-gradient conv ran at 181 TF where the full-height gate
 // conv reaches 314 (profiles/r04_wf_*).  The tile becomes 64 rows x 128 columns: the four compute waves sit side by side (64 rows x 32
 // columns each: NB = 2), the loader waves fetch ONE A unit per lane, image and chunk instead of two, the A images take half the LDS.
-template <int EPI, int NI, int MG = 1, bool M64 = false>
+// CG2 (MG = 2, NI = 2 only): the two compute groups sit side by side instead of on top of each other -- a 128 x 256 tile whose groups share
+// the A image of every chunk (16 KB of weights + 32 KB of activations per chunk for two 128 x 128 tiles instead of 2 x 32 KB).  For
+// products with at most 128 rows, which cannot share a B image between row groups (WaveFlow's gate conv: M = 2 Cd = 128): with two
+// 128 x 128 workgroups per CU that launch takes in 39 GB/s per CU, the per-CU limit, at 38 % of the matrix peak (profiles/r04_wf_*).
+template <int EPI, int NI, int MG = 1, bool M64 = false, bool CG2 = false>
 __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16sArgs aa)
 {
     static_assert(MG == 1 || NI == 2, "the two-group workgroup is built for the 128-column tile");
     static_assert(!M64 || (MG == 1 && NI == 2), "the 64-row tile is built for the 128-column tile of one compute group");
-    typedef typename std::conditional<M64, Stage6a, typename StageOf<MG == 2 ? 1 : NI>::type>::type Stage;   // loads per loader lane and chunk: MG = 1: 4 A + 2 NI B; MG = 2: 4 A + 2 B; M64: 2 A + 4 B
-    constexpr int AIMG = (M64 ? 64 : 128 * MG) * WG16Q_ROWB;  // 128 MG rows x 64 B (M64: 64 rows)
-    constexpr int BIMG = 64 * NI * WG16Q_ROWB;
+    static_assert(!CG2 || (MG == 2 && NI == 2 && !M64), "column groups: the two-group workgroup only");
+    typedef typename std::conditional<M64 || CG2, Stage6a, typename StageOf<MG == 2 ? 1 : NI>::type>::type Stage;   // loads per loader lane and chunk: MG = 1: 4 A + 2 NI B; MG = 2: 4 A + 2 B; M64 / CG2: 2 A + 4 B
+    constexpr int AIMG = (M64 ? 64 : CG2 ? 128 : 128 * MG) * WG16Q_ROWB;  // 128 MG rows x 64 B (M64: 64 rows; CG2: 128)
+    constexpr int BIMG = (CG2 ? 256 : 64 * NI) * WG16Q_ROWB;
     constexpr int BUF = 2 * AIMG + 2 * BIMG;
-    constexpr int TT = 64 * NI;                               // columns per tile
+    constexpr int TT = CG2 ? 256 : 64 * NI;                   // columns per tile
     constexpr int NB = M64 ? NI : 2 * NI;                     // 16-column blocks per wave
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
     const ConvGemmArgs &a = aa.c;
@@ -579,10 +584,10 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
                 id = (((int)blockIdx.x & 7) + 8 * zl) * xper + (rem % aa.nty) * aa.ntx + rem / aa.nty;
             }
             const int tx = id % aa.ntx, q = id / aa.ntx, ty = q % aa.nty, tz = q / aa.nty;
-            t0 = tx * TT; m0 = ty * (M64 ? 64 : WG_TILE * MG);
+            t0 = tx * TT; m0 = ty * (M64 ? 64 : CG2 ? WG_TILE : WG_TILE * MG);
             b = a.row_sel1 ? tz * g.rows + a.row_sel1 - 1 : tz;
         } else {
-            t0 = blockIdx.x * TT; m0 = blockIdx.y * (M64 ? 64 : WG_TILE * MG);
+            t0 = blockIdx.x * TT; m0 = blockIdx.y * (M64 ? 64 : CG2 ? WG_TILE : WG_TILE * MG);
             b = a.row_sel1 ? (int)blockIdx.z * g.rows + a.row_sel1 - 1 : (int)blockIdx.z;
         }
     };
@@ -593,7 +598,8 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
 #if defined(WG_OPT_LOADER_PRIO)
         __builtin_amdgcn_s_setprio(WG_OPT_LOADER_PRIO);      // experiment: the loaders' few instructions never queue behind the compute waves
 #endif
-        const int bt = NI == 2 ? (lt & 127) : (lt & 63), cg0 = NI == 2 ? (lt >> 7) : (lt >> 6);     // B unit: position, k-group
+        // (CG2, 512 loader lanes: B units (column lt & 255, k-groups lt >> 8 and + 2) of the 256-column image)
+        const int bt = CG2 ? (lt & 255) : NI == 2 ? (lt & 127) : (lt & 63), cg0 = CG2 ? (lt >> 8) : NI == 2 ? (lt >> 7) : (lt >> 6);     // B unit: position, k-group
         const int nil = aa.tap_il * aa.tap_chunks;            // chunks walked interleaved over the taps (ConvGemm16sArgs::tap_il; 0: none)
         int cur_seg = aa.tap_il, cur_c = 0, chunk = nil, v = 0; // v: position in the tile's walk; (cur_seg, cur_c, chunk): the sequential part behind
         int gchunk = 0, tk = 0, t0, m0, b;
@@ -602,6 +608,7 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
         // A pieces of a lane.  MG = 1: pieces lt and lt + 256 of the 128-row block: row lt & 127, k-groups (lt >> 7) and (lt >> 7) + 2.
         // MG = 2 (512 loader lanes): piece lt (row lt & 127, k-group lt >> 7) of BOTH 128-row blocks of the tile.
         // M64: ONE piece per lane: row lt & 63, k-group lt >> 6 of the 64 live rows of the (128-row) image block.
+        // CG2: ONE piece per lane of the single 128-row block: row lt & 127, k-group lt >> 7 (0 .. 3).
         const int arow = M64 ? (lt & 63) : (lt & 127), akg = M64 ? (lt >> 6) : (lt >> 7);
         const int a_off[2] = {wg16q_off(arow, akg), MG == 2 ? wg16q_off(128 + arow, akg) : wg16q_off(arow, akg + 2)};
         constexpr int A_NEXT = MG == 2 ? 4096 : 2048;         // elements from a lane's first A piece to its second
@@ -611,6 +618,16 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
 #define WG_LD(dst, base, voff) asm volatile("" : "=v"(dst) : "v"(voff), "s"(base))
 #else
 #define WG_LD(dst, base, voff) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
+#endif
+        // EXPERIMENT -DWG_OPT_A_POLICY=1 (sc1) / 2 (nt): the WEIGHT images fetched past the CU's L1 -- a workgroup reads its A chunks once,
+        // while the taps of a layer re-read overlapping windows of the activation planes a few chunks apart (tap_il): an L1 that is not
+        // flushed by the weight stream could serve those
+#if defined(WG_OPT_A_POLICY) && WG_OPT_A_POLICY == 1 && !defined(WG_DBG_NOLOAD)
+#define WG_LDA(dst, base, voff) asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
+#elif defined(WG_OPT_A_POLICY) && WG_OPT_A_POLICY == 2 && !defined(WG_DBG_NOLOAD)
+#define WG_LDA(dst, base, voff) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(voff), "s"(base) : "memory")
+#else
+#define WG_LDA(dst, base, voff) WG_LD(dst, base, voff)
 #endif
         // (measured: the non-temporal policy -- "nt" -- on the activation stream costs 7 % of a training step: the m-tiles of a column
         // tile and the taps of a layer re-read those lines from L2)
@@ -638,14 +655,14 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
             const unsigned short *pa0 = live ? ih : zsrc, *pa1 = live ? ih + A_NEXT : zsrc;
             const unsigned short *pl0 = live ? il_ : zsrc, *pl1 = live ? il_ + A_NEXT : zsrc;
             const unsigned va = live ? voff_a : 0u;
-            if constexpr (M64) {
-                WG_LD(st.ah[0], pa0, va);   WG_LD(st.al[0], pl0, va);
+            if constexpr (M64 || CG2) {
+                WG_LDA(st.ah[0], pa0, va);   WG_LDA(st.al[0], pl0, va);
                 (void)pa1; (void)pl1;
             } else {
-                WG_LD(st.ah[0], pa0, va);   WG_LD(st.ah[1], pa1, va);
-                WG_LD(st.al[0], pl0, va);   WG_LD(st.al[1], pl1, va);
+                WG_LDA(st.ah[0], pa0, va);   WG_LDA(st.ah[1], pa1, va);
+                WG_LDA(st.al[0], pl0, va);   WG_LDA(st.al[1], pl1, va);
             }
-            if constexpr (NI == 2 && MG == 1) {
+            if constexpr ((NI == 2 && MG == 1) || CG2) {
                 const unsigned short *b0 = row0 + (size_t)(g.H + t0 + shift) * 8, *b0l = b0 + ss.lo_off;
                 const unsigned short *b1 = b0 + (size_t)2 * g.P * 8, *b1l = b1 + ss.lo_off;
                 const unsigned short *pb0 = blive ? b0 : zsrc, *pb0l = blive ? b0l : zsrc;
@@ -674,15 +691,16 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
             }
         };
 #undef WG_LD
+#undef WG_LDA
         auto write = [&](const Stage &st, int buf) {
             char *sb = smem + buf * BUF;
 #pragma unroll
-            for (int j = 0; j < (M64 ? 1 : 2); ++j) {
+            for (int j = 0; j < ((M64 || CG2) ? 1 : 2); ++j) {
                 *reinterpret_cast<u32x4 *>(sb + a_off[j]) = st.ah[j];
                 *reinterpret_cast<u32x4 *>(sb + AIMG + a_off[j]) = st.al[j];
             }
 #pragma unroll
-            for (int j = 0; j < (MG == 2 ? 1 : NI); ++j) {
+            for (int j = 0; j < (CG2 ? 2 : MG == 2 ? 1 : NI); ++j) {
                 *reinterpret_cast<u32x4 *>(sb + 2 * AIMG + b_off[j]) = st.bh[j];
                 *reinterpret_cast<u32x4 *>(sb + 2 * AIMG + BIMG + b_off[j]) = st.bl[j];
             }
@@ -712,7 +730,8 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
     const int grp = wave >> 2, wr = M64 ? 0 : (wave >> 1) & 1, wc = M64 ? (wave & 3) : (wave & 1);       // grp: which 128-row half of the tile (MG = 2)
     f32x4 acc[4][NB];
     const int r16 = lane & 15, kg = lane >> 4;
-    const int ao = wg16q_off(grp * 128 + wr * 64 + r16, kg), bo = wg16q_off(wc * (16 * NB) + r16, kg);      // + 16-row block * 1024
+    // CG2: both groups read the one 128-row A block; group grp multiplies columns grp * 128 .. + 127 of the 256-column B image
+    const int ao = wg16q_off((CG2 ? 0 : grp * 128) + wr * 64 + r16, kg), bo = wg16q_off((CG2 ? grp * 128 : 0) + wc * (16 * NB) + r16, kg);      // + 16-row block * 1024
 #define WGQ_SB() __builtin_amdgcn_sched_barrier(0)
     bf16x8 ah[4], al[4], bh[2], bl[2];
     auto rd = [&](const char *q) { return *reinterpret_cast<const bf16x8 *>(q); };
@@ -721,7 +740,8 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
     auto do_tile = [&](int k) {
         int t0, m0, b;
         tile_at(k, t0, m0, b);
-        m0 += grp * 128;
+        if (CG2) t0 += grp * 128;                            // (the epilogue's columns; the loaders keep the tile's own t0)
+        else m0 += grp * 128;
         int ln = lane;
         if (PERSIST) {
             asm volatile("" : "+v"(ln)::"memory");

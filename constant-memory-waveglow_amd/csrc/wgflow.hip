@@ -1038,6 +1038,23 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                 }
                 return;
             }
+#if !defined(WG_OPT_NO_CG2)
+            // products with ONE 128-row tile (WaveFlow's gate conv, M = 2 Cd = 128) on 128 x 256 tiles: one 16-wave workgroup per CU whose two
+            // compute groups share the A image of every chunk (convgemm16q_kernel<.., CG2>) -- 25 % less L2 -> LDS traffic for a launch
+            // that sits at the per-CU intake limit
+            if (epi == EPI_GATE && (int)grid.y == 1 && g.Tt % 256 == 0 && cus % 8 == 0) {
+                as.ntx = (int)grid.x / 2;
+                const int nt2 = as.ntx * as.nty * as.ntz;
+                if (nt2 >= cus) {
+                    as.xcd_items = 0;
+                    const dim3 gc(std::min(nt2, cus));
+                    if (so_gate) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE_SO, 2, 2, false, true>), gc, dim3(1024), 0, as); return; }
+                    WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE, 2, 2, false, true>), gc, dim3(1024), 0, as);
+                    return;
+                }
+                as.ntx = (int)grid.x;
+            }
+#endif
 #if !defined(WG_OPT_NO_MG2)
             // 256 x 128 tiles, one 16-wave workgroup per CU (the compute groups share every chunk's B image: 25 % less L2 -> LDS
             // traffic, no slower co-resident workgroup left to finish alone): gate conv 125.7 -> 118.6 us.  Only where the tiles deal out

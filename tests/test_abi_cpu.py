@@ -160,9 +160,9 @@ def test_hand_issued_loads_are_never_touched_before_their_wait():
     # conv: 4 epilogues x 2 tile widths of convgemm16q + its three 256 x 128 (MG = 2) instantiations + 3 x convgemm16h; wgrad16s: 2 tile
     # heights + the paired launch; wgrad16t; the stage interpreter wf_rowsteps_kernel (three convgemm16h bodies inside); the one-launch
     # layers convlayer16h_kernel (two convgemm16h-shaped phases, the second with sc1 operand loads) and convlayer16q_kernel (the 256 x 128
-    # form walking a list of gate and residual tiles); five 64-row (M64) instantiations of convgemm16q.  (The superseded
+    # form walking a list of gate and residual tiles); five 64-row (M64) and two column-group (CG2) instantiations of convgemm16q.  (The superseded
     # 32x32x16 kernels -- A/B builds only -- are checked with --defines WG_OPT_MFMA32.)
-    assert len(lines) == 37 and any("convlayer16h_kernel" in l for l in lines) and any("convlayer16q_kernel" in l for l in lines) and all(l.rstrip().endswith(" 0 violations") for l in lines), r.stdout
+    assert len(lines) == 39 and any("convlayer16h_kernel" in l for l in lines) and any("convlayer16q_kernel" in l for l in lines) and all(l.rstrip().endswith(" 0 violations") for l in lines), r.stdout
 
 
 def test_wsrglow_state_dict_layout_matches_reference(golden_dir):
