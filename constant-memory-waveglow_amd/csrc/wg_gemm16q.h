@@ -573,13 +573,22 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
     constexpr bool PERSIST = EPI != EPI_DGATE && EPI != EPI_DGATE_SO;                // (the gate backward keeps one workgroup per tile: see convgemm16w_kernel)
     const int ntiles = aa.ntx * aa.nty * aa.ntz, G = (int)gridDim.x;
     // (xcd_items: the workgroup's XCD owns ntz / 8 plane rows = xl tiles, dealt to its G / 8 workgroups; see ConvGemm16sArgs)
-    const int xper = aa.ntx * aa.nty, xl = aa.xcd_items * xper, xslots = G >> 3, xslot = (int)blockIdx.x >> 3;
+    // (xcd_items < 0, "XCD columns": plane rows that do not divide by 8 -- WSRGlow's batch of 12 --: the ntx * ntz column tiles are cut into
+    // eight contiguous ranges, XCD x walks range x with the column tile fastest, so that the chunk streams of its 64 workgroup slots
+    // share BOTH operands in its L2: a weight block is streamed once per XCD instead of once per column tile.  The conditioning
+    // gradient of WSRGlow -- 29 row tiles x 48 column tiles x K = 4096 -- fetched 3.26 GB per launch for 0.25 GB of operands at 6.3 TB/s.)
+    const int xper = aa.ntx * aa.nty, xslots = G >> 3, xslot = (int)blockIdx.x >> 3, xid = (int)blockIdx.x & 7;
+    const int ncol = aa.ntx * aa.ntz, xc0 = aa.xcd_items < 0 ? xid * ncol / 8 : 0, xcn = aa.xcd_items < 0 ? (xid + 1) * ncol / 8 - xc0 : 0;
+    const int xl = aa.xcd_items < 0 ? xcn * aa.nty : aa.xcd_items * xper;
     const int mine = !PERSIST ? 1 : aa.xcd_items ? (xslot < xl ? (xl - 1 - xslot) / xslots + 1 : 0) : (ntiles - 1 - (int)blockIdx.x) / G + 1;
     const int total = mine * nchunks;
     auto tile_at = [&](int k, int &t0, int &m0, int &b) {
         if constexpr (PERSIST) {
             int id = (int)blockIdx.x + k * G;
-            if (aa.xcd_items) {                                 // local tile -> (plane row of this XCD, time tile, row tile): row tiles adjacent
+            if (aa.xcd_items < 0) {                             // local tile -> (row tile, column tile of this XCD's range): column tiles adjacent
+                const int local = xslot + k * xslots, ty = local / max(xcn, 1), c = xc0 + local - ty * xcn;
+                id = (c / aa.ntx * aa.nty + ty) * aa.ntx + c % aa.ntx;
+            } else if (aa.xcd_items) {                          // local tile -> (plane row of this XCD, time tile, row tile): row tiles adjacent
                 const int local = xslot + k * xslots, zl = local / xper, rem = local - zl * xper;
                 id = (((int)blockIdx.x & 7) + 8 * zl) * xper + (rem % aa.nty) * aa.ntx + rem / aa.nty;
             }

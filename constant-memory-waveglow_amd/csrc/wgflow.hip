@@ -960,6 +960,12 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
 #endif
                 ;
             if (xcd_rows && ntiles >= slots && slots % 8 == 0) as.xcd_items = as.ntz / 8;
+#if !defined(WG_OPT_NO_XCD_COLS)
+            // XCD columns (ConvGemm16sArgs::xcd_items < 0): full persistent grids whose plane rows do NOT divide by the 8 XCDs
+            // (measured, WSRGlow at batch 12: the conditioning gradient -- 29 row tiles -- 516.9 -> 478.6 us; launches with few row tiles do not
+            // gain -- the gate conv, 4 row tiles: 107.6 -> 109.3 us -- so the order is used from 8 row tiles on)
+            else if (epi != EPI_DGATE && g.rows == 0 && !cx.row_sel1 && ntiles >= slots && slots % 8 == 0 && as.ntx * as.ntz >= 8 && as.nty >= 8) as.xcd_items = -1;
+#endif
             if (cx.cap) {                                     // describe, do not launch: the 256 x 128-tile form with S-plane-only epilogues
                 const bool sg = epi == EPI_GATE && as.s0.hi && !a.out0.p && WG_TS_INTERLEAVED;
                 const bool se = epi == EPI_STORE && as.s0.hi && !a.out0.p && !a.aux0.p;
