@@ -658,7 +658,11 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
                 rowok = r >= 0 && r < g.rows;
                 bsrc = ss.per_item ? item : b + ss.row_off;
             }
+#if defined(WG_DBG_TAPB)       // timing experiment only (results are garbage): the B operand of every tap but the first is not fetched -- what a
+            const bool blive = live && rowok && !(il && sgi % WG_DBG_TAPB != 0), full = blive && (nch - ci > 16);      // B window held in LDS across the taps could win at most
+#else
             const bool blive = live && rowok, full = blive && (nch - ci > 16);
+#endif
             const unsigned short *ih = aa.img + ((size_t)chi * a.lda + m0) * WG16_BK, *il_ = ih + aa.img_stride;
             const unsigned short *row0 = ss.hi + ((size_t)bsrc * (ss.Cp >> 3) + ((ss.ch0 + ci) >> 3)) * g.P * 8;
             const unsigned short *pa0 = live ? ih : zsrc, *pa1 = live ? ih + A_NEXT : zsrc;
