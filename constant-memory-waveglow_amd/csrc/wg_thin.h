@@ -287,3 +287,55 @@ __global__ __launch_bounds__(WGTH_THREADS) void thin_end_kernel(const ThinEndArg
             for (int k = 0; k < K2P; ++k) mine[(size_t)k * a.Cs + m] = acc[r][k];
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// WN.start forward (model/waveglow.py:99; WN2D.start, waveflow.py:119): h_0 = W_start xa with at most 16 input channels.  As an MFMA conv it was
+// TWO launches per WN pass -- xa converted to an S-plane (its K padded from 2-4 channels to 16), then a 128-row-tile product of which
+// a fraction of one chunk is real work -- in front of every flow's layer chain (forward, recompute, synthesis).  Here a thread owns one
+// time step and 8 output channels: fp32 FMAs on the input values themselves (at least as exact as the split product), the fp32 plane
+// (where the chain still has one) and the S-plane unit written straight from registers.
+// ------------------------------------------------------------------------------------------------
+struct StartFwdArgs {
+    PRef X;              // xa = X channels [ch0, ch0 + ic)
+    const float *W;      // fp32 effective weights [C][ldw]: W[c][j]
+    int ldw, C, ic;
+    PRef H;              // fp32 output plane (p == nullptr: none)
+    SRef HS;             // S-plane output
+    Geo g;
+    int row_sel1;        // Geo::rows > 0: r + 1 = blockIdx.z is the item and the launch covers its height row r
+};
+__global__ __launch_bounds__(256) void start_fwd_kernel(const StartFwdArgs a)
+{
+    __shared__ float w[8][16];
+    const Geo g = a.g;
+    const int tid = threadIdx.x, t = blockIdx.x * 256 + tid, cg = blockIdx.y;
+    const int b = a.row_sel1 ? (int)blockIdx.z * g.rows + a.row_sel1 - 1 : (int)blockIdx.z;
+    if (tid < 8 * a.ic) {
+        const int e = tid / a.ic, j = tid - e * a.ic;
+        w[e][j] = cg * 8 + e < a.C ? a.W[(size_t)(cg * 8 + e) * a.ldw + j] : 0.f;
+    }
+    __syncthreads();
+    if (t >= g.T) return;
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < a.ic; ++j) {
+        const float xv = *paddr(a.X, g, b, j, t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = fmaf(w[e][j], xv, o[e]);
+    }
+    if (a.H.p) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (cg * 8 + e < a.C) *paddr(a.H, g, b, cg * 8 + e, t) = o[e];
+    }
+    u32x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        unsigned hh, ll;
+        split2(o[2 * e], o[2 * e + 1], hh, ll);
+        h[e] = hh; l[e] = ll;
+    }
+    const size_t i = s_index(a.HS, g, b, cg * 8, t);
+    *reinterpret_cast<u32x4 *>(a.HS.hi + i) = h;
+    *reinterpret_cast<u32x4 *>(a.HS.hi + a.HS.lo_off + i) = l;
+}
+

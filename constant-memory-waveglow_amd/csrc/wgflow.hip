@@ -1515,6 +1515,25 @@ SegSpec ones_seg(Ctx &cx, const WnRun &r, bool fill)
     return s;
 }
 
+// The thin products of WN's backward (wg_thin.h): precision 2, inside a FinQueue (the partials come from its arena).
+// Dynamic LDS of the two kernels (floats -> bytes): the [channels][65] tile, the thin operand's tile, the per-wave shares and the weights.
+static int thin_icp(const WnD &d) { return d.ic <= 4 ? 4 : d.ic <= 8 ? 8 : 16; }
+static int thin_k2p(const WnD &d) { return 2 * d.ic <= 8 ? 8 : 2 * d.ic <= 16 ? 16 : 32; }
+static size_t thin_start_lds(const WnD &d) { const int icp = thin_icp(d); return ((size_t)d.C * WGTH_LDT + WGTH_TB * icp + 4 * icp * 64 + (size_t)d.C * icp) * sizeof(float); }
+static size_t thin_end_lds(const WnD &d) { const int k2p = thin_k2p(d); return ((size_t)d.Cs * WGTH_LDT + WGTH_TB * k2p + (size_t)k2p * d.Cs) * sizeof(float); }
+#define WG_LDS_BYTES (160 * 1024)      // gfx950: LDS per CU = the most one workgroup can ask for
+// the shape part of thin_ok (shapes whose tiles do not fit the LDS -- 512 channels with more than 8 thin rows -- keep the split-K MFMA
+// products + convs)
+static bool thin_shape_ok(const WnD &d)
+{
+#if defined(WG_OPT_NO_THIN)
+    return false;
+#else
+    return !d.bias && d.ic <= 16 && d.C % 8 == 0 && d.Cs % 8 == 0 && d.C <= WGTH_MAXROWS * WGTH_THREADS && d.Cs <= WGTH_MAXROWS * WGTH_THREADS &&
+           thin_start_lds(d) <= WG_LDS_BYTES && thin_end_lds(d) <= WG_LDS_BYTES;
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------
 // One launch per WN layer (wg_layer16h.h) where both of the layer's products would take the 64 x 64-tile kernel: the two launches are
 // RECORDED (the recorder of the stage interpreter: run_convgemm fills its argument block instead of launching), checked to be the
@@ -1632,14 +1651,32 @@ void wn_forward(Ctx &cx, const WnRun &r)
     const Geo &g = r.g;
     float *ws = r.ws;
     const bool sp = cx.prec == 2;
-    if (sp) run_to_splane(cx, g, r.X, d.ic, ws + r.w.XaS, r.L.kp_start);      // xa -> S-plane (re-based to channel 0)
     const int nb = d.bias ? 1 : 0;
     const SegSpec sone = d.bias ? ones_seg(cx, r, true) : SegSpec{};
-    SegSpec s0[2] = {{r.X.p, r.X.Cp, r.X.ch0, r.L.kp_start, 0, ws + r.w.XaS, r.L.kp_start, 0}, sone};
     const int cols0 = (cx.row_sel1 && g.rows > 0 ? g.B / g.rows : g.B) * g.Tt;
     const bool so = s_only_chain(cx, d) && fused_skip(d) && cols0 >= WG_FUSED_SKIP_MIN_COLS;      // residual stream as S-planes only
-    run_convgemm(cx, g, r.pk + r.L.startT, r.L.ld_startT, d.C, s0, 1 + nb, EPI_STORE, so ? pnull() : pref(ws + r.w.H[0], d.C), pnull(), pnull(),
-                 pnull(), pnull(), 0, 0, sp ? sref(g, ws + r.w.HS[0], d.C) : snull());             // waveglow.py:99
+    // WN.start on the vector ALU in ONE launch (start_fwd_kernel, wg_thin.h) instead of an S-plane conversion + an MFMA conv on a K of 2-4
+    // channels; a pass that keeps its activations takes it only where the backward's thin start product reads xa itself (thin_shape_ok)
+    // -- the MFMA weight gradient would want xa's S-plane
+    const bool vstart = sp && !nb && !cx.rec && d.ic <= 16 && d.C % 8 == 0 && (!r.save || thin_shape_ok(d))
+#if defined(WG_OPT_NO_VSTART)
+                        && false
+#endif
+        ;
+    if (vstart) {
+        StartFwdArgs a;
+        memset(&a, 0, sizeof(a));
+        a.X = r.X; a.W = r.pk + r.L.startN; a.ldw = r.L.ld_startN; a.C = d.C; a.ic = d.ic;
+        a.H = so ? pnull() : pref(ws + r.w.H[0], d.C);
+        a.HS = sref(g, ws + r.w.HS[0], d.C);
+        a.g = g; a.row_sel1 = cx.row_sel1;
+        WG_LAUNCH(cx, start_fwd_kernel, dim3((g.T + 255) / 256, d.C / 8, cx.row_sel1 && g.rows > 0 ? g.B / g.rows : g.B), dim3(256), 0, a);
+    } else {
+        if (sp) run_to_splane(cx, g, r.X, d.ic, ws + r.w.XaS, r.L.kp_start);      // xa -> S-plane (re-based to channel 0)
+        SegSpec s0[2] = {{r.X.p, r.X.Cp, r.X.ch0, r.L.kp_start, 0, ws + r.w.XaS, r.L.kp_start, 0}, sone};
+        run_convgemm(cx, g, r.pk + r.L.startT, r.L.ld_startT, d.C, s0, 1 + nb, EPI_STORE, so ? pnull() : pref(ws + r.w.H[0], d.C), pnull(), pnull(),
+                     pnull(), pnull(), 0, 0, sp ? sref(g, ws + r.w.HS[0], d.C) : snull());             // waveglow.py:99
+    }
     // one long product (depth x Cd / 32 chunks in a row) only pays where launches are bound by bytes, not by their chunk latency chain:
     // single-utterance synthesis (2 048 columns) lost 9 % with it, the training shapes gain 2.5 % per step
     const int cols = (cx.row_sel1 && g.rows > 0 ? g.B / g.rows : g.B) * g.Tt;
@@ -1716,21 +1753,12 @@ void run_end_affine(Ctx &cx, const WnRun &r, int mode, PRef dX, float *log_s_out
     else WG_LAUNCH(cx, end_affine_kernel<32>, dim3(r.g.Tt / WG_AFF_T, r.g.B), dim3(256), 0, a);
 }
 
-// The thin products of WN's backward (wg_thin.h): precision 2, inside a FinQueue (the partials come from its arena).
-// Dynamic LDS of the two kernels (floats -> bytes): the [channels][65] tile, the thin operand's tile, the per-wave shares and the weights.
-static int thin_icp(const WnD &d) { return d.ic <= 4 ? 4 : d.ic <= 8 ? 8 : 16; }
-static int thin_k2p(const WnD &d) { return 2 * d.ic <= 8 ? 8 : 2 * d.ic <= 16 ? 16 : 32; }
-static size_t thin_start_lds(const WnD &d) { const int icp = thin_icp(d); return ((size_t)d.C * WGTH_LDT + WGTH_TB * icp + 4 * icp * 64 + (size_t)d.C * icp) * sizeof(float); }
-static size_t thin_end_lds(const WnD &d) { const int k2p = thin_k2p(d); return ((size_t)d.Cs * WGTH_LDT + WGTH_TB * k2p + (size_t)k2p * d.Cs) * sizeof(float); }
-#define WG_LDS_BYTES (160 * 1024)      // gfx950: LDS per CU = the most one workgroup can ask for
 bool thin_ok(const Ctx &cx, const WnD &d)
 {
 #if defined(WG_OPT_NO_THIN)
     return false;
 #else
-    // (shapes whose tiles do not fit the LDS -- 512 channels with more than 8 thin rows -- keep the split-K MFMA products + convs)
-    return cx.prec == 2 && cx.fq && !cx.rec && !d.bias && d.ic <= 16 && d.C % 8 == 0 && d.Cs % 8 == 0 && d.C <= WGTH_MAXROWS * WGTH_THREADS &&
-           d.Cs <= WGTH_MAXROWS * WGTH_THREADS && thin_start_lds(d) <= WG_LDS_BYTES && thin_end_lds(d) <= WG_LDS_BYTES;
+    return cx.prec == 2 && cx.fq && !cx.rec && thin_shape_ok(d);
 #endif
 }
 static int thin_grid(int tiles)
