@@ -1693,6 +1693,9 @@ void wn_forward(Ctx &cx, const WnRun &r)
             d.tap(i, kt, ts, ro);
             sg[ns++] = {Hin, d.C, 0, d.C, ts, ws + r.w.HS[hin], d.C, 0, ro, 0};
         }
+#if defined(WG_DBG_NOCOND)      // timing experiment only (results are garbage): the gate conv without its conditioning segment
+        if (false)
+#endif
         sg[ns++] = {r.Y, d.auxp(), 0, d.auxp(), 0, r.YS, d.auxp(), 0, 0, d.mode2d};
         if (nb) sg[ns++] = sone;
         // fp32 gate plane: only the on-the-fly weight-gradient kernel still reads it (backward); the S-plane feeds W_o
