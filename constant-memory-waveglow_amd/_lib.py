@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "wg_wf_inverse", "wg_wf_backward", "wg_melspec_frames", "wg_melspec", "wg_lowpass_workspace_bytes", "wg_lowpass", "wg_train_step",
     "wg_nll_scratch_floats", "wg_train_scratch_floats",
     "wg_timer_create", "wg_timer_attach", "wg_timer_count", "wg_timer_read", "wg_timer_read_info", "wg_timer_destroy", "wg_stat_wgrad16t_launches",
-    "wg_stat_layer_launches",
+    "wg_stat_layer_launches", "wg_layer_workspace_bytes", "wg_layer_apply",
 ]
 K_CONV_STORE, K_CONV_GATE, K_CONV_RESSKIP, K_CONV_DGATE, K_WGRAD, K_LAYER = range(6)
 
@@ -39,6 +39,10 @@ class WgWfConfig(C.Structure):
 
 class WgWnDims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("in_ch", "aux_ch", "res_ch", "dil_ch", "skip_ch", "depth", "radix", "precision", "bias")]
+
+
+class WgLayerDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("res_ch", "dil_ch", "skip_ch", "radix", "dilation", "last_layer")]
 
 
 PREC_F32, PREC_BF16X3, PREC_BF16X3_PLANES = 0, 1, 2
@@ -139,6 +143,9 @@ def lib():
     L.wg_stat_wgrad16t_launches.argtypes = []
     L.wg_stat_layer_launches.restype = C.c_longlong
     L.wg_stat_layer_launches.argtypes = []
+    L.wg_layer_workspace_bytes.restype = sz
+    L.wg_layer_workspace_bytes.argtypes = [C.POINTER(WgLayerDims), i, i]
+    L.wg_layer_apply.argtypes = [C.POINTER(WgLayerDims), vp, vp, vp, i, i, vp, vp, vp, sz, vp]
     L.wg_timer_destroy.argtypes = [vp]
     L.wg_timer_destroy.restype = None
     _LIB = L

@@ -965,3 +965,44 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a)
         adam_one(a.p[i], a.g[i], a.m[i], a.v[i], a);
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Stand-alone NonCausalLayer (model/waveglow.py:18-46; wg_layer_apply): the two conv weights materialised (old-style weight norm over all dims
+// but 0 when g is given, utils.py:14-16) into the k-major fp32 matrices the exact-fp32 conv kernel takes.  One block per weight row.
+//   kind 0: W [2 Cd][C][radix]  -> Acat[k = tap * C + c][m'], m' = the gate interleave of the row (64-blocks [32 tanh | 32 sigmoid]),
+//           followed by an identity block: Acat[radix * C + j][m'(j)] = 1, so that the caller's conditioning y[2 Cd] is one more K segment
+//   kind 1: W_o [R][Cd][1]      -> WoT[k = cd][m = row]
+// ------------------------------------------------------------------------------------------------
+struct LayerPackArgs {
+    const float *g, *v;      // g nullable: plain conv weight
+    float *dst;              // k-major, leading dimension ld (zero-filled by the caller)
+    int rows, fan, ld;       // rows of the weight, elements per row, leading dimension of dst
+    int kind, C, Cd, radix;
+};
+__global__ __launch_bounds__(256) void layer_pack_kernel(const LayerPackArgs a)
+{
+    __shared__ float red[256];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float *vr = a.v + (size_t)row * a.fan;
+    float ss = 0.f;
+    for (int e = tid; e < a.fan; e += 256) ss += vr[e] * vr[e];
+    red[tid] = ss;
+    __syncthreads();
+    for (int q = 128; q > 0; q >>= 1) {
+        if (tid < q) red[tid] += red[tid + q];
+        __syncthreads();
+    }
+    const float scale = a.g ? a.g[row] / sqrtf(red[0]) : 1.0f;
+    if (a.kind == 0) {
+        const int ch = row < a.Cd ? row : row - a.Cd;
+        const int m = (ch >> 5) * 64 + (row < a.Cd ? 0 : 32) + (ch & 31);
+        for (int e = tid; e < a.fan; e += 256) {              // v[row][c][tap]
+            const int c = e / a.radix, tap = e - c * a.radix;
+            a.dst[(size_t)(tap * a.C + c) * a.ld + m] = vr[e] * scale;
+        }
+        if (tid == 0) a.dst[(size_t)(a.radix * a.C + row) * a.ld + m] = 1.0f;
+    } else {
+        for (int e = tid; e < a.fan; e += 256) a.dst[(size_t)e * a.ld + row] = vr[e] * scale;
+    }
+}
+

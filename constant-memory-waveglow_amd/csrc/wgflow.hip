@@ -3182,6 +3182,79 @@ int wg_wn_apply(const wg_wn_dims *dd, const void *packed, const float *x, const 
     return cx.err;
 }
 
+// ---- stand-alone NonCausalLayer (waveglow.py:18-46) ----
+struct LayerWs {
+    Geo g;
+    int Cp, Yp, Dp, Sp, ldA, ldO, KA, R;
+    size_t X, Y, gate, res, skip, Acat, WoT, total;
+};
+static int layer_check(const wg_layer_dims *d)
+{
+    if (!d || d->res_ch < 16 || d->dil_ch < 32 || d->skip_ch < 16 || d->res_ch % 16 || d->dil_ch % 32 || d->skip_ch % 16) return WG_EUNSUPPORTED;
+    if (d->radix < 1 || d->radix > WG_MAX_SEG - 1 || !(d->radix & 1) || d->dilation < 1) return WG_EUNSUPPORTED;
+    return 0;
+}
+static LayerWs layer_ws_layout(const wg_layer_dims *d, int B, int T)
+{
+    LayerWs w;
+    Bump bp;
+    w.g = make_geo(B, T, d->dilation * (d->radix - 1) / 2);
+    w.Cp = d->res_ch; w.Yp = 2 * d->dil_ch; w.Dp = d->dil_ch; w.Sp = d->skip_ch;
+    w.R = d->last_layer ? d->skip_ch : d->res_ch + d->skip_ch;
+    w.KA = d->radix * d->res_ch + 2 * d->dil_ch;
+    w.ldA = rup(2 * d->dil_ch, WG_TILE); w.ldO = rup(w.R, WG_TILE);
+    w.X = bp.take((size_t)B * w.Cp * w.g.P);
+    w.Y = bp.take((size_t)B * w.Yp * w.g.P);
+    w.gate = bp.take((size_t)B * w.Dp * w.g.P);
+    w.res = bp.take((size_t)B * w.Cp * w.g.P);
+    w.skip = bp.take((size_t)B * w.Sp * w.g.P);
+    w.Acat = bp.take((size_t)w.KA * w.ldA);
+    w.WoT = bp.take((size_t)d->dil_ch * w.ldO);
+    w.total = bp.off + 1024;
+    return w;
+}
+size_t wg_layer_workspace_bytes(const wg_layer_dims *d, int B, int T)
+{
+    if (layer_check(d) || B < 1 || T < 1) return 0;
+    return layer_ws_layout(d, B, T).total * sizeof(float);
+}
+int wg_layer_apply(const wg_layer_dims *d, const void *const *params, const float *x, const float *y, int B, int T, float *res, float *skip,
+                   void *wsv, size_t ws_bytes, void *stream)
+{
+    int rc = layer_check(d);
+    if (rc) return rc;
+    if (!params || !params[1] || !params[3] || !x || !y || !skip || (!res && !d->last_layer) || !wsv || B < 1 || T < 1) return WG_EINVAL;
+    const LayerWs W = layer_ws_layout(d, B, T);
+    if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
+    Ctx cx = {(hipStream_t)stream, 0, 0};                      // the exact-fp32 conv kernel: fp32 planes, fp32 k-major weights, no images
+    float *ws = (float *)wsv;
+    const Geo g = W.g;
+    const int C = d->res_ch, Cd = d->dil_ch, Cs = d->skip_ch;
+    // (the whole workspace is zeroed by every call: plane halos and the padding of the weight matrices; this entry point exists for API
+    // parity, not for speed)
+    if (hipMemsetAsync(ws, 0, W.total * sizeof(float), cx.st) != hipSuccess) return WG_ELAUNCH;
+    LayerPackArgs pa;
+    pa.g = (const float *)params[0]; pa.v = (const float *)params[1]; pa.dst = ws + W.Acat; pa.rows = 2 * Cd; pa.fan = C * d->radix; pa.ld = W.ldA;
+    pa.kind = 0; pa.C = C; pa.Cd = Cd; pa.radix = d->radix;
+    WG_LAUNCH(cx, layer_pack_kernel, dim3(pa.rows), dim3(256), 0, pa);
+    pa.g = (const float *)params[2]; pa.v = (const float *)params[3]; pa.dst = ws + W.WoT; pa.rows = W.R; pa.fan = Cd; pa.ld = W.ldO; pa.kind = 1;
+    WG_LAUNCH(cx, layer_pack_kernel, dim3(pa.rows), dim3(256), 0, pa);
+    PRef X = pref(ws + W.X, W.Cp), Y = pref(ws + W.Y, W.Yp);
+    WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, C, B), dim3(256), 0, x, X, g, C);
+    WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, 2 * Cd, B), dim3(256), 0, y, Y, g, 2 * Cd);
+    SegSpec sg[WG_MAX_SEG];
+    int ns = 0;
+    for (int kt = 0; kt < d->radix; ++kt) sg[ns++] = {ws + W.X, W.Cp, 0, C, (kt - (d->radix - 1) / 2) * d->dilation, nullptr, 0, 0};
+    sg[ns++] = {ws + W.Y, W.Yp, 0, 2 * Cd, 0, nullptr, 0, 0};   // + y: the identity block of Acat
+    run_convgemm(cx, g, ws + W.Acat, W.ldA, 2 * Cd, sg, ns, EPI_GATE, pref(ws + W.gate, W.Dp), pnull(), pnull(), pnull(), pnull(), 0, 0);     // waveglow.py:42-44
+    SegSpec sgt[1] = {{ws + W.gate, W.Dp, 0, Cd, 0, nullptr, 0, 0}};
+    run_convgemm(cx, g, ws + W.WoT, W.ldO, W.R, sgt, 1, EPI_RESSKIP, pref(ws + W.res, W.Cp), pref(ws + W.skip, W.Sp), pnull(), X, pnull(),
+                 d->last_layer ? 0 : C, 0);                                                                                                     // :45-46
+    if (!d->last_layer) WG_LAUNCH(cx, export_kernel, dim3((T + 255) / 256, C, B), dim3(256), 0, pref(ws + W.res, W.Cp), res, g, C, 1.0f);
+    WG_LAUNCH(cx, export_kernel, dim3((T + 255) / 256, Cs, B), dim3(256), 0, pref(ws + W.skip, W.Sp), skip, g, Cs, 1.0f);
+    return cx.err;
+}
+
 int wg_coupling_backward(const wg_wn_dims *dd, const void *const *params, const void *packed, const float *z, const float *y,
                          const float *dz, const float *dlog_s, int B, int T, int reverse, float *x, float *dx, float *dy,
                          void *const *grads, void *wsv, size_t ws_bytes, void *stream)

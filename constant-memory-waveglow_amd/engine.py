@@ -395,6 +395,29 @@ class CouplingEngine:
 
 
 _INV_BUFFERS = _Buffers()
+_LAYER_BUFFERS = _Buffers()
+
+
+@on_device
+def layer_apply(dims, params, x, y):
+    """NonCausalLayer.forward on its own (model/waveglow.py:41-46; wg_layer_apply): params = [W.g or None, W.v, W_o.g or None, W_o.v].
+    Returns (res or None, skip)."""
+    require_device(x, y, *params)
+    x, y = x.contiguous(), y.contiguous()
+    B, Cin, T = x.shape
+    if Cin != dims.res_ch or tuple(y.shape) != (B, 2 * dims.dil_ch, T):
+        raise WgError("NonCausalLayer: x %s / y %s do not match the layer (x [B, %d, T], y [B, %d, T])"
+                      % (tuple(x.shape), tuple(y.shape), dims.res_ch, 2 * dims.dil_ch))
+    nbytes = _lib.lib().wg_layer_workspace_bytes(C.byref(dims), B, T)
+    if nbytes == 0:
+        raise WgError("NonCausalLayer shape not supported by the HIP kernels (residual / skip channels multiples of 16, dilation channels "
+                      "a multiple of 32, odd radix <= 9)")
+    ws = _LAYER_BUFFERS.get((x.device, dims.res_ch, dims.dil_ch, dims.skip_ch, dims.radix, dims.dilation, B, T), nbytes, x.device)
+    res = None if dims.last_layer else torch.empty_like(x)
+    skip = torch.empty(B, dims.skip_ch, T, dtype=torch.float32, device=x.device)
+    check(_lib.lib().wg_layer_apply(C.byref(dims), _table([None if p is None else p.contiguous() for p in params]), _p(x), _p(y), B, T, _p(res),
+                                    _p(skip), _p(ws), ws.numel(), _stream()), "wg_layer_apply")
+    return res, skip
 
 
 @on_device

@@ -28,9 +28,10 @@ def fused_gate(x1: Tensor, x2: Tensor) -> Tensor:
 
 
 class NonCausalLayer(nn.Module):
-    """Parameter container of one WN layer: W = dilated conv (residual -> 2*dilation channels), W_o = 1x1
-    (dilation -> residual+skip, or skip only on the last layer)  (waveglow.py:18-46).  Its arithmetic runs inside
-    the fused WN kernels, so calling it on its own is not supported."""
+    """One WN layer: W = dilated conv (residual -> 2*dilation channels), W_o = 1x1 (dilation -> residual+skip, or skip only on the
+    last layer)  (waveglow.py:18-46).  Inside a WN its arithmetic runs in the WN kernels; called on its own, `forward` runs the two
+    products through the C ABI (wg_layer_apply: exact fp32 MFMA, any dilation, forward only -- the class has no backward upstream
+    either: gradients flow through AffineCouplingBlock)."""
 
     def __init__(self, dilation, dilation_channels, residual_channels, skip_channels, radix, bias, last_layer=False):
         super().__init__()
@@ -41,7 +42,19 @@ class NonCausalLayer(nn.Module):
         self.chs_split = [skip_channels] if last_layer else [residual_channels, skip_channels]
 
     def forward(self, x, y):
-        raise WgError("NonCausalLayer is executed inside the fused HIP WN kernels; call WN / AffineCouplingBlock instead")
+        """x [B, residual, T], y [B, 2 * dilation, T] (this layer's slice of the conditioning projection) -> (x + res or None, skip)
+        as waveglow.py:41-46."""
+        if self.W.bias is not None or self.W_o.bias is not None:
+            raise WgError("NonCausalLayer(bias=True) is served inside WN only (the block-level path folds the biases into its K segments)")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            warnings.warn("NonCausalLayer.forward on its own runs without autograd; gradients flow through AffineCouplingBlock", stacklevel=2)
+        from ._lib import WgLayerDims
+        last = len(self.chs_split) == 1
+        dims = WgLayerDims(self.W.in_channels, self.W.out_channels // 2, self.chs_split[-1], self.W.kernel_size[0], self.W.dilation[0], int(last))
+        wg_, wv = conv_gv(self.W)
+        og, ov = conv_gv(self.W_o)
+        with torch.no_grad():
+            return engine.layer_apply(dims, [wg_, wv, og, ov], x, y)
 
 
 class WN(nn.Module):

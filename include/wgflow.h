@@ -81,7 +81,7 @@ const char *wg_strerror(int code);
  * training scalars and take their scratch from the caller, wg_melspec returns the power spectrogram on request, wg_wf_config gained
  * use_conv1x1, wg_wf_upsample; 4: wg_timer_create(-1, ..) times every kernel class, wg_timer_read_info, wg_stat_wgrad16t_launches,
  * wg_wf_* accept every WG_PREC_*; 5: wg_config and wg_wn_dims gained bias; 6: wg_stat_layer_launches, the workspaces carry the one-launch
- * layer's hand-off counters).  A binding built against another revision must not pass its
+ * layer's hand-off counters, wg_layer_apply / wg_layer_workspace_bytes).  A binding built against another revision must not pass its
  * structs: the Python loader compares this with its own ABI_VERSION and refuses the library otherwise. */
 #define WG_ABI_VERSION 6
 int wg_abi_version(void);
@@ -189,6 +189,16 @@ int wg_coupling_apply(const wg_wn_dims *d, const void *packed, const float *x, c
 /* WN.forward (waveglow.py:98-105): x[B,in_ch,T], y[B,aux,T] -> (log_s, t), each [B,in_ch,T]. */
 int wg_wn_apply(const wg_wn_dims *d, const void *packed, const float *x, const float *y, int B, int T,
                 float *log_s, float *t, void *ws, size_t ws_bytes, void *stream);
+/* NonCausalLayer.forward on its own (waveglow.py:18-46): xy = W(x) + y; gate = tanh(xy[:Cd]) * sigmoid(xy[Cd:]); o = W_o(gate);
+ * returns (o[:C] + x, o[C:]) -- or (none, o) for the last layer.  Any dilation, odd radix <= 9, no bias; exact fp32 MFMA arithmetic.
+ * params = {W.weight_g (NULL: plain weight), W.weight_v [2 Cd, C, radix], W_o.weight_g (NULL: plain), W_o.weight_v [C + Cs or Cs, Cd, 1]};
+ * x[B,C,T], y[B,2 Cd,T] (the layer's slice of the conditioning projection V(y)) -> res[B,C,T] (NULL when last_layer), skip[B,Cs,T]. */
+typedef struct wg_layer_dims {
+    int32_t res_ch, dil_ch, skip_ch, radix, dilation, last_layer;
+} wg_layer_dims;
+size_t wg_layer_workspace_bytes(const wg_layer_dims *d, int B, int T);
+int wg_layer_apply(const wg_layer_dims *d, const void *const *params, const float *x, const float *y, int B, int T,
+                   float *res, float *skip, void *ws, size_t ws_bytes, void *stream);
 /* AffineCouplingFunc.backward / InvAffineCouplingFunc.backward (efficient_modules.py:118-154, 175-212):
  * from the block OUTPUT z, y, dz, dlog_s: rebuilt input x, dx, dy (nullable), parameter grads. */
 int wg_coupling_backward(const wg_wn_dims *d, const void *const *params, const void *packed,

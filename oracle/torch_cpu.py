@@ -61,6 +61,19 @@ def _wn_forward(p, xa, y, depth, C, radix):
     return out[:, :ic], out[:, ic:]
 
 
+def noncausal_layer(Wg, Wv, Og, Ov, x, y, dilation, last_layer):
+    """NonCausalLayer.forward on its own (model/waveglow.py:41-46): -> (x + res or None, skip).  Weights as (g or None, v) pairs."""
+    W = _wn(None if Wg is None else torch.from_numpy(Wg), torch.from_numpy(Wv))
+    Wo = _wn(None if Og is None else torch.from_numpy(Og), torch.from_numpy(Ov))
+    xt = torch.from_numpy(np.ascontiguousarray(x, np.float32))
+    radix, Cd, C = W.shape[2], W.shape[0] // 2, W.shape[1]
+    xy = Fn.conv1d(xt, W, padding=dilation * (radix - 1) // 2, dilation=dilation) + torch.from_numpy(np.ascontiguousarray(y, np.float32))
+    o = Fn.conv1d(torch.tanh(xy[:, :Cd]) * torch.sigmoid(xy[:, Cd:]), Wo)
+    if last_layer:
+        return None, o.numpy()
+    return (o[:, :C] + xt).numpy(), o[:, C:].numpy()
+
+
 def set_threads(n):
     torch.set_num_threads(max(1, int(n)))
     return torch.get_num_threads()

@@ -261,6 +261,45 @@ def test_full_size_properties(dev):
         assert float((a - b).abs().max()) <= GRAD_RTOL * float(b.abs().max()) + 1e-12, n
 
 
+@pytest.mark.parametrize("cname", ["d4", "last", "r5d3"])
+def test_noncausal_layer_alone_vs_reference_golden(dev, golden_dir, precision, cname):
+    """NonCausalLayer.forward on its own (model/waveglow.py:18-46, 41-46) through wg_layer_apply: against the reference's own output
+    (block_layer.npz) and a plain torch fp32 evaluation of the same formulas; weight norm on and off, the last-layer form (no residual),
+    a dilation that is not a power of two and radix 5."""
+    if precision != "f32":
+        pytest.skip("the stand-alone layer always runs the exact-fp32 kernels")
+    import torch.nn.functional as Fn
+    from make_golden import LAYER_CASES, layer_inputs
+    C, Cd, Cs, radix, dil, last, wn, B, Tn = LAYER_CASES[cname]
+    P, x, y = layer_inputs(cname)
+    gold = np.load(os.path.join(golden_dir, "block_layer.npz"))
+    m = cm.NonCausalLayer(dil, Cd, C, Cs, radix, False, last_layer=last)
+    if wn:
+        m.apply(cm.add_weight_norms)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    else:
+        m.load_state_dict({"W.weight": torch.from_numpy(P["W.weight_v"]), "W_o.weight": torch.from_numpy(P["W_o.weight_v"])})
+    m = m.to(dev)
+    with torch.no_grad():
+        res, skip = m(T(x, dev), T(y, dev))
+
+    def eff(v, g):
+        v = torch.from_numpy(v)
+        return v if g is None else v * (torch.from_numpy(g) / v.flatten(1).norm(dim=1).view(-1, 1, 1))
+    W, Wo = eff(P["W.weight_v"], P.get("W.weight_g")), eff(P["W_o.weight_v"], P.get("W_o.weight_g"))
+    xt = torch.from_numpy(x)
+    xy = Fn.conv1d(xt, W, padding=dil * (radix - 1) // 2, dilation=dil) + torch.from_numpy(y)
+    o = Fn.conv1d(torch.tanh(xy[:, :Cd]) * torch.sigmoid(xy[:, Cd:]), Wo)
+    want_skip = o if last else o[:, C:]
+    assert np.abs(npy(skip) - gold[cname + "/skip"]).max() < 2e-5 and np.abs(npy(skip) - want_skip.numpy()).max() < 2e-5
+    if last:
+        assert res is None
+    else:
+        assert np.abs(npy(res) - gold[cname + "/res"]).max() < 2e-5 and np.abs(npy(res) - (o[:, :C] + xt).numpy()).max() < 2e-5
+    with pytest.raises(cm.WgError):                              # shapes outside the kernels' set are refused, not approximated
+        cm.NonCausalLayer(1, 24, 32, 32, 3, False).to(dev)(torch.zeros(1, 32, 64, device=dev), torch.zeros(1, 48, 64, device=dev))
+
+
 @pytest.mark.parametrize("name", ["micro", "c1", "c2"])
 def test_one_launch_layer_vs_two_launches(dev, precision, monkeypatch, name):
     """convlayer16h_kernel (wg_layer16h.h): one launch per WN layer -- gate conv -> gate -> W_o -> residual / skip, model/waveglow.py:41-46 --

@@ -374,3 +374,20 @@ def test_torch_cpu_step_matches_reference(golden_dir, name):
         assert abs(nrm - g["grad_norm"][i]) <= 1e-5 * g["grad_norm"][i] + 1e-12, n
         if "grad::" + n in g:
             assert _relmax(r["grads"][i], g["grad::" + n]) < 1e-5, n
+
+
+@pytest.mark.parametrize("cname", ["d4", "last", "r5d3"])
+def test_noncausal_layer_restatement_vs_reference_golden(golden_dir, cname):
+    """oracle/torch_cpu.noncausal_layer (model/waveglow.py:41-46) against the reference's own NonCausalLayer output (block_layer.npz)."""
+    from make_golden import LAYER_CASES, layer_inputs
+    from oracle import torch_cpu
+    C, Cd, Cs, radix, dil, last, wn, B, Tn = LAYER_CASES[cname]
+    P, x, y = layer_inputs(cname)
+    gold = np.load(os.path.join(golden_dir, "block_layer.npz"))
+    res, skip = torch_cpu.noncausal_layer(P.get("W.weight_g"), P["W.weight_v"], P.get("W_o.weight_g"), P["W_o.weight_v"], x, y, dil, last)
+    assert np.abs(skip - gold[cname + "/skip"]).max() < 2e-6
+    if last:
+        assert res is None
+    else:
+        assert np.abs(res - gold[cname + "/res"]).max() < 2e-6
+
