@@ -1178,6 +1178,40 @@ def test_waveflow_shipped_width_vs_oracle(dev, precision):
     assert np.abs(npy(x) - audio).max() < Z_ATOL
 
 
+def test_waveflow_chip_filling_shape_vs_oracle(dev, precision):
+    """The shipped WaveFlow width at a size that FILLS the chip -- batch 4 x 16000 samples = 256 plane rows x 250 columns -- against the
+    C oracle: the launches the small fixtures never reach: 64-row tiles for the 64-row products (convgemm16q_kernel<.., M64>: the
+    data-gradient conv, residual / skip products, gate backward), the gate conv on 128 x 256 column-group tiles (<.., CG2>), the grouped
+    weight-gradient launch at K = 64 000 columns, wf_rowsum_s_kernel's four-way row split (configs/waveflow_LJ_speech.json is this
+    network at batch 12)."""
+    if precision != "bf16x3p":
+        pytest.skip("the chip-filling WaveFlow case runs in the default arithmetic only (CPU oracle time)")
+    from oracle import wf_oracle as wfo
+    name = "wf_chip"
+    cfg = dict(flows=8, n_group=64, n_mels=80, dilation_channels=64, residual_channels=64, skip_channels=64)
+    B, N, F = 4, 16000, 63
+    specs = fill.waveflow_param_specs(cfg)
+    P = fill.fill_params(specs, name + "/")
+    audio, mel = fill.waveflow_inputs(name, B, N, F, cfg["n_mels"])
+    ref = wfo.train_step(wfo.make_config(**cfg), fill.table(specs, P), audio, mel, fill.SIGMA, need_dmel=True)
+    m = cm.WaveFlow(use_conv1x1=False, memory_efficient=False, bias=False, **cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    m = m.to(dev)
+    ht = T(mel, dev).requires_grad_(True)
+    z, logdet = m(T(audio, dev), ht)
+    loss = cm.WaveGlowLoss(fill.SIGMA)(z, logdet)
+    loss.backward()
+    assert np.abs(npy(z) - ref["z"]).max() < Z_ATOL
+    assert logdet_close(npy(logdet), ref["logdet"], N)
+    assert abs(float(loss.detach()) - ref["loss"]) < LOSS_ATOL
+    assert relmax(npy(ht.grad), ref["dmel"]) < GRAD_RTOL
+    named = dict(m.named_parameters())
+    for i, (n, _, _) in enumerate(specs):
+        if n.endswith("start.weight_v"):
+            continue
+        assert relmax(npy(named[n].grad), ref["grads"][i]) < GRAD_RTOL, n
+
+
 # ---- log-mel conditioner (SURVEY.md 8f rank 3) -----------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("B,N", [(1, 4096), (3, 16000), (2, 22016)])
@@ -1317,12 +1351,14 @@ def test_waveflow_after_remove_weight_norms(dev, precision):
 @pytest.mark.parametrize("B,Tn,depth,aux,ch,planned", [(3, 1000, 8, 80, 256, True), (5, 130, 8, 80, 256, True), (2, 2000, 4, 80, 256, True),
                                                        (4, 2000, 2, 80, 256, True), (1, 300, 8, 80, 256, True), (2, 700, 2, 80, 256, True),
                                                        (1, 64, 8, 80, 256, True), (2, 500, 3, 80, 256, True), (2, 512, 8, 1500, 256, True),
-                                                       (3, 700, 5, 3659, 256, True), (2, 500, 3, 80, 64, False), (24, 2000, 8, 80, 256, True)])
+                                                       (3, 700, 5, 3659, 256, True), (2, 500, 3, 80, 64, False), (24, 2000, 8, 80, 256, True),
+                                                       (6, 1024, 8, 1500, 256, True)])
 def test_weight_gradient_kernel_plans_vs_oracle(dev, precision, B, Tn, depth, aux, ch, planned):
     """wgrad16t_kernel (one workgroup per CU, planned phases, wg_wgrad16t.h) at the shipped WN width over several (batch, length, depth,
     conditioning width) combinations: different K ranges, part counts and phase shapes of the two planners -- the two-phase plan of the
     headline shape; the ROUNDS plan for a layer count that does not divide the 8 XCDs and for rows of tiles wider than an XCD (WSRGlow's
-    3 659 conditioning channels: 35 column tiles in sub-sets of 7); the headline shape's own K = 24 x 2000 columns -- against the oracle, and a case WITHOUT a plan (a 64-channel WN: its
+    3 659 conditioning channels: 35 column tiles in sub-sets of 7); the headline shape's own K = 24 x 2000 columns; six items of 1024 columns with 1 500 conditioning channels, whose conditioning gradient (12 row
+    tiles x 48 column tiles, plane rows that do not divide by the 8 XCDs) walks the XCD-column tile order (ConvGemm16sArgs::xcd_items < 0) -- against the oracle, and a case WITHOUT a plan (a 64-channel WN: its
     products have 128 rows, the kernel's tiles 256), which must take the two-workgroup kernel and agree as well."""
     if precision != "bf16x3p":
         pytest.skip("the grouped weight-gradient launches exist in the S-plane mode only")
