@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "wg_wf_inverse", "wg_wf_backward", "wg_melspec_frames", "wg_melspec", "wg_lowpass_workspace_bytes", "wg_lowpass", "wg_train_step",
     "wg_nll_scratch_floats", "wg_train_scratch_floats",
     "wg_timer_create", "wg_timer_attach", "wg_timer_count", "wg_timer_read", "wg_timer_read_info", "wg_timer_destroy", "wg_stat_wgrad16t_launches",
-    "wg_stat_layer_launches", "wg_layer_workspace_bytes", "wg_layer_apply",
+    "wg_stat_layer_launches", "wg_layer_workspace_bytes", "wg_layer_apply", "wg_wf_wn_apply",
 ]
 K_CONV_STORE, K_CONV_GATE, K_CONV_RESSKIP, K_CONV_DGATE, K_WGRAD, K_LAYER = range(6)
 
@@ -125,6 +125,7 @@ def lib():
     L.wg_wf_upsample.argtypes = [wfp, vp, vp, vp, i, i, i, vp, vp]
     L.wg_wf_forward.argtypes = [wfp, vp, vp, vp, vp, i, i, i, vp, vp, vp, vp, sz, vp]
     L.wg_wf_inverse.argtypes = [wfp, vp, vp, vp, vp, i, i, i, vp, vp, vp, sz, vp]
+    L.wg_wf_wn_apply.argtypes = [wfp, vp, vp, vp, vp, i, i, i, vp, vp, vp, sz, vp]
     L.wg_wf_backward.argtypes = [wfp, vp, vp, vp, vp, vp, vp, i, i, i, vp, vp, vp, vp, sz, vp]
     L.wg_melspec_frames.argtypes = [i, i, i]
     L.wg_melspec.argtypes = [vp, i, i, i, i, i, C.c_double, C.c_double, i, vp, vp, vp]

@@ -143,6 +143,8 @@ struct WfCoupleArgs {
     Geo g;
     int mode;
     int noflip;             // use_conv1x1: x_next = cat(x[0], xout) (the 1x1 over the height axis follows) instead of cat(flip(xout), x[0])
+    float *raw_ls, *raw_t;  // mode 3 (WN2D.forward on its own, waveflow.py:128-135): plain [items][raw_rows][T] outputs of WN2D.end, no coupling
+    int raw_rows;
 };
 // (a device function: the stage interpreter, wg_stage.h, runs it as one stage; NT threads, `blk` = the block index, row_sel overrides a.row_sel)
 template <int NT>
@@ -155,6 +157,21 @@ __device__ __forceinline__ void wf_couple_body(const WfCoupleArgs &a, int blk, i
     const int x0row = b * H + (a.noflip ? 0 : H - 1);          // where x[0] goes in x_next
     const int orow = b * H + (a.noflip ? r + 1 : H - 2 - r);   // where xout[r] goes
     float lsum = 0.f;
+    if (a.mode == 3) {                                         // (log_s, t) of the row as they are
+        if (r >= a.raw_rows) return;
+        for (int t = tid; t < g.T; t += NT) {
+            float ls = 0.f, tt = 0.f;
+            for (int c = 0; c < a.Cs; ++c) {
+                const float s = *paddr(a.S, g, row, c, t);
+                ls = fmaf(a.endw[c], s, ls);
+                tt = fmaf(a.endw[a.Cs + c], s, tt);
+            }
+            const size_t o = ((size_t)b * a.raw_rows + r) * g.T + t;
+            a.raw_ls[o] = ls;
+            a.raw_t[o] = tt;
+        }
+        return;
+    }
     if (r == H - 1) {                                          // not a WN output row: x_next[x0row] = x[0] and its gradient
         for (int t = tid; t < g.T; t += NT) {
             if (a.mode == 0) *paddr(a.Xn, g, x0row, 0, t) = *paddr(a.X, g, b * H, 0, t);
@@ -467,3 +484,14 @@ __global__ __launch_bounds__(256) void wf_rowsum_s_kernel(SRef in, Geo g, SRef o
     *reinterpret_cast<u32x4 *>(out.hi + o) = oh;
     *reinterpret_cast<u32x4 *>(out.hi + out.lo_off + o) = ol;
 }
+
+// WN2D.forward on its own: x[items][rows_in][T] (plain) into the n_group-row planes; the rows below it are zero (the convs are causal along
+// the height axis: they cannot reach the rows above them)
+__global__ void wf_rows_in_kernel(const float *__restrict__ x, PRef X, Geo g, int rows_in)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
+    if (t >= g.T) return;
+    const int b = row / g.rows, r = row - b * g.rows;
+    *paddr(X, g, row, 0, t) = r < rows_in ? x[((size_t)b * rows_in + r) * g.T + t] : 0.f;
+}
+

@@ -2748,6 +2748,37 @@ int wg_wf_forward(const wg_wf_config *cf, const void *const *params, const void 
     return cx.err;
 }
 
+// WN2D.forward on its own (waveflow.py:128-135)
+int wg_wf_wn_apply(const wg_wf_config *cf, const void *const *params, const void *packed, const float *x, const float *y, int B, int rows, int Wd,
+                   float *log_s, float *t, void *wsv, size_t ws_bytes, void *stream)
+{
+    int rc = wf_check(cf);
+    if (rc) return rc;
+    if (!params || !params[3 + 36] || !packed || !x || !y || !log_s || !t || !wsv || B < 1 || Wd < 1 || rows < 1 || rows > cf->n_group) return WG_EINVAL;
+    const WfWs W = wf_ws_layout(cf, B, Wd, 0);
+    if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
+    Ctx cx = {(hipStream_t)stream, 0, cf->precision};
+    const float *pk = (const float *)packed;
+    const WfPack L = wf_pack_layout(cf);
+    float *ws = (float *)wsv;
+    const Geo g = W.g;
+    layer_sync_clear(cx, ws, W.wn.lsync);
+    WG_LAUNCH(cx, wf_rows_in_kernel, dim3((g.T + 255) / 256, g.B), dim3(256), 0, x, pref(ws + W.X[0], 1), g, rows);
+    WG_LAUNCH(cx, import_kernel, dim3((Wd + 255) / 256, cf->n_mels, B), dim3(256), 0, y, pref(ws + W.Y, W.auxp), W.gi, cf->n_mels);
+    if (cx.prec == 2) run_to_splane(cx, W.gi, pref(ws + W.Y, W.auxp), cf->n_mels, ws + W.YS, W.auxp);
+    WnRun r;
+    r.d = wf_wn(cf); r.L = wn_pack_layout(r.d); r.g = g; r.ws = ws; r.w = W.wn; r.Y = ws + W.Y; r.YS = ws + W.YS; r.save = 0;
+    r.pk = pk + L.wn[0]; r.X = pref(ws + W.X[0], 1);
+    wn_forward(cx, r);
+    WfCoupleArgs a;
+    memset(&a, 0, sizeof(a));
+    a.endw = (const float *)params[3 + 36];                    // end.weight [2][Cs][1][1], read as it is (like wf_couple)
+    a.S = pref(ws + W.wn.skip, r.d.Cs); a.Cs = r.d.Cs;
+    a.g = g; a.mode = 3; a.raw_ls = log_s; a.raw_t = t; a.raw_rows = rows;
+    WG_LAUNCH(cx, wf_couple_kernel, dim3(g.B), dim3(256), 0, a);
+    return cx.err;
+}
+
 // WaveFlow.reverse_computation (waveflow.py:210-253): per flow (last first) flip, then one height row at a time -- WN2D on row r
 // from rows <= r (what reverse_mode_forward's ring buffers hold), x[r+1] = (z[r+1] - t[r]) / exp(log_s[r]).
 int wg_wf_inverse(const wg_wf_config *cf, const void *const *params, const void *packed, const float *z, const float *mel,

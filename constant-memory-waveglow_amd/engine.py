@@ -613,6 +613,36 @@ class WaveFlowEngine:
         return grads, dmel, dx
 
 
+class WN2DEngine(WaveFlowEngine):
+    """WN2D.forward on its own (wg_wf_wn_apply): the packing and workspaces of a one-flow WaveFlow whose upsampler entries are placeholders."""
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self._dummy = None
+
+    def table(self, wn_params, device):
+        if self._dummy is None or self._dummy[0].device != device:
+            M, s = self.cfg.n_mels, 256 // self.cfg.n_group
+            self._dummy = [torch.zeros(M, device=device), torch.ones(M, M, 2 * s + 1, device=device)]
+        return [self._dummy[0], None, self._dummy[1]] + list(wn_params)
+
+    @on_device
+    def apply(self, wn_params, x, y):
+        require_device(x, y, *wn_params)
+        B, one, rows, W = x.shape
+        if one != 1 or rows > self.cfg.n_group or tuple(y.shape) != (B, self.cfg.n_mels, W):
+            raise WgError("WN2D: x %s / y %s do not match (x [B, 1, rows <= %d, W], y [B, %d, W])"
+                          % (tuple(x.shape), tuple(y.shape), self.cfg.n_group, self.cfg.n_mels))
+        x, y = x.contiguous(), y.contiguous()
+        params = self.table(wn_params, x.device)
+        pk = self._pack(params, x.device)
+        ws = self._ws(B, W * self.cfg.n_group, 0, x.device)
+        log_s, t = torch.empty_like(x), torch.empty_like(x)
+        check(_lib.lib().wg_wf_wn_apply(C.byref(self.cfg), _table(params), _p(pk), _p(x), _p(y), B, rows, W, _p(log_s), _p(t), _p(ws),
+                                        ws.numel(), _stream()), "wg_wf_wn_apply")
+        return log_s, t
+
+
 # ---- log-mel conditioner (include/wgflow.h: wg_melspec) -------------------------------------------------------------------------
 @on_device
 def melspec(x, sr, n_fft, hop, f_min, f_max, n_mels, return_power=False):

@@ -76,7 +76,15 @@ class WN2D(nn.Module):
         return tab
 
     def forward(self, x, y):
-        raise WgError("WN2D is executed inside the fused HIP kernels; call WaveFlow")
+        """x [B, 1, rows <= n_group, W], y [B, aux, W] -> (log_s, t), each [B, 1, rows, W] (waveflow.py:128-135).  Forward only: inside
+        WaveFlow the gradients flow through wg_wf_backward."""
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            warnings.warn("WN2D.forward on its own runs without autograd; gradients flow through WaveFlow", stacklevel=2)
+        if getattr(self, "_engine", None) is None:
+            self._engine = engine.WN2DEngine(WgWfConfig(1, self.n_group, self.aux_chs, self.res_chs, self.dil_chs, self.skp_chs,
+                                                         default_precision(), 0))
+        with torch.no_grad():
+            return self._engine.apply([None if p is None else p.detach() for p in self.param_table()], x.float(), y.float())
 
 
 class _WaveFlowFn(Function):

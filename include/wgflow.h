@@ -81,7 +81,7 @@ const char *wg_strerror(int code);
  * training scalars and take their scratch from the caller, wg_melspec returns the power spectrogram on request, wg_wf_config gained
  * use_conv1x1, wg_wf_upsample; 4: wg_timer_create(-1, ..) times every kernel class, wg_timer_read_info, wg_stat_wgrad16t_launches,
  * wg_wf_* accept every WG_PREC_*; 5: wg_config and wg_wn_dims gained bias; 6: wg_stat_layer_launches, the workspaces carry the one-launch
- * layer's hand-off counters, wg_layer_apply / wg_layer_workspace_bytes).  A binding built against another revision must not pass its
+ * layer's hand-off counters, wg_layer_apply / wg_layer_workspace_bytes, wg_wf_wn_apply).  A binding built against another revision must not pass its
  * structs: the Python loader compares this with its own ABI_VERSION and refuses the library otherwise. */
 #define WG_ABI_VERSION 6
 int wg_abi_version(void);
@@ -260,6 +260,11 @@ int wg_wf_forward(const wg_wf_config *cfg, const void *const *params, const void
 /* WaveFlow.reverse_computation (waveflow.py:210-253): the row-by-row autoregressive inverse. */
 int wg_wf_inverse(const wg_wf_config *cfg, const void *const *params, const void *packed, const float *z, const float *mel,
                   int B, int N, int F, float *x, float *logdet, void *ws, size_t ws_bytes, void *stream);
+/* WN2D.forward on its own (waveflow.py:128-135): x[B,1,rows,W] with rows <= n_group, y[B,n_mels,W] (already at the flow's time
+ * resolution) -> log_s, t, each [B,1,rows,W].  `params` / `packed`: the table and wg_wf_pack_weights of a configuration with flows = 1 whose
+ * WN2D entries are this module's parameters (the three upsampler entries are packed but not read here). */
+int wg_wf_wn_apply(const wg_wf_config *cfg, const void *const *params, const void *packed, const float *x, const float *y, int B, int rows, int W,
+                   float *log_s, float *t, void *ws, size_t ws_bytes, void *stream);
 /* What autograd computes upstream for z, logdet = model(x, mel) (the reference trains this model with memory_efficient=False):
  * every parameter gradient (table order), d mel (nullable), d audio (nullable), from the tape wg_wf_forward wrote. */
 int wg_wf_backward(const wg_wf_config *cfg, const void *const *params, const void *packed, const void *tape, const float *mel,

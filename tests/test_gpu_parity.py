@@ -1178,6 +1178,23 @@ def test_waveflow_shipped_width_vs_oracle(dev, precision):
     assert np.abs(npy(x) - audio).max() < Z_ATOL
 
 
+@pytest.mark.parametrize("cname", ["wf8", "wf64", "wf64_short"])
+def test_wn2d_alone_vs_reference_golden(dev, golden_dir, precision, cname):
+    """WN2D.forward on its own (model/waveflow.py:128-135) through wg_wf_wn_apply against the reference's own WN2D (block_wn2d.npz):
+    the input has fewer rows than n_group (WaveFlow passes x[:, :, :-1]; 20 of 64 in the short case), the rest of the planes is zero."""
+    from make_golden import wn2d_inputs
+    cfg, P, x, y = wn2d_inputs(cname)
+    gold = np.load(os.path.join(golden_dir, "block_wn2d.npz"))
+    m = cm.waveflow.WN2D(cfg["n_group"], cfg["n_mels"], dilation_channels=cfg["dilation_channels"], residual_channels=cfg["residual_channels"],
+                         skip_channels=cfg["skip_channels"], bias=False, zero_init=False)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    m = m.to(dev)
+    with torch.no_grad():
+        ls, t = m(T(x, dev), T(y, dev))
+    assert ls.shape == t.shape == x.shape
+    assert np.abs(npy(ls) - gold[cname + "/log_s"]).max() < Z_ATOL and np.abs(npy(t) - gold[cname + "/t"]).max() < Z_ATOL
+
+
 def test_waveflow_chip_filling_shape_vs_oracle(dev, precision):
     """The shipped WaveFlow width at a size that FILLS the chip -- batch 4 x 16000 samples = 256 plane rows x 250 columns -- against the
     C oracle: the launches the small fixtures never reach: 64-row tiles for the 64-row products (convgemm16q_kernel<.., M64>: the
