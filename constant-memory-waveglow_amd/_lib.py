@@ -42,7 +42,7 @@ class WgWnDims(C.Structure):
 
 
 class WgLayerDims(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("res_ch", "dil_ch", "skip_ch", "radix", "dilation", "last_layer")]
+    _fields_ = [(n, C.c_int32) for n in ("res_ch", "dil_ch", "skip_ch", "radix", "dilation", "last_layer", "h_dilation", "rows")]
 
 
 PREC_F32, PREC_BF16X3, PREC_BF16X3_PLANES = 0, 1, 2

@@ -1005,4 +1005,19 @@ __global__ __launch_bounds__(256) void layer_pack_kernel(const LayerPackArgs a)
         for (int e = tid; e < a.fan; e += 256) a.dst[(size_t)e * a.ld + row] = vr[e] * scale;
     }
 }
+// x[items][C][H][T] (the layout of a Conv2d activation) <-> planes with one plane row per (item, height row)
+__global__ void import2d_kernel(const float *__restrict__ src, PRef X, Geo g, int C)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, row = blockIdx.z;
+    if (t >= g.T) return;
+    const int b = row / g.rows, h = row - b * g.rows;
+    *paddr(X, g, row, c, t) = src[(((size_t)b * C + c) * g.rows + h) * g.T + t];
+}
+__global__ void export2d_kernel(PRef X, float *__restrict__ dst, Geo g, int C)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y, row = blockIdx.z;
+    if (t >= g.T) return;
+    const int b = row / g.rows, h = row - b * g.rows;
+    dst[(((size_t)b * C + c) * g.rows + h) * g.T + t] = *paddr(X, g, row, c, t);
+}
 

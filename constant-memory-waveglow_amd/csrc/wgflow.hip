@@ -3213,32 +3213,38 @@ int wg_wn_apply(const wg_wn_dims *dd, const void *packed, const float *x, const 
     return cx.err;
 }
 
-// ---- stand-alone NonCausalLayer (waveglow.py:18-46) ----
+// ---- stand-alone NonCausalLayer / NonCausalLayer2D (waveglow.py:18-46, waveflow.py:14-51) ----
 struct LayerWs {
-    Geo g;
-    int Cp, Yp, Dp, Sp, ldA, ldO, KA, R;
+    Geo g, gi;           // gi: one plane row per item (the 2-D layer's conditioning); == g for the 1-D layer
+    int Cp, Yp, Dp, Sp, ldA, ldO, KA, R, taps;
     size_t X, Y, gate, res, skip, Acat, WoT, total;
 };
 static int layer_check(const wg_layer_dims *d)
 {
     if (!d || d->res_ch < 16 || d->dil_ch < 32 || d->skip_ch < 16 || d->res_ch % 16 || d->dil_ch % 32 || d->skip_ch % 16) return WG_EUNSUPPORTED;
-    if (d->radix < 1 || d->radix > WG_MAX_SEG - 1 || !(d->radix & 1) || d->dilation < 1) return WG_EUNSUPPORTED;
+    if (d->radix < 1 || !(d->radix & 1) || d->dilation < 1 || d->h_dilation < 0) return WG_EUNSUPPORTED;
+    const int taps = d->h_dilation > 0 ? d->radix * d->radix : d->radix;
+    if (taps > WG_MAX_SEG - 1) return WG_EUNSUPPORTED;
+    if ((d->h_dilation > 0) != (d->rows > 0)) return WG_EINVAL;
     return 0;
 }
 static LayerWs layer_ws_layout(const wg_layer_dims *d, int B, int T)
 {
     LayerWs w;
     Bump bp;
-    w.g = make_geo(B, T, d->dilation * (d->radix - 1) / 2);
+    w.gi = make_geo(B, T, d->dilation * (d->radix - 1) / 2);
+    w.g = w.gi;
+    if (d->rows > 0) { w.g.B = B * d->rows; w.g.rows = d->rows; }
+    w.taps = d->h_dilation > 0 ? d->radix * d->radix : d->radix;
     w.Cp = d->res_ch; w.Yp = 2 * d->dil_ch; w.Dp = d->dil_ch; w.Sp = d->skip_ch;
     w.R = d->last_layer ? d->skip_ch : d->res_ch + d->skip_ch;
-    w.KA = d->radix * d->res_ch + 2 * d->dil_ch;
+    w.KA = w.taps * d->res_ch + 2 * d->dil_ch;
     w.ldA = rup(2 * d->dil_ch, WG_TILE); w.ldO = rup(w.R, WG_TILE);
-    w.X = bp.take((size_t)B * w.Cp * w.g.P);
-    w.Y = bp.take((size_t)B * w.Yp * w.g.P);
-    w.gate = bp.take((size_t)B * w.Dp * w.g.P);
-    w.res = bp.take((size_t)B * w.Cp * w.g.P);
-    w.skip = bp.take((size_t)B * w.Sp * w.g.P);
+    w.X = bp.take((size_t)w.g.B * w.Cp * w.g.P);
+    w.Y = bp.take((size_t)B * w.Yp * w.gi.P);
+    w.gate = bp.take((size_t)w.g.B * w.Dp * w.g.P);
+    w.res = bp.take((size_t)w.g.B * w.Cp * w.g.P);
+    w.skip = bp.take((size_t)w.g.B * w.Sp * w.g.P);
     w.Acat = bp.take((size_t)w.KA * w.ldA);
     w.WoT = bp.take((size_t)d->dil_ch * w.ldO);
     w.total = bp.off + 1024;
@@ -3261,28 +3267,43 @@ int wg_layer_apply(const wg_layer_dims *d, const void *const *params, const floa
     float *ws = (float *)wsv;
     const Geo g = W.g;
     const int C = d->res_ch, Cd = d->dil_ch, Cs = d->skip_ch;
+    const bool two_d = d->rows > 0;
     // (the whole workspace is zeroed by every call: plane halos and the padding of the weight matrices; this entry point exists for API
     // parity, not for speed)
     if (hipMemsetAsync(ws, 0, W.total * sizeof(float), cx.st) != hipSuccess) return WG_ELAUNCH;
     LayerPackArgs pa;
-    pa.g = (const float *)params[0]; pa.v = (const float *)params[1]; pa.dst = ws + W.Acat; pa.rows = 2 * Cd; pa.fan = C * d->radix; pa.ld = W.ldA;
-    pa.kind = 0; pa.C = C; pa.Cd = Cd; pa.radix = d->radix;
+    pa.g = (const float *)params[0]; pa.v = (const float *)params[1]; pa.dst = ws + W.Acat; pa.rows = 2 * Cd; pa.fan = C * W.taps; pa.ld = W.ldA;
+    pa.kind = 0; pa.C = C; pa.Cd = Cd; pa.radix = W.taps;      // (the 2-D weight [2 Cd][C][kh][kw] is a radix^2-tap weight: tap = kh * radix + kw)
     WG_LAUNCH(cx, layer_pack_kernel, dim3(pa.rows), dim3(256), 0, pa);
     pa.g = (const float *)params[2]; pa.v = (const float *)params[3]; pa.dst = ws + W.WoT; pa.rows = W.R; pa.fan = Cd; pa.ld = W.ldO; pa.kind = 1;
     WG_LAUNCH(cx, layer_pack_kernel, dim3(pa.rows), dim3(256), 0, pa);
     PRef X = pref(ws + W.X, W.Cp), Y = pref(ws + W.Y, W.Yp);
-    WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, C, B), dim3(256), 0, x, X, g, C);
-    WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, 2 * Cd, B), dim3(256), 0, y, Y, g, 2 * Cd);
+    if (two_d) WG_LAUNCH(cx, import2d_kernel, dim3((T + 255) / 256, C, g.B), dim3(256), 0, x, X, g, C);
+    else WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, C, B), dim3(256), 0, x, X, g, C);
+    WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, 2 * Cd, B), dim3(256), 0, y, Y, W.gi, 2 * Cd);
     SegSpec sg[WG_MAX_SEG];
     int ns = 0;
-    for (int kt = 0; kt < d->radix; ++kt) sg[ns++] = {ws + W.X, W.Cp, 0, C, (kt - (d->radix - 1) / 2) * d->dilation, nullptr, 0, 0};
-    sg[ns++] = {ws + W.Y, W.Yp, 0, 2 * Cd, 0, nullptr, 0, 0};   // + y: the identity block of Acat
+    const int half = (d->radix - 1) / 2;
+    if (two_d) {                                               // waveflow.py:42: F.pad(x, [pad, pad, h_pad, 0]): causal along the height axis
+        for (int kh = 0; kh < d->radix; ++kh)
+            for (int kw = 0; kw < d->radix; ++kw)
+                sg[ns++] = {ws + W.X, W.Cp, 0, C, (kw - half) * d->dilation, nullptr, 0, 0, (kh - (d->radix - 1)) * d->h_dilation, 0};
+        sg[ns++] = {ws + W.Y, W.Yp, 0, 2 * Cd, 0, nullptr, 0, 0, 0, 1};      // + y, one plane row per item: the identity block of Acat
+    } else {
+        for (int kt = 0; kt < d->radix; ++kt) sg[ns++] = {ws + W.X, W.Cp, 0, C, (kt - half) * d->dilation, nullptr, 0, 0};
+        sg[ns++] = {ws + W.Y, W.Yp, 0, 2 * Cd, 0, nullptr, 0, 0};           // + y: the identity block of Acat
+    }
     run_convgemm(cx, g, ws + W.Acat, W.ldA, 2 * Cd, sg, ns, EPI_GATE, pref(ws + W.gate, W.Dp), pnull(), pnull(), pnull(), pnull(), 0, 0);     // waveglow.py:42-44
     SegSpec sgt[1] = {{ws + W.gate, W.Dp, 0, Cd, 0, nullptr, 0, 0}};
     run_convgemm(cx, g, ws + W.WoT, W.ldO, W.R, sgt, 1, EPI_RESSKIP, pref(ws + W.res, W.Cp), pref(ws + W.skip, W.Sp), pnull(), X, pnull(),
                  d->last_layer ? 0 : C, 0);                                                                                                     // :45-46
-    if (!d->last_layer) WG_LAUNCH(cx, export_kernel, dim3((T + 255) / 256, C, B), dim3(256), 0, pref(ws + W.res, W.Cp), res, g, C, 1.0f);
-    WG_LAUNCH(cx, export_kernel, dim3((T + 255) / 256, Cs, B), dim3(256), 0, pref(ws + W.skip, W.Sp), skip, g, Cs, 1.0f);
+    if (two_d) {
+        if (!d->last_layer) WG_LAUNCH(cx, export2d_kernel, dim3((T + 255) / 256, C, g.B), dim3(256), 0, pref(ws + W.res, W.Cp), res, g, C);
+        WG_LAUNCH(cx, export2d_kernel, dim3((T + 255) / 256, Cs, g.B), dim3(256), 0, pref(ws + W.skip, W.Sp), skip, g, Cs);
+    } else {
+        if (!d->last_layer) WG_LAUNCH(cx, export_kernel, dim3((T + 255) / 256, C, B), dim3(256), 0, pref(ws + W.res, W.Cp), res, g, C, 1.0f);
+        WG_LAUNCH(cx, export_kernel, dim3((T + 255) / 256, Cs, B), dim3(256), 0, pref(ws + W.skip, W.Sp), skip, g, Cs, 1.0f);
+    }
     return cx.err;
 }
 

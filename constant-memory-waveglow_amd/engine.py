@@ -404,17 +404,23 @@ def layer_apply(dims, params, x, y):
     Returns (res or None, skip)."""
     require_device(x, y, *params)
     x, y = x.contiguous(), y.contiguous()
-    B, Cin, T = x.shape
-    if Cin != dims.res_ch or tuple(y.shape) != (B, 2 * dims.dil_ch, T):
-        raise WgError("NonCausalLayer: x %s / y %s do not match the layer (x [B, %d, T], y [B, %d, T])"
-                      % (tuple(x.shape), tuple(y.shape), dims.res_ch, 2 * dims.dil_ch))
+    if dims.rows > 0:                                        # NonCausalLayer2D: x [B, C, H, W], y [B, 2 Cd, 1, W]
+        B, Cin, H, T = x.shape
+        if Cin != dims.res_ch or H != dims.rows or tuple(y.shape) != (B, 2 * dims.dil_ch, 1, T):
+            raise WgError("NonCausalLayer2D: x %s / y %s do not match the layer (x [B, %d, H, W], y [B, %d, 1, W])"
+                          % (tuple(x.shape), tuple(y.shape), dims.res_ch, 2 * dims.dil_ch))
+    else:
+        B, Cin, T = x.shape
+        if Cin != dims.res_ch or tuple(y.shape) != (B, 2 * dims.dil_ch, T):
+            raise WgError("NonCausalLayer: x %s / y %s do not match the layer (x [B, %d, T], y [B, %d, T])"
+                          % (tuple(x.shape), tuple(y.shape), dims.res_ch, 2 * dims.dil_ch))
     nbytes = _lib.lib().wg_layer_workspace_bytes(C.byref(dims), B, T)
     if nbytes == 0:
         raise WgError("NonCausalLayer shape not supported by the HIP kernels (residual / skip channels multiples of 16, dilation channels "
                       "a multiple of 32, odd radix <= 9)")
-    ws = _LAYER_BUFFERS.get((x.device, dims.res_ch, dims.dil_ch, dims.skip_ch, dims.radix, dims.dilation, B, T), nbytes, x.device)
+    ws = _LAYER_BUFFERS.get((x.device, dims.res_ch, dims.dil_ch, dims.skip_ch, dims.radix, dims.dilation, dims.h_dilation, dims.rows, B, T), nbytes, x.device)
     res = None if dims.last_layer else torch.empty_like(x)
-    skip = torch.empty(B, dims.skip_ch, T, dtype=torch.float32, device=x.device)
+    skip = torch.empty((B, dims.skip_ch) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
     check(_lib.lib().wg_layer_apply(C.byref(dims), _table([None if p is None else p.contiguous() for p in params]), _p(x), _p(y), B, T, _p(res),
                                     _p(skip), _p(ws), ws.numel(), _stream()), "wg_layer_apply")
     return res, skip

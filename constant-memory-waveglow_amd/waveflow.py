@@ -23,7 +23,8 @@ from .utils import add_weight_norms, conv_gv
 
 
 class NonCausalLayer2D(nn.Module):
-    """Parameter container of one WN2D layer (waveflow.py:14-51): W = 3x3 conv with dilation (h_dilation, dilation), W_o = 1x1."""
+    """One WN2D layer (waveflow.py:14-51): W = 3x3 conv with dilation (h_dilation, dilation), causal along the height axis, W_o = 1x1.  Inside
+    WaveFlow its arithmetic runs in the WN kernels; called on its own, `forward` goes through wg_layer_apply."""
 
     def __init__(self, h_dilation, dilation, dilation_channels, residual_channels, skip_channels, radix, bias, last_layer=False):
         super().__init__()
@@ -38,7 +39,20 @@ class NonCausalLayer2D(nn.Module):
             self.chs_split.insert(0, residual_channels)
 
     def forward(self, x, y):
-        raise WgError("NonCausalLayer2D is executed inside the fused HIP kernels; call WaveFlow")
+        """x [B, residual, H, W], y [B, 2 * dilation, 1, W] -> (x + res or None, skip) as waveflow.py:41-51 (wg_layer_apply: exact fp32 MFMA,
+        forward only)."""
+        if self.W.bias is not None or self.W_o.bias is not None:
+            raise WgError("NonCausalLayer2D(bias=True) is not built into the HIP kernels")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            warnings.warn("NonCausalLayer2D.forward on its own runs without autograd; gradients flow through WaveFlow", stacklevel=2)
+        from ._lib import WgLayerDims
+        last = len(self.chs_split) == 1
+        dims = WgLayerDims(self.W.in_channels, self.W.out_channels // 2, self.chs_split[-1], self.W.kernel_size[0], self.W.dilation[1], int(last),
+                           self.W.dilation[0], x.shape[2])
+        wg_, wv = conv_gv(self.W)
+        og, ov = conv_gv(self.W_o)
+        with torch.no_grad():
+            return engine.layer_apply(dims, [wg_, wv, og, ov], x.float(), y.float())
 
 
 class WN2D(nn.Module):

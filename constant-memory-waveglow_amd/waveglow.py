@@ -50,7 +50,7 @@ class NonCausalLayer(nn.Module):
             warnings.warn("NonCausalLayer.forward on its own runs without autograd; gradients flow through AffineCouplingBlock", stacklevel=2)
         from ._lib import WgLayerDims
         last = len(self.chs_split) == 1
-        dims = WgLayerDims(self.W.in_channels, self.W.out_channels // 2, self.chs_split[-1], self.W.kernel_size[0], self.W.dilation[0], int(last))
+        dims = WgLayerDims(self.W.in_channels, self.W.out_channels // 2, self.chs_split[-1], self.W.kernel_size[0], self.W.dilation[0], int(last), 0, 0)
         wg_, wv = conv_gv(self.W)
         og, ov = conv_gv(self.W_o)
         with torch.no_grad():

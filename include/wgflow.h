@@ -189,12 +189,14 @@ int wg_coupling_apply(const wg_wn_dims *d, const void *packed, const float *x, c
 /* WN.forward (waveglow.py:98-105): x[B,in_ch,T], y[B,aux,T] -> (log_s, t), each [B,in_ch,T]. */
 int wg_wn_apply(const wg_wn_dims *d, const void *packed, const float *x, const float *y, int B, int T,
                 float *log_s, float *t, void *ws, size_t ws_bytes, void *stream);
-/* NonCausalLayer.forward on its own (waveglow.py:18-46): xy = W(x) + y; gate = tanh(xy[:Cd]) * sigmoid(xy[Cd:]); o = W_o(gate);
+/* NonCausalLayer.forward / NonCausalLayer2D.forward on its own (waveglow.py:18-46, waveflow.py:14-51): xy = W(x) + y; gate = tanh(xy[:Cd]) * sigmoid(xy[Cd:]); o = W_o(gate);
  * returns (o[:C] + x, o[C:]) -- or (none, o) for the last layer.  Any dilation, odd radix <= 9, no bias; exact fp32 MFMA arithmetic.
  * params = {W.weight_g (NULL: plain weight), W.weight_v [2 Cd, C, radix], W_o.weight_g (NULL: plain), W_o.weight_v [C + Cs or Cs, Cd, 1]};
  * x[B,C,T], y[B,2 Cd,T] (the layer's slice of the conditioning projection V(y)) -> res[B,C,T] (NULL when last_layer), skip[B,Cs,T]. */
 typedef struct wg_layer_dims {
     int32_t res_ch, dil_ch, skip_ch, radix, dilation, last_layer;
+    int32_t h_dilation, rows;   /* NonCausalLayer2D (waveflow.py:14-51): h_dilation > 0 = a radix x radix conv, causal along the height axis
+                                 * (dilation h_dilation there); x[B,C,rows,T], y[B,2 Cd,1,T] -> res[B,C,rows,T], skip[B,Cs,rows,T].  0, 0: the 1-D layer */
 } wg_layer_dims;
 size_t wg_layer_workspace_bytes(const wg_layer_dims *d, int B, int T);
 int wg_layer_apply(const wg_layer_dims *d, const void *const *params, const float *x, const float *y, int B, int T,

@@ -300,6 +300,32 @@ def test_noncausal_layer_alone_vs_reference_golden(dev, golden_dir, precision, c
         cm.NonCausalLayer(1, 24, 32, 32, 3, False).to(dev)(torch.zeros(1, 32, 64, device=dev), torch.zeros(1, 48, 64, device=dev))
 
 
+@pytest.mark.parametrize("cname", ["hd2d4", "last"])
+def test_noncausal_layer2d_alone_vs_reference_golden(dev, golden_dir, precision, cname):
+    """NonCausalLayer2D.forward on its own (model/waveflow.py:14-51): the 3x3 conv dilated (h_dilation, dilation), causal along the height
+    axis, as nine K segments with plane-row offsets; against the reference's own output (block_layer.npz, keys 2d_*)."""
+    if precision != "f32":
+        pytest.skip("the stand-alone layer always runs the exact-fp32 kernels")
+    from make_golden import LAYER2D_CASES, layer2d_inputs
+    C, Cd, Cs, hd, dil, last, wn, B, H, W = LAYER2D_CASES[cname]
+    P, x, y = layer2d_inputs(cname)
+    gold = np.load(os.path.join(golden_dir, "block_layer.npz"))
+    m = cm.waveflow.NonCausalLayer2D(hd, dil, Cd, C, Cs, 3, False, last_layer=last)
+    if wn:
+        m.apply(cm.add_weight_norms)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    else:
+        m.load_state_dict({"W.weight": torch.from_numpy(P["W.weight_v"]), "W_o.weight": torch.from_numpy(P["W_o.weight_v"])})
+    m = m.to(dev)
+    with torch.no_grad():
+        res, skip = m(T(x, dev), T(y, dev))
+    assert np.abs(npy(skip) - gold["2d_" + cname + "/skip"]).max() < 2e-5
+    if last:
+        assert res is None
+    else:
+        assert np.abs(npy(res) - gold["2d_" + cname + "/res"]).max() < 2e-5
+
+
 @pytest.mark.parametrize("name", ["micro", "c1", "c2"])
 def test_one_launch_layer_vs_two_launches(dev, precision, monkeypatch, name):
     """convlayer16h_kernel (wg_layer16h.h): one launch per WN layer -- gate conv -> gate -> W_o -> residual / skip, model/waveglow.py:41-46 --
