@@ -121,15 +121,20 @@ class _WaveFlowFn(Function):
         grads, dmel, dx = model._engine.backward([None if t is None else t.detach() for t in table], ctx.tape, h, dz, dlogdet,
                                                  ctx.needs_input_grad[2], ctx.needs_input_grad[1])
         by_id = {id(t): g for t, g in zip(table, grads) if t is not None}
+        mix = model._mix_modules()
+        for m, t in zip(mix, table[len(table) - len(mix):]):
+            if t is not m.weight:                               # reverse_mode: the engine was handed M = W^-1, so dL/dW = -M^T (dL/dM) M^T
+                mt = t.squeeze(-1).double().t()
+                by_id[id(m.weight)] = (-(mt @ by_id[id(t)].squeeze(-1).double() @ mt)).float().unsqueeze(-1)
         return (None, dx, dmel) + tuple(by_id.get(id(p)) for p in model.parameters())
 
 
 class WaveFlow(FlowBase):
     def __init__(self, flows, n_group, n_mels, use_conv1x1, memory_efficient, reverse_mode=False, **kwargs):
         super().__init__(256, reverse_mode)
-        if reverse_mode:
-            # (base.py:20-28: forward would then be the row-by-row autoregressive loop, trained through reverse_mode_forward's buffers)
-            raise WgError("WaveFlow(reverse_mode=True) is not built into the HIP engine")
+        # reverse_mode=True (base.py:20-28): `forward` is then the row-by-row loop (wg_wf_inverse: no autograd -- the reference trains that
+        # direction through reverse_mode_forward's buffers, this engine does not) and `reverse` / `infer` the parallel map (wg_wf_forward,
+        # differentiable); the 1x1 convs, when present, swap too: W in the row loop, W^-1 in the parallel map (efficient_modules.py:30-56).
         self.flows, self.n_group, self.n_mels = flows, n_group, n_mels
         self.sub_sr = self._hop_length // n_group
         self.upsampler = nn.Sequential(
@@ -152,9 +157,27 @@ class WaveFlow(FlowBase):
         tab = [up.bias, g, v]
         for wn in self.WNs:
             tab += wn.param_table()
-        if hasattr(self, "invconv1x1"):
-            tab += [m.weight for m in self.invconv1x1]
-        return tab
+        mix = self._mix_modules()
+        # the engine applies its 1x1 matrix in the parallel map and the inverse of it in the row loop: under reverse_mode hand it W^-1
+        return tab + (self._inverse_mats(mix) if mix and self._reverse_mode else [m.weight for m in mix])
+
+    def _mix_modules(self):
+        return list(self.invconv1x1) if hasattr(self, "invconv1x1") else []
+
+    def _inverse_mats(self, mix):
+        """W^-1 of every 1x1, recomputed when a weight changed.  The tensors live as long as the model and are rewritten IN PLACE, so that
+        their version counters tell the engine's pack cache (a fresh temporary could reuse a freed address at version 0)."""
+        key = tuple((m.weight.data_ptr(), m.weight._version) for m in mix)
+        if getattr(self, "_inv_key", None) != key:
+            new = [torch.linalg.inv(m.weight.detach().squeeze(-1).double()).float().contiguous().unsqueeze(-1) for m in mix]
+            old = getattr(self, "_inv", None)
+            if old is not None and old[0].device == new[0].device:
+                for a, b in zip(old, new):
+                    a.copy_(b)
+            else:
+                self._inv = new
+            self._inv_key = key
+        return self._inv
 
     def _check(self, x: Tensor, h: Tensor):
         if x.dim() != 2 or h.dim() != 3:
@@ -172,6 +195,7 @@ class WaveFlow(FlowBase):
 
     def reverse_computation(self, z: Tensor, h: Tensor) -> Tuple[Tensor, Tensor]:
         self._check(z, h)
-        if torch.is_grad_enabled() and (z.requires_grad or h.requires_grad):
-            warnings.warn("WaveFlow.reverse runs without autograd in the HIP engine", stacklevel=3)
+        if torch.is_grad_enabled() and (z.requires_grad or h.requires_grad or
+                                        (self._reverse_mode and any(p.requires_grad for p in self.parameters()))):
+            warnings.warn("WaveFlow's row-by-row direction runs without autograd in the HIP engine", stacklevel=3)
         return self._engine.inverse([None if t is None else t.detach() for t in self.param_table()], z.detach(), h.detach())

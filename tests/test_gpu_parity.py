@@ -1050,6 +1050,44 @@ def test_waveflow_model_vs_reference_golden(dev, golden_dir, precision, name):
     assert y_up.shape == gold["y_up"].shape and np.abs(y_up - gold["y_up"]).max() < 2e-6     # WaveFlow._upsample_h (waveflow.py:255-257)
 
 
+@pytest.mark.parametrize("name", ["wf8", "wf8c"])
+def test_waveflow_reverse_mode_vs_reference_golden(dev, golden_dir, precision, name):
+    """WaveFlow(reverse_mode=True) against the reference's own run (make_golden.waveflow_rm_fixture): `forward` is the row loop, `reverse` and
+    `infer` the parallel map (differentiable), the 1x1 convs swap direction with the model (base.py:20-28, efficient_modules.py:30-56)."""
+    cfg = fill.WF_CONFIGS[name]
+    B, N, F = fill.WF_SHAPES[name]
+    specs = fill.waveflow_param_specs(cfg)
+    P = fill.fill_params(specs, name + "/")
+    audio, mel = fill.waveflow_inputs(name, B, N, F, cfg["n_mels"])
+    gold = np.load(os.path.join(golden_dir, "model_%s_rm.npz" % name))
+    m = cm.WaveFlow(memory_efficient=False, reverse_mode=True, bias=False, **dict({"use_conv1x1": False}, **cfg))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    m = m.to(dev)
+    with torch.no_grad():
+        z, ld = m(T(audio, dev), T(mel, dev))
+    assert np.abs(npy(z) - gold["z"]).max() < Z_ATOL
+    assert logdet_close(npy(ld), gold["logdet"], N)
+    ht = T(mel, dev).requires_grad_(True)
+    x, ldx = m.reverse(T(gold["z"], dev), ht)
+    loss = cm.WaveGlowLoss(fill.SIGMA)(x, ldx)
+    loss.backward()
+    assert np.abs(npy(x) - gold["x_rev"]).max() < Z_ATOL and np.abs(npy(x) - audio).max() < Z_ATOL
+    assert logdet_close(npy(ldx), gold["logdet_rev"], N)
+    assert abs(float(loss) - float(gold["loss"])) < LOSS_ATOL
+    assert relmax(npy(ht.grad), gold["dmel"]) < GRAD_RTOL
+    named = dict(m.named_parameters())
+    for i, (n, _, _) in enumerate(specs):
+        if n.endswith("start.weight_v"):
+            continue
+        g = npy(named[n].grad).astype(np.float64)
+        assert abs(np.sqrt((g ** 2).sum()) - float(gold["grad_norm"][i])) <= GRAD_RTOL * float(gold["grad_norm"][i]) + 1e-12, n
+        if "grad::" + n in gold:
+            assert relmax(g, gold["grad::" + n]) < GRAD_RTOL, n
+    torch.manual_seed(3)
+    y = m.infer(T(mel, dev)[0], 0.7)                              # infer = the parallel map on a fresh latent
+    assert y.shape == (mel.shape[2] * 256,) and bool(torch.isfinite(y).all())
+
+
 def test_waveflow_two_forwards_before_backward(dev, precision):
     """Two forwards of the same shape, then backward through BOTH (two losses / gradient accumulation): each autograd node owns
     the tape of its own forward, so the first backward recomputes from the first call's flow inputs, not the second's."""

@@ -220,6 +220,42 @@ def test_wsr_cond_edge_cases():
 
 # ---- WaveFlow ---------------------------------------------------------------------------------------
 
+@pytest.mark.parametrize("name", ["wf8", "wf8c"])
+def test_waveflow_reverse_mode_matches_reference(golden_dir, name):
+    """WaveFlow(reverse_mode=True) (model/base.py:20-28; make_golden.waveflow_rm_fixture): `forward` = the row loop, `reverse` = the parallel
+    map, the 1x1 convs swapped as well -- for the oracle that is the SAME two functions with the matrices W^-1 in the parameter table."""
+    from oracle import wf_oracle as wfo
+    cfg = fill.WF_CONFIGS[name]
+    B, N, F = fill.WF_SHAPES[name]
+    specs = fill.waveflow_param_specs(cfg)
+    P = fill.fill_params(specs, name + "/")
+    audio, mel = fill.waveflow_inputs(name, B, N, F, cfg["n_mels"])
+    G = np.load(os.path.join(golden_dir, "model_%s_rm.npz" % name))
+    tab = fill.table(specs, P)
+    mix = [i for i, (n, _, _) in enumerate(specs) if "invconv1x1" in n]
+    for i in mix:
+        tab[i] = np.linalg.inv(tab[i][:, :, 0].astype(np.float64)).astype(np.float32)[:, :, None]
+    oc = wfo.make_config(**cfg)
+    z, ld = wfo.inverse(oc, tab, audio, mel)
+    assert np.abs(z - G["z"]).max() < 2e-5                        # (the row loop amplifies rounding: 2e-5 as for the model's own inverse)
+    assert _logdet_close(ld, G["logdet"], N)
+    r = wfo.train_step(oc, tab, G["z"], mel, fill.SIGMA, need_dmel=True)
+    assert np.abs(r["z"] - G["x_rev"]).max() < 2e-5 and np.abs(r["z"] - audio).max() < 5e-5
+    assert _logdet_close(r["logdet"], G["logdet_rev"], N)
+    assert abs(r["loss"] - float(G["loss"])) < 1e-6
+    assert np.abs(r["dmel"] - G["dmel"]).max() < 1e-5 * np.abs(G["dmel"]).max()
+    for i, (n, _, _) in enumerate(specs):
+        g = r["grads"][i].astype(np.float64)
+        if n.endswith("start.weight_v"):
+            continue
+        if i in mix:                                              # dL/dW = -M^T (dL/dM) M^T with M = W^-1
+            mt = tab[i][:, :, 0].astype(np.float64).T
+            g = -(mt @ g[:, :, 0] @ mt)[:, :, None]
+            assert np.abs(g - G["grad::" + n]).max() <= 2e-5 * np.abs(G["grad::" + n]).max(), n
+        gn = float(np.sqrt((g ** 2).sum()))
+        assert abs(gn - float(G["grad_norm"][i])) <= 2e-5 * float(G["grad_norm"][i]) + 1e-12, n
+
+
 @pytest.mark.parametrize("name", ["wf8", "wf64", "wf8c", "wf64c"])
 @pytest.mark.parametrize("double", [False, True])
 def test_waveflow_matches_reference(golden_dir, name, double):
