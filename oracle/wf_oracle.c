@@ -38,6 +38,7 @@ typedef struct {
     int32_t flows, n_group, n_mels;
     int32_t res_ch, dil_ch, skip_ch;
     int32_t use_conv1x1;        /* WaveFlow(use_conv1x1=True): parameters invconv1x1.{k}.weight [H,H,1] follow the WN2D tables */
+    int32_t bias;               /* WN2D(bias=True) (waveflow.py:77,100-122): every conv of every WN2D has a bias */
 } wfo_config;
 
 static void *xmalloc(size_t n)
@@ -163,8 +164,10 @@ static void wn_bwd(const float *g, const float *v, const real *dw, int rows, int
 
 /* parameter table = named_parameters() order of WaveFlow(use_conv1x1=False, bias=False):
  *   0 upsampler.1.bias  1 upsampler.1.weight_g  2 upsampler.1.weight_v
- *   per flow (37 entries): V.g V.v start.g start.v {W.g W.v W_o.g W_o.v} x 8  end.weight */
-#define WF_PF (4 + 4 * WF_DEPTH + 1)
+ *   per flow (37 entries): V.g V.v start.g start.v {W.g W.v W_o.g W_o.v} x 8  end.weight
+ *   bias=True: 19 more per flow behind end.weight -- V.bias start.bias {W.bias W_o.bias} x 8 end.bias (the order of the 1-D WN's table) */
+#define WF_PW (4 + 4 * WF_DEPTH + 1)
+#define WF_PF (WF_PW + (cf->bias ? 2 + 2 * WF_DEPTH + 1 : 0))
 WFO_API int wfo_param_count(const wfo_config *cf) { return 3 + cf->flows * WF_PF + (cf->use_conv1x1 ? cf->flows : 0); }
 
 typedef struct {            /* effective (weight-normed) weights of one flow */
@@ -173,6 +176,7 @@ typedef struct {            /* effective (weight-normed) weights of one flow */
     real *W[WF_DEPTH];      /* [2 Cd][C][3][3] */
     real *Wo[WF_DEPTH];     /* [rows_i][Cd] */
     real *end;              /* [2][Cs] */
+    real *bV, *bstart, *bW[WF_DEPTH], *bWo[WF_DEPTH], *bend;      /* the biases (zeros without bias=True) */
 } flow_w;
 
 static int wo_rows(const wfo_config *cf, int i) { return i == WF_DEPTH - 1 ? cf->skip_ch : cf->res_ch + cf->skip_ch; }
@@ -192,11 +196,25 @@ static void flow_w_build(const wfo_config *cf, const float *const *p, flow_w *w)
     }
     w->end = ralloc((size_t)2 * Cs);
     for (int j = 0; j < 2 * Cs; ++j) w->end[j] = (real)p[4 + 4 * WF_DEPTH][j];
+    const float *const *pb = cf->bias ? p + WF_PW : NULL;
+    w->bV = rzalloc((size_t)16 * Cd); w->bstart = rzalloc(C); w->bend = rzalloc(2);
+    if (pb) {
+        for (int j = 0; j < 16 * Cd; ++j) w->bV[j] = (real)pb[0][j];
+        for (int j = 0; j < C; ++j) w->bstart[j] = (real)pb[1][j];
+        for (int j = 0; j < 2; ++j) w->bend[j] = (real)pb[2 + 2 * WF_DEPTH][j];
+    }
+    for (int i = 0; i < WF_DEPTH; ++i) {
+        w->bW[i] = rzalloc((size_t)2 * Cd); w->bWo[i] = rzalloc((size_t)wo_rows(cf, i));
+        if (pb) {
+            for (int j = 0; j < 2 * Cd; ++j) w->bW[i][j] = (real)pb[2 + 2 * i][j];
+            for (int j = 0; j < wo_rows(cf, i); ++j) w->bWo[i][j] = (real)pb[3 + 2 * i][j];
+        }
+    }
 }
 static void flow_w_free(flow_w *w)
 {
-    free(w->V); free(w->start); free(w->end);
-    for (int i = 0; i < WF_DEPTH; ++i) { free(w->W[i]); free(w->Wo[i]); }
+    free(w->V); free(w->start); free(w->end); free(w->bV); free(w->bstart); free(w->bend);
+    for (int i = 0; i < WF_DEPTH; ++i) { free(w->W[i]); free(w->Wo[i]); free(w->bW[i]); free(w->bWo[i]); }
 }
 
 /* ---- upsampler ------------------------------------------------------------------------------------------------------- */
@@ -250,7 +268,7 @@ static void layer_rows(const wfo_config *cf, const flow_w *w, int i, int hd, int
     for (int r = r0; r < r1; ++r)
         for (int t = 0; t < Wd; ++t) {
             for (int m = 0; m < 2 * Cd; ++m) {
-                real acc = vy[((long)i * 2 * Cd + m) * Wd + t];
+                real acc = vy[((long)i * 2 * Cd + m) * Wd + t] + w->bW[i][m];
                 for (int kh = 0; kh < 3; ++kh) {
                     const int rr = r + (kh - 2) * hd;
                     if (rr < 0) continue;
@@ -271,7 +289,7 @@ static void layer_rows(const wfo_config *cf, const flow_w *w, int i, int hd, int
                 gate[idx] = a * b;
             }
             for (int m = 0; m < rows; ++m) {
-                real acc = 0;
+                real acc = w->bWo[i][m];
                 for (int c = 0; c < Cd; ++c) acc += w->Wo[i][(long)m * Cd + c] * gate[((long)c * R + r) * Wd + t];
                 o[m] = acc;
             }
@@ -291,7 +309,7 @@ static void cond_project(const wfo_config *cf, const flow_w *w, const real *y, i
     const int M = cf->n_mels, rows = 16 * cf->dil_ch;
     for (int m = 0; m < rows; ++m)
         for (int t = 0; t < Wd; ++t) {
-            real acc = 0;
+            real acc = w->bV[m];
             for (int c = 0; c < M; ++c) acc += w->V[(long)m * M + c] * y[(long)c * Wd + t];
             vy[(long)m * Wd + t] = acc;
         }
@@ -307,13 +325,13 @@ static void wn_forward(const wfo_config *cf, const flow_w *w, const int *hd, con
     real *vy = ralloc((size_t)16 * cf->dil_ch * Wd);
     cond_project(cf, w, y, Wd, vy);
     for (int c = 0; c < C; ++c)
-        for (long e = 0; e < (long)R * Wd; ++e) sv->hin[0][(long)c * R * Wd + e] = w->start[c] * x[e];
+        for (long e = 0; e < (long)R * Wd; ++e) sv->hin[0][(long)c * R * Wd + e] = w->start[c] * x[e] + w->bstart[c];
     memset(sv->S, 0, sizeof(real) * Cs * R * Wd);
     real *spare = ralloc((size_t)C * R * Wd);
     for (int i = 0; i < WF_DEPTH; ++i)
         layer_rows(cf, w, i, hd[i], R, Wd, 0, R, sv->hin[i], vy, sv->tw[i], sv->sf[i], sv->gate[i], i < WF_DEPTH - 1 ? sv->hin[i + 1] : spare, sv->S);
     for (long e = 0; e < (long)R * Wd; ++e) {
-        real a = 0, b = 0;
+        real a = w->bend[0], b = w->bend[1];
         for (int c = 0; c < Cs; ++c) { a += w->end[c] * sv->S[(long)c * R * Wd + e]; b += w->end[Cs + c] * sv->S[(long)c * R * Wd + e]; }
         ls[e] = a; tt[e] = b;
     }
@@ -425,11 +443,11 @@ WFO_API int wfo_inverse(const wfo_config *cf, const float *const *params, const 
             for (int r = 0; r < R; ++r) {
                 /* WN row r from input rows <= r, then x[r+1] = (z[r+1] - t[r]) / exp(ls[r]) */
                 for (int c = 0; c < C; ++c)
-                    for (int t = 0; t < Wd; ++t) sv.hin[0][((long)c * R + r) * Wd + t] = w->start[c] * x[(long)r * Wd + t];
+                    for (int t = 0; t < Wd; ++t) sv.hin[0][((long)c * R + r) * Wd + t] = w->start[c] * x[(long)r * Wd + t] + w->bstart[c];
                 for (int i = 0; i < WF_DEPTH; ++i)
                     layer_rows(cf, w, i, hd[i], R, Wd, r, r + 1, sv.hin[i], vy, NULL, NULL, sv.gate[i], i < WF_DEPTH - 1 ? sv.hin[i + 1] : spare, sv.S);
                 for (int t = 0; t < Wd; ++t) {
-                    real a = 0, bb = 0;
+                    real a = w->bend[0], bb = w->bend[1];
                     for (int c = 0; c < Cs; ++c) {
                         const real sv_ = sv.S[((long)c * R + r) * Wd + t];
                         a += w->end[c] * sv_; bb += w->end[Cs + c] * sv_;
@@ -453,6 +471,7 @@ WFO_API int wfo_inverse(const wfo_config *cf, const float *const *params, const 
 /* ---- training step: forward, NLL (loss.py:10-15), backward ----------------------------------------------------------------- */
 typedef struct {            /* gradient accumulators of one flow's EFFECTIVE weights */
     real *V, *start, *W[WF_DEPTH], *Wo[WF_DEPTH], *end;
+    real *bV, *bstart, *bW[WF_DEPTH], *bWo[WF_DEPTH], *bend;
 } flow_g;
 static void flow_g_alloc(const wfo_config *cf, flow_g *g)
 {
@@ -461,11 +480,13 @@ static void flow_g_alloc(const wfo_config *cf, flow_g *g)
     g->start = rzalloc(C);
     for (int i = 0; i < WF_DEPTH; ++i) { g->W[i] = rzalloc((size_t)2 * Cd * C * 9); g->Wo[i] = rzalloc((size_t)wo_rows(cf, i) * Cd); }
     g->end = rzalloc((size_t)2 * Cs);
+    g->bV = rzalloc((size_t)16 * Cd); g->bstart = rzalloc(C); g->bend = rzalloc(2);
+    for (int i = 0; i < WF_DEPTH; ++i) { g->bW[i] = rzalloc((size_t)2 * Cd); g->bWo[i] = rzalloc((size_t)wo_rows(cf, i)); }
 }
 static void flow_g_free(flow_g *g)
 {
-    free(g->V); free(g->start); free(g->end);
-    for (int i = 0; i < WF_DEPTH; ++i) { free(g->W[i]); free(g->Wo[i]); }
+    free(g->V); free(g->start); free(g->end); free(g->bV); free(g->bstart); free(g->bend);
+    for (int i = 0; i < WF_DEPTH; ++i) { free(g->W[i]); free(g->Wo[i]); free(g->bW[i]); free(g->bWo[i]); }
 }
 static void flow_g_add(const wfo_config *cf, flow_g *a, const flow_g *b)
 {
@@ -477,6 +498,13 @@ static void flow_g_add(const wfo_config *cf, flow_g *a, const flow_g *b)
         for (long j = 0; j < (long)wo_rows(cf, i) * Cd; ++j) a->Wo[i][j] += b->Wo[i][j];
     }
     for (int j = 0; j < 2 * Cs; ++j) a->end[j] += b->end[j];
+    for (int j = 0; j < 16 * Cd; ++j) a->bV[j] += b->bV[j];
+    for (int j = 0; j < C; ++j) a->bstart[j] += b->bstart[j];
+    for (int j = 0; j < 2; ++j) a->bend[j] += b->bend[j];
+    for (int i = 0; i < WF_DEPTH; ++i) {
+        for (int j = 0; j < 2 * Cd; ++j) a->bW[i][j] += b->bW[i][j];
+        for (int j = 0; j < wo_rows(cf, i); ++j) a->bWo[i][j] += b->bWo[i][j];
+    }
 }
 
 /* WN2D backward on one item: given d log_s, d t [R][Wd] -> dx [R][Wd] (added), dy [n_mels][Wd] (added), weight grads (added) */
@@ -497,6 +525,7 @@ static void wn_backward(const wfo_config *cf, const flow_w *w, const int *hd, co
         }
         g->end[c] += ga; g->end[Cs + c] += gb;
     }
+    for (long e = 0; e < RW; ++e) { g->bend[0] += dls[e]; g->bend[1] += dtt[e]; }
     for (int i = WF_DEPTH - 1; i >= 0; --i) {
         const int d = 1 << i, rows = wo_rows(cf, i), last = i == WF_DEPTH - 1;
         /* do = last ? dS : cat(dh_{i+1}, dS) ; dW_o += do gate^T ; dgate = W_o^T do */
@@ -520,14 +549,23 @@ static void wn_backward(const wfo_config *cf, const flow_w *w, const int *hd, co
                 g->Wo[i][(long)m * Cd + c] += acc;
             }
         }
+        for (int m = 0; m < rows; ++m) {
+            real acc = 0;
+            for (long e = 0; e < RW; ++e) acc += last ? dS[(long)m * RW + e] : (m < C ? dh[(long)m * RW + e] : dS[(long)(m - C) * RW + e]);
+            g->bWo[i][m] += acc;
+        }
         /* xy = W (*) hin + V_i y : dW, dV_i y part, dhin */
         for (int m = 0; m < 2 * Cd; ++m) {
             const real *dp = dxy + (long)m * RW;
+            real tot = 0;
             for (int t = 0; t < Wd; ++t) {
                 real acc = 0;
                 for (int r = 0; r < R; ++r) acc += dp[(long)r * Wd + t];
                 dvy[((long)i * 2 * Cd + m) * Wd + t] = acc;          /* the conditioning is broadcast over rows (waveflow.py:123) */
+                tot += acc;
             }
+            g->bW[i][m] += tot;
+            g->bV[(long)i * 2 * Cd + m] += tot;                      /* V.bias and W.bias meet in the same pre-activation */
         }
         /* residual path: dh_i = (last ? 0 : dh_{i+1}) + W^T (*) dxy */
         if (last) memset(dhn, 0, sizeof(real) * C * RW);
@@ -569,8 +607,10 @@ static void wn_backward(const wfo_config *cf, const flow_w *w, const int *hd, co
     /* start: h0 = w_start[c] x */
     for (int c = 0; c < C; ++c) {
         real acc = 0;
-        for (long e = 0; e < RW; ++e) { acc += dh[(long)c * RW + e] * x[e]; dx[e] += w->start[c] * dh[(long)c * RW + e]; }
+        real bacc = 0;
+        for (long e = 0; e < RW; ++e) { acc += dh[(long)c * RW + e] * x[e]; dx[e] += w->start[c] * dh[(long)c * RW + e]; bacc += dh[(long)c * RW + e]; }
         g->start[c] += acc;
+        g->bstart[c] += bacc;
     }
     free(dS); free(dh); free(dhn); free(dxy); free(dvy);
 }
@@ -713,6 +753,16 @@ WFO_API int wfo_train_step(const wfo_config *cf, const float *const *params, con
             wn_bwd(p[6 + 4 * i], p[7 + 4 * i], fg[k].Wo[i], wo_rows(cf, i), cf->dil_ch, g[6 + 4 * i], g[7 + 4 * i]);
         }
         for (int j = 0; j < 2 * cf->skip_ch; ++j) g[4 + 4 * WF_DEPTH][j] = (float)fg[k].end[j];
+        if (cf->bias) {
+            float *const *gb = g + WF_PW;
+            for (int j = 0; j < 16 * cf->dil_ch; ++j) gb[0][j] = (float)fg[k].bV[j];
+            for (int j = 0; j < cf->res_ch; ++j) gb[1][j] = (float)fg[k].bstart[j];
+            for (int i = 0; i < WF_DEPTH; ++i) {
+                for (int j = 0; j < 2 * cf->dil_ch; ++j) gb[2 + 2 * i][j] = (float)fg[k].bW[i][j];
+                for (int j = 0; j < wo_rows(cf, i); ++j) gb[3 + 2 * i][j] = (float)fg[k].bWo[i][j];
+            }
+            for (int j = 0; j < 2; ++j) gb[2 + 2 * WF_DEPTH][j] = (float)fg[k].bend[j];
+        }
         flow_w_free(&fw[k]); flow_g_free(&fg[k]);
         if (conv) {
             float *gw = grads[3 + nf * WF_PF + k];

@@ -17,12 +17,12 @@ _LIBS = {}
 
 
 class Config(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("flows", "n_group", "n_mels", "res_ch", "dil_ch", "skip_ch", "use_conv1x1")]
+    _fields_ = [(n, C.c_int32) for n in ("flows", "n_group", "n_mels", "res_ch", "dil_ch", "skip_ch", "use_conv1x1", "bias")]
 
 
-def make_config(flows, n_group, n_mels, dilation_channels=256, residual_channels=256, skip_channels=256, use_conv1x1=False, **_unused):
+def make_config(flows, n_group, n_mels, dilation_channels=256, residual_channels=256, skip_channels=256, use_conv1x1=False, bias=False, **_unused):
     """keyword names of the reference's WaveFlow(**arch.args) (model/waveflow.py:156-162, configs/waveflow_LJ_speech.json)"""
-    return Config(flows, n_group, n_mels, residual_channels, dilation_channels, skip_channels, int(bool(use_conv1x1)))
+    return Config(flows, n_group, n_mels, residual_channels, dilation_channels, skip_channels, int(bool(use_conv1x1)), int(bool(bias)))
 
 
 def _lib(double=False):

@@ -215,6 +215,11 @@ def waveflow_param_specs(cfg):
             specs += [(p + "layers.%d.W.weight_g" % i, (2 * Cd, 1, 1, 1), "g"), (p + "layers.%d.W.weight_v" % i, (2 * Cd, C, 3, 3), "v"),
                       (p + "layers.%d.W_o.weight_g" % i, (rows, 1, 1, 1), "g"), (p + "layers.%d.W_o.weight_v" % i, (rows, Cd, 1, 1), "v")]
         specs.append((p + "end.weight", (2, Cs, 1, 1), "end"))
+        if cfg.get("bias"):                                # WN2D(bias=True) (waveflow.py:77): table order as the 1-D WN's, behind end.weight
+            specs += [(p + "V.bias", (16 * Cd,), "bias"), (p + "start.bias", (C,), "bias")]
+            for i in range(8):
+                specs += [(p + "layers.%d.W.bias" % i, (2 * Cd,), "bias"), (p + "layers.%d.W_o.bias" % i, (Cs if i == 7 else C + Cs,), "bias")]
+            specs.append((p + "end.bias", (2,), "bias"))
     if cfg.get("use_conv1x1"):                             # registered after WNs (waveflow.py:176-181): invconv1x1.{k}.weight [H, H, 1]
         specs += [("invconv1x1.%d.weight" % k, (H, H, 1), "orth") for k in range(cfg["flows"])]
     return specs
@@ -229,8 +234,12 @@ WF_CONFIGS = {
 # use_conv1x1=True: an invertible 1x1 conv over the height axis replaces the flip between flows (waveflow.py:203-206)
 WF_CONFIGS["wf8c"] = dict(WF_CONFIGS["wf8"], use_conv1x1=True)
 WF_CONFIGS["wf64c"] = dict(WF_CONFIGS["wf64"], use_conv1x1=True)
+# WN2D(bias=True) (no shipped config sets it): a bias on every conv of every WN2D
+WF_CONFIGS["wf8b"] = dict(WF_CONFIGS["wf8"], bias=True)
+WF_CONFIGS["wf64b"] = dict(WF_CONFIGS["wf64"], bias=True)
 WF_SHAPES = {"wf8": (2, 8 * 96, 3), "wf64": (2, 64 * 24, 6)}       # (batch, samples, mel frames)
 WF_SHAPES["wf8c"], WF_SHAPES["wf64c"] = WF_SHAPES["wf8"], WF_SHAPES["wf64"]
+WF_SHAPES["wf8b"], WF_SHAPES["wf64b"] = WF_SHAPES["wf8"], WF_SHAPES["wf64"]
 
 
 def waveflow_inputs(tag, B, N, F, n_mels):

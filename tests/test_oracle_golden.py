@@ -256,12 +256,13 @@ def test_waveflow_reverse_mode_matches_reference(golden_dir, name):
         assert abs(gn - float(G["grad_norm"][i])) <= 2e-5 * float(G["grad_norm"][i]) + 1e-12, n
 
 
-@pytest.mark.parametrize("name", ["wf8", "wf64", "wf8c", "wf64c"])
+@pytest.mark.parametrize("name", ["wf8", "wf64", "wf8c", "wf64c", "wf8b", "wf64b"])
 @pytest.mark.parametrize("double", [False, True])
 def test_waveflow_matches_reference(golden_dir, name, double):
     """oracle/wf_oracle.c against the reference's WaveFlow (model/waveflow.py) run by make_golden.waveflow_fixture:
     z, logdet, loss, every parameter-gradient norm and head, d loss / d mel, and the row-by-row inverse.
-    "wf8c" / "wf64c": use_conv1x1=True (an invertible 1x1 conv over the height axis instead of the flip, waveflow.py:203-206)."""
+    "wf8c" / "wf64c": use_conv1x1=True (an invertible 1x1 conv over the height axis instead of the flip, waveflow.py:203-206);
+    "wf8b" / "wf64b": WN2D(bias=True) (waveflow.py:77), every bias gradient stored in full."""
     from oracle import wf_oracle as wfo
     cfg = fill.WF_CONFIGS[name]
     B, N, F = fill.WF_SHAPES[name]
