@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WGFLOW_LIB") or os.path.join(_HERE, "csrc", "libwgflow.so")   # WGFLOW_LIB: developer A/B builds
 _LIB = None
 
-ABI_VERSION = 6          # include/wgflow.h WG_ABI_VERSION (6: wg_stat_layer_launches; workspaces carry the one-launch layer's counters)
+ABI_VERSION = 7          # include/wgflow.h WG_ABI_VERSION (7: wg_wf_config gained bias)
 ABI_SYMBOLS = [
     "wg_strerror", "wg_abi_version", "wg_param_count", "wg_packed_bytes", "wg_workspace_bytes",
     "wg_wn_param_count", "wg_wn_packed_bytes", "wg_coupling_workspace_bytes", "wg_invconv_workspace_bytes",
@@ -34,7 +34,7 @@ class WgConfig(C.Structure):
 
 
 class WgWfConfig(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("flows", "n_group", "n_mels", "res_ch", "dil_ch", "skip_ch", "precision", "use_conv1x1")]
+    _fields_ = [(n, C.c_int32) for n in ("flows", "n_group", "n_mels", "res_ch", "dil_ch", "skip_ch", "precision", "use_conv1x1", "bias")]
 
 
 class WgWnDims(C.Structure):

@@ -41,7 +41,7 @@ __device__ __forceinline__ float *paddr(const PRef &r, const Geo &g, int b, int 
 #define WG_TILE 128        // output tile edge (M and N) of both kernels
 #define WG_BK 16           // channels per chunk (convgemm)
 #define WG_WBK 32          // time steps per chunk (wgrad)
-#define WG_MAX_SEG 10     // 3x3 taps + conditioning (WaveFlow); the 1-D WN uses 4
+#define WG_MAX_SEG 11     // 3x3 taps + conditioning + the ones segment of a WN2D with biases (WaveFlow); the 1-D WN uses 4 or 5
 
 // ------------------------------------------------------------------------------------------------
 // shared inner product: acc[mi][ni] += As[k][wr*64 + mi*32 + r] * Bs[k][wc*64 + ni*32 + c], k < BKK

@@ -132,6 +132,7 @@ __global__ __launch_bounds__(256) void wf_upsample_bwd_kernel(const WfUpBwdArgs 
 // ------------------------------------------------------------------------------------------------
 struct WfCoupleArgs {
     const float *endw;      // [2][Cs]
+    const float *endb;      // [2]: WN2D(bias=True)'s end.bias, or null
     PRef S;                 // cumulated skip [rows][Cs][P]
     int Cs;
     PRef X, Xn;             // current / next flow state (1 channel)
@@ -160,7 +161,7 @@ __device__ __forceinline__ void wf_couple_body(const WfCoupleArgs &a, int blk, i
     if (a.mode == 3) {                                         // (log_s, t) of the row as they are
         if (r >= a.raw_rows) return;
         for (int t = tid; t < g.T; t += NT) {
-            float ls = 0.f, tt = 0.f;
+            float ls = a.endb ? a.endb[0] : 0.f, tt = a.endb ? a.endb[1] : 0.f;
             for (int c = 0; c < a.Cs; ++c) {
                 const float s = *paddr(a.S, g, row, c, t);
                 ls = fmaf(a.endw[c], s, ls);
@@ -185,7 +186,7 @@ __device__ __forceinline__ void wf_couple_body(const WfCoupleArgs &a, int blk, i
         return;
     }
     for (int t = tid; t < g.T; t += NT) {
-        float ls = 0.f, tt = 0.f;
+        float ls = a.endb ? a.endb[0] : 0.f, tt = a.endb ? a.endb[1] : 0.f;
         for (int c = 0; c < a.Cs; ++c) {
             const float s = *paddr(a.S, g, row, c, t);
             ls = fmaf(a.endw[c], s, ls);
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(1024) void wf_couple_row_kernel(const WfCoupleArgs 
     float lsum = 0.f;
     for (int t0 = 0; t0 < g.T; t0 += 256) {                    // (every thread takes part in every barrier)
         const int t = t0 + tq;
-        float ls = 0.f, tt = 0.f;
+        float ls = (!cq && a.endb) ? a.endb[0] : 0.f, tt = (!cq && a.endb) ? a.endb[1] : 0.f;
         if (t < g.T) {
 #pragma unroll 8
             for (int c = c0; c < c1; ++c) {

@@ -196,7 +196,7 @@ int wn_check(const WnD &d)
     if (d.ic < 1 || d.aux < 1 || d.depth < 1 || d.depth > 16) return WG_EINVAL;
     if (d.mode2d ? d.radix != 9 : (d.radix != 1 && d.radix != 3)) return WG_EUNSUPPORTED;   // 1-D: kernels 1 and 3; 2-D: 3x3
     if (d.C % 32 || d.Cd % 32 || d.Cs % 32) return WG_EUNSUPPORTED;       // MFMA tile granularity
-    if (d.bias && (d.mode2d || d.radix + 2 > WG_MAX_SEG)) return WG_EUNSUPPORTED;   // the ones segment needs a free K-segment slot (WN2D: 9 taps + conditioning fill all ten)
+    if (d.bias && d.radix + 2 > WG_MAX_SEG) return WG_EUNSUPPORTED;      // the ones segment needs a K-segment slot (WN2D: 9 taps + conditioning + ones = 11)
     if (2 * d.ic > WG_MAXC) return WG_EUNSUPPORTED;                       // end-conv rows handled by one MFMA tile
     if (d.C * d.radix > WG_FIN_MAXCOLS || d.aux > WG_FIN_MAXCOLS || d.Cd > WG_FIN_MAXCOLS) return WG_EUNSUPPORTED;
     return 0;
@@ -2042,7 +2042,7 @@ WnD wf_wn(const wg_wf_config *cf)
 {
     WnD d;
     d.ic = 1; d.aux = cf->n_mels; d.C = cf->res_ch; d.Cd = cf->dil_ch; d.Cs = cf->skip_ch; d.depth = 8; d.radix = 9;
-    d.prec = cf->precision; d.mode2d = 1;
+    d.prec = cf->precision; d.mode2d = 1; d.bias = cf->bias ? 1 : 0;
     static const int d8[8] = {1, 1, 1, 1, 1, 1, 1, 1}, d32[8] = {1, 2, 4, 1, 2, 4, 1, 2}, d64[8] = {1, 2, 4, 8, 16, 1, 2, 4},
                      d128[8] = {1, 2, 4, 8, 16, 32, 64, 1};                 // waveflow.py:81-87
     const int *hd = cf->n_group == 32 ? d32 : cf->n_group == 64 ? d64 : cf->n_group == 128 ? d128 : d8;
@@ -2066,7 +2066,11 @@ struct WfPack {
     size_t ones, up_scale, wn[WG_MAX_FLOWS], mix, total;
     int mix_stride;             // use_conv1x1: per flow [W | W^-1 | logdet W] (floats from `mix`)
 };
-inline int wf_nparams(const wg_wf_config *cf) { return 3 + cf->flows * 37 + (cf->use_conv1x1 ? cf->flows : 0); }
+// parameter-table entries of one flow's WN2D: 37 weights (V.g V.v start.g start.v {W.g W.v W_o.g W_o.v} x 8 end.weight) and, with
+// bias=True, the 19 biases behind them (WnD::pb)
+inline int wf_pf(const wg_wf_config *cf) { return 37 + (cf->bias ? 19 : 0); }
+inline int wf_nparams(const wg_wf_config *cf) { return 3 + cf->flows * wf_pf(cf) + (cf->use_conv1x1 ? cf->flows : 0); }
+inline const float *wf_end_bias(const wg_wf_config *cf, const float *const *p, int k) { return cf->bias ? p[3 + wf_pf(cf) * k + 37 + 18] : nullptr; }
 WfPack wf_pack_layout(const wg_wf_config *cf)
 {
     WfPack L;
@@ -2150,12 +2154,12 @@ void run_hmix(Ctx &cx, const Geo &g, PRef src, PRef dst, const float *Mx, int tr
     WG_LAUNCH(cx, wf_hmix_kernel, dim3((g.T + 255) / 256, (g.rows + WF_MIX_ROWS - 1) / WF_MIX_ROWS, g.B / g.rows), dim3(256), 0, src, dst, g, Mx,
               transpose);
 }
-void wf_couple(Ctx &cx, const WnRun &r, const float *endw, int mode, PRef X, PRef Xn, PRef dXn, PRef dX, const float *dld,
+void wf_couple(Ctx &cx, const WnRun &r, const float *endw, const float *endb, int mode, PRef X, PRef Xn, PRef dXn, PRef dX, const float *dld,
                float *rowsum, int row_sel, int noflip = 0)
 {
     WfCoupleArgs a;
     memset(&a, 0, sizeof(a));
-    a.endw = endw;
+    a.endw = endw; a.endb = endb;
     a.S = pref(r.ws + r.w.skip, r.d.Cs); a.Cs = r.d.Cs;
     a.X = X; a.Xn = Xn; a.dXn = dXn; a.dX = dX;
     a.G = pref(r.ws + r.w.G, r.L.kp_end);
@@ -2668,9 +2672,9 @@ int wg_wf_pack_weights(const wg_wf_config *cf, const void *const *params, void *
     WG_LAUNCH(cx, fill_rows_kernel, dim3(WG_ONES / 256, 1, 1), dim3(256), 0, pref(ones, 1), Geo{1, WG_ONES, WG_ONES, 0, WG_ONES}, (const float *)nullptr, 1.0f);
     JobBatch jb(&cx);
     jb.norm(p[1], p[2], pk + L.up_scale, cf->n_mels, cf->n_mels * (2 * s + 1));      // ConvTranspose1d: dim 0 is the input channel
-    for (int k = 0; k < cf->flows; ++k) wn_pack_norms(jb, d, WL, p + 3 + 37 * k, pk + L.wn[k]);
+    for (int k = 0; k < cf->flows; ++k) wn_pack_norms(jb, d, WL, p + 3 + wf_pf(cf) * k, pk + L.wn[k]);
     jb.flush_norm();
-    for (int k = 0; k < cf->flows; ++k) wn_pack_mats(jb, d, WL, p + 3 + 37 * k, pk + L.wn[k], ones);
+    for (int k = 0; k < cf->flows; ++k) wn_pack_mats(jb, d, WL, p + 3 + wf_pf(cf) * k, pk + L.wn[k], ones);
     jb.flush_pack();
     ImgBatch ib(&cx);
     for (int k = 0; k < cf->flows; ++k) wn_pack_images(ib, d, WL, pk + L.wn[k]);
@@ -2679,7 +2683,7 @@ int wg_wf_pack_weights(const wg_wf_config *cf, const void *const *params, void *
         LuBigArgs lu;
         memset(&lu, 0, sizeof(lu));
         lu.n = cf->flows; lu.c = cf->n_group; lu.ostride = L.mix_stride; lu.out = pk + L.mix;
-        for (int k = 0; k < cf->flows; ++k) lu.W[k] = p[3 + 37 * cf->flows + k];
+        for (int k = 0; k < cf->flows; ++k) lu.W[k] = p[3 + wf_pf(cf) * cf->flows + k];
         const size_t lds = ((size_t)lu.c * (lu.c + 1) + lu.c) * sizeof(float);
         if (!cx.err) cx.err = ensure_dynamic_lds((const void *)lu_big_kernel, 0, lds);
         WG_LAUNCH(cx, lu_big_kernel, dim3(cf->flows), dim3(256), lds, lu);
@@ -2738,7 +2742,7 @@ int wg_wf_forward(const wg_wf_config *cf, const void *const *params, const void 
         r.pk = pk + L.wn[k]; r.X = pref(xk(k), 1);
         wn_forward(cx, r);                                                                                           // :197
         // x_next = cat(flip(xout), x0), or with the 1x1 conv W cat(x0, xout)                                        // :198-206
-        wf_couple(cx, r, p[3 + 37 * k + 36], 0, pref(xk(k), 1), pref(conv ? ws + W.Xt : xk(k + 1), 1), pnull(), pnull(), nullptr,
+        wf_couple(cx, r, p[3 + wf_pf(cf) * k + 36], wf_end_bias(cf, p, k), 0, pref(xk(k), 1), pref(conv ? ws + W.Xt : xk(k + 1), 1), pnull(), pnull(), nullptr,
                   ws + W.rowsum + (size_t)k * g.B, 0, conv);
         if (conv) run_hmix(cx, g, pref(ws + W.Xt, 1), pref(xk(k + 1), 1), pk + L.mix + (size_t)k * L.mix_stride, 0);
     }
@@ -2773,6 +2777,7 @@ int wg_wf_wn_apply(const wg_wf_config *cf, const void *const *params, const void
     WfCoupleArgs a;
     memset(&a, 0, sizeof(a));
     a.endw = (const float *)params[3 + 36];                    // end.weight [2][Cs][1][1], read as it is (like wf_couple)
+    a.endb = wf_end_bias(cf, (const float *const *)params, 0);
     a.S = pref(ws + W.wn.skip, r.d.Cs); a.Cs = r.d.Cs;
     a.g = g; a.mode = 3; a.raw_ls = log_s; a.raw_t = t; a.raw_rows = rows;
     WG_LAUNCH(cx, wf_couple_kernel, dim3(g.B), dim3(256), 0, a);
@@ -2825,7 +2830,7 @@ int wg_wf_inverse(const wg_wf_config *cf, const void *const *params, const void 
             cx.rec = &rec;
             cx.row_sel1 = 1;
             wn_forward(cx, r);
-            wf_couple(cx, r, p[3 + 37 * k + 36], 2, pref(Zf, 1), pref(Xb, 1), pnull(), pnull(), nullptr, ws + W.rowsum + (size_t)k * g.B, 0);
+            wf_couple(cx, r, p[3 + wf_pf(cf) * k + 36], wf_end_bias(cf, p, k), 2, pref(Zf, 1), pref(Xb, 1), pnull(), pnull(), nullptr, ws + W.rowsum + (size_t)k * g.B, 0);
             cx.rec = nullptr;
             cx.row_sel1 = 0;
 #if defined(WG_DBG_ROWWALK_HOSTREPLAY)   // debugging aid: the recorded program replayed launch by launch from the host
@@ -2879,7 +2884,7 @@ int wg_wf_inverse(const wg_wf_config *cf, const void *const *params, const void 
         for (int row = 0; row < H - 1 && !walked; ++row) {
             cx.row_sel1 = row + 1;
             wn_forward(cx, r);
-            wf_couple(cx, r, p[3 + 37 * k + 36], 2, pref(Zf, 1), pref(Xb, 1), pnull(), pnull(), nullptr,
+            wf_couple(cx, r, p[3 + wf_pf(cf) * k + 36], wf_end_bias(cf, p, k), 2, pref(Zf, 1), pref(Xb, 1), pnull(), pnull(), nullptr,
                       ws + W.rowsum + (size_t)k * g.B, row);                                                         // :236-243
         }
         cx.row_sel1 = 0;
@@ -2946,7 +2951,7 @@ int wg_wf_backward(const wg_wf_config *cf, const void *const *params, const void
             run_hmix(cx, g, pref((float *)Xn, 1), pref(ws + W.Xt, 1), mx + (size_t)H * H, 0);
             WG_LAUNCH(cx, wf_hgram_kernel, dim3((g.T + 63) / 64, B), dim3(256), (size_t)2 * H * 65 * sizeof(float), pref(dXn, 1), pref(ws + W.Xt, 1), g,
                       ws + W.gram);
-            float *dWk = gr[3 + 37 * cf->flows + k];
+            float *dWk = gr[3 + wf_pf(cf) * cf->flows + k];
             if (dWk)
                 WG_LAUNCH(cx, wf_hgram_reduce_kernel, dim3((H * H + 255) / 256), dim3(256), 0, (const float *)(ws + W.gram), W.gram_blocks, H,
                           mx + (size_t)H * H, dlogdet, B, (float)g.T, dWk);
@@ -2954,8 +2959,8 @@ int wg_wf_backward(const wg_wf_config *cf, const void *const *params, const void
         }
         r.pk = pk + L.wn[k]; r.X = pref((float *)Xk, 1);
         wn_forward(cx, r);
-        wf_couple(cx, r, p[3 + 37 * k + 36], 1, pref((float *)Xk, 1), pnull(), pref(conv ? ws + W.dXt : dXn, 1), pref(dXc, 1), dlogdet, nullptr, 0, conv);
-        wn_backward(cx, r, p + 3 + 37 * k, gr + 3 + 37 * k, pref(dXc, 1), ws + W.dYrow);
+        wf_couple(cx, r, p[3 + wf_pf(cf) * k + 36], wf_end_bias(cf, p, k), 1, pref((float *)Xk, 1), pnull(), pref(conv ? ws + W.dXt : dXn, 1), pref(dXc, 1), dlogdet, nullptr, 0, conv);
+        wn_backward(cx, r, p + 3 + wf_pf(cf) * k, gr + 3 + wf_pf(cf) * k, pref(dXc, 1), ws + W.dYrow);
         std::swap(dXn, dXc);
     }
     if (dx) WG_LAUNCH(cx, wf_unsqueeze_kernel, rgrid, dim3(256), 0, pref(dXn, 1), g, N, dx);

@@ -56,14 +56,14 @@ class NonCausalLayer2D(nn.Module):
 
 
 class WN2D(nn.Module):
-    """Parameter container of WN2D (waveflow.py:70-135)."""
+    """Parameter container of WN2D (waveflow.py:70-135).  bias=True (no shipped config sets it): every conv carries a bias -- in the kernels one
+    more K segment of ones behind the nine taps and the conditioning (csrc/wgflow.hip WnD::bias)."""
 
     H_DILATIONS = {8: [1] * 8, 16: [1] * 8, 32: [1, 2, 4] * 2 + [1, 2], 64: [1, 2, 4, 8, 16, 1, 2, 4], 128: [1, 2, 4, 8, 16, 32, 64, 1]}
 
     def __init__(self, n_group, aux_channels, dilation_channels=256, residual_channels=256, skip_channels=256, bias=False, zero_init=True):
         super().__init__()
-        if bias:
-            raise WgError("WN2D(bias=True) is not built into the HIP kernels (the reference config uses bias=False)")
+        self.has_bias = bool(bias)
         self.h_dilations = self.H_DILATIONS[n_group]
         self.dilations = [2 ** i for i in range(8)]
         self.n_group = n_group
@@ -81,12 +81,20 @@ class WN2D(nn.Module):
         self.end = nn.Conv2d(skip_channels, 2, 1, bias=bias)
         if zero_init:
             self.end.weight.data.zero_()
+            if bias:
+                self.end.bias.data.zero_()
 
     def param_table(self):
+        """the flow's part of the C-ABI table (include/wgflow.h wg_wf_config): 37 weights, then -- bias=True -- the 19 biases"""
         tab = list(conv_gv(self.V)) + list(conv_gv(self.start))
         for layer in self.layers:
             tab += list(conv_gv(layer.W)) + list(conv_gv(layer.W_o))
         tab.append(self.end.weight)
+        if self.has_bias:
+            tab += [self.V.bias, self.start.bias]
+            for layer in self.layers:
+                tab += [layer.W.bias, layer.W_o.bias]
+            tab.append(self.end.bias)
         return tab
 
     def forward(self, x, y):
@@ -96,7 +104,7 @@ class WN2D(nn.Module):
             warnings.warn("WN2D.forward on its own runs without autograd; gradients flow through WaveFlow", stacklevel=2)
         if getattr(self, "_engine", None) is None:
             self._engine = engine.WN2DEngine(WgWfConfig(1, self.n_group, self.aux_chs, self.res_chs, self.dil_chs, self.skp_chs,
-                                                         default_precision(), 0))
+                                                         default_precision(), 0, int(self.has_bias)))
         with torch.no_grad():
             return self._engine.apply([None if p is None else p.detach() for p in self.param_table()], x.float(), y.float())
 
@@ -148,7 +156,7 @@ class WaveFlow(FlowBase):
                 InvertibleConv1x1(n_group, memory_efficient=memory_efficient, reverse_mode=reverse_mode) for _ in range(flows))
         wn0 = self.WNs[0]
         self._engine = engine.WaveFlowEngine(WgWfConfig(flows, n_group, n_mels, wn0.res_chs, wn0.dil_chs, wn0.skp_chs, default_precision(),
-                                                        int(bool(use_conv1x1))))
+                                                        int(bool(use_conv1x1)), int(wn0.has_bias)))
 
     def param_table(self):
         """C-ABI parameter table (include/wgflow.h): upsampler.1 bias, g, v; per flow the WN2D table."""

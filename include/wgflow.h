@@ -81,9 +81,9 @@ const char *wg_strerror(int code);
  * training scalars and take their scratch from the caller, wg_melspec returns the power spectrogram on request, wg_wf_config gained
  * use_conv1x1, wg_wf_upsample; 4: wg_timer_create(-1, ..) times every kernel class, wg_timer_read_info, wg_stat_wgrad16t_launches,
  * wg_wf_* accept every WG_PREC_*; 5: wg_config and wg_wn_dims gained bias; 6: wg_stat_layer_launches, the workspaces carry the one-launch
- * layer's hand-off counters, wg_layer_apply / wg_layer_workspace_bytes, wg_wf_wn_apply).  A binding built against another revision must not pass its
+ * layer's hand-off counters, wg_layer_apply / wg_layer_workspace_bytes, wg_wf_wn_apply; 7: wg_wf_config gained bias).  A binding built against another revision must not pass its
  * structs: the Python loader compares this with its own ABI_VERSION and refuses the library otherwise. */
-#define WG_ABI_VERSION 6
+#define WG_ABI_VERSION 7
 int wg_abi_version(void);
 
 /* Diagnostics (no counterpart upstream; the reference times with wall-clock time(), inference.py:39-53): while a
@@ -246,6 +246,9 @@ typedef struct wg_wf_config {
     int32_t precision;
     int32_t use_conv1x1;    /* WaveFlow(use_conv1x1=True) (waveflow.py:176-181,203-206,224-229): an InvertibleConv1x1(n_group) over the height
                                axis replaces the flip between flows; the parameter table then ends with invconv1x1.{k}.weight [H,H,1] per flow */
+    int32_t bias;           /* WN2D(bias=True) (waveflow.py:77,100-122): every conv of every WN2D has a bias.  A flow's part of the table then
+                               continues behind end.weight with V.bias, start.bias, 8 x (layers.i.W.bias, layers.i.W_o.bias), end.bias
+                               (3 + 56 per flow; the 1x1 weights, when present, still come last) */
 } wg_wf_config;
 int wg_wf_param_count(const wg_wf_config *cfg);
 size_t wg_wf_packed_bytes(const wg_wf_config *cfg);

@@ -76,27 +76,28 @@ def noncausal_layer(Wg, Wv, Og, Ov, x, y, dilation, last_layer):
 
 def wn2d_forward(params, n_group, x, y):
     """WN2D.forward on its own (model/waveflow.py:70-135, layers :41-51): 3x3 convs dilated (h_dilation, 2^i), causal along the height axis
-    (top padding only), the conditioning projection broadcast over the height axis.  params: [Vg, Vv, Sg, Sv, (Wg, Wv, Og, Ov) * 8, End]."""
+    (top padding only), the conditioning projection broadcast over the height axis.  params: [Vg, Vv, Sg, Sv, (Wg, Wv, Og, Ov) * 8, End] (+ the 19 biases, WN2D(bias=True))."""
     hds = {8: [1] * 8, 16: [1] * 8, 32: [1, 2, 4] * 2 + [1, 2], 64: [1, 2, 4, 8, 16, 1, 2, 4], 128: [1, 2, 4, 8, 16, 32, 64, 1]}[n_group]
     p = [None if a is None else torch.from_numpy(np.ascontiguousarray(a, np.float32)) for a in params]
     xt, yt = torch.from_numpy(np.ascontiguousarray(x, np.float32)), torch.from_numpy(np.ascontiguousarray(y, np.float32))
-    h = Fn.conv2d(xt, _wn(p[2], p[3]))
-    v = Fn.conv1d(yt, _wn(p[0], p[1])).unsqueeze(2)
+    b = p[37:] if len(p) > 37 else [None] * 19          # bias=True: V.bias, start.bias, (W.bias, W_o.bias) x 8, end.bias behind end.weight
+    h = Fn.conv2d(xt, _wn(p[2], p[3]), b[1])
+    v = Fn.conv1d(yt, _wn(p[0], p[1]), b[0]).unsqueeze(2)
     Cd = p[5].shape[0] // 2
     C = p[5].shape[1]
     skip = None
     for i in range(8):
         Wg, Wv, Og, Ov = p[4 + 4 * i: 8 + 4 * i]
         d, hd = 2 ** i, hds[i]
-        xy = Fn.conv2d(Fn.pad(h, [d, d, 2 * hd, 0]), _wn(Wg, Wv), dilation=(hd, d)) + v[:, 2 * Cd * i: 2 * Cd * (i + 1)]
-        o = Fn.conv2d(torch.tanh(xy[:, :Cd]) * torch.sigmoid(xy[:, Cd:]), _wn(Og, Ov))
+        xy = Fn.conv2d(Fn.pad(h, [d, d, 2 * hd, 0]), _wn(Wg, Wv), b[2 + 2 * i], dilation=(hd, d)) + v[:, 2 * Cd * i: 2 * Cd * (i + 1)]
+        o = Fn.conv2d(torch.tanh(xy[:, :Cd]) * torch.sigmoid(xy[:, Cd:]), _wn(Og, Ov), b[3 + 2 * i])
         if i < 7:
             h = o[:, :C] + h
             sk = o[:, C:]
         else:
             sk = o
         skip = sk if skip is None else skip + sk
-    out = Fn.conv2d(skip, p[36])
+    out = Fn.conv2d(skip, p[36], b[18])
     return out[:, :1].numpy(), out[:, 1:].numpy()
 
 

@@ -1002,10 +1002,11 @@ def test_shape_sweep_vs_oracle(dev, case):
 
 # ---- WaveFlow ---------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("name", ["wf8", "wf64", "wf8c", "wf64c"])
+@pytest.mark.parametrize("name", ["wf8", "wf64", "wf8c", "wf64c", "wf8b", "wf64b"])
 def test_waveflow_model_vs_reference_golden(dev, golden_dir, precision, name):
     """WaveFlow forward + NLL + backward + row-by-row inverse against the reference's own run (model_wf*.npz) and the oracle.
-    "wf8c" / "wf64c": use_conv1x1=True (an invertible 1x1 conv over the height axis instead of the flip, waveflow.py:203-206)."""
+    "wf8c" / "wf64c": use_conv1x1=True (an invertible 1x1 conv over the height axis instead of the flip, waveflow.py:203-206);
+    "wf8b" / "wf64b": WN2D(bias=True) (waveflow.py:77): the ones segment behind nine taps + conditioning, every bias gradient."""
     from oracle import wf_oracle as wfo
     cfg = fill.WF_CONFIGS[name]
     B, N, F = fill.WF_SHAPES[name]
@@ -1015,8 +1016,11 @@ def test_waveflow_model_vs_reference_golden(dev, golden_dir, precision, name):
     gold = np.load(os.path.join(golden_dir, "model_%s.npz" % name))
     ref = wfo.train_step(wfo.make_config(**cfg), fill.table(specs, P), audio, mel, fill.SIGMA, need_dmel=True)
     conv = bool(cfg.get("use_conv1x1"))
-    m = cm.WaveFlow(memory_efficient=False, bias=False, **dict({"use_conv1x1": False}, **cfg))
-    assert [n for n, _ in m.named_parameters()] == [n for n, _, _ in specs]          # invconv1x1.* after WNs.*, as upstream
+    m = cm.WaveFlow(memory_efficient=False, **dict({"use_conv1x1": False, "bias": False}, **cfg))
+    if cfg.get("bias"):                                                               # (the specs list the biases behind end.weight: table order)
+        assert sorted(n for n, _ in m.named_parameters()) == sorted(n for n, _, _ in specs)
+    else:
+        assert [n for n, _ in m.named_parameters()] == [n for n, _, _ in specs]      # invconv1x1.* after WNs.*, as upstream
     m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
     m = m.to(dev)
     ht = T(mel, dev).requires_grad_(True)
@@ -1242,7 +1246,7 @@ def test_waveflow_shipped_width_vs_oracle(dev, precision):
     assert np.abs(npy(x) - audio).max() < Z_ATOL
 
 
-@pytest.mark.parametrize("cname", ["wf8", "wf64", "wf64_short"])
+@pytest.mark.parametrize("cname", ["wf8", "wf64", "wf64_short", "wf8b"])
 def test_wn2d_alone_vs_reference_golden(dev, golden_dir, precision, cname):
     """WN2D.forward on its own (model/waveflow.py:128-135) through wg_wf_wn_apply against the reference's own WN2D (block_wn2d.npz):
     the input has fewer rows than n_group (WaveFlow passes x[:, :, :-1]; 20 of 64 in the short case), the rest of the planes is zero."""
@@ -1250,7 +1254,7 @@ def test_wn2d_alone_vs_reference_golden(dev, golden_dir, precision, cname):
     cfg, P, x, y = wn2d_inputs(cname)
     gold = np.load(os.path.join(golden_dir, "block_wn2d.npz"))
     m = cm.waveflow.WN2D(cfg["n_group"], cfg["n_mels"], dilation_channels=cfg["dilation_channels"], residual_channels=cfg["residual_channels"],
-                         skip_channels=cfg["skip_channels"], bias=False, zero_init=False)
+                         skip_channels=cfg["skip_channels"], bias=bool(cfg.get("bias")), zero_init=False)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
     m = m.to(dev)
     with torch.no_grad():

@@ -429,7 +429,7 @@ def test_noncausal_layer_restatement_vs_reference_golden(golden_dir, cname):
         assert np.abs(res - gold[cname + "/res"]).max() < 2e-6
 
 
-@pytest.mark.parametrize("cname", ["wf8", "wf64", "wf64_short"])
+@pytest.mark.parametrize("cname", ["wf8", "wf64", "wf64_short", "wf8b"])
 def test_wn2d_restatement_vs_reference_golden(golden_dir, cname):
     """oracle/torch_cpu.wn2d_forward (model/waveflow.py:128-135) against the reference's own WN2D output (block_wn2d.npz)."""
     from make_golden import wn2d_inputs
@@ -440,6 +440,8 @@ def test_wn2d_restatement_vs_reference_golden(golden_dir, cname):
     for i in range(8):
         order += ["layers.%d.W.weight_g" % i, "layers.%d.W.weight_v" % i, "layers.%d.W_o.weight_g" % i, "layers.%d.W_o.weight_v" % i]
     order.append("end.weight")
+    if cfg.get("bias"):
+        order += ["V.bias", "start.bias"] + [n for i in range(8) for n in ("layers.%d.W.bias" % i, "layers.%d.W_o.bias" % i)] + ["end.bias"]
     ls, t = torch_cpu.wn2d_forward([P[k] for k in order], cfg["n_group"], x, y)
     assert np.abs(ls - gold[cname + "/log_s"]).max() < 5e-6 and np.abs(t - gold[cname + "/t"]).max() < 5e-6
 
