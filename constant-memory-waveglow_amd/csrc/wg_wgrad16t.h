@@ -295,6 +295,9 @@ __global__ __launch_bounds__(768) void wgrad16t_kernel(const WgtArgs aa_by_value
         // per chunk for 1 536 cycles of MFMAs -- 1 890 with the compute waves alone and their barrier, 1 529 without barriers: phase-locked
         // at a barrier the two compute waves of a SIMD wait for their fragments at the same moments instead of filling each other's gaps,
         // and every wave waits for the slowest of twelve (profiles/r03c_wgrad_phases.txt).
+        // (WGT_ORDER: a compiler-level fence -- no instruction -- on either side of every progress word access, so that the data reads /
+        // writes the word stands for cannot be moved across it by any pass; the hardware side is the in-order LDS)
+#define WGT_ORDER() __atomic_signal_fence(__ATOMIC_SEQ_CST)
         auto wait_done = [&](unsigned want) {                 // every compute wave has read chunk want - 1
             for (int spins = 0;;) {
                 const unsigned v = __hip_atomic_load(&s_done[lane & 7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -305,6 +308,7 @@ __global__ __launch_bounds__(768) void wgrad16t_kernel(const WgtArgs aa_by_value
                 __builtin_amdgcn_s_sleep(WGT_POLL_SLEEP);
                 if (++spins > WGT_SPIN_CAP) { s_fail = 1; break; }      // (a hand-over that never comes is a bug: poison the result, do not hang the GPU)
             }
+            WGT_ORDER();
         };
         WgtStage s0, s1;
         issue(s0);                                            // chunk 0
@@ -314,6 +318,7 @@ __global__ __launch_bounds__(768) void wgrad16t_kernel(const WgtArgs aa_by_value
             wgt_wait_stage(st);
             if (j >= 3) wait_done((unsigned)(j - 2));
             write(st, wb);
+            WGT_ORDER();
             __hip_atomic_store(&s_ready[lw], (unsigned)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             wb = wb == 2 ? 0 : wb + 1;
             ++j;
@@ -380,6 +385,7 @@ __global__ __launch_bounds__(768) void wgrad16t_kernel(const WgtArgs aa_by_value
             __builtin_amdgcn_s_sleep(1);
             if (++spins > WGT_SPIN_CAP) { s_fail = 1; break; }
         }
+        WGT_ORDER();
     };
     auto chunk = [&](auto full_tag, int nbv) {
         constexpr bool FULL = decltype(full_tag)::value;
@@ -418,6 +424,7 @@ __global__ __launch_bounds__(768) void wgrad16t_kernel(const WgtArgs aa_by_value
                     bl[nx] = nb == 3 ? rdB(nxt, 0, 1) : rdB(cur, nb + 1, 1);
 #if !defined(WG_DBG_NOHANDOVER)
                     if (nb == 2) {
+                        WGT_ORDER();
                         __hip_atomic_store(&s_done[wave], (unsigned)(gc + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
 #endif

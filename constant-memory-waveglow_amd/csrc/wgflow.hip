@@ -656,8 +656,11 @@ static WgtPlan plan_wgt_rounds(int tm0, int tn0, int tm1, int tn1, int ng, int K
     }
     return best;
 }
+int device_cus();
 static WgtPlan plan_wgt_any(int tm0, int tn0, int tm1, int tn1, int ng, int K)
 {
+    // the plans (and wgrad16t_kernel's slot -> XCD arithmetic) are written for 8 XCDs of 32 CUs: any other part takes the grouped kernel
+    if (device_cus() != 256) return WgtPlan{};
     const WgtPlan a = plan_wgt(tm0, tn0, tm1, tn1, ng, K);
     return a.ok ? a : plan_wgt_rounds(tm0, tn0, tm1, tn1, ng, K);
 }
