@@ -194,7 +194,7 @@ Geo make_geo(int B, int T, int halo_need)
 int wn_check(const WnD &d)
 {
     if (d.ic < 1 || d.aux < 1 || d.depth < 1 || d.depth > 16) return WG_EINVAL;
-    if (d.mode2d ? d.radix != 9 : (d.radix != 1 && d.radix != 3)) return WG_EUNSUPPORTED;   // 1-D: kernels 1 and 3; 2-D: 3x3
+    if (d.mode2d ? d.radix != 9 : (d.radix < 1 || !(d.radix & 1) || d.radix > 9)) return WG_EUNSUPPORTED;   // 1-D: odd kernels up to 9 taps; 2-D: 3x3
     if (d.C % 32 || d.Cd % 32 || d.Cs % 32) return WG_EUNSUPPORTED;       // MFMA tile granularity
     if (d.bias && d.radix + 2 > WG_MAX_SEG) return WG_EUNSUPPORTED;      // the ones segment needs a K-segment slot (WN2D: 9 taps + conditioning + ones = 11)
     if (2 * d.ic > WG_MAXC) return WG_EUNSUPPORTED;                       // end-conv rows handled by one MFMA tile

@@ -164,7 +164,7 @@ class ModelEngine:
             nbytes = L.wg_packed_bytes(C.byref(self.cfg))
             if nbytes == 0:
                 raise WgError("WaveGlow configuration not supported by the HIP kernels "
-                              "(channels must be multiples of 32, radix 1 or 3, n_group <= 32)")
+                              "(channels must be multiples of 32, odd radix <= 9, n_group <= 32)")
             if self.packed.buf is None or self.packed.buf.numel() < nbytes or self.packed.buf.device != device:
                 self.packed.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
             check(L.wg_pack_weights(C.byref(self.cfg), _table(params), _p(self.packed.buf), _stream()), "wg_pack_weights")
@@ -340,7 +340,7 @@ class CouplingEngine:
             nbytes = L.wg_wn_packed_bytes(C.byref(self.dims))
             if nbytes == 0:
                 raise WgError("WN configuration not supported by the HIP kernels "
-                              "(channels must be multiples of 32, radix 1 or 3, in_channels <= 16)")
+                              "(channels must be multiples of 32, odd radix <= 9, in_channels <= 16)")
             if self.packed.buf is None or self.packed.buf.numel() < nbytes or self.packed.buf.device != device:
                 self.packed.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
             check(L.wg_wn_pack_weights(C.byref(self.dims), _table(params), _p(self.packed.buf), _stream()), "wg_wn_pack_weights")

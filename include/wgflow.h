@@ -55,7 +55,7 @@ extern "C" {
 typedef struct wg_config {
     int32_t n_flows, n_group, n_early_every, n_early_size, n_mels;
     int32_t up_stride, up_kernel, up_pad;            /* ConvTranspose1d(n_mels,n_mels,K,stride,pad,groups=n_mels) */
-    int32_t res_ch, dil_ch, skip_ch, depth, radix;   /* WN: residual/dilation/skip channels, layers, kernel size */
+    int32_t res_ch, dil_ch, skip_ch, depth, radix;   /* WN: residual/dilation/skip channels, layers, kernel size (odd, <= 9) */
     int32_t precision;                               /* WG_PREC_* : arithmetic of the MFMA contractions (not upstream) */
     int32_t reverse_mode;                            /* WaveGlow(reverse_mode=...) (waveglow.py:116, base.py:20-28): wg_forward is what
                                                         model.forward computes in that architecture, wg_inverse what model.reverse does */

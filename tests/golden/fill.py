@@ -150,6 +150,8 @@ CONFIGS = {
 }
 # WN(bias=True) (model/waveglow.py:58; no shipped config sets it): the micro model with a bias on every conv of every WN
 CONFIGS["micro_bias"] = dict(CONFIGS["micro"], bias=True)
+# WN(radix=5) (model/waveglow.py:57,28-30: any odd kernel size; the shipped configs use 3): five taps per dilated conv
+CONFIGS["micro_r5"] = dict(CONFIGS["micro"], radix=5)
 # the WaveGlow core of WSRGlow (model/wsrglow.py:22-25: n_group = hop = 8r, stride-1 upsampler, very wide conditioning), scaled
 # down: odd conditioning width (not a multiple of 8), 16 squeezed channels, upsample factor 1
 CONFIGS["wsr_like"] = dict(flows=4, n_group=16, n_early_every=2, n_early_size=2, hop_size=16, n_mels=83,
@@ -163,6 +165,7 @@ WSR_TABLES = [("mu_enc.1.weight", (256, 400)), ("angle_embed.embed.weight", (120
 SHAPES = {  # (batch, samples, mel frames)
     "micro": (2, 512, 8),
     "micro_bias": (2, 512, 8),
+    "micro_r5": (2, 512, 8),
     "c1": (2, 4000, 16),
     "c2": (1, 16000, 63),
     "wsr_like": (2, 16 * 300, 300),

@@ -20,7 +20,7 @@ def test_make_golden_main_regenerates_every_fixture(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(GOLD, "make_golden.py")], env=env, cwd=str(tmp_path), capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     committed = sorted(glob.glob(os.path.join(GOLD, "*.npz")))
-    assert len(committed) == 23
+    assert len(committed) == 24
     for f in committed:
         g = os.path.join(str(tmp_path), os.path.basename(f))
         assert os.path.exists(g), "main() did not write %s" % os.path.basename(f)

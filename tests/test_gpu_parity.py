@@ -63,7 +63,7 @@ def build(name, dev, mem_eff=True, reverse_mode=False):
     return m.to(dev), cfg, specs, P
 
 
-@pytest.mark.parametrize("name", ["micro", "micro_bias", "c1", "wsr_like"])
+@pytest.mark.parametrize("name", ["micro", "micro_bias", "micro_r5", "c1", "wsr_like"])
 def test_model_step_vs_oracle_and_golden(dev, golden_dir, name):
     m, cfg, specs, P = build(name, dev)
     B, N, F = fill.SHAPES[name]
@@ -137,7 +137,7 @@ def test_bias_wide_batch_step_vs_oracle(dev):
     assert np.abs(npy(xr) - audio).max() < Z_ATOL
 
 
-@pytest.mark.parametrize("name", ["micro", "micro_bias", "c1"])
+@pytest.mark.parametrize("name", ["micro", "micro_bias", "micro_r5", "c1"])
 def test_model_inverse_and_infer(dev, golden_dir, name):
     m, cfg, specs, P = build(name, dev)
     B, N, F = fill.SHAPES[name]
