@@ -1491,6 +1491,7 @@ struct WnRun {
     int save;            // keep all layers (backward) or ping-pong
     Geo gi;              // mode2d: the per-item geometry (conditioning, its gradient)
     float *rs;           // mode2d: S-plane [items][2 Cd][P] for the height-axis sum of dxy
+    size_t rs_step = 0;  // floats between the layers' copies of it (0: one plane reused by every layer)
 };
 
 // WnD::bias: the plane of ones the bias rows multiply (every WN pass refills it: a workspace may have served another shape in between)
@@ -1851,7 +1852,13 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
     // the layers' weight gradients as ONE grouped launch behind the loop (every layer's dxy and dh is kept then: dxyS_step, dHS_step)
     const bool gw = grouped_wgrad(cx.prec, d) && r.w.dHS_step && r.w.dxyS_step && nd >= 2;
     auto dHSp = [&](int j) { return ws + r.w.dHS + (size_t)j * r.w.dHS_step; };      // S-plane of dh_j (one plane for all j unless gw)
-    WgradGroupSpec gsT[WG_GRP_MAX], gsO[WG_GRP_MAX];
+    WgradGroupSpec gsT[WG_GRP_MAX], gsO[WG_GRP_MAX], gsV[WG_GRP_MAX];
+    // WN2D: the conditioning is broadcast over the height axis, so dV_i = (sum over an item's rows of dxy_i) (x) y -- the row sums exist
+    // anyway (the conditioning's own gradient is taken from them).  With a plane of them per layer the conditioning leaves the big
+    // weight-gradient product (672 -> 576 columns at the shipped width: five column tiles instead of six) and dV becomes one small grouped
+    // product over items x T columns instead of plane rows x T.
+    const bool hv = d.mode2d && dY && sp && gw && r.rs_step > 0 && !d.bias;
+    auto rsp = [&](int j) { return r.rs + (size_t)j * (hv ? r.rs_step : 0); };
     // WnD::bias: the plane of ones closes the B side of every weight-gradient product; column 0 of its 32-column block is the bias gradient
     const int nb = d.bias ? 1 : 0;
     WSegSpec wone = {nullptr, 32, 0, 32, 0, nullptr, 32, 0};
@@ -1920,8 +1927,12 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
                 d.tap(i, kt, ts, ro);
                 gsT[i].sb[kt] = {nullptr, d.C, 0, d.C, ts, ws + r.w.HS[i], d.C, 0, ro, 0};
             }
-            gsT[i].sb[d.radix] = {nullptr, d.auxp(), 0, d.aux, 0, r.YS, d.auxp(), 0, 0, d.mode2d};
-            if (nb) gsT[i].sb[d.radix + 1] = wone;             // (WN2D: 9 taps + conditioning fill all ten slots; it has no bias)
+            if (!hv) gsT[i].sb[d.radix] = {nullptr, d.auxp(), 0, d.aux, 0, r.YS, d.auxp(), 0, 0, d.mode2d};
+            if (nb) gsT[i].sb[d.radix + 1] = wone;
+            if (hv) {
+                gsV[i].sa[0] = {nullptr, 2 * d.Cd, 0, 2 * d.Cd, 0, rsp(i), 2 * d.Cd, 0};
+                gsV[i].sb[0] = {nullptr, d.auxp(), 0, d.aux, 0, r.YS, d.auxp(), 0};
+            }
         } else {
             WSegSpec sa = {dxy, 2 * d.Cd, 0, 2 * d.Cd, 0, sp ? dxyS : nullptr, 2 * d.Cd, 0};
             WSegSpec sb[WG_MAX_SEG];
@@ -1948,11 +1959,11 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
             // the product, no per-row gradient plane), then dy[item] += V_i^T rowsum
             if (sp)
                 WG_LAUNCH(cx, wf_rowsum_s_kernel, dim3((g.T + 63) / 64, 2 * d.Cd / 8, r.gi.B), dim3(256), 0, sref(g, dxyS, 2 * d.Cd), g,
-                          sref(r.gi, r.rs, 2 * d.Cd), r.gi);
+                          sref(r.gi, rsp(i), 2 * d.Cd), r.gi);
             else                                              // exact-fp32 mode: the same sum on the fp32 plane (r.rs holds 2 Cd fp32 channels then)
                 WG_LAUNCH(cx, wf_rowsum_kernel, dim3((g.T + 255) / 256, 2 * d.Cd, r.gi.B), dim3(256), 0, pref(dxy, 2 * d.Cd), g,
                           pref(r.rs, 2 * d.Cd), r.gi, 2 * d.Cd);
-            SegSpec s = {sp ? nullptr : r.rs, 2 * d.Cd, 0, 2 * d.Cd, 0, sp ? r.rs : nullptr, 2 * d.Cd, 0};
+            SegSpec s = {sp ? nullptr : r.rs, 2 * d.Cd, 0, 2 * d.Cd, 0, sp ? rsp(i) : nullptr, 2 * d.Cd, 0};
             run_convgemm(cx, r.gi, r.pk + r.L.VN[i], r.L.ld_VN, d.aux, &s, 1, EPI_STORE, pref(dY, d.auxp()), pnull(), pnull(),
                          pref(dY, d.auxp()), pnull(), 0, 0);
         } else if (dY && !fdy) {
@@ -1983,17 +1994,28 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
         pair = false;
 #endif
         // (one after the other, each finalisation queued behind its own launch: the second product's slabs may then reuse the arena)
-        if (pair) run_wgrad_group_pair(cx, g, gsT, 1, d.radix + 1 + nb, wo, gsO, 2, 1 + nb, woO, nd, ws + r.w.dSS);
-        else run_wgrad_group(cx, g, gsT, nd, 1, d.radix + 1 + nb, ws + r.w.dSS, wo);
+        const int nsbT = d.radix + (hv ? 0 : 1) + nb;
+        if (pair) run_wgrad_group_pair(cx, g, gsT, 1, nsbT, wo, gsO, 2, 1 + nb, woO, nd, ws + r.w.dSS);
+        else run_wgrad_group(cx, g, gsT, nd, 1, nsbT, ws + r.w.dSS, wo);
         for (int i = 0; i < nd && !cx.err; ++i) {
             run_finalize(cx, slab, wo[i], 0, 2 * d.Cd, d.C, d.radix, 0, 1, C32, p[4 + 4 * i], p[5 + 4 * i], grads[4 + 4 * i], grads[5 + 4 * i]);
             const size_t ro = (size_t)i * 2 * d.Cd;
+            if (!hv)
             run_finalize(cx, slab, wo[i], 0, 2 * d.Cd, d.aux, 1, d.radix * C32, 1, 0, p[0] ? p[0] + ro : nullptr, p[1] + ro * d.aux,
                          grads[0] ? grads[0] + ro : nullptr, grads[1] ? grads[1] + ro * d.aux : nullptr);
             fin_bias(slab, wo[i], 0, 2 * d.Cd, d.radix * C32 + rup(d.aux, 32), gb(2 + 2 * i));
             fin_bias(slab, wo[i], 0, 2 * d.Cd, d.radix * C32 + rup(d.aux, 32), gb(0) ? gb(0) + ro : nullptr);
         }
         if (!pair) run_wgrad_group(cx, g, gsO, nd, 2, 1 + nb, ws + r.w.dSS, woO);
+        if (hv) {                                             // dV of every layer: items x T columns against the conditioning itself
+            WgradOut woV[WG_GRP_MAX];
+            run_wgrad_group(cx, r.gi, gsV, nd, 1, 1, ws + r.w.dSS, woV);
+            for (int i = 0; i < nd && !cx.err; ++i) {
+                const size_t ro = (size_t)i * 2 * d.Cd;
+                run_finalize(cx, slab, woV[i], 0, 2 * d.Cd, d.aux, 1, 0, 1, 0, p[0] ? p[0] + ro : nullptr, p[1] + ro * d.aux,
+                             grads[0] ? grads[0] + ro : nullptr, grads[1] ? grads[1] + ro * d.aux : nullptr);
+            }
+        }
         for (int i = 0; i < nd && !cx.err; ++i) {
             const int last = i == nd - 1;
             run_finalize(cx, slab, woO[i], last ? d.C : 0, d.wo_rows(i), d.Cd, 1, 0, 1, 0, p[6 + 4 * i], p[7 + 4 * i], grads[6 + 4 * i], grads[7 + 4 * i]);
@@ -2092,7 +2114,7 @@ WfPack wf_pack_layout(const wg_wf_config *cf)
 struct WfWs {
     Geo g, gi;              // one plane row per (item, height row) / one per item
     int auxp;
-    size_t Y, YS, X[2], rowsum, dX[2], dYrow, rs, gp, dwup, Xt, dXt, gram, total;    // Xt / dXt / gram: use_conv1x1 only
+    size_t Y, YS, X[2], rowsum, dX[2], dYrow, rs, rs_step, gp, dwup, Xt, dXt, gram, total;    // Xt / dXt / gram: use_conv1x1 only
     size_t prog;            // the inverse's recorded row-step program (wg_stage.h): WF_PROG_STAGES argument blocks + the barrier words
     int gram_blocks;
     WnWs wn;
@@ -2119,11 +2141,14 @@ WfWs wf_ws_layout(const wg_wf_config *cf, int B, int Wd, int mode)
         w.Xt = bp.take(xplane);                                          // cat(x[0], xout): the 1x1's input
         if (mode) { w.dXt = bp.take(xplane); w.gram = bp.take((size_t)w.gram_blocks * H * H); }
     }
-    w.dX[0] = w.dX[1] = w.dYrow = w.rs = w.gp = w.dwup = 0;
+    w.dX[0] = w.dX[1] = w.dYrow = w.rs = w.rs_step = w.gp = w.dwup = 0;
     if (mode) {
         w.dX[0] = bp.take(xplane); w.dX[1] = bp.take(xplane);
         w.dYrow = bp.take((size_t)B * w.auxp * w.gi.P);                 // conditioning gradient, per item
-        w.rs = bp.take((size_t)B * 2 * d.Cd * w.gi.P);
+        // (S-plane mode, no biases: one plane per layer -- the conditioning's weight gradient is taken from these sums after the layer loop,
+        // wn_backward)
+        w.rs_step = (cf->precision == WG_PREC_BF16X3_PLANES && !d.bias && grouped_wgrad(cf->precision, d)) ? rupz((size_t)B * 2 * d.Cd * w.gi.P, 64) : 0;
+        w.rs = bp.take(w.rs_step ? w.rs_step * d.depth : (size_t)B * 2 * d.Cd * w.gi.P);
         w.gp = bp.take((size_t)B * cf->n_mels * Wd);
         w.dwup = bp.take((size_t)cf->n_mels * cf->n_mels * (2 * s + 1));
     }
@@ -2938,7 +2963,7 @@ int wg_wf_backward(const wg_wf_config *cf, const void *const *params, const void
     if (cx.err == 0 && hipMemsetAsync(ws + W.dYrow, 0, (size_t)B * W.auxp * W.gi.P * sizeof(float), cx.st) != hipSuccess) cx.err = WG_ELAUNCH;
     WnRun r;
     r.d = wf_wn(cf); r.L = wn_pack_layout(r.d); r.g = g; r.ws = ws; r.w = W.wn; r.Y = ws + W.Y; r.YS = ws + W.YS; r.save = 1;
-    r.gi = W.gi; r.rs = ws + W.rs;
+    r.gi = W.gi; r.rs = ws + W.rs; r.rs_step = W.rs_step;
     const int conv = cf->use_conv1x1, H = g.rows;
     if (conv) {
         const size_t lds = (size_t)2 * H * 65 * sizeof(float);
