@@ -534,7 +534,7 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
 #else
 #define WGQ_TRACE_NI 2
 #endif
-#define WGQ_TRACE(slot) do { if (EPI == EPI_GATE && NI == WGQ_TRACE_NI && lane == 0 && wave == 0 && (slot) < 16) { \
+#define WGQ_TRACE(slot) do { if ((EPI == EPI_GATE || EPI == EPI_GATE_SO) && NI == WGQ_TRACE_NI && lane == 0 && wave == 0 && (slot) < 16) { \
         wg_dbg_trace[blockIdx.x * 16 + (slot)] = wall_clock64(); wg_dbg_trace_cyc[blockIdx.x * 16 + (slot)] = clock64(); } } while (0)
 #else
 #define WGQ_TRACE(slot) do { } while (0)
