@@ -1,0 +1,487 @@
+// wg_gemm16g.h -- the conv product on 256 x 192 tiles: eight waves that all multiply, operands by LDS-DMA ("g": global_load_lds).
+//
+// Why another form (round 5).  convgemm16q_kernel<.., 2, 2> (wg_gemm16q.h) runs the headline gate conv -- M = 512, K = 848, 24 x 2000
+// columns (model/waveglow.py:41-46) -- at 117-122 us with the matrix pipe 56 % busy: per 32-deep chunk of its 256 x 128 tile it moves
+// 48 KB from L2 into LDS through the registers of eight loader waves (global_load -> VGPR -> ds_write_b128), its eight compute waves
+// (64 x 64 each, 128 registers) re-read 128 KB of fragments from LDS, and a barrier joins the two roles (DESIGN.md sections 4a, 4d, 7).
+// What the measurements of rounds 2-4 say pays on this power-limited part is less energy and fewer bytes per MFMA, so here:
+//   * tile 256 rows x 192 columns, columns FLATTENED over (plane row, time): 24 x 2048 padded columns are exactly 256 column tiles, so
+//     the gate conv is 2 tiles per CU and the 256-row products (data-gradient conv, skip product, residual conv) 1 tile per CU, where
+//     128-column tiles gave 3 and 1.5 (the half-empty second round of the latter is why they never ran on the 256-row tile);
+//     a chunk streams 32 KB of weights + 24 KB of activations for 256 x 192 x 32 MACs: 37 KB per 256 x 128 x 32 against 48 KB;
+//   * NO loader waves: every wave multiplies a 64-row x 96-column tile (4 x 2 waves; 96 accumulators, up to 256 registers per wave) and
+//     issues seven global_load_lds_dwordx4 per chunk; operands never pass through registers or ds_write;
+//   * per chunk a wave reads 8 A + 12 B fragments for 72 MFMAs (0.28 reads per MFMA against 0.33); the CU reads 160 KB of fragments
+//     per 256 x 192 chunk = 107 KB per 256 x 128 x 32 against 128 KB;
+//   * LDS images are k-group PLANES: [hi | lo][k-group q][row][16 B].  One DMA instruction is 64 lanes x 16 B = 64 consecutive rows of
+//     one plane = 1 KB contiguous in LDS AND in memory (the weight image is stored k-group-major per 128-row block, an S-plane is
+//     [c / 8][p][8]): no swizzle on either side.  The 16x16x32 fragment read (lane l: row l & 15, k-group l >> 4) is conflict free
+//     because ds_read_b128 is served in four groups of 16 lanes -- {0-3, 12-15, 20-27}, ... (MI355X_MICROARCH.md, LDS) -- whose two
+//     k-groups read complementary row sets, and the planes are a multiple of 256 B apart;
+//   * ring: two A buffers (32 KB each; A of chunk c + 1 is copied into a second register set during the second half of chunk c), three
+//     B buffers (24 KB each, read where they are used): 136 KB.  Two barriers per chunk (2 304 MFMA cycles per SIMD); a chunk's
+//     loads are issued two chunks ahead of its use: the weights have 1.5 chunk times to land, the activations 2.
+// Protocol per chunk c (every wave): TOP: wait until the own pieces of B(c) have landed (vmcnt(7): in order, all but the seven of
+// chunk c + 1), all own LDS reads done (lgkmcnt(0)), barrier -- now A(c)'s buffer (in registers since the last half chunk) and
+// B(c - 1)'s are free: issue A(c + 2), B(c + 2); multiply column blocks 0-2.  MID: wait for the own pieces of A(c + 1) (vmcnt(10)),
+// barrier; multiply column blocks 3-5 and copy A(c + 1) into the other register set.  An LDS-DMA write is ordered for a reader only by
+// the issuing wave's vmcnt wait followed by a barrier the reader has passed (cdna_hip_programming.md, "Read a staged buffer one phase
+// AFTER the wait that retires it").  Past the stream's end the same instructions fetch the zero halo, so the counts never change.
+#pragma once
+#include "wg_gemm16q.h"
+
+#define WGG_BM 256
+#define WGG_BN 192
+#define WGG_APLANE (WGG_BM * 16)
+#define WGG_AIMG (4 * WGG_APLANE)
+#define WGG_ABUF (2 * WGG_AIMG)
+#define WGG_BPLANE (WGG_BN * 16)
+#define WGG_BIMG (4 * WGG_BPLANE)
+#define WGG_BBUF (2 * WGG_BIMG)
+#define WGG_BBASE (2 * WGG_ABUF)
+#define WGG_LDS (2 * WGG_ABUF + 3 * WGG_BBUF)             // 139 264 bytes
+
+typedef __attribute__((address_space(3))) char wgg_lds_char;
+
+// one LDS-DMA instruction: 64 lanes x 16 bytes from sbase + voff (per lane) to LDS bytes [lds_dst, lds_dst + 1024).  M0 carries the
+// LDS address; it is compiler-reserved, so it is written and restored inside the statement (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void wgg_glds16(const void *sbase, unsigned voff, unsigned lds_dst)
+{
+#if defined(WGG_DBG_NOLOAD)                               // timing build: the address work stays, nothing is fetched (results are garbage)
+    asm volatile("" ::"v"(voff), "s"(lds_dst), "s"(sbase) : "memory");
+#else
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds_dst), "s"(sbase)
+                 : "memory");
+#endif
+}
+
+// EPI_GATE_SO, column block NBI of the wave tile: 16 columns of plane row b from time step t0 on (the flattened columns of a tile may
+// belong to two plane rows, so every block has its own bases; otherwise as wgq_gate_nb)
+template <int NBI>
+__device__ __forceinline__ void wgg_gate_nb(const ConvGemmArgs &a, const SRef &s0, f32x4 (&acc)[4][6], int b, int t0, int chb, int lane)
+{
+    const Geo g = a.g;
+    const int col = lane & 15, rq = lane >> 4;
+    const bool live = b < g.B && t0 + col < g.T;
+    const bool has_ts = a.out1.p != nullptr;
+    const unsigned vo_t = (unsigned)((rq * g.P + col) * 16), vo_s = (unsigned)(((rq >> 1) * g.P + col) * 16 + 8 * (rq & 1));
+    float tw[8], sf[8], gv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        tw[i] = wg_tanh(acc[i >> 2][NBI][i & 3]);
+        sf[i] = wg_sigmoid(acc[2 + (i >> 2)][NBI][i & 3]);
+        gv[i] = tw[i] * sf[i];
+    }
+    const int bb = min(b, g.B - 1);
+#pragma unroll
+    for (int mbp = 0; mbp < 2; ++mbp) {
+        const float *bt = has_ts ? paddr4(a.out1, g, bb, chb + mbp * 16, t0) : nullptr;
+        const float *bs = has_ts ? paddr4(a.out2, g, bb, chb + mbp * 16, t0) : nullptr;
+        const unsigned short *sh = s0.hi + s_index(s0, g, bb, chb + mbp * 16, t0), *sl = sh + s0.lo_off;
+        f32x4 vt, vs;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vt[e] = tw[4 * mbp + e]; vs[e] = sf[4 * mbp + e]; }
+        u32x2 vh, vl;
+        unsigned hh, ll;
+        split2(gv[4 * mbp], gv[4 * mbp + 1], hh, ll); vh[0] = hh; vl[0] = ll;
+        split2(gv[4 * mbp + 2], gv[4 * mbp + 3], hh, ll); vh[1] = hh; vl[1] = ll;
+        if (live) {
+            if (has_ts) { wgq_st16nt<0>(bt, vo_t, vt); wgq_st16nt<0>(bs, vo_t, vs); }
+            wgq_st8<0>(sh, vo_s, vh);
+            wgq_st8<0>(sl, vo_s, vl);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// EPI_STORE_SO, column block NBI: the lane's 4 rows of each of the wave's four 16-row blocks as S-plane half units
+template <int NBI>
+__device__ __forceinline__ void wgg_store_nb(const ConvGemmArgs &a, const SRef &s0, f32x4 (&acc)[4][6], int b, int t0, int mw, int lane)
+{
+    const Geo g = a.g;
+    const int col = lane & 15, rq = lane >> 4;
+    const bool live = b < g.B && t0 + col < g.T;
+    const int bb = min(b, g.B - 1);
+    const unsigned vo = (unsigned)(((rq >> 1) * g.P + col) * 16 + 8 * (rq & 1));
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const int mbase = mw + mb * 16;
+        const unsigned short *hb = s0.hi + s_index(s0, g, bb, mbase, t0), *lb = hb + s0.lo_off;
+        u32x2 ph, pl;
+        unsigned hh, ll;
+        split2(acc[mb][NBI][0], acc[mb][NBI][1], hh, ll); ph[0] = hh; pl[0] = ll;
+        split2(acc[mb][NBI][2], acc[mb][NBI][3], hh, ll); ph[1] = hh; pl[1] = ll;
+        if (live && mbase + 4 * rq < a.M) { wgq_st8<0>(hb, vo, ph); wgq_st8<0>(lb, vo, pl); }
+    }
+}
+// the accumulate-into value of EPI_STORE_SO (an S-plane: x = hi + lo), column block NBI
+template <int NBI>
+__device__ __forceinline__ void wgg_init_nb(const ConvGemmArgs &a, const SRef &saux, f32x4 (&acc)[4][6], int b, int t0, int mw, int lane)
+{
+    const Geo g = a.g;
+    const int col = lane & 15, rq = lane >> 4;
+    const bool live = b < g.B && t0 + col < g.T;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const int m = mw + mb * 16 + 4 * rq;
+        u32x2 vh = {0u, 0u}, vl = {0u, 0u};
+        if (live && m < a.M) {
+            const size_t i = s_index(saux, g, b, m, t0 + col);
+            vh = *reinterpret_cast<const u32x2 *>(saux.hi + i);
+            vl = *reinterpret_cast<const u32x2 *>(saux.hi + saux.lo_off + i);
+        }
+        acc[mb][NBI][0] = __uint_as_float(vh[0] << 16) + __uint_as_float(vl[0] << 16);
+        acc[mb][NBI][1] = __uint_as_float(vh[0] & 0xffff0000u) + __uint_as_float(vl[0] & 0xffff0000u);
+        acc[mb][NBI][2] = __uint_as_float(vh[1] << 16) + __uint_as_float(vl[1] << 16);
+        acc[mb][NBI][3] = __uint_as_float(vh[1] & 0xffff0000u) + __uint_as_float(vl[1] & 0xffff0000u);
+    }
+}
+
+// What a chunk of the K walk needs to be fetched, independent of the tile: built ONCE per workgroup (thread v describes chunk v) into an
+// LDS table, because the walk itself -- interleaved taps, segment boundaries, half chunks: two integer divisions and a dozen 64-bit
+// multiply-adds per chunk -- measured 334 scalar instructions per chunk and wave in the first version of this kernel: with all eight waves
+// multiplying, nobody hides them (compute-only timing build: 118 us per gate conv for 62 us of MFMA issue).  From it every wave derives,
+// once per TILE, the byte offsets of its seven pieces for every chunk (lane v computes chunk v: WggOffs, a second LDS table per wave), so
+// that a chunk costs the wave three broadcast LDS reads, seven vector adds and two readfirstlane.
+struct WggDesc {
+    unsigned long long b_base;    // the chunk's operand plane: address of its hi array
+    unsigned a_off;               // bytes from the weight image's first chunk to this chunk's (hi image, row 0)
+    unsigned b_off;               // bytes from b_base to the unit (plane row 0, first k-group of the chunk, position H + shift)
+    unsigned lo_off;              // bytes from the hi to the lo array of that plane
+    unsigned item_stride;         // bytes from one plane row to the next
+    unsigned nq;                  // k-groups of the chunk that hold channels (1..4); the others are fetched from the zero halo
+    unsigned pad;
+};
+struct WggOffs { unsigned a[4], b[3], pad; };             // a: bytes from the weight image, b: bytes from the chunk's b_base
+#define WGG_MAXCHUNKS 64
+#define WGG_TAB WGG_LDS                                   // the tables sit behind the rings
+#define WGG_WTAB (WGG_TAB + WGG_MAXCHUNKS * 32)
+#define WGG_LDS_ALL (WGG_WTAB + 8 * WGG_MAXCHUNKS * 32)   // 157 696 bytes
+static_assert(sizeof(WggDesc) == 32 && sizeof(WggOffs) == 32 && WGG_LDS_ALL <= 160 * 1024, "LDS budget");
+
+// ConvGemm16sArgs as for convgemm16q_kernel, with ntx = column tiles of 192 flattened columns (ceil(B * Tt / 192)), nty = 256-row tiles,
+// ntz unused.  Requires: Geo::rows == 0, no row_sel1, M a multiple of 256, H >= 64 (the zero halo serves as the 1 KB zero source),
+// S-plane operands whose hi + lo arrays span less than 4 GB, a weight image (hi + lo) of less than 4 GB, at most WGG_MAXCHUNKS chunks.  Grid: min(tiles, CUs) workgroups of 512
+// threads; with a grid that is a multiple of 8, XCD x (workgroup id & 7) owns the column tiles [x ntx / 8, (x + 1) ntx / 8) and all their
+// row tiles, row tile fastest: the row tiles of a column tile run side by side on one L2, and a dilation tap's window is a neighbouring
+// column tile's centre window on the same XCD.
+template <int EPI>
+__global__ __launch_bounds__(512) void convgemm16g_kernel(const ConvGemm16sArgs aa)
+{
+    static_assert(EPI == EPI_GATE_SO || EPI == EPI_STORE_SO, "S-plane-only epilogues");
+    __shared__ __attribute__((aligned(1024))) char smem[WGG_LDS_ALL];
+    const ConvGemmArgs &a = aa.c;
+    const Geo g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = (unsigned)(size_t)(wgg_lds_char *)smem;
+    int nchunks = 0;
+    for (int s = 0; s < a.nseg; ++s) nchunks += (a.seg[s].nch + WG16_BK - 1) / WG16_BK;
+    const int nil = aa.tap_il * aa.tap_chunks;                // chunks walked interleaved over the taps (ConvGemm16sArgs::tap_il)
+    const int G = (int)gridDim.x, bid = (int)blockIdx.x;
+    const bool xm = (G & 7) == 0;
+    const int nx = xm ? 8 : 1, xid = xm ? (bid & 7) : 0, slot = xm ? (bid >> 3) : bid, xslots = xm ? (G >> 3) : G;
+    const int c_lo = xid * aa.ntx / nx, n_local = ((xid + 1) * aa.ntx / nx - c_lo) * aa.nty;
+    const int mine = slot < n_local ? (n_local - 1 - slot) / xslots + 1 : 0;
+    const int total = mine * nchunks;
+    if (total == 0) return;
+    auto tile_at = [&](int k, int &ct, int &m0) __attribute__((always_inline)) {
+        const int L = slot + min(k, mine - 1) * xslots, cl = L / aa.nty;
+        ct = c_lo + cl; m0 = (L - cl * aa.nty) * WGG_BM;
+    };
+    const int ncols = g.B * g.Tt;
+
+    // ---------------------------------------------- the chunk table ----------------------------------------------
+    if (tid < nchunks) {
+        const int v = tid;
+        int sg, ci, chi;
+        if (v < nil) {
+            sg = v % aa.tap_il;
+            const int cbi = v / aa.tap_il;
+            ci = cbi * WG16_BK; chi = sg * aa.tap_chunks + cbi;
+        } else {
+            int c = nil, s = aa.tap_il;
+            for (;;) {
+                const int n = (a.seg[s].nch + WG16_BK - 1) / WG16_BK;
+                if (v < c + n || s + 1 >= a.nseg) break;
+                c += n; ++s;
+            }
+            sg = s; ci = (v - c) * WG16_BK; chi = v;
+        }
+        const SSeg ss = aa.sseg[sg];
+        WggDesc d;
+        d.b_base = (unsigned long long)(size_t)ss.hi;
+        d.a_off = (unsigned)chi * (unsigned)a.lda * (unsigned)(WG16_BK * 2);
+        d.b_off = ((unsigned)((ss.ch0 + ci) >> 3) * (unsigned)g.P + (unsigned)(g.H + a.seg[sg].shift)) * 16u;
+        d.lo_off = (unsigned)(ss.lo_off * 2);
+        d.item_stride = (unsigned)(ss.Cp >> 3) * (unsigned)g.P * 16u;
+        d.nq = (unsigned)min(4, (a.seg[sg].nch - ci + 7) >> 3);
+        d.pad = 0;
+        *reinterpret_cast<WggDesc *>(smem + WGG_TAB + v * 32) = d;
+    }
+    __syncthreads();
+
+    // ---------------------------------------------- the wave's DMA pieces ----------------------------------------------
+    // A: instruction i = wave + 8 k (k = 0..3) of the 32 per chunk: image i >> 4 (hi, lo), k-group (i >> 2) & 3, 64-row part i & 3
+    // B: instruction i = wave + 8 k (k = 0..2) of the 24: image i / 12, k-group (i % 12) / 3, 64-column piece i % 3
+    unsigned a_src[4], a_dst[4], b_dst[3], b_hl[3], b_q[3];   // a_src: bytes from a chunk's image block (hi, tile row 0) to the piece
+    int b_pc[3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = wave + 8 * k, hl = i >> 4, q = (i >> 2) & 3, part = i & 3;
+        a_src[k] = 2u * ((unsigned)hl * (unsigned)aa.img_stride + (unsigned)((part >> 1) * (128 * WG16_BK) + (q * 128 + 64 * (part & 1)) * 8));
+        a_dst[k] = lds0 + (unsigned)(hl * WGG_AIMG + q * WGG_APLANE + part * 1024);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int i = wave + 8 * k;
+        b_hl[k] = (unsigned)(i / 12); b_q[k] = (unsigned)((i % 12) / 3); b_pc[k] = i % 3;
+        b_dst[k] = lds0 + (unsigned)(WGG_BBASE + (int)b_hl[k] * WGG_BIMG + (int)b_q[k] * WGG_BPLANE + b_pc[k] * 1024);
+    }
+    const unsigned voff = (unsigned)lane * 16u;
+    int gi = 0, ik = 0, iv = 0, ict, im0;
+    char *const wtab = smem + WGG_WTAB + wave * (WGG_MAXCHUNKS * 32);
+    // per tile: lane v < nchunks writes the wave's seven byte offsets of chunk v (k-groups without channels: offset 0 = position 0 of the
+    // plane, H >= 64 columns of zeros = 1 KB).  Written and read by this wave only: the LDS serves a wave's operations in order.
+    auto build_table = [&]() __attribute__((always_inline)) {
+        unsigned pb[3], pc[3];                                // plane row / byte offset (k-group row + first time step) of the three B pieces
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int cf = ict * WGG_BN + 64 * b_pc[k];
+            if (cf >= ncols) cf = 0;                          // (a piece past the last column: fetch something valid, nothing of it is stored)
+            const int b = cf / g.Tt;
+            pb[k] = (unsigned)b; pc[k] = (b_q[k] * (unsigned)g.P + (unsigned)(cf - b * g.Tt)) * 16u;
+        }
+        if (lane < nchunks) {
+            const WggDesc d = *reinterpret_cast<const WggDesc *>(smem + WGG_TAB + lane * 32);
+            WggOffs o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o.a[k] = d.a_off + a_src[k] + (unsigned)im0 * (unsigned)(WG16_BK * 2);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) o.b[k] = b_q[k] < d.nq ? d.b_off + b_hl[k] * d.lo_off + pb[k] * d.item_stride + pc[k] : 0u;
+            o.pad = 0;
+            *reinterpret_cast<WggOffs *>(wtab + lane * 32) = o;
+        }
+    };
+    tile_at(0, ict, im0);
+    build_table();
+    // the seven instructions of a chunk: desc_request() asks for the chunk's offsets a little ahead, prep() adds the lane's own 16 bytes
+    // and steps the stream, fire<k>() issues one -- a phase spreads them over its column blocks.  Past the stream's end the last chunk is
+    // fetched again (valid addresses, buffers nobody reads): the instruction counts the waits rely on never change.
+    u32x4 e0, e1;
+    u32x2 ebs;
+    unsigned va[4], vb[3], bd;
+    const void *sbB;
+    auto desc_request = [&]() __attribute__((always_inline)) {
+        e0 = *reinterpret_cast<const u32x4 *>(wtab + iv * 32); e1 = *reinterpret_cast<const u32x4 *>(wtab + iv * 32 + 16);
+        ebs = *reinterpret_cast<const u32x2 *>(smem + WGG_TAB + iv * 32);
+    };
+    auto prep = [&](int bslot) __attribute__((always_inline)) {
+        // (the builtin returns int: through unsigned, or the low word's sign bit would fill the high word)
+        auto rfl = [](unsigned x) __attribute__((always_inline)) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); };
+        sbB = reinterpret_cast<const void *>((unsigned long long)rfl(ebs[0]) | ((unsigned long long)rfl(ebs[1]) << 32));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) va[k] = e0[k] + voff;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) vb[k] = e1[k] + voff;
+        bd = (unsigned)bslot * WGG_BBUF;
+        if (gi < total) {
+            ++gi;
+            if (++iv == nchunks) {
+                iv = 0; ++ik;
+                tile_at(ik, ict, im0);
+                build_table();
+            }
+        }
+    };
+    auto fire = [&](auto ABUF, auto KC) __attribute__((always_inline)) {
+        constexpr int k = decltype(KC)::value, abuf = decltype(ABUF)::value;
+        if constexpr (k < 4) wgg_glds16(aa.img, va[k], a_dst[k] + (unsigned)(abuf * WGG_ABUF));
+        else wgg_glds16(sbB, vb[k - 4], b_dst[k - 4] + bd);
+    };
+    auto issue = [&](auto ABUF, int bslot) __attribute__((always_inline)) {
+        desc_request();
+        prep(bslot);
+        fire(ABUF, std::integral_constant<int, 0>()); fire(ABUF, std::integral_constant<int, 1>()); fire(ABUF, std::integral_constant<int, 2>());
+        fire(ABUF, std::integral_constant<int, 3>()); fire(ABUF, std::integral_constant<int, 4>()); fire(ABUF, std::integral_constant<int, 5>());
+        fire(ABUF, std::integral_constant<int, 6>());
+    };
+
+    // ---------------------------------------------- multiply ----------------------------------------------
+    const int wr = wave >> 1, wc = wave & 1;                  // 4 x 2 waves: rows 64 wr .., columns 96 wc ..
+    const int ao = (lane >> 4) * WGG_APLANE + (64 * wr + (lane & 15)) * 16;           // + 256 per 16-row block, + WGG_AIMG for lo
+    const int bo = WGG_BBASE + (lane >> 4) * WGG_BPLANE + (96 * wc + (lane & 15)) * 16;
+    f32x4 acc[4][6];
+    bf16x8 Ah[2][4], Al[2][4], Bh[2], Bl[2];
+    auto rd = [&](const char *q) __attribute__((always_inline)) { return *reinterpret_cast<const bf16x8 *>(q); };
+#define WGG_SB() __builtin_amdgcn_sched_barrier(0)
+#if defined(WGG_DBG_NOMFMA)                               // timing build: fragments are read, nothing is multiplied
+#define WGG_MFMA(A_, B_, C_) asm volatile("" : "+v"(C_) : "v"(A_), "v"(B_))
+#else
+#define WGG_MFMA(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_, B_, C_, 0, 0, 0)
+#endif
+#if defined(WGG_DBG_NOBAR)                                // timing build: no barriers (results are garbage)
+#define WGG_BAR() asm volatile("" ::: "memory")
+#else
+#define WGG_BAR() do { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#endif
+    int ck = 0, cc = 0, ct, m0, bs = 0, gc = 0;
+    tile_at(0, ct, m0);
+    // the wave's six column blocks: plane row and first time step of each (a block of 16 never straddles plane rows: Tt is a multiple of 16)
+    int eb[6], et[6];
+    auto block_pos = [&]() __attribute__((always_inline)) {
+        const int cf0 = ct * WGG_BN + 96 * wc;
+        int b = cf0 / g.Tt, t = cf0 - b * g.Tt;
+#pragma unroll
+        for (int nb = 0; nb < 6; ++nb) {
+            eb[nb] = b; et[nb] = t;
+            t += 16;
+            if (t >= g.Tt) { t = 0; ++b; }
+        }
+    };
+    auto acc_start = [&]() __attribute__((always_inline)) {
+        if (EPI == EPI_STORE_SO && aa.saux.hi) {
+            const int mw = m0 + 64 * wr;
+            block_pos();
+            wgg_init_nb<0>(a, aa.saux, acc, eb[0], et[0], mw, lane); wgg_init_nb<1>(a, aa.saux, acc, eb[1], et[1], mw, lane);
+            wgg_init_nb<2>(a, aa.saux, acc, eb[2], et[2], mw, lane); wgg_init_nb<3>(a, aa.saux, acc, eb[3], et[3], mw, lane);
+            wgg_init_nb<4>(a, aa.saux, acc, eb[4], et[4], mw, lane); wgg_init_nb<5>(a, aa.saux, acc, eb[5], et[5], mw, lane);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[i][j][q] = 0.f;
+        }
+    };
+    auto epilogue = [&]() __attribute__((always_inline)) {
+#if !defined(WGG_DBG_NOEPI)
+        block_pos();
+        if constexpr (EPI == EPI_GATE_SO) {
+            const int chb = (m0 >> 1) + 32 * wr;                 // the wave's 64 rows = [32 tanh | 32 sigmoid] of 32 gate channels
+            wgg_gate_nb<0>(a, aa.s0, acc, eb[0], et[0], chb, lane); wgg_gate_nb<1>(a, aa.s0, acc, eb[1], et[1], chb, lane);
+            wgg_gate_nb<2>(a, aa.s0, acc, eb[2], et[2], chb, lane); wgg_gate_nb<3>(a, aa.s0, acc, eb[3], et[3], chb, lane);
+            wgg_gate_nb<4>(a, aa.s0, acc, eb[4], et[4], chb, lane); wgg_gate_nb<5>(a, aa.s0, acc, eb[5], et[5], chb, lane);
+        } else {
+            const int mw = m0 + 64 * wr;
+            wgg_store_nb<0>(a, aa.s0, acc, eb[0], et[0], mw, lane); wgg_store_nb<1>(a, aa.s0, acc, eb[1], et[1], mw, lane);
+            wgg_store_nb<2>(a, aa.s0, acc, eb[2], et[2], mw, lane); wgg_store_nb<3>(a, aa.s0, acc, eb[3], et[3], mw, lane);
+            wgg_store_nb<4>(a, aa.s0, acc, eb[4], et[4], mw, lane); wgg_store_nb<5>(a, aa.s0, acc, eb[5], et[5], mw, lane);
+        }
+#else
+        if (acc[0][0][0] + acc[1][1][1] + acc[2][4][2] + acc[3][5][3] == 12345.f) aa.s0.hi[lane] = 1;
+#endif
+    };
+    // one column block: 12 MFMAs, a different accumulator every time; behind the first four: the next block's B fragments, in the second
+    // half of a chunk two row blocks of the next chunk's A, and a share of chunk gc + 2's DMA (block 0 prepares and issues A piece 0,
+    // block 1 A pieces 1 and 2, block 2 A piece 3, blocks 3-5 the three B pieces)
+    auto block = [&](auto PARC, auto NBC, const char *pbuf, const char *pan) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(PARC)::value, nb = decltype(NBC)::value, cur = nb & 1, nxt = cur ^ 1;
+        WGG_SB();
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) WGG_MFMA(Al[PAR][mb], Bh[cur], acc[mb][nb]);
+        WGG_SB();
+        if constexpr (nb < 5) { Bh[nxt] = rd(pbuf + (nb + 1) * 256); Bl[nxt] = rd(pbuf + WGG_BIMG + (nb + 1) * 256); }
+        if constexpr (nb == 3 || nb == 4) {
+#pragma unroll
+            for (int mb = 2 * (nb - 3); mb < 2 * (nb - 3) + 2; ++mb) { Ah[PAR ^ 1][mb] = rd(pan + mb * 256); Al[PAR ^ 1][mb] = rd(pan + WGG_AIMG + mb * 256); }
+        }
+        WGG_SB();
+#if !defined(WGG_OPT_ISSUE_TOP)
+        if constexpr (nb == 0) { prep(bs >= 1 ? bs - 1 : 2); fire(PARC, std::integral_constant<int, 0>()); }
+        if constexpr (nb == 1) { fire(PARC, std::integral_constant<int, 1>()); fire(PARC, std::integral_constant<int, 2>()); }
+        if constexpr (nb >= 2) fire(PARC, std::integral_constant<int, nb + 1>());
+        WGG_SB();
+#endif
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) WGG_MFMA(Ah[PAR][mb], Bl[cur], acc[mb][nb]);
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) WGG_MFMA(Ah[PAR][mb], Bh[cur], acc[mb][nb]);
+        WGG_SB();
+    };
+#if defined(WG_DBG_TRACE)
+    // slots 0-7: inside the chunk WGG_TRACE_GC (before the TOP wait, after it, after the barrier, after blocks 0 and 2, after the MID wait,
+    // after its barrier, after block 5); 8: kernel entry, 9: first chunk, 10 / 11: tile 0's main loop / epilogue done, 12 / 13: tile 1's
+#if !defined(WGG_TRACE_GC)
+#define WGG_TRACE_GC 12
+#endif
+#define WGG_TRACE(slot) do { if (EPI == EPI_GATE_SO && lane == 0 && wave == WGG_TRACE_WAVE) { \
+        wg_dbg_trace[blockIdx.x * 16 + (slot)] = wall_clock64(); wg_dbg_trace_cyc[blockIdx.x * 16 + (slot)] = clock64(); } } while (0)
+#define WGG_TRACE_IN(slot) do { if (gc == WGG_TRACE_GC) WGG_TRACE(slot); } while (0)
+#if !defined(WGG_TRACE_WAVE)
+#define WGG_TRACE_WAVE 0
+#endif
+#else
+#define WGG_TRACE(slot) do { } while (0)
+#define WGG_TRACE_IN(slot) do { } while (0)
+#endif
+    auto phase = [&](auto PARC) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(PARC)::value;
+        WGG_TRACE_IN(0);
+        // TOP: B(gc) has landed everywhere, A(gc)'s and B(gc - 1)'s buffers are free
+        asm volatile("s_waitcnt vmcnt(7)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        WGG_TRACE_IN(1);
+        WGG_BAR();
+        WGG_TRACE_IN(2);
+        const char *pbuf = smem + bs * WGG_BBUF + bo, *pan = smem + (PAR ^ 1) * WGG_ABUF + ao;
+        Bh[0] = rd(pbuf); Bl[0] = rd(pbuf + WGG_BIMG);
+#if defined(WGG_OPT_ISSUE_TOP)
+        WGG_SB();
+        issue(PARC, bs >= 1 ? bs - 1 : 2);                   // chunk gc + 2: A buffer gc & 1, B slot (gc + 2) % 3
+#else
+        desc_request();
+#endif
+        WGG_SB();
+        block(PARC, std::integral_constant<int, 0>(), pbuf, pan);
+        WGG_TRACE_IN(3);
+        block(PARC, std::integral_constant<int, 1>(), pbuf, pan);
+        block(PARC, std::integral_constant<int, 2>(), pbuf, pan);
+        WGG_TRACE_IN(4);
+        // MID: A(gc + 1) has landed everywhere (younger: the three B pieces of chunk gc + 1 and the four A pieces of chunk gc + 2)
+#if defined(WGG_OPT_ISSUE_TOP)
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+#endif
+        WGG_TRACE_IN(5);
+        WGG_BAR();
+        WGG_TRACE_IN(6);
+        block(PARC, std::integral_constant<int, 3>(), pbuf, pan);
+        block(PARC, std::integral_constant<int, 4>(), pbuf, pan);
+        block(PARC, std::integral_constant<int, 5>(), pbuf, pan);
+        WGG_TRACE_IN(7);
+        bs = bs == 2 ? 0 : bs + 1;
+        ++gc;
+        if (++cc == nchunks) {
+            if (ck < 2) WGG_TRACE(10 + 2 * ck);
+            epilogue();
+            if (ck < 2) WGG_TRACE(11 + 2 * ck);
+            cc = 0; ++ck;
+            tile_at(ck, ct, m0);
+            if (gc < total) acc_start();
+        }
+    };
+    WGG_TRACE(8);
+    issue(std::integral_constant<int, 0>(), 0);
+    issue(std::integral_constant<int, 1>(), 1);
+    acc_start();
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");        // the own pieces of A(0)
+    WGG_BAR();
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) { Ah[0][mb] = rd(smem + ao + mb * 256); Al[0][mb] = rd(smem + WGG_AIMG + ao + mb * 256); }
+    WGG_TRACE(9);
+    while (gc < total) {
+        phase(std::integral_constant<int, 0>());
+        if (gc < total) phase(std::integral_constant<int, 1>());
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the trailing fetches must not land in another workgroup's LDS
+#undef WGG_SB
+#undef WGG_MFMA
+#undef WGG_BAR
+#undef WGG_TRACE
+#undef WGG_TRACE_IN
+}

@@ -6,6 +6,7 @@
 #include "wg_gemm16.h"
 #include "wg_gemm16s.h"
 #include "wg_gemm16q.h"
+#include "wg_gemm16g.h"
 #include "wg_gemm16h.h"
 #include "wg_wgrad16t.h"
 #include "wg_wsr.h"
@@ -865,6 +866,13 @@ int ensure_dynamic_lds(const void *kernel, int slot, size_t bytes)
     return 0;
 }
 
+// env WG_G192 (read once): 0 = the conv products never take the 256 x 192-tile kernel of wg_gemm16g.h (A/B runs in one build)
+static bool g192_on()
+{
+    static const int on = [] { const char *e = getenv("WG_G192"); return e ? atoi(e) : 1; }();
+    return on != 0;
+}
+
 void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const SegSpec *segs, int nseg, int epi,
                   PRef out0, PRef out1, PRef out2, PRef aux0, PRef aux1, int nsplit, int accumulate, SRef s0 = snull(), SRef saux = snull())
 {
@@ -1023,6 +1031,20 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                                 && false
 #endif
                 ;
+#if !defined(WG_OPT_NO_G192)
+            // 256 x 192 tiles over flattened columns, eight multiplying waves fed by LDS-DMA (wg_gemm16g.h): the S-plane-only gate conv and
+            // store / data-gradient / skip products whose tiles deal out evenly over the CUs (env WG_G192=0 restores the 256 x 128 / 128 x 128 forms)
+            if (g192_on() && !small && (so_gate || so_epi) && g.rows == 0 && !cx.row_sel1 && !cx.rec && M % WGG_BM == 0 && g.H >= 64 && cus % 8 == 0) {
+                const int nct = (g.B * g.Tt + WGG_BN - 1) / WGG_BN, nrb = M / WGG_BM, nt = nct * nrb;
+                const int rounds = (nt + cus - 1) / cus;
+                if (nt >= cus && (double)(rounds * cus - nt) <= 0.1 * rounds * cus) {
+                    as.ntx = nct; as.nty = nrb; as.ntz = 1; as.xcd_items = 0;
+                    if (so_gate) WG_LAUNCH(cx, convgemm16g_kernel<EPI_GATE_SO>, dim3(cus), dim3(512), 0, as);
+                    else WG_LAUNCH(cx, convgemm16g_kernel<EPI_STORE_SO>, dim3(cus), dim3(512), 0, as);
+                    return;
+                }
+            }
+#endif
 #if !defined(WG_OPT_NO_M64)
             // products with at most 64 rows on 64 x 128 tiles (convgemm16q_kernel<.., M64>): WaveFlow's 64-channel WN2D -- on 128-row tiles
             // half of every MFMA multiplied padding (the data-gradient conv: 181 TF against 314 for the full-height gate conv)
