@@ -88,10 +88,22 @@ __device__ __forceinline__ void wgg_gate_nb(const ConvGemmArgs &a, const SRef &s
         unsigned hh, ll;
         split2(gv[4 * mbp], gv[4 * mbp + 1], hh, ll); vh[0] = hh; vl[0] = ll;
         split2(gv[4 * mbp + 2], gv[4 * mbp + 3], hh, ll); vh[1] = hh; vl[1] = ll;
+#if defined(WGG_DBG_NOSTORE)                              // timing build: the epilogue's arithmetic without its stores
+        if (live && vh[0] == 0x12345u && vl[1] == 0x54321u) {
+#else
         if (live) {
+#endif
             if (has_ts) { wgq_st16nt<0>(bt, vo_t, vt); wgq_st16nt<0>(bs, vo_t, vs); }
+#if defined(WGG_OPT_ST_SC1)                               // experiment: write-through stores (no dirty lines left for the end-of-kernel write-back)
+            asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(vo_s), "v"(vh), "s"(sh) : "memory");
+            asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(vo_s), "v"(vl), "s"(sl) : "memory");
+#elif defined(WGG_OPT_ST_NT)
+            asm volatile("global_store_dwordx2 %0, %1, %2 nt" ::"v"(vo_s), "v"(vh), "s"(sh) : "memory");
+            asm volatile("global_store_dwordx2 %0, %1, %2 nt" ::"v"(vo_s), "v"(vl), "s"(sl) : "memory");
+#else
             wgq_st8<0>(sh, vo_s, vh);
             wgq_st8<0>(sl, vo_s, vl);
+#endif
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -227,6 +239,13 @@ __global__ __launch_bounds__(512) void convgemm16g_kernel(const ConvGemm16sArgs 
     // ---------------------------------------------- the wave's DMA pieces ----------------------------------------------
     // A: instruction i = wave + 8 k (k = 0..3) of the 32 per chunk: image i >> 4 (hi, lo), k-group (i >> 2) & 3, 64-row part i & 3
     // B: instruction i = wave + 8 k (k = 0..2) of the 24: image i / 12, k-group (i % 12) / 3, 64-column piece i % 3
+    // MEASURED AND NOT ADOPTED: an uneven split.  Of the two waves of a SIMD the older one (waves 0-3) wins every arbitration, finishes
+    // its multiplications first and waits at the chunk's barrier (phase stamps: 800 cycles per chunk on wave 0 against 160 on wave 4)
+    // while its partner, alone, cannot keep the matrix pipe busy through its own DMA issue (an LDS-DMA instruction holds its wave for
+    // 60-180 cycles).  With waves 0-3 (kept in front by s_setprio 1) issuing 5 + 5, 6 + 4 or 7 + 5 of the 8 A + 6 B instructions a
+    // SIMD's pair owes per chunk the waits even out (236 / 164 cycles) and the launch takes 110-114 us against 107.5-109.4 --
+    // MI355X_MICROARCH.md, "Two waves per SIMD", item 3: moving work between the two waves of a SIMD is zero- or negative-sum.  (Also
+    // slower: the even split with waves 0-3 on the hi and waves 4-7 on the lo images, 114-116 us.)
     unsigned a_src[4], a_dst[4], b_dst[3], b_hl[3], b_q[3];   // a_src: bytes from a chunk's image block (hi, tile row 0) to the piece
     int b_pc[3];
 #pragma unroll
@@ -302,12 +321,11 @@ __global__ __launch_bounds__(512) void convgemm16g_kernel(const ConvGemm16sArgs 
         if constexpr (k < 4) wgg_glds16(aa.img, va[k], a_dst[k] + (unsigned)(abuf * WGG_ABUF));
         else wgg_glds16(sbB, vb[k - 4], b_dst[k - 4] + bd);
     };
+#define WGG_IC(n) std::integral_constant<int, n>()
     auto issue = [&](auto ABUF, int bslot) __attribute__((always_inline)) {
         desc_request();
         prep(bslot);
-        fire(ABUF, std::integral_constant<int, 0>()); fire(ABUF, std::integral_constant<int, 1>()); fire(ABUF, std::integral_constant<int, 2>());
-        fire(ABUF, std::integral_constant<int, 3>()); fire(ABUF, std::integral_constant<int, 4>()); fire(ABUF, std::integral_constant<int, 5>());
-        fire(ABUF, std::integral_constant<int, 6>());
+        fire(ABUF, WGG_IC(0)); fire(ABUF, WGG_IC(1)); fire(ABUF, WGG_IC(2)); fire(ABUF, WGG_IC(3)); fire(ABUF, WGG_IC(4)); fire(ABUF, WGG_IC(5)); fire(ABUF, WGG_IC(6));
     };
 
     // ---------------------------------------------- multiply ----------------------------------------------
@@ -315,7 +333,7 @@ __global__ __launch_bounds__(512) void convgemm16g_kernel(const ConvGemm16sArgs 
     const int ao = (lane >> 4) * WGG_APLANE + (64 * wr + (lane & 15)) * 16;           // + 256 per 16-row block, + WGG_AIMG for lo
     const int bo = WGG_BBASE + (lane >> 4) * WGG_BPLANE + (96 * wc + (lane & 15)) * 16;
     f32x4 acc[4][6];
-    bf16x8 Ah[2][4], Al[2][4], Bh[2], Bl[2];
+    bf16x8 Ah[2][4], Al[2][4];
     auto rd = [&](const char *q) __attribute__((always_inline)) { return *reinterpret_cast<const bf16x8 *>(q); };
 #define WGG_SB() __builtin_amdgcn_sched_barrier(0)
 #if defined(WGG_DBG_NOMFMA)                               // timing build: fragments are read, nothing is multiplied
@@ -376,41 +394,14 @@ __global__ __launch_bounds__(512) void convgemm16g_kernel(const ConvGemm16sArgs 
         if (acc[0][0][0] + acc[1][1][1] + acc[2][4][2] + acc[3][5][3] == 12345.f) aa.s0.hi[lane] = 1;
 #endif
     };
-    // one column block: 12 MFMAs, a different accumulator every time; behind the first four: the next block's B fragments, in the second
-    // half of a chunk two row blocks of the next chunk's A, and a share of chunk gc + 2's DMA (block 0 prepares and issues A piece 0,
-    // block 1 A pieces 1 and 2, block 2 A piece 3, blocks 3-5 the three B pieces)
-    auto block = [&](auto PARC, auto NBC, const char *pbuf, const char *pan) __attribute__((always_inline)) {
-        constexpr int PAR = decltype(PARC)::value, nb = decltype(NBC)::value, cur = nb & 1, nxt = cur ^ 1;
-        WGG_SB();
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) WGG_MFMA(Al[PAR][mb], Bh[cur], acc[mb][nb]);
-        WGG_SB();
-        if constexpr (nb < 5) { Bh[nxt] = rd(pbuf + (nb + 1) * 256); Bl[nxt] = rd(pbuf + WGG_BIMG + (nb + 1) * 256); }
-        if constexpr (nb == 3 || nb == 4) {
-#pragma unroll
-            for (int mb = 2 * (nb - 3); mb < 2 * (nb - 3) + 2; ++mb) { Ah[PAR ^ 1][mb] = rd(pan + mb * 256); Al[PAR ^ 1][mb] = rd(pan + WGG_AIMG + mb * 256); }
-        }
-        WGG_SB();
-#if !defined(WGG_OPT_ISSUE_TOP)
-        if constexpr (nb == 0) { prep(bs >= 1 ? bs - 1 : 2); fire(PARC, std::integral_constant<int, 0>()); }
-        if constexpr (nb == 1) { fire(PARC, std::integral_constant<int, 1>()); fire(PARC, std::integral_constant<int, 2>()); }
-        if constexpr (nb >= 2) fire(PARC, std::integral_constant<int, nb + 1>());
-        WGG_SB();
-#endif
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) WGG_MFMA(Ah[PAR][mb], Bl[cur], acc[mb][nb]);
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) WGG_MFMA(Ah[PAR][mb], Bh[cur], acc[mb][nb]);
-        WGG_SB();
-    };
 #if defined(WG_DBG_TRACE)
     // slots 0-7: inside the chunk WGG_TRACE_GC (before the TOP wait, after it, after the barrier, after blocks 0 and 2, after the MID wait,
     // after its barrier, after block 5); 8: kernel entry, 9: first chunk, 10 / 11: tile 0's main loop / epilogue done, 12 / 13: tile 1's
 #if !defined(WGG_TRACE_GC)
 #define WGG_TRACE_GC 12
 #endif
-#define WGG_TRACE(slot) do { if (EPI == EPI_GATE_SO && lane == 0 && wave == WGG_TRACE_WAVE) { \
-        wg_dbg_trace[blockIdx.x * 16 + (slot)] = wall_clock64(); wg_dbg_trace_cyc[blockIdx.x * 16 + (slot)] = clock64(); } } while (0)
+#define WGG_TRACE(slot) do { if (lane == 0 && wave == WGG_TRACE_WAVE) { const int r_ = (EPI == EPI_GATE_SO ? 0 : 256) + blockIdx.x; \
+        wg_dbg_trace[r_ * 16 + (slot)] = wall_clock64(); wg_dbg_trace_cyc[r_ * 16 + (slot)] = clock64(); } } while (0)
 #define WGG_TRACE_IN(slot) do { if (gc == WGG_TRACE_GC) WGG_TRACE(slot); } while (0)
 #if !defined(WGG_TRACE_WAVE)
 #define WGG_TRACE_WAVE 0
@@ -419,57 +410,88 @@ __global__ __launch_bounds__(512) void convgemm16g_kernel(const ConvGemm16sArgs 
 #define WGG_TRACE(slot) do { } while (0)
 #define WGG_TRACE_IN(slot) do { } while (0)
 #endif
+    // ------------------------------------------------------------------------------------------------------------------------
+    // ONE barrier per chunk, the chunk's last column block multiplied BEHIND the next chunk's barrier (107.6-110.1 us per gate conv
+    // against 113.6 for the first form of this kernel, which had a second barrier in the middle of the chunk for A(c + 1)):
+    //   TOP(c): wait until the own pieces of A(c + 1) and B(c) have landed (vmcnt(3): all but the three B pieces of chunk c + 1), all own
+    //           LDS reads returned (lgkmcnt(0)); barrier.  Now A(c + 1) and B(c) are readable, A(c)'s buffer (in registers since phase
+    //           c - 1) and B(c - 1)'s (its last fragments are in registers) are free.
+    //   then:   request B(c)'s first fragments; multiply column block 5 of chunk c - 1 from registers (that covers the LDS round trip
+    //           which otherwise every wave of the workgroup sits out at once behind the barrier); if chunk c - 1 ended a tile: epilogue;
+    //           column blocks 0-4 of chunk c, each requesting the next block's B fragments (three register pairs in rotation), block
+    //           n < 4 copying row block n of A(c + 1) into the other A register set, blocks 0-1 issuing the four A pieces of chunk
+    //           c + 2, blocks 2-4 its three B pieces.
+    // The weights have ~0.9 chunk times to land (L2 hits), the activations ~1.7.
+    // ------------------------------------------------------------------------------------------------------------------------
+    bf16x8 B3h[3], B3l[3];
+    auto mm4 = [&](const bf16x8 (&A_)[4], const bf16x8 &B_, auto NBC) __attribute__((always_inline)) {
+        constexpr int nb = decltype(NBC)::value;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) WGG_MFMA(A_[mb], B_, acc[mb][nb]);
+    };
+    auto sblock = [&](auto PARC, auto NBC, const char *pbuf, const char *pan) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(PARC)::value, nb = decltype(NBC)::value, cur = nb % 3, nxt = (nb + 1) % 3;
+        WGG_SB();
+        mm4(Al[PAR], B3h[cur], NBC);
+        WGG_SB();
+        B3h[nxt] = rd(pbuf + (nb + 1) * 256); B3l[nxt] = rd(pbuf + WGG_BIMG + (nb + 1) * 256);
+        if constexpr (nb < 4) { Ah[PAR ^ 1][nb] = rd(pan + nb * 256); Al[PAR ^ 1][nb] = rd(pan + WGG_AIMG + nb * 256); }
+        WGG_SB();
+        if constexpr (nb == 0) { prep(bs >= 1 ? bs - 1 : 2); fire(PARC, WGG_IC(0)); fire(PARC, WGG_IC(1)); }
+        if constexpr (nb == 1) { fire(PARC, WGG_IC(2)); fire(PARC, WGG_IC(3)); }
+        if constexpr (nb >= 2) fire(PARC, WGG_IC(nb + 2));
+        WGG_SB();
+        mm4(Ah[PAR], B3l[cur], NBC);
+        mm4(Ah[PAR], B3h[cur], NBC);
+        WGG_SB();
+    };
+    // column block 5 of the chunk whose A fragments are register set PAR (its B fragments: pair 2)
+    auto last_block = [&](auto PARC) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(PARC)::value;
+        WGG_SB();
+        mm4(Al[PAR], B3h[2], std::integral_constant<int, 5>());
+        mm4(Ah[PAR], B3l[2], std::integral_constant<int, 5>());
+        mm4(Ah[PAR], B3h[2], std::integral_constant<int, 5>());
+        WGG_SB();
+    };
+    auto tile_done = [&]() __attribute__((always_inline)) {
+        if (ck < 2) WGG_TRACE(10 + 2 * ck);
+        epilogue();
+        if (ck < 2) WGG_TRACE(11 + 2 * ck);
+        ++ck;
+        tile_at(ck, ct, m0);
+    };
     auto phase = [&](auto PARC) __attribute__((always_inline)) {
         constexpr int PAR = decltype(PARC)::value;
         WGG_TRACE_IN(0);
-        // TOP: B(gc) has landed everywhere, A(gc)'s and B(gc - 1)'s buffers are free
-        asm volatile("s_waitcnt vmcnt(7)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
         WGG_TRACE_IN(1);
         WGG_BAR();
         WGG_TRACE_IN(2);
         const char *pbuf = smem + bs * WGG_BBUF + bo, *pan = smem + (PAR ^ 1) * WGG_ABUF + ao;
-        Bh[0] = rd(pbuf); Bl[0] = rd(pbuf + WGG_BIMG);
-#if defined(WGG_OPT_ISSUE_TOP)
-        WGG_SB();
-        issue(PARC, bs >= 1 ? bs - 1 : 2);                   // chunk gc + 2: A buffer gc & 1, B slot (gc + 2) % 3
-#else
+        B3h[0] = rd(pbuf); B3l[0] = rd(pbuf + WGG_BIMG);
         desc_request();
-#endif
-        WGG_SB();
-        block(PARC, std::integral_constant<int, 0>(), pbuf, pan);
+        if (gc > 0) {
+            last_block(std::integral_constant<int, PAR ^ 1>());
+            if (cc == 0) { tile_done(); acc_start(); }
+        }
         WGG_TRACE_IN(3);
-        block(PARC, std::integral_constant<int, 1>(), pbuf, pan);
-        block(PARC, std::integral_constant<int, 2>(), pbuf, pan);
+        sblock(PARC, std::integral_constant<int, 0>(), pbuf, pan);
+        sblock(PARC, std::integral_constant<int, 1>(), pbuf, pan);
+        sblock(PARC, std::integral_constant<int, 2>(), pbuf, pan);
         WGG_TRACE_IN(4);
-        // MID: A(gc + 1) has landed everywhere (younger: the three B pieces of chunk gc + 1 and the four A pieces of chunk gc + 2)
-#if defined(WGG_OPT_ISSUE_TOP)
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-#else
-        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-#endif
-        WGG_TRACE_IN(5);
-        WGG_BAR();
-        WGG_TRACE_IN(6);
-        block(PARC, std::integral_constant<int, 3>(), pbuf, pan);
-        block(PARC, std::integral_constant<int, 4>(), pbuf, pan);
-        block(PARC, std::integral_constant<int, 5>(), pbuf, pan);
+        sblock(PARC, std::integral_constant<int, 3>(), pbuf, pan);
+        sblock(PARC, std::integral_constant<int, 4>(), pbuf, pan);
         WGG_TRACE_IN(7);
         bs = bs == 2 ? 0 : bs + 1;
         ++gc;
-        if (++cc == nchunks) {
-            if (ck < 2) WGG_TRACE(10 + 2 * ck);
-            epilogue();
-            if (ck < 2) WGG_TRACE(11 + 2 * ck);
-            cc = 0; ++ck;
-            tile_at(ck, ct, m0);
-            if (gc < total) acc_start();
-        }
+        if (++cc == nchunks) cc = 0;
     };
     WGG_TRACE(8);
     issue(std::integral_constant<int, 0>(), 0);
     issue(std::integral_constant<int, 1>(), 1);
     acc_start();
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");        // the own pieces of A(0)
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");        // the own pieces of A(0): younger are B(0), A(1), B(1)
     WGG_BAR();
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) { Ah[0][mb] = rd(smem + ao + mb * 256); Al[0][mb] = rd(smem + WGG_AIMG + ao + mb * 256); }
@@ -478,10 +500,15 @@ __global__ __launch_bounds__(512) void convgemm16g_kernel(const ConvGemm16sArgs 
         phase(std::integral_constant<int, 0>());
         if (gc < total) phase(std::integral_constant<int, 1>());
     }
+    if (total & 1) last_block(std::integral_constant<int, 0>());      // (the last chunk's A fragments: register set (total - 1) & 1)
+    else last_block(std::integral_constant<int, 1>());
+    tile_done();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the trailing fetches must not land in another workgroup's LDS
+    WGG_TRACE(14);                                           // (every load and store of the wave is done)
 #undef WGG_SB
 #undef WGG_MFMA
 #undef WGG_BAR
+#undef WGG_IC
 #undef WGG_TRACE
 #undef WGG_TRACE_IN
 }

@@ -32,7 +32,11 @@ wb, cb = (C.c_ulonglong * N)(), (C.c_ulonglong * N)()
 L.wg_dbg_trace_read.argtypes = [C.c_void_p, C.c_int]
 L.wg_dbg_trace_read_cycles.argtypes = [C.c_void_p, C.c_int]
 assert L.wg_dbg_trace_read(wb, N) == 0 and L.wg_dbg_trace_read_cycles(cb, N) == 0
-wall = np.frombuffer(wb, dtype=np.uint64).reshape(512, 16).astype(np.float64)[:256] / 100.0      # us
+wall_all = np.frombuffer(wb, dtype=np.uint64).reshape(512, 16).astype(np.float64) / 100.0       # us
+wall = wall_all[:256]
+res = wall_all[256:]                                  # the last residual conv (EPI_STORE_SO) launch: the one in front of the last gate conv
+print("residual conv in front: entry %.1f .. exit %.1f us before the gate conv's first entry; gate conv entry spread %.2f us, exit (max) %.1f us after its first entry" % (
+    wall[:, 8].min() - res[:, 8].min(), wall[:, 8].min() - res[:, 14].max(), wall[:, 8].max() - wall[:, 8].min(), wall[:, 14].max() - wall[:, 8].min()))
 cyc = np.frombuffer(cb, dtype=np.uint64).reshape(512, 16).astype(np.float64)[:256]
 inn = ["top wait", "top barrier", "block 0", "blocks 1-2", "mid wait", "mid barrier", "blocks 3-5"]
 d = np.diff(cyc[:, :8], axis=1)
@@ -41,9 +45,9 @@ for n, col in zip(inn, d.T):
     print("  %-12s %6.0f %6.0f %6.0f" % (n, np.median(col), col.mean(), np.percentile(col, 90)))
 print("  %-12s %6.0f   (MFMA issue: 2304 per SIMD)" % ("chunk", np.median(cyc[:, 7] - cyc[:, 0])))
 t0 = wall[:, 8].min()
-names = ["entry", "loop", "ml0", "ep0", "ml1", "ep1"]
-tl = wall[:, 8:14] - t0
+names = ["entry", "loop", "ml0", "ep0", "ml1", "ep1", "exit"]
+tl = wall[:, 8:15] - t0
 print("timeline, us from the first workgroup's entry (mean / max): " + "  ".join("%s %.1f/%.1f" % (n, v, m) for n, v, m in zip(names, tl.mean(axis=0), tl.max(axis=0))))
-dc, dw = np.diff(cyc[:, 8:14], axis=1), np.diff(wall[:, 8:14], axis=1) * 100.0
+dc, dw = np.diff(cyc[:, 8:15], axis=1), np.diff(wall[:, 8:15], axis=1) * 100.0
 print("clock (GHz): " + "  ".join("%s %.2f" % (n, v) for n, v in zip(names[1:], np.median(dc / np.maximum(dw, 1) / 10.0, axis=0))))
 print("cycles per chunk over tile 0's main loop: %.0f" % np.median((cyc[:, 10] - cyc[:, 9]) / 27.0))
