@@ -17,14 +17,17 @@ of the gradients when N > 1).  Data loading, mel computation, optimizer step and
 SURVEY.md 8d.  Per-GPU batch is fixed (weak scaling): configs[1] of BASELINE.json at N=1, configs[2] at N=8.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline     : the dominant kernel (dilated conv + conditioning + gate, convgemm16q_kernel<EPI_GATE>) timed with HIP
-                 events over the timed steps, algorithmic FLOPs / average launch duration vs the dense bf16 MFMA peak
+  roofline     : the dominant kernel (dilated conv + conditioning + gate; the line names the instantiation that RAN, as the library
+                 reports it per launch: wg_timer_read_name) timed with HIP events over as many EXTRA steps behind the timed ones
+                 (nothing is attached while the headline runs), algorithmic FLOPs / average launch duration vs the dense bf16 MFMA peak
                  (2.5 PF; only algorithmic FLOPs are credited, the 3 issued bf16 products per fp32 product are overhead;
                  `f32_mode` carries the exact-fp32 run against the 157.3 TF fp32 MFMA peak);
   cpu_baseline : the CPU path (oracle/torch_cpu.py: the algorithm restated on ATen's CPU kernels, the library the reference runs
                  on) timed on the host cores on one 16 000-sample segment of the same workload (rank 0, N=1 only), with the plain-C
                  oracle next to it as `c_port`;
-  inverse_khz  : single-GPU synthesis speed, timed as the reference does (inference.py:50-56).
+  inverse_khz  : single-GPU synthesis speed, timed as the reference does (inference.py:50-56);
+  box          : a fixed matrix-pipe + LDS loop of the library (wg_box_probe, ~0.5 s before the warm-up is over): issued TFLOP/s and the
+                 in-kernel clock of THIS GPU -- the boxes of the pool differ by a few per cent, this makes that a measured field.
 """
 import argparse
 import ctypes as C
@@ -59,12 +62,33 @@ def build_model(dev, seed=0):
     return model.to(dev)
 
 
-def _traffic(kernel, prefix=""):
-    """(HBM bytes per launch of the dominant kernel, the file it was read from).  NOT measured in this run: the bytes come from the
-    newest committed PMC summary (profiles/*_hbm_traffic.json, produced by tools/profile_summary.py from separate rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes); (None, None) if absent."""
+EPI_NUM = {"EPI_STORE": 0, "EPI_GATE": 1, "EPI_RESSKIP": 2, "EPI_DGATE": 3, "EPI_STORE_SO": 4, "EPI_GATE_SO": 5, "EPI_DGATE_SO": 6,
+           "EPI_STORE_FO": 7}               # csrc/wg_gemm.h
+
+
+def launch_site_to_rocprof(expr):
+    """The kernel expression of a launch site as the library records it (wg_timer_read_name: "(convgemm16q_kernel<EPI_GATE_SO, 2, 2>)")
+    in the form rocprofv3 prints, WITHOUT the closing bracket and the defaulted template arguments the launch site leaves out
+    ("convgemm16q_kernel<5, 2, 2"): a prefix of the rocprofv3 name ("void convgemm16q_kernel<5, 2, 2, false, false>(ConvGemm16sArgs)")."""
+    e = expr.strip()
+    while e.startswith("(") and e.endswith(")"):
+        e = e[1:-1].strip()
+    if "<" not in e:
+        return e
+    name, targs = e.split("<", 1)
+    targs = targs.rsplit(">", 1)[0]
+    parts = [str(EPI_NUM.get(a.strip(), a.strip())) for a in targs.split(",")]
+    return "%s<%s" % (name.strip(), ", ".join(parts))
+
+
+def _traffic(kernel_prefix, prefix=""):
+    """(HBM bytes per launch of the dominant kernel, the file it was read from, the kernel's full name there).  NOT measured in this
+    run: the bytes come from the newest committed PMC summary (profiles/*_hbm_traffic.json, produced by tools/profile_summary.py from
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes)
+    whose kernel table holds a name that STARTS with `kernel_prefix` (launch_site_to_rocprof of the instantiation that ran in THIS run: a
+    summary of another kernel is never cited); (None, None, None) if there is none."""
     import glob
-    best = (None, None)
+    best = (None, None, None)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
         tag = os.path.basename(f)
         if (prefix and prefix not in tag) or (not prefix and ("_wf_" in tag or "_wsr_" in tag)):
@@ -73,9 +97,28 @@ def _traffic(kernel, prefix=""):
             k = json.load(open(f))["kernels"]
         except Exception:
             continue
-        if kernel in k:
-            best = (k[kernel]["hbm_bytes_per_launch"], os.path.relpath(f, ROOT))
+        for name, row in k.items():
+            bare = name[5:] if name.startswith("void ") else name
+            if bare.startswith(kernel_prefix) and bare[len(kernel_prefix):len(kernel_prefix) + 1] in (",", ">", "("):
+                best = (row["hbm_bytes_per_launch"], os.path.relpath(f, ROOT), bare)
     return best
+
+
+def box_probe(dev, ms=500):
+    """`box`: the library's fixed matrix-pipe + LDS loop (wg_box_probe, csrc/wg_probe.h) on this GPU, ~0.5 s: issued TFLOP/s and the
+    clock the chip holds in it.  The boxes of the pool differ by a few per cent on exactly this; with it in the line a reader can tell a
+    slower box from a slower build."""
+    from constant_memory_waveglow_amd import _lib
+    L = _lib.lib()
+    scratch = torch.empty(int(L.wg_box_probe_bytes()), dtype=torch.uint8, device=dev)
+    out = (C.c_double * 3)()
+    torch.cuda.synchronize()
+    rc = L.wg_box_probe(scratch.data_ptr(), int(ms), out, torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        return {"error": rc}
+    return {"probe": "wg_box_probe: 256 workgroups x 8 waves, 64 x 64 tile per wave, hi / lo fragments re-read from LDS, 3 v_mfma_f32_16x16x32_bf16 "
+                     "per fragment pair, random data, no global traffic; ~%d ms of back-to-back launches" % ms,
+            "tflops_issued": out[0], "clock_ghz": out[1], "ms_per_launch": out[2]}
 
 
 def _cpu_model():
@@ -539,6 +582,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-inverse", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the WSRGlow / WaveFlow step timings (SURVEY.md 8f rows)")
+    ap.add_argument("--no-box", action="store_true", help="skip the 0.5 s box-calibration probe (`box` in the line)")
     ap.add_argument("--spawn", action="store_true", help="go through the launcher even for --gpus 1 (a 1-rank RCCL group)")
     ap.add_argument("--dry-run", action="store_true", help="launcher only: print the child command and environment as JSON, start nothing")
     ap.add_argument("--oversubscribe", action="store_true",
@@ -680,48 +724,59 @@ def main(argv=None):
     for _ in range(args.warmup):
         step()
     L = _lib.lib()
+    box = box_probe(dev) if rank == 0 and not args.no_box else None
     per_step_gate = wl["gate_launches_per_step"]
-    timer = L.wg_timer_create(_lib.K_CONV_GATE, per_step_gate * args.steps) if rank == 0 else None
     barrier()
-    if timer:
-        L.wg_timer_attach(timer)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps):                                   # the headline: NOTHING attached, no event beyond the two brackets
         loss = step()
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0                             # this rank's own time (before the barrier: comm.per_rank_ms)
     barrier()
-    dt_own = time.perf_counter() - t0
-    if timer:
-        L.wg_timer_attach(None)
-    tmax = torch.tensor([dt_own], device=dev, dtype=torch.float64)
+    dt_all = time.perf_counter() - t0
+    logged = trainer.metrics_dict() if (rank == 0 and trainer is not None) else None     # (of the last TIMED step: before comm_report's un-reduced ones)
+    tmax = torch.tensor([dt_all], device=dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
     value = world * B * SEGW * args.steps / dt
     comm = comm_report(wl, args, use_dist, world, rank, dev, dt_own, ms_per_step, barrier) if use_dist else None
+    # the dominant kernel's launch duration: HIP events around every launch of its class over `args.steps` EXTRA steps (every rank runs
+    # them: the collectives need all ranks), outside the timed region; the library reports which instantiation each launch ran
+    timer = L.wg_timer_create(_lib.K_CONV_GATE, per_step_gate * args.steps) if rank == 0 else None
+    barrier()
+    if timer:
+        L.wg_timer_attach(timer)
+    for _ in range(args.steps):
+        step()
+    barrier()
+    if timer:
+        L.wg_timer_attach(None)
 
     out = None
     if rank == 0:
         n = L.wg_timer_count(timer)
         buf = (C.c_float * n)()
         L.wg_timer_read(timer, buf, n)
+        names = {}
+        nb = C.create_string_buffer(256)
+        for i in range(n):
+            if L.wg_timer_read_name(timer, i, nb, 256) >= 0:
+                names[nb.value.decode()] = names.get(nb.value.decode(), 0) + 1
         L.wg_timer_destroy(timer)
-        gate_ms = float(np.mean(np.frombuffer(buf, dtype=np.float32))) if n else float("nan")
+        ms_all = np.frombuffer(buf, dtype=np.float32)
+        gate_ms = float(np.mean(ms_all)) if n else float("nan")
         gate_flop = wl["gate_flop_per_launch"]                           # algorithmic FLOPs of one launch
         achieved = gate_flop / (gate_ms * 1e-3) / 1e12
         split = _lib.default_precision() != _lib.PREC_F32
-        kname = {0: 'convgemm_kernel', 1: 'convgemm16_kernel', 2: 'convgemm16q_kernel'}[_lib.default_precision()]
         # bf16x3: every fp32 product costs three bf16 MFMAs; the roofline is the bf16 matrix pipe and only the
         # algorithmic FLOPs are credited (the 3x is overhead, not work) -- SURVEY.md 8d
         peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
-        # template arguments as rocprofv3 prints them: <EPI_GATE_SO = 5 (EPI_GATE = 1 where a fp32 gate plane is written), NI = 2 (128 columns), MG = 2 (256-row tile, one workgroup per CU)>
-        targs = {"convgemm_kernel": ["<1>"], "convgemm16_kernel": ["<1, 4>", "<1, 2>"], "convgemm16q_kernel": ["<5, 2, 2>", "<5, 2, 1>", "<1, 2, 2>", "<1, 2, 1>"]}[kname]   # 5 = EPI_GATE_SO: EPI_GATE with hand-issued stores (wg_gemm.h)
-        traffic, traffic_src, tsel = None, None, targs[0]
-        for ta in targs:
-            traffic, traffic_src = _traffic(kname + ta, wl["profile_prefix"])
-            if traffic is not None:
-                tsel = ta
-                break
+        # the instantiation most of the timed launches ran (a model may take more than one: small flows, other tile forms)
+        site = max(names, key=names.get) if names else ""
+        kprefix = launch_site_to_rocprof(site)
+        traffic, traffic_src, kfull = _traffic(kprefix, wl["profile_prefix"]) if kprefix else (None, None, None)
         if traffic_src:
             traffic_src += " (committed rocprofv3 --pmc summary of this command; not re-measured in this run)"
         STEP_FLOP = wl["step_flop_per_sample"]
@@ -736,10 +791,13 @@ def main(argv=None):
             "dtype": "f32 (contractions as split bf16x3 MFMA, fp32 accumulate)" if split else "f32", "data": "synthetic",
             "config": {"workload": wl["workload"] + (" + RCCL grad all-reduce" if world > 1 else ""),
                        "global_batch": B * world, "segment": SEGW, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "%s%s (EPI_GATE: %s)" % (kname, tsel, wl["gate_what"]),
+            "roofline": {"bound": "mfma", "kernel": "%s (EPI_GATE: %s)" % (kfull or (kprefix + ">" if "<" in kprefix else kprefix), wl["gate_what"]),
+                         "kernel_launch_sites": names,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "launch_ms": gate_ms, "launches_timed": n, "flop_per_launch": gate_flop,
+                         "launch_ms": gate_ms, "launches_timed": n, "launch_timing": "HIP events around every launch of the class over %d extra steps "
+                                                                                    "behind the timed ones (nothing is attached while the headline runs)" % args.steps,
+                         "flop_per_launch": gate_flop,
                          "mfma_tflops_issued": achieved * (3 if split else 1),
                          "x_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS},
             "step_flop_per_sample": STEP_FLOP,
@@ -748,8 +806,10 @@ def main(argv=None):
             "step_frac_of_bf16_mfma_peak": value * STEP_FLOP / 1e12 / world / BF16_MFMA_PEAK_TFLOPS,
             "loss": float(loss),
         }
-        if trainer is not None:
-            out["logged"] = trainer.metrics_dict()     # the scalars LightModel.training_step logs (lightning.py:58-64), rank-mean
+        if box is not None:
+            out["box"] = box
+        if logged is not None:
+            out["logged"] = logged                     # the scalars LightModel.training_step logs (lightning.py:58-64), rank-mean, of the last timed step
         if comm is not None:
             out["comm"] = comm
         if args.model != "waveglow":

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WGFLOW_LIB") or os.path.join(_HERE, "csrc", "libwgflow.so")   # WGFLOW_LIB: developer A/B builds
 _LIB = None
 
-ABI_VERSION = 7          # include/wgflow.h WG_ABI_VERSION (7: wg_wf_config gained bias)
+ABI_VERSION = 8          # include/wgflow.h WG_ABI_VERSION (8: wg_timer_read_name, wg_box_probe)
 ABI_SYMBOLS = [
     "wg_strerror", "wg_abi_version", "wg_param_count", "wg_packed_bytes", "wg_workspace_bytes",
     "wg_wn_param_count", "wg_wn_packed_bytes", "wg_coupling_workspace_bytes", "wg_invconv_workspace_bytes",
@@ -22,6 +22,7 @@ ABI_SYMBOLS = [
     "wg_nll_scratch_floats", "wg_train_scratch_floats",
     "wg_timer_create", "wg_timer_attach", "wg_timer_count", "wg_timer_read", "wg_timer_read_info", "wg_timer_destroy", "wg_stat_wgrad16t_launches",
     "wg_stat_layer_launches", "wg_layer_workspace_bytes", "wg_layer_apply", "wg_wf_wn_apply",
+    "wg_timer_read_name", "wg_box_probe_bytes", "wg_box_probe",
 ]
 K_CONV_STORE, K_CONV_GATE, K_CONV_RESSKIP, K_CONV_DGATE, K_WGRAD, K_LAYER = range(6)
 
@@ -149,6 +150,10 @@ def lib():
     L.wg_layer_apply.argtypes = [C.POINTER(WgLayerDims), vp, vp, vp, i, i, vp, vp, vp, sz, vp]
     L.wg_timer_destroy.argtypes = [vp]
     L.wg_timer_destroy.restype = None
+    L.wg_timer_read_name.argtypes = [vp, i, C.c_char_p, i]
+    L.wg_box_probe_bytes.restype = C.c_size_t
+    L.wg_box_probe_bytes.argtypes = []
+    L.wg_box_probe.argtypes = [vp, i, vp, vp]
     _LIB = L
     return L
 

@@ -16,6 +16,7 @@
 #include "wg_layer16h.h"
 #include "wg_layer16q.h"
 #include "wg_thin.h"
+#include "wg_probe.h"
 
 #include <algorithm>
 #include <atomic>
@@ -63,10 +64,14 @@ struct StageRec {
         return x;
     }
 };
+// (g_last_launch: the kernel expression of the calling thread's most recent launch as written at the launch site -- an attached timer
+// keeps it per recorded launch, wg_timer_read_name, so that a benchmark names the instantiation that RAN)
+thread_local const char *g_last_launch = "";
 #define WG_LAUNCH(ctx, kern, grid, block, shmem, ...)                         \
     do {                                                                      \
         if ((ctx).rec) (ctx).rec->ok = false;   /* not a recordable launch */ \
         else if ((ctx).err == 0) {                                            \
+            g_last_launch = #kern;                                            \
             hipLaunchKernelGGL(kern, grid, block, shmem, (ctx).st, __VA_ARGS__); \
             if (hipGetLastError() != hipSuccess) (ctx).err = WG_ELAUNCH;      \
         }                                                                     \
@@ -78,6 +83,7 @@ struct KernelTimer {
     int kernel_id, capacity, count;      // kernel_id < 0: every timed kernel class
     hipEvent_t *start, *stop;
     long long *info;                     // per recorded launch: class, M, K, columns, algorithmic HBM bytes (wg_timer_read_info)
+    const char **name;                   // per recorded launch: the kernel expression of its launch site (wg_timer_read_name)
 };
 std::atomic<KernelTimer *> g_timer{nullptr};
 std::atomic<long long> g_wgrad16t_launches{0};               // diagnostics: launches of wgrad16t_kernel by this process (wg_stat_wgrad16t_launches)
@@ -96,7 +102,7 @@ struct TimerScope {
             (void)hipEventRecord(t->start[slot], st);
         }
     }
-    ~TimerScope() { if (slot >= 0) (void)hipEventRecord(t->stop[slot], st); }
+    ~TimerScope() { if (slot >= 0) { (void)hipEventRecord(t->stop[slot], st); t->name[slot] = g_last_launch; } }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -866,6 +872,15 @@ int ensure_dynamic_lds(const void *kernel, int slot, size_t bytes)
     return 0;
 }
 
+// the 32-bit byte offsets of convgemm16g_kernel: every operand's hi + lo arrays and the weight image's hi + lo halves span less than 4 GB
+static bool g192_fits(const ConvGemm16sArgs &as, size_t img_stride, int nseg)
+{
+    if (img_stride * 4 >= (1ull << 32)) return false;
+    for (int s = 0; s < nseg; ++s)
+        if (as.sseg[s].lo_off * 4 >= (1ull << 32)) return false;
+    return true;
+}
+
 // env WG_G192 (read once): 0 = the conv products never take the 256 x 192-tile kernel of wg_gemm16g.h (A/B runs in one build)
 static bool g192_on()
 {
@@ -1034,7 +1049,10 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
 #if !defined(WG_OPT_NO_G192)
             // 256 x 192 tiles over flattened columns, eight multiplying waves fed by LDS-DMA (wg_gemm16g.h): the S-plane-only gate conv and
             // store / data-gradient / skip products whose tiles deal out evenly over the CUs (env WG_G192=0 restores the 256 x 128 / 128 x 128 forms)
-            if (g192_on() && !small && (so_gate || so_epi) && g.rows == 0 && !cx.row_sel1 && !cx.rec && M % WGG_BM == 0 && g.H >= 64 && cus % 8 == 0) {
+            // (products of fewer than 16 chunks -- the residual conv, K = 256: 36.6 against 35.3 us -- stay on the older kernel: a tile that
+            // short is mostly this kernel's longer prologue; S-plane arrays and weight images beyond 4 GB: its 32-bit offsets)
+            if (g192_on() && !small && (so_gate || so_epi) && g.rows == 0 && !cx.row_sel1 && !cx.rec && M % WGG_BM == 0 && g.H >= 64 && cus % 8 == 0 &&
+                nc >= 16 && nc <= WGG_MAXCHUNKS && g192_fits(as, a16.img_stride, nseg)) {
                 const int nct = (g.B * g.Tt + WGG_BN - 1) / WGG_BN, nrb = M / WGG_BM, nt = nct * nrb;
                 const int rounds = (nt + cus - 1) / cus;
                 if (nt >= cus && (double)(rounds * cus - nt) <= 0.1 * rounds * cus) {
@@ -1466,7 +1484,24 @@ void run_wgrad_group_pair(Ctx &cx, const Geo &g, const WgradGroupSpec *gs0, int 
         pp.p[w].sync_n = pp.gx[w] * pp.gy[w];
     }
     pp.n0 = pp.n[0];
-    TimerScope ts(WG_K_WGRAD, cx.st);
+    // (the launch as ONE timer entry, like the planned kernel above: M = sum of the gradients' sizes, K = 1, columns = time steps)
+    long long mm = 0, ch = 0, slabf = 0;
+    for (int w = 0; w < 2; ++w) {
+        const WgradSArgs &q = pp.p[w];
+        long long rows = 0, colsB = 0, distinct = 0;
+        for (int u = 0; u < q.nseg_a; ++u) rows += q.sa[u].nch;
+        for (int u = 0; u < q.nseg_b; ++u) {
+            colsB += q.sb[u].nch;
+            bool seen = false;
+            for (int v = 0; v < u; ++v) seen = seen || q.b_plane_of[v] == q.b_plane_of[u];
+            if (!seen) distinct += q.sb[u].nch;
+        }
+        mm += (long long)ng * rows * colsB;
+        ch += (long long)ng * (rows + distinct);
+        slabf += (long long)group_slab_floats(q);
+    }
+    const long long tsteps = (long long)g.B * g.T;
+    TimerScope ts(WG_K_WGRAD, cx.st, mm, 1, tsteps, 4 * ch * tsteps + 4 * slabf);
     WG_LAUNCH(cx, wgrad16s_pair_kernel, dim3(pp.n[0] + pp.n[1]), dim3(256), 0, pp);
 }
 
@@ -1666,8 +1701,12 @@ bool run_convlayer_big(Ctx &cx, float *ws, size_t lsync, FA &&gate_call, FB &&re
 
 // (the counters are left at zero by every launch; a call that was cut short -- an error half way -- is the reason they are cleared
 // once at the start of every entry point that may use them)
+// (only where one of the one-launch layer kernels can run at all: they are opt-in through WG_LAYER_FUSION / WG_LAYER_FUSION_BIG; without them
+// every forward / inverse call paid a 64 KB memset for counters nobody reads)
 void layer_sync_clear(Ctx &cx, float *ws, size_t lsync)
 {
+    const char *e0 = getenv("WG_LAYER_FUSION"), *e1 = getenv("WG_LAYER_FUSION_BIG");
+    if (!((e0 && e0[0] == '1') || (e1 && e1[0] == '1'))) return;
     if (cx.prec == 2 && !cx.err && hipMemsetAsync(ws + lsync, 0, WGL_SYNC_WORDS * sizeof(unsigned), cx.st) != hipSuccess) cx.err = WG_ELAUNCH;
 }
 
@@ -2259,6 +2298,7 @@ void *wg_timer_create(int kernel_id, int capacity)
     t->start = new hipEvent_t[capacity];
     t->stop = new hipEvent_t[capacity];
     t->info = new long long[5 * (size_t)capacity]();
+    t->name = new const char *[capacity]();
     for (int i = 0; i < capacity; ++i) { (void)hipEventCreate(&t->start[i]); (void)hipEventCreate(&t->stop[i]); }
     return t;
 }
@@ -2289,7 +2329,59 @@ void wg_timer_destroy(void *timer)
     if (!t) return;
     if (g_timer.load() == t) g_timer.store(nullptr);
     for (int i = 0; i < t->capacity; ++i) { (void)hipEventDestroy(t->start[i]); (void)hipEventDestroy(t->stop[i]); }
-    delete[] t->start; delete[] t->stop; delete[] t->info; delete t;
+    delete[] t->start; delete[] t->stop; delete[] t->info; delete[] t->name; delete t;
+}
+/* the kernel expression of recorded launch `index` as written at its launch site, e.g. "(convgemm16q_kernel<EPI_GATE_SO, 2, 2>)"
+ * (template arguments by name; defaulted ones absent); returns its length, or a negative error */
+int wg_timer_read_name(void *timer, int index, char *buf, int n)
+{
+    KernelTimer *t = (KernelTimer *)timer;
+    if (!t || !buf || n < 1 || index < 0 || index >= t->count) return WG_EINVAL;
+    const char *q = t->name[index] ? t->name[index] : "";
+    const int len = (int)strlen(q);
+    snprintf(buf, (size_t)n, "%s", q);
+    return len;
+}
+
+/* Box calibration: a FIXED matrix-pipe + LDS loop (every CU: eight waves, 64 x 64 tile per wave, hi / lo fragments re-read from LDS, three
+ * v_mfma_f32_16x16x32_bf16 per fragment pair -- the conv kernels' mix with no global traffic; tools/experiments/shape_probe.hip) on random
+ * data, launched back to back for about `ms` milliseconds.  out[0] = issued TFLOP/s of the last launches, out[1] = the clock held inside
+ * the kernel (GHz: shader cycles / 100 MHz wall clock, median over the workgroups), out[2] = ms per launch.  The boxes of a pool differ
+ * by a few per cent on exactly this (MI355X_MICROARCH.md, DVFS give-back item 5): a benchmark line that carries these numbers lets a
+ * reader tell a slower box from a slower build.  scratch: at least wg_box_probe_bytes() bytes of device memory. */
+size_t wg_box_probe_bytes(void) { return (size_t)65536 * 16 + (size_t)256 * 512 * 4 + 512 * 8; }
+int wg_box_probe(void *scratch, int ms, double *out, void *stream)
+{
+    if (!scratch || !out || ms < 1) return WG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    char *base = (char *)scratch;
+    u32x4 *rnd = (u32x4 *)base;
+    float *res = (float *)(base + (size_t)65536 * 16);
+    unsigned long long *stamps = (unsigned long long *)(base + (size_t)65536 * 16 + (size_t)256 * 512 * 4);
+    hipLaunchKernelGGL(box_fill_kernel, dim3(256), dim3(256), 0, st, rnd);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return WG_ELAUNCH;
+    float one = 0.f, last = 0.f;
+    (void)hipEventRecord(e0, st);
+    hipLaunchKernelGGL(box_probe_kernel, dim3(256), dim3(512), 0, st, rnd, res, stamps);
+    (void)hipEventRecord(e1, st);
+    if (hipStreamSynchronize(st) != hipSuccess || hipEventElapsedTime(&one, e0, e1) != hipSuccess) return WG_ELAUNCH;
+    const int batch = 8, rounds = std::max(1, (int)((double)ms / (std::max(one, 0.05f) * batch)));
+    for (int r = 0; r < rounds; ++r) {
+        (void)hipEventRecord(e0, st);
+        for (int i = 0; i < batch; ++i) hipLaunchKernelGGL(box_probe_kernel, dim3(256), dim3(512), 0, st, rnd, res, stamps);
+        (void)hipEventRecord(e1, st);
+        if (hipStreamSynchronize(st) != hipSuccess || hipEventElapsedTime(&last, e0, e1) != hipSuccess) return WG_ELAUNCH;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    std::vector<unsigned long long> h(512);
+    if (hipMemcpy(h.data(), stamps, 512 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return WG_ELAUNCH;
+    std::vector<double> ghz;
+    for (int b = 0; b < 256; ++b) ghz.push_back(h[2 * b + 1] ? (double)h[2 * b] / (double)h[2 * b + 1] / 10.0 : 0.0);
+    std::sort(ghz.begin(), ghz.end());
+    const double per = last / batch, flops = 256.0 * 8 * (double)WG_BOX_CHUNKS * 2.0 * 64 * 64 * 32 * 3;
+    out[0] = flops / (per * 1e-3) / 1e12; out[1] = ghz[128]; out[2] = per;
+    return 0;
 }
 
 int wg_param_count(const wg_config *cf) { return cf ? 3 + cf->n_flows + cf->n_flows * flow_wn(cf, 0).nparams() : WG_EINVAL; }
@@ -2516,6 +2608,7 @@ static int model_backward(const wg_config *cf, const void *const *params, const 
     const Geo g = W.g;
     const int G = cf->n_group;
     PRef X = pref(ws + W.X, W.Gp), dX = pref(ws + W.dX, W.Gp);
+    layer_sync_clear(cx, ws, W.wn.lsync);                   // (the recompute pass may take the one-launch layer: an aborted call must not leave its counters set)
     if (!resume) WG_LAUNCH(cx, squeeze_kernel, dim3((T + 255) / 256, B), dim3(256), 0, z, X, g, G, N);
     WG_LAUNCH(cx, squeeze_kernel, dim3((T + 255) / 256, B), dim3(256), 0, dz, dX, g, G, N);
     if (!resume) {
@@ -3376,6 +3469,7 @@ int wg_coupling_backward(const wg_wn_dims *dd, const void *const *params, const 
     float *ws = (float *)wsv;
     const Geo g = W.g;
     PRef X = pref(ws + W.X, W.Xp), dX = pref(ws + W.dX, W.Xp);
+    layer_sync_clear(cx, ws, W.wn.lsync);
     WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, 2 * d.ic, B), dim3(256), 0, z, X, g, 2 * d.ic);
     WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, 2 * d.ic, B), dim3(256), 0, dz, dX, g, 2 * d.ic);
     WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, d.aux, B), dim3(256), 0, y, pref(ws + W.Y, W.auxp), g, d.aux);

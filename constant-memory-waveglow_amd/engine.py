@@ -11,6 +11,9 @@ from . import _lib
 from ._lib import WgConfig, WgWnDims, WgError, check
 
 
+_CAPTURE_LOCK = __import__("threading").Lock()
+
+
 def _graph_mode():
     """How synthesis calls use hipGraphs (WG_GRAPHS): "0" never, "1" always (captured on the first call of a shape), unset = auto: a small
     call (at most 65 536 samples: ~250 launches of a few microseconds each) whose exact shape and buffers have been seen twice before is
@@ -234,7 +237,9 @@ class ModelEngine:
             self._launch(pk, ws, sz, sh, True)                      # warm-up outside capture
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: only THIS thread's calls are illegal during the capture -- another thread of the process (a serving thread,
+            # an nn.DataParallel replica sharing this engine) that allocates or launches meanwhile is left alone; one capture at a time
+            with _CAPTURE_LOCK, torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 out, logdet = self._launch(pk, ws, sz, sh, True)
             while len(self._graphs) >= 4:
                 self._graphs.pop(next(iter(self._graphs)))

@@ -52,6 +52,18 @@ class SlotTable:
         # does not keep its module alive (no module <-> table reference cycle).
         self._method, self._state = method, None
 
+    # The cached resolution holds a weak reference and the module tree's own dicts: neither survives (nor belongs in) a pickle.  A
+    # pickled / deep-copied table carries its method name only and resolves again on first use -- torch.save(model), multiprocessing
+    # and ddp_spawn pickle whole modules (the reference's configs are trained through Lightning's ddp plugin, train.py:51-53).
+    def __getstate__(self):
+        return {"_method": self._method, "_state": None}
+
+    def __setstate__(self, state):
+        self._method, self._state = state["_method"], None
+
+    def __deepcopy__(self, memo):
+        return SlotTable(self._method)
+
     def _resolve(self, owner):
         import weakref
         slots = getattr(owner, self._method)()

@@ -118,6 +118,8 @@ class _WaveFlowFn(Function):
         # (Function.forward runs with grad mode off; whether a backward can follow is what needs_input_grad says)
         z, logdet, tape = model._engine.forward(table, x.detach(), h.detach(), keep_tape=any(ctx.needs_input_grad))
         ctx.model, ctx.tape = model, tape
+        # (reverse_mode: the engine was handed M = W^-1 of the 1x1 weights AS THEY ARE NOW; the backward's chain rule must use the same M)
+        ctx.inv_key = getattr(model, "_inv_key", None) if (model._reverse_mode and model._mix_modules()) else None
         ctx.save_for_backward(h)
         return z, logdet
 
@@ -126,6 +128,12 @@ class _WaveFlowFn(Function):
         (h,) = ctx.saved_tensors
         model = ctx.model
         table = model.param_table()
+        if ctx.inv_key is not None and getattr(model, "_inv_key", None) != ctx.inv_key:
+            # param_table() has just rewritten the cached W^-1 in place from CHANGED 1x1 weights: dW = -M^T G M^T with that M would be a
+            # gradient of another function than the one the tape was produced with (the non-reverse path reads the live weights, where
+            # autograd's version counters flag the same mistake)
+            raise RuntimeError("WaveFlow(reverse_mode=True): a 1x1 weight was modified between forward and backward "
+                               "(or another forward ran in between); run backward before changing the weights")
         grads, dmel, dx = model._engine.backward([None if t is None else t.detach() for t in table], ctx.tape, h, dz, dlogdet,
                                                  ctx.needs_input_grad[2], ctx.needs_input_grad[1])
         by_id = {id(t): g for t, g in zip(table, grads) if t is not None}

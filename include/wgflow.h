@@ -81,9 +81,10 @@ const char *wg_strerror(int code);
  * training scalars and take their scratch from the caller, wg_melspec returns the power spectrogram on request, wg_wf_config gained
  * use_conv1x1, wg_wf_upsample; 4: wg_timer_create(-1, ..) times every kernel class, wg_timer_read_info, wg_stat_wgrad16t_launches,
  * wg_wf_* accept every WG_PREC_*; 5: wg_config and wg_wn_dims gained bias; 6: wg_stat_layer_launches, the workspaces carry the one-launch
- * layer's hand-off counters, wg_layer_apply / wg_layer_workspace_bytes, wg_wf_wn_apply; 7: wg_wf_config gained bias).  A binding built against another revision must not pass its
+ * layer's hand-off counters, wg_layer_apply / wg_layer_workspace_bytes, wg_wf_wn_apply; 7: wg_wf_config gained bias; 8: wg_timer_read_name,
+ * wg_box_probe / wg_box_probe_bytes).  A binding built against another revision must not pass its
  * structs: the Python loader compares this with its own ABI_VERSION and refuses the library otherwise. */
-#define WG_ABI_VERSION 7
+#define WG_ABI_VERSION 8
 int wg_abi_version(void);
 
 /* Diagnostics (no counterpart upstream; the reference times with wall-clock time(), inference.py:39-53): while a
@@ -105,7 +106,17 @@ int   wg_timer_read(void *timer, float *ms, int n);   /* after a stream sync; re
  * weight-gradient launch reports M = the summed sizes of its gradients, K = 1), algorithmic HBM bytes (every operand plane once, the
  * weights, the outputs and auxiliary planes of the epilogue); launches that are not conv / weight-gradient products report zeros */
 int   wg_timer_read_info(void *timer, long long *info, int n);
+/* the kernel expression of recorded launch `index` as written at its launch site in csrc/wgflow.hip, e.g.
+ * "(convgemm16q_kernel<EPI_GATE_SO, 2, 2>)" (template arguments by name, defaulted ones absent): which instantiation RAN.  Returns the
+ * name's length (it is truncated to n - 1 characters), or a negative error */
+int   wg_timer_read_name(void *timer, int index, char *buf, int n);
 void  wg_timer_destroy(void *timer);
+/* Box calibration (no counterpart upstream): a fixed matrix-pipe + LDS loop without global traffic on random data (csrc/wg_probe.h), run
+ * back to back for about `ms` milliseconds on `stream`.  out[0] = issued TFLOP/s, out[1] = the clock held inside the kernel (GHz),
+ * out[2] = ms per launch.  The boxes of a pool differ by a few per cent on exactly this loop; a benchmark line that carries these
+ * numbers tells a slower box from a slower build.  scratch: wg_box_probe_bytes() bytes of device memory.  Synchronises the stream. */
+size_t wg_box_probe_bytes(void);
+int    wg_box_probe(void *scratch, int ms, double *out, void *stream);
 /* diagnostics: how many times this process has launched wgrad16t_kernel (the one-workgroup-per-CU weight-gradient kernel; shapes
  * without a plan take wgrad16s_pair_kernel) -- lets a test assert which kernel a shape ran on */
 long long wg_stat_wgrad16t_launches(void);

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(L, s), "libwgflow.so lacks %s" % s
     assert sorted(_lib.ABI_SYMBOLS) == declared
-    assert L.wg_abi_version() == _lib.ABI_VERSION == 7
+    assert L.wg_abi_version() == _lib.ABI_VERSION == 8
     header = open(os.path.join(ROOT, "include", "wgflow.h")).read()
     assert "#define WG_ABI_VERSION %d" % _lib.ABI_VERSION in header
     # the ctypes mirror of wg_config has exactly the fields the header declares, in order
@@ -231,6 +231,35 @@ def test_param_table_follows_replaced_submodules():
     rep._modules["upsampler"] = cm.WaveGlow(**kw).upsampler
     assert rep.param_table()[0] is rep._modules["upsampler"].bias
     assert m.param_table()[0] is m.upsampler.bias
+
+
+def test_model_pickles_after_its_parameter_table_was_resolved():
+    """torch.save(model), multiprocessing and ddp_spawn pickle whole modules; the cached table (a weak owner reference + the module
+    tree's own dicts) must not ride along -- a restored or deep-copied model resolves its own."""
+    import copy
+    import io
+    import pickle
+    import torch
+    import constant_memory_waveglow_amd as cm
+    kw = dict(flows=2, n_group=8, n_early_every=4, n_early_size=2, hop_size=256, n_mels=20, memory_efficient=True, dilation_channels=32,
+              residual_channels=32, skip_channels=32, depth=2, radix=3, bias=False)
+    m = cm.WaveGlow(**kw)
+    m.param_table()
+    m2 = pickle.loads(pickle.dumps(m))
+    t2 = m2.param_table()
+    assert t2[0] is m2.upsampler.bias and t2[0] is not m.upsampler.bias and torch.equal(t2[0], m.upsampler.bias)
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m3 = torch.load(buf, weights_only=False)
+    assert m3.param_table()[-1] is m3.WNs[1].F.end.weight
+    m.apply(cm.remove_weight_norms)       # (torch cannot deep-copy a module under the old-style weight norm: its `weight` is not a leaf)
+    m.param_table()
+    m4 = copy.deepcopy(m)
+    assert m4.param_table()[0] is m4.upsampler.bias and m.param_table()[0] is m.upsampler.bias
+    blk = cm.AffineCouplingBlock(cm.WN, True, in_channels=4, aux_channels=20, dilation_channels=32, residual_channels=32, skip_channels=32, depth=2)
+    blk.F.param_table() if hasattr(blk.F, "param_table") else None
+    pickle.loads(pickle.dumps(blk))
 
 
 def test_packed_weights_key_is_committed_only_after_a_successful_pack():

@@ -87,3 +87,31 @@ def test_model_flag_reaches_every_rank(model):
 def test_unknown_model_is_refused():
     r = _run("--model", "melglow", "--dry-run")
     assert r.returncode != 0
+
+
+def test_launch_site_names_match_rocprof_names_by_prefix(tmp_path, monkeypatch):
+    """roofline.traffic is looked up under the kernel that RAN (wg_timer_read_name -> launch_site_to_rocprof), by prefix against the
+    names rocprofv3 prints: defaulted template arguments and the `void` / argument list are rocprofv3's, not the launch site's."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.launch_site_to_rocprof("(convgemm16q_kernel<EPI_GATE_SO, 2, 2>)") == "convgemm16q_kernel<5, 2, 2"
+    assert bench.launch_site_to_rocprof("convgemm16g_kernel<EPI_GATE_SO>") == "convgemm16g_kernel<5"
+    assert bench.launch_site_to_rocprof("(convgemm16q_kernel<EPI_GATE, 2, 2, false, true>)") == "convgemm16q_kernel<1, 2, 2, false, true"
+    assert bench.launch_site_to_rocprof("wgrad16t_kernel") == "wgrad16t_kernel"
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "r09a_hbm_traffic.json").write_text(json.dumps({"kernels": {
+        "void convgemm16q_kernel<5, 2, 2, false, false>(ConvGemm16sArgs)": {"hbm_bytes_per_launch": 2.0e8},
+        "void convgemm16q_kernel<5, 2, 1, false, false>(ConvGemm16sArgs)": {"hbm_bytes_per_launch": 9.0e8},
+        "void convgemm16g_kernel<5>(ConvGemm16sArgs)": {"hbm_bytes_per_launch": 1.9e8}}}))
+    (prof / "r09a_wsr_hbm_traffic.json").write_text(json.dumps({"kernels": {
+        "void convgemm16q_kernel<5, 1, 1, false, false>(ConvGemm16sArgs)": {"hbm_bytes_per_launch": 3.0e8}}}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    t, src, full = bench._traffic("convgemm16q_kernel<5, 2, 2")
+    assert t == 2.0e8 and src.endswith("r09a_hbm_traffic.json") and full.startswith("convgemm16q_kernel<5, 2, 2, false, false>")
+    t, src, full = bench._traffic("convgemm16g_kernel<5")
+    assert t == 1.9e8 and full == "convgemm16g_kernel<5>(ConvGemm16sArgs)"
+    assert bench._traffic("convgemm16q_kernel<1, 2, 2")[0] is None        # (a kernel no committed summary holds: nothing is cited)
+    assert bench._traffic("convgemm16q_kernel<5, 1, 1", "_wsr_")[0] == 3.0e8
