@@ -157,7 +157,11 @@ __device__ __forceinline__ void conv_acc_init_q(const ConvGemmArgs &a, const SRe
 template <int OFF>
 __device__ __forceinline__ void wgq_st8(const unsigned short *base, unsigned voff, const u32x2 &v)
 {
+#if defined(WG_OPT_ST_SC1)     // experiment: write-through S-plane stores -- fewer dirty lines for the end-of-kernel write-back (the kernel boundary costs
+    asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3 sc1" ::"v"(voff), "v"(v), "s"(base), "n"(OFF) : "memory");      // ~1.5 us + dirty bytes / 6 TB/s)
+#else
     asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" ::"v"(voff), "v"(v), "s"(base), "n"(OFF) : "memory");
+#endif
 }
 template <int OFF>
 __device__ __forceinline__ void wgq_st16nt(const float *base, unsigned voff, const f32x4 &v)

@@ -615,6 +615,63 @@ def test_coupling_block_on_shared_b_tiles_vs_oracle(dev, precision):
         assert relmax(npy(named[n].grad), want["grads"][i]) < GRAD_RTOL, n
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Tn,want_store", [(12, 2000, False), (1, 24400, False), (24, 2000, True)])
+def test_coupling_block_on_flattened_column_tiles_vs_oracle(dev, precision, B, Tn, want_store):
+    """convgemm16g_kernel (csrc/wg_gemm16g.h): 256 x 192 tiles over the FLATTENED (plane row, time) columns, eight multiplying waves fed by
+    LDS-DMA.  One coupling block at the shipped WN (256 channels, depth 8: halo 128) against the oracle, forward and backward, at shapes
+    that put the tile seams everywhere: 12 x 2048 padded columns = 128 column tiles that straddle plane rows (2048 = 10.67 tiles); one
+    plane row of 24 400 steps whose last column tile is partial; 24 x 2000, the headline columns, where the 256-row data-gradient conv
+    runs on the kernel as well (one tile per CU).  The library names the instantiation every timed launch ran (wg_timer_read_name)."""
+    if precision != "bf16x3p":
+        pytest.skip("the LDS-DMA kernel exists in the S-plane mode only")
+    import ctypes as C
+    from constant_memory_waveglow_amd import _lib
+    wn = dict(in_channels=4, aux_channels=80, residual_channels=256, dilation_channels=256, skip_channels=256, depth=8, radix=3)
+    specs = fill.wn_param_specs("F.", 4, 80, 256, 256, 256, 8, 3)
+    tag = "coupling/g192/%d" % B
+    P = fill.fill_params(specs, tag + "/")
+    x = fill.uniform(tag + "/x", (B, 8, Tn))
+    y = fill.normal(tag + "/y", (B, 80, Tn))
+    gz = fill.normal(tag + "/gz", x.shape)
+    gls = fill.normal(tag + "/gls", (B, 4, Tn))
+    z_ref, ls_ref = orc.coupling_apply(wn, fill.table(specs, P), x, y)
+    ref = orc.coupling_backward(wn, fill.table(specs, P), z_ref, y, gz, gls)
+    blk = cm.AffineCouplingBlock(cm.WN, True, zero_init=False, **wn)
+    blk.load_state_dict({n: torch.from_numpy(v) for n, v in P.items()})
+    blk = blk.to(dev)
+    L = _lib.lib()
+    timer = L.wg_timer_create(-1, 4096)
+    L.wg_timer_attach(timer)
+    try:
+        xt, yt = T(x, dev).requires_grad_(True), T(y, dev).requires_grad_(True)
+        z, ls = blk(xt.clone(), yt)
+        ((z * T(gz, dev)).sum() + (ls * T(gls, dev)).sum()).backward()
+        torch.cuda.synchronize()
+    finally:
+        L.wg_timer_attach(None)
+    n = L.wg_timer_count(timer)
+    info = (C.c_longlong * (5 * n))()
+    L.wg_timer_read_info(timer, info, n)
+    nb = C.create_string_buffer(256)
+    sites = {}
+    for i in range(n):
+        assert L.wg_timer_read_name(timer, i, nb, 256) >= 0
+        sites.setdefault((int(info[5 * i]), nb.value.decode()), 0)
+        sites[(int(info[5 * i]), nb.value.decode())] += 1
+    L.wg_timer_destroy(timer)
+    gate = {k[1]: v for k, v in sites.items() if k[0] == _lib.K_CONV_GATE}
+    assert gate.get("convgemm16g_kernel<EPI_GATE_SO>", 0) == 16, sites          # 8 layers, forward + the backward's recompute
+    store = sum(v for k, v in sites.items() if k[0] == _lib.K_CONV_STORE and k[1] == "convgemm16g_kernel<EPI_STORE_SO>")
+    assert (store >= 8) == want_store, sites                                     # the 8 data-gradient convs (K = 1536) of the backward
+    assert np.abs(npy(z) - z_ref).max() < 1e-5 and np.abs(npy(ls) - ls_ref).max() < 1e-5
+    got = dict(dx=npy(xt.grad), dy=npy(yt.grad))
+    assert relmax(got["dx"], ref["dx"]) < GRAD_RTOL and relmax(got["dy"], ref["dy"]) < GRAD_RTOL
+    named = dict(blk.named_parameters())
+    for i, (n_, _, _) in enumerate(specs):
+        assert relmax(npy(named[n_].grad), ref["grads"][i]) < GRAD_RTOL, n_
+
+
 def test_wn_forward_standalone(dev):
     wn = cm.WN(4, 80, 64, 64, 64, depth=4, zero_init=False).to(dev)
     specs = fill.wn_param_specs("", 4, 80, 64, 64, 64, 4, 3)

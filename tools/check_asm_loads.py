@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Static check of the hand-issued global loads in the wave-specialised conv kernels (convgemm16w / 16q / 16h _kernel<*>) and the weight-
-gradient kernels (wgrad16s_kernel, wgrad16s_pair_kernel, wgrad16t_kernel).
+gradient kernels (wgrad16s_kernel, wgrad16s_pair_kernel, wgrad16t_kernel), and of the LDS-DMA instruction counts behind the waits of
+convgemm16g_kernel (check_dma_kernel).
 
 The loader waves issue `global_load_dwordx4` from inline asm and retire them with hand-counted `s_waitcnt vmcnt(N)`; the
 compiler believes an asm output is valid right after the asm statement, so nothing but OUR waits keeps it from reading, copying
@@ -137,6 +138,59 @@ def sgpr_hazards(name, lines):
     return errors
 
 
+def check_dma_kernel(name, lines):
+    """convgemm16g_kernel (csrc/wg_gemm16g.h): every wave issues SEVEN LDS-DMA instructions per chunk from inline asm and retires them with
+    counted waits whose immediates assume exactly that: `s_waitcnt vmcnt(3)` at a chunk's barrier (all but the three B pieces of the
+    youngest chunk), `vmcnt(10)` once behind the two chunks of the prologue, `vmcnt(0)` before the wave ends.  Walks every control-flow
+    path with the number of LDS-DMA instructions in flight (at most) as the state -- a wait for vmcnt(N) leaves min(in flight, N) --
+    and checks that a `vmcnt(3)` always finds 10 (the three B pieces of chunk c + 1 and the seven of chunk c + 2) and the `vmcnt(10)` 14, that every
+    DMA's scalar operands follow the M0 recipe (s_mov_b32 m0, sN / s_nop 0 in front, inside the same statement), and that the wave never
+    ends with a DMA not waited for (it would land in the next workgroup's LDS)."""
+    ins, labels = parse(lines)
+    errors, seen = [], set()
+    ndma = sum(1 for _, t, a in ins if a and t.startswith("global_load_lds"))
+    nwait = sum(1 for _, t, a in ins if a and t.startswith("s_waitcnt") and "vmcnt" in t)
+    for n, (no, t, a) in enumerate(ins):
+        if a and t.startswith("global_load_lds"):
+            if n < 2 or not ins[n - 1][1].startswith("s_nop") or not re.match(r"s_mov_b32 m0, s\d+", ins[n - 2][1]):
+                errors.append("%s:%d: LDS-DMA without `s_mov_b32 m0, sN; s_nop 0` in front" % (name, no))
+    work, visited = [(0, 0, True)], set()
+    while work:
+        pc, cnt, drained = work.pop()
+        while pc < len(ins):
+            if (pc, cnt, drained) in visited:
+                break
+            visited.add((pc, cnt, drained))
+            no, t, inasm = ins[pc]
+            ops = [o for o in re.split(r"[ ,]+", t) if o]
+            op = ops[0]
+            if inasm and op.startswith("global_load_lds"):
+                cnt, drained = min(cnt + 1, 99), False
+            elif inasm and op == "s_waitcnt" and "vmcnt" in t:
+                keep = int(re.search(r"vmcnt\((\d+)\)", t).group(1))
+                want = {10: 14, 3: 10}.get(keep)
+                if want is not None and cnt != want and (no, cnt) not in seen:
+                    seen.add((no, cnt))
+                    errors.append("%s:%d: `%s` with %d LDS-DMA instructions in flight (the immediate assumes %d)" % (name, no, t, cnt, want))
+                if keep not in (0, 3, 10) and no not in seen:
+                    seen.add(no)
+                    errors.append("%s:%d: unexpected hand-written wait `%s`" % (name, no, t))
+                cnt, drained = min(cnt, keep), keep == 0
+            elif op == "s_endpgm":
+                if not drained and ("end", no) not in seen:
+                    seen.add(("end", no))
+                    errors.append("%s:%d: wave ends with LDS-DMA instructions in flight" % (name, no))
+                break
+            else:
+                if op == "s_branch":
+                    pc = labels[ops[1]]
+                    continue
+                if op.startswith("s_cbranch"):
+                    work.append((labels[ops[1]], cnt, drained))
+            pc += 1
+    return ndma, nwait, errors
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--defines", default="")
@@ -152,6 +206,15 @@ def main():
         print("no convgemm16w_kernel instantiation in the ISA")
         return 1
     bad = 0
+    for s in [i for i, l in enumerate(text) if re.match(r"^_Z\d+convgemm16g_kernel\w*:", l)]:
+        e = next(i for i in range(s, len(text)) if ".amdhsa_kernel" in text[i] or text[i].startswith(".Lfunc_end"))
+        kname = text[s].split(":")[0]
+        ndma, nwait, errors = check_dma_kernel(kname, text[s:e])
+        errors += sgpr_hazards(kname, text[s:e])
+        print("%s: %d LDS-DMA instructions, %d counted waits, %d violations" % (kname, ndma, nwait, len(errors)))
+        for m in errors[:10]:
+            print("   ", m)
+        bad += len(errors) + (1 if ndma == 0 else 0)
     for s in starts:
         e = next(i for i in range(s, len(text)) if ".amdhsa_kernel" in text[i] or text[i].startswith(".Lfunc_end"))
         kname = text[s].split(":")[0]
