@@ -129,27 +129,71 @@ __device__ __forceinline__ void wgg_store_nb(const ConvGemmArgs &a, const SRef &
         if (live && mbase + 4 * rq < a.M) { wgq_st8<0>(hb, vo, ph); wgq_st8<0>(lb, vo, pl); }
     }
 }
-// the accumulate-into value of EPI_STORE_SO (an S-plane: x = hi + lo), column block NBI
+// EPI_STORE_FO, column block NBI: an fp32 plane as the only output (skip sum): the lane's 4 rows of every 16-row block are four rows of the
+// plane, 4 bytes each (a wave instruction covers 4 x 64 contiguous bytes)
 template <int NBI>
-__device__ __forceinline__ void wgg_init_nb(const ConvGemmArgs &a, const SRef &saux, f32x4 (&acc)[4][6], int b, int t0, int mw, int lane)
+__device__ __forceinline__ void wgg_store_fo_nb(const ConvGemmArgs &a, f32x4 (&acc)[4][6], int b, int t0, int mw, int lane)
 {
     const Geo g = a.g;
     const int col = lane & 15, rq = lane >> 4;
     const bool live = b < g.B && t0 + col < g.T;
+    const int bb = min(b, g.B - 1);
+    unsigned vo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vo[e] = (unsigned)(((4 * rq + e) * g.P + col) * 4);
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
-        const int m = mw + mb * 16 + 4 * rq;
-        u32x2 vh = {0u, 0u}, vl = {0u, 0u};
-        if (live && m < a.M) {
-            const size_t i = s_index(saux, g, b, m, t0 + col);
-            vh = *reinterpret_cast<const u32x2 *>(saux.hi + i);
-            vl = *reinterpret_cast<const u32x2 *>(saux.hi + saux.lo_off + i);
-        }
-        acc[mb][NBI][0] = __uint_as_float(vh[0] << 16) + __uint_as_float(vl[0] << 16);
-        acc[mb][NBI][1] = __uint_as_float(vh[0] & 0xffff0000u) + __uint_as_float(vl[0] & 0xffff0000u);
-        acc[mb][NBI][2] = __uint_as_float(vh[1] << 16) + __uint_as_float(vl[1] << 16);
-        acc[mb][NBI][3] = __uint_as_float(vh[1] & 0xffff0000u) + __uint_as_float(vl[1] & 0xffff0000u);
+        const int mbase = mw + mb * 16;
+        const float *fb = paddr(a.out0, g, bb, mbase, t0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (live && mbase + 4 * rq + e < a.M) wgq_st4<0>(fb, vo[e], acc[mb][NBI][e]);
     }
+}
+// The accumulate-into value of EPI_STORE_SO (an S-plane: x = hi + lo): 48 loads per lane (8 bytes each: the lane's 4 rows of one column as
+// half units of the hi and of the lo array).  A product on its own leaves them to the compiler, behind the prologue's DMA (hand-issued IN
+// FRONT of the DMA -- scalar bases, one lane offset, one wait -- measured slower: data-gradient conv 99 against 95 us; the whole chip
+// reads 50 MB at once and the first chunks queue behind it).  Inside convlayer16g_kernel the residual product's loads are hand-issued by
+// the GATE product's tail, right behind its last stores, so that this burst runs under the drain, the barrier and the residual product's
+// own prologue instead of in front of its main loop (11-13 us of prologue before).
+__device__ __forceinline__ void wgg_ld8(u32x2 &v, const unsigned short *base, unsigned voff)
+{
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(base) : "memory");
+}
+// column block NBI: issue
+template <int NBI>
+__device__ __forceinline__ void wgg_init_issue(const ConvGemmArgs &a, const SRef &saux, u32x2 (&rh)[4][6], u32x2 (&rl)[4][6], int b, int t0, int mw, int lane)
+{
+    const Geo g = a.g;
+    const int col = lane & 15, rq = lane >> 4;
+    const int bb = min(b, g.B - 1);                           // (a column block past the last plane row: anything valid, it is never stored)
+    const unsigned vo = (unsigned)(((rq >> 1) * g.P + col) * 16 + 8 * (rq & 1));
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const unsigned short *hb = saux.hi + s_index(saux, g, bb, mw + mb * 16, t0);
+        wgg_ld8(rh[mb][NBI], hb, vo);
+        wgg_ld8(rl[mb][NBI], hb + saux.lo_off, vo);
+    }
+}
+// every load above has landed: names the registers so that nothing that reads them moves above the wait
+__device__ __forceinline__ void wgg_init_tie(u32x2 (&r)[4][6])
+{
+    asm volatile("" : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[0][2]), "+v"(r[0][3]), "+v"(r[0][4]), "+v"(r[0][5]), "+v"(r[1][0]), "+v"(r[1][1]), "+v"(r[1][2]),
+                      "+v"(r[1][3]), "+v"(r[1][4]), "+v"(r[1][5]), "+v"(r[2][0]), "+v"(r[2][1]), "+v"(r[2][2]), "+v"(r[2][3]), "+v"(r[2][4]), "+v"(r[2][5]),
+                      "+v"(r[3][0]), "+v"(r[3][1]), "+v"(r[3][2]), "+v"(r[3][3]), "+v"(r[3][4]), "+v"(r[3][5])::"memory");
+}
+__device__ __forceinline__ void wgg_init_convert(f32x4 (&acc)[4][6], const u32x2 (&rh)[4][6], const u32x2 (&rl)[4][6])
+{
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 6; ++nb) {
+            const u32x2 vh = rh[mb][nb], vl = rl[mb][nb];
+            acc[mb][nb][0] = __uint_as_float(vh[0] << 16) + __uint_as_float(vl[0] << 16);
+            acc[mb][nb][1] = __uint_as_float(vh[0] & 0xffff0000u) + __uint_as_float(vl[0] & 0xffff0000u);
+            acc[mb][nb][2] = __uint_as_float(vh[1] << 16) + __uint_as_float(vl[1] << 16);
+            acc[mb][nb][3] = __uint_as_float(vh[1] & 0xffff0000u) + __uint_as_float(vl[1] & 0xffff0000u);
+        }
 }
 
 // What a chunk of the K walk needs to be fetched, independent of the tile: built ONCE per workgroup (thread v describes chunk v) into an
@@ -175,16 +219,22 @@ struct WggOffs { unsigned a[4], b[3], pad; };             // a: bytes from the w
 static_assert(sizeof(WggDesc) == 32 && sizeof(WggOffs) == 32 && WGG_LDS_ALL <= 160 * 1024, "LDS budget");
 
 // ConvGemm16sArgs as for convgemm16q_kernel, with ntx = column tiles of 192 flattened columns (ceil(B * Tt / 192)), nty = 256-row tiles,
-// ntz unused.  Requires: Geo::rows == 0, no row_sel1, M a multiple of 256, H >= 64 (the zero halo serves as the 1 KB zero source),
+// ntz unused.  EPI_STORE_FO: no accumulate-into plane.  Requires: Geo::rows == 0, no row_sel1, M a multiple of 256, H >= 64 (the zero halo serves as the 1 KB zero source),
 // S-plane operands whose hi + lo arrays span less than 4 GB, a weight image (hi + lo) of less than 4 GB, at most WGG_MAXCHUNKS chunks.  Grid: min(tiles, CUs) workgroups of 512
 // threads; with a grid that is a multiple of 8, XCD x (workgroup id & 7) owns the column tiles [x ntx / 8, (x + 1) ntx / 8) and all their
 // row tiles, row tile fastest: the row tiles of a column tile run side by side on one L2, and a dilation tap's window is a neighbouring
 // column tile's centre window on the same XCD.
-template <int EPI>
-__global__ __launch_bounds__(512) void convgemm16g_kernel(const ConvGemm16sArgs aa)
+// xcd_items (reused): 0 = the row tiles of a column tile on neighbouring workgroups of the XCD, in step (above); 1 = a workgroup OWNS its
+// column tiles and walks their row tiles one after the other (convlayer16g_kernel below: the residual product that follows needs the whole
+// gate of its columns on one CU; the activations of a column tile are then streamed once per row tile instead of being shared in L2).
+// One product as a device function: everything from the chunk table to the last tile's stores (every wave returns with all its loads
+// and stores done, vmcnt(0)); smem: WGG_LDS_ALL bytes.
+// PRE: the accumulate-into loads of this product's FIRST tile are already in flight in (ih, il), issued by the product in front; NEXTI: this
+// product's tail issues those of the product `nx` behind it (`nxt`: same column tiles, one row tile) and returns with them in flight
+template <int EPI, bool LAYERK = false, bool PRE = false, bool NEXTI = false>
+__device__ __forceinline__ void wgg_stream(const ConvGemm16sArgs &aa, char *smem, u32x2 (&ih)[4][6], u32x2 (&il)[4][6], const ConvGemm16sArgs *nxt)
 {
-    static_assert(EPI == EPI_GATE_SO || EPI == EPI_STORE_SO, "S-plane-only epilogues");
-    __shared__ __attribute__((aligned(1024))) char smem[WGG_LDS_ALL];
+    static_assert(EPI == EPI_GATE_SO || EPI == EPI_STORE_SO || EPI == EPI_STORE_FO, "the hand-issued epilogues");
     const ConvGemmArgs &a = aa.c;
     const Geo g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -196,13 +246,20 @@ __global__ __launch_bounds__(512) void convgemm16g_kernel(const ConvGemm16sArgs 
     const int G = (int)gridDim.x, bid = (int)blockIdx.x;
     const bool xm = (G & 7) == 0;
     const int nx = xm ? 8 : 1, xid = xm ? (bid & 7) : 0, slot = xm ? (bid >> 3) : bid, xslots = xm ? (G >> 3) : G;
-    const int c_lo = xid * aa.ntx / nx, n_local = ((xid + 1) * aa.ntx / nx - c_lo) * aa.nty;
-    const int mine = slot < n_local ? (n_local - 1 - slot) / xslots + 1 : 0;
+    const bool own = aa.xcd_items == 1;
+    const int c_lo = xid * aa.ntx / nx, n_cols = (xid + 1) * aa.ntx / nx - c_lo, n_local = n_cols * aa.nty;
+    const int mine = own ? (slot < n_cols ? ((n_cols - 1 - slot) / xslots + 1) * aa.nty : 0) : (slot < n_local ? (n_local - 1 - slot) / xslots + 1 : 0);
     const int total = mine * nchunks;
     if (total == 0) return;
     auto tile_at = [&](int k, int &ct, int &m0) __attribute__((always_inline)) {
-        const int L = slot + min(k, mine - 1) * xslots, cl = L / aa.nty;
-        ct = c_lo + cl; m0 = (L - cl * aa.nty) * WGG_BM;
+        const int kk = min(k, mine - 1);
+        if (own) {
+            const int ci = kk / aa.nty;
+            ct = c_lo + slot + ci * xslots; m0 = (kk - ci * aa.nty) * WGG_BM;
+        } else {
+            const int L = slot + kk * xslots, cl = L / aa.nty;
+            ct = c_lo + cl; m0 = (L - cl * aa.nty) * WGG_BM;
+        }
     };
     const int ncols = g.B * g.Tt;
 
@@ -360,13 +417,26 @@ __global__ __launch_bounds__(512) void convgemm16g_kernel(const ConvGemm16sArgs 
             if (t >= g.Tt) { t = 0; ++b; }
         }
     };
-    auto acc_start = [&]() __attribute__((always_inline)) {
+    // the accumulators' initial value: zero, or (EPI_STORE_SO with an accumulate-into S-plane) that plane's tile
+    auto acc_start = [&](auto FIRST) __attribute__((always_inline)) {
         if (EPI == EPI_STORE_SO && aa.saux.hi) {
-            const int mw = m0 + 64 * wr;
-            block_pos();
-            wgg_init_nb<0>(a, aa.saux, acc, eb[0], et[0], mw, lane); wgg_init_nb<1>(a, aa.saux, acc, eb[1], et[1], mw, lane);
-            wgg_init_nb<2>(a, aa.saux, acc, eb[2], et[2], mw, lane); wgg_init_nb<3>(a, aa.saux, acc, eb[3], et[3], mw, lane);
-            wgg_init_nb<4>(a, aa.saux, acc, eb[4], et[4], mw, lane); wgg_init_nb<5>(a, aa.saux, acc, eb[5], et[5], mw, lane);
+            if constexpr (PRE && decltype(FIRST)::value) {
+                // (in flight since the product in front finished; younger: the 14 pieces of chunks 0 and 1)
+                asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+                wgg_init_tie(ih); wgg_init_tie(il);
+            } else {
+                const int mw = m0 + 64 * wr, col = lane & 15, rq = lane >> 4;
+                block_pos();
+#pragma unroll
+                for (int nb = 0; nb < 6; ++nb)
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) {
+                        const size_t i = s_index(aa.saux, g, min(eb[nb], g.B - 1), mw + mb * 16 + 4 * rq, et[nb] + col);
+                        ih[mb][nb] = *reinterpret_cast<const u32x2 *>(aa.saux.hi + i);
+                        il[mb][nb] = *reinterpret_cast<const u32x2 *>(aa.saux.hi + aa.saux.lo_off + i);
+                    }
+            }
+            wgg_init_convert(acc, ih, il);
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -384,6 +454,11 @@ __global__ __launch_bounds__(512) void convgemm16g_kernel(const ConvGemm16sArgs 
             wgg_gate_nb<0>(a, aa.s0, acc, eb[0], et[0], chb, lane); wgg_gate_nb<1>(a, aa.s0, acc, eb[1], et[1], chb, lane);
             wgg_gate_nb<2>(a, aa.s0, acc, eb[2], et[2], chb, lane); wgg_gate_nb<3>(a, aa.s0, acc, eb[3], et[3], chb, lane);
             wgg_gate_nb<4>(a, aa.s0, acc, eb[4], et[4], chb, lane); wgg_gate_nb<5>(a, aa.s0, acc, eb[5], et[5], chb, lane);
+        } else if constexpr (EPI == EPI_STORE_FO) {
+            const int mw = m0 + 64 * wr;
+            wgg_store_fo_nb<0>(a, acc, eb[0], et[0], mw, lane); wgg_store_fo_nb<1>(a, acc, eb[1], et[1], mw, lane);
+            wgg_store_fo_nb<2>(a, acc, eb[2], et[2], mw, lane); wgg_store_fo_nb<3>(a, acc, eb[3], et[3], mw, lane);
+            wgg_store_fo_nb<4>(a, acc, eb[4], et[4], mw, lane); wgg_store_fo_nb<5>(a, acc, eb[5], et[5], mw, lane);
         } else {
             const int mw = m0 + 64 * wr;
             wgg_store_nb<0>(a, aa.s0, acc, eb[0], et[0], mw, lane); wgg_store_nb<1>(a, aa.s0, acc, eb[1], et[1], mw, lane);
@@ -400,7 +475,12 @@ __global__ __launch_bounds__(512) void convgemm16g_kernel(const ConvGemm16sArgs 
 #if !defined(WGG_TRACE_GC)
 #define WGG_TRACE_GC 12
 #endif
-#define WGG_TRACE(slot) do { if (lane == 0 && wave == WGG_TRACE_WAVE) { const int r_ = (EPI == EPI_GATE_SO ? 0 : 256) + blockIdx.x; \
+#if defined(WGG_TRACE_LAYER)       // stamp the products of convlayer16g_kernel only (otherwise: those of the plain launches only)
+#define WGG_TRACE_ON LAYERK
+#else
+#define WGG_TRACE_ON (!LAYERK)
+#endif
+#define WGG_TRACE(slot) do { if (WGG_TRACE_ON && lane == 0 && wave == WGG_TRACE_WAVE) { const int r_ = (EPI == EPI_GATE_SO ? 0 : 256) + blockIdx.x; \
         wg_dbg_trace[r_ * 16 + (slot)] = wall_clock64(); wg_dbg_trace_cyc[r_ * 16 + (slot)] = clock64(); } } while (0)
 #define WGG_TRACE_IN(slot) do { if (gc == WGG_TRACE_GC) WGG_TRACE(slot); } while (0)
 #if !defined(WGG_TRACE_WAVE)
@@ -473,7 +553,7 @@ __global__ __launch_bounds__(512) void convgemm16g_kernel(const ConvGemm16sArgs 
         desc_request();
         if (gc > 0) {
             last_block(std::integral_constant<int, PAR ^ 1>());
-            if (cc == 0) { tile_done(); acc_start(); }
+            if (cc == 0) { tile_done(); acc_start(std::false_type()); }
         }
         WGG_TRACE_IN(3);
         sblock(PARC, std::integral_constant<int, 0>(), pbuf, pan);
@@ -490,7 +570,7 @@ __global__ __launch_bounds__(512) void convgemm16g_kernel(const ConvGemm16sArgs 
     WGG_TRACE(8);
     issue(std::integral_constant<int, 0>(), 0);
     issue(std::integral_constant<int, 1>(), 1);
-    acc_start();
+    acc_start(std::true_type());
     asm volatile("s_waitcnt vmcnt(10)" ::: "memory");        // the own pieces of A(0): younger are B(0), A(1), B(1)
     WGG_BAR();
 #pragma unroll
@@ -503,12 +583,65 @@ __global__ __launch_bounds__(512) void convgemm16g_kernel(const ConvGemm16sArgs 
     if (total & 1) last_block(std::integral_constant<int, 0>());      // (the last chunk's A fragments: register set (total - 1) & 1)
     else last_block(std::integral_constant<int, 1>());
     tile_done();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the trailing fetches must not land in another workgroup's LDS
-    WGG_TRACE(14);                                           // (every load and store of the wave is done)
+    if constexpr (NEXTI) {
+        // the accumulate-into tile of the next product's first tile (the workgroup's first column tile, one row tile: its geometry is
+        // this product's), 48 loads per lane right behind the last stores; wait for everything in front of them -- the stores, the trailing
+        // fetches (they must not land in another product's LDS) -- and return with the loads in flight
+        ck = 0;
+        tile_at(0, ct, m0);
+        block_pos();
+        const int mw = 64 * wr;
+        wgg_init_issue<0>(nxt->c, nxt->saux, ih, il, eb[0], et[0], mw, lane); wgg_init_issue<1>(nxt->c, nxt->saux, ih, il, eb[1], et[1], mw, lane);
+        wgg_init_issue<2>(nxt->c, nxt->saux, ih, il, eb[2], et[2], mw, lane); wgg_init_issue<3>(nxt->c, nxt->saux, ih, il, eb[3], et[3], mw, lane);
+        wgg_init_issue<4>(nxt->c, nxt->saux, ih, il, eb[4], et[4], mw, lane); wgg_init_issue<5>(nxt->c, nxt->saux, ih, il, eb[5], et[5], mw, lane);
+        asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the trailing fetches must not land in another workgroup's LDS
+    }
+    WGG_TRACE(14);                                           // (every store of the wave is done)
 #undef WGG_SB
 #undef WGG_MFMA
 #undef WGG_BAR
 #undef WGG_IC
 #undef WGG_TRACE
+#undef WGG_TRACE_ON
 #undef WGG_TRACE_IN
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void convgemm16g_kernel(const ConvGemm16sArgs aa)
+{
+    __shared__ __attribute__((aligned(1024))) char smem[WGG_LDS_ALL];
+    u32x2 ih[4][6], il[4][6];
+    wgg_stream<EPI>(aa, smem, ih, il, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// A WN layer's gate conv AND the residual product behind it in one launch (model/waveglow.py:41-46: conv -> gate -> W_o -> res + x).
+// Rounds 2-4 built this three times with the gate crossing WORKGROUPS inside the launch (counters, write-through stores, polls) and
+// measured each form no faster than two launches.  Here nothing crosses: with 256 x 192 tiles over flattened
+// columns a workgroup owns whole column tiles (p[0].xcd_items = 1), computes BOTH 256-row tiles of the gate for them one after the other
+// and stores them as usual; when its own stores have reached L2 (every wave's vmcnt(0), a barrier) the same workgroup streams that gate
+// back in as the B operand of the residual product h_{i+1} = h_i + W_res gate (p[1]: K = the gate's channels, 8 chunks; the accumulate-into
+// value is h_i's S-plane) for the same columns.  What it saves is a launch per layer -- 161 per training step at the headline shape, each
+// ~35 us for 12 us of main loop: dispatch gap, prologue, a cold L2 -- for 8 more chunks and one more epilogue on a workgroup that is
+// running anyway.  What it costs: the two row tiles of a column tile no longer run side by side on two CUs sharing the activations in
+// L2, so the activations are fetched once per row tile.
+// ------------------------------------------------------------------------------------------------------------------------------------
+struct ConvLayer16gArgs {
+    ConvGemm16sArgs p[2];         // [0] the gate conv (EPI_GATE_SO, nty row tiles), [1] the residual product (EPI_STORE_SO, one row tile); both xcd_items = 1
+};
+static_assert(sizeof(ConvLayer16gArgs) <= 4096, "kernel arguments are limited to 4 KB");
+__global__ __launch_bounds__(512) void convlayer16g_kernel(const ConvLayer16gArgs la)
+{
+    __shared__ __attribute__((aligned(1024))) char smem[WGG_LDS_ALL];
+    u32x2 ih[4][6], il[4][6];                                 // the residual product's accumulate-into tile, in flight across the seam
+    wgg_stream<EPI_GATE_SO, true, false, true>(la.p[0], smem, ih, il, &la.p[1]);
+    // every wave has waited for its own stores (the gate tiles are in L2, this CU's L1 never held those lines) and for its DMA; nobody
+    // may still be reading the rings or the tables when the next product's prologue overwrites them.  (The tile positions the gate
+    // product's tail used for the loads are the residual product's own: same column tiles, same workgroup order, row tile 0.)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    wgg_stream<EPI_STORE_SO, true, true, false>(la.p[1], smem, ih, il, nullptr);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (nothing the gate product's tail issued outlives the wave on any path)
 }

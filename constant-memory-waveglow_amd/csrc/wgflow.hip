@@ -884,8 +884,8 @@ static bool g192_fits(const ConvGemm16sArgs &as, size_t img_stride, int nseg)
 // env WG_G192 (read once): 0 = the conv products never take the 256 x 192-tile kernel of wg_gemm16g.h (A/B runs in one build)
 static bool g192_on()
 {
-    static const int on = [] { const char *e = getenv("WG_G192"); return e ? atoi(e) : 1; }();
-    return on != 0;
+    const char *e = getenv("WG_G192");                       // (per call: tests and A/B runs switch it inside one process)
+    return !(e && e[0] == '0');
 }
 
 void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const SegSpec *segs, int nseg, int epi,
@@ -1051,13 +1051,16 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
             // store / data-gradient / skip products whose tiles deal out evenly over the CUs (env WG_G192=0 restores the 256 x 128 / 128 x 128 forms)
             // (products of fewer than 16 chunks -- the residual conv, K = 256: 36.6 against 35.3 us -- stay on the older kernel: a tile that
             // short is mostly this kernel's longer prologue; S-plane arrays and weight images beyond 4 GB: its 32-bit offsets)
-            if (g192_on() && !small && (so_gate || so_epi) && g.rows == 0 && !cx.row_sel1 && !cx.rec && M % WGG_BM == 0 && g.H >= 64 && cus % 8 == 0 &&
+            const bool fo_g = fo_epi && !a.aux0.p;               // (the skip sum: fp32 plane out, nothing to accumulate into)
+            if (g192_on() && !small && (so_gate || so_epi || fo_g) && g.rows == 0 && !cx.row_sel1 && !cx.rec && M % WGG_BM == 0 && g.H >= 64 && cus % 8 == 0 &&
                 nc >= 16 && nc <= WGG_MAXCHUNKS && g192_fits(as, a16.img_stride, nseg)) {
                 const int nct = (g.B * g.Tt + WGG_BN - 1) / WGG_BN, nrb = M / WGG_BM, nt = nct * nrb;
                 const int rounds = (nt + cus - 1) / cus;
                 if (nt >= cus && (double)(rounds * cus - nt) <= 0.1 * rounds * cus) {
                     as.ntx = nct; as.nty = nrb; as.ntz = 1; as.xcd_items = 0;
+                    { static const int own = [] { const char *e = getenv("WG_G192_OWN"); return e ? atoi(e) : 0; }(); if (own) as.xcd_items = 1; }   // experiment: column ownership
                     if (so_gate) WG_LAUNCH(cx, convgemm16g_kernel<EPI_GATE_SO>, dim3(cus), dim3(512), 0, as);
+                    else if (fo_g) WG_LAUNCH(cx, convgemm16g_kernel<EPI_STORE_FO>, dim3(cus), dim3(512), 0, as);
                     else WG_LAUNCH(cx, convgemm16g_kernel<EPI_STORE_SO>, dim3(cus), dim3(512), 0, as);
                     return;
                 }
@@ -1699,6 +1702,64 @@ bool run_convlayer_big(Ctx &cx, float *ws, size_t lsync, FA &&gate_call, FB &&re
 #endif
 }
 
+// The layer as ONE launch of convlayer16g_kernel (wg_gemm16g.h): a workgroup owns whole 192-column tiles, computes both 256-row gate tiles
+// for them and then, from its own stores, the residual product -- nothing crosses workgroups.  The two launches are described through
+// the same capture as above; returns false (nothing launched) when the shapes do not qualify.  env WG_LAYER_G=0 switches it off.
+std::atomic<long long> g_layerg_launches{0};                  // diagnostics (wg_stat_layer_launches)
+template <class FA, class FB>
+bool run_convlayer_g(Ctx &cx, FA &&gate_call, FB &&res_call)
+{
+#if defined(WG_OPT_NO_G192) || defined(WG_OPT_NO_LAYERG)
+    return false;
+#else
+    {   // (read per call: tests switch it inside one process; WG_LAYER_FUSION_BIG=1 asks for the older one-launch layer instead)
+        const char *e = getenv("WG_LAYER_G"), *big = getenv("WG_LAYER_FUSION_BIG");
+        if ((e && e[0] == '0') || (big && big[0] == '1')) return false;
+    }
+    if (!g192_on() || cx.prec != 2 || cx.rec || cx.cap || cx.err) return false;
+    BigCap cg, cr;
+    cg.ok = cr.ok = false;
+    cx.cap = &cg;
+    gate_call();
+    cx.cap = &cr;
+    res_call();
+    cx.cap = nullptr;
+    if (!cg.ok || !cr.ok || cx.err) return false;
+    ConvLayer16gArgs la;
+    la.p[0] = cg.as; la.p[1] = cr.as;
+    ConvGemm16sArgs &A = la.p[0], &R = la.p[1];
+    const Geo &g = A.c.g;
+    const int cus = device_cus();
+    // the residual's operand IS the gate (one K segment, no shift), it accumulates into an S-plane, both products over the same planes
+    if (R.c.nseg != 1 || R.sseg[0].hi != A.s0.hi || R.c.seg[0].shift || !R.saux.hi || R.c.M != WGG_BM || A.c.M % WGG_BM || A.c.M / WGG_BM < 1) return false;
+    if (g.rows != 0 || g.H < 64 || cus % 8 || R.c.g.B != g.B || R.c.g.Tt != g.Tt || R.c.g.P != g.P) return false;
+    int ncA = 0, ncR = 0;
+    for (int q = 0; q < A.c.nseg; ++q) ncA += (A.c.seg[q].nch + WG16_BK - 1) / WG16_BK;
+    for (int q = 0; q < R.c.nseg; ++q) ncR += (R.c.seg[q].nch + WG16_BK - 1) / WG16_BK;
+    if (ncA < 16 || ncA > WGG_MAXCHUNKS || ncR < 2 || ncR > WGG_MAXCHUNKS) return false;
+    if (!g192_fits(A, A.img_stride, A.c.nseg) || !g192_fits(R, R.img_stride, R.c.nseg)) return false;
+    const int nct = (g.B * g.Tt + WGG_BN - 1) / WGG_BN;
+    const int rounds = (nct + cus - 1) / cus;
+    if (nct < cus || (double)(rounds * cus - nct) > 0.1 * rounds * cus) return false;       // column tiles deal out evenly over the CUs
+    A.ntx = R.ntx = nct; A.nty = A.c.M / WGG_BM; R.nty = 1; A.ntz = R.ntz = 1; A.xcd_items = R.xcd_items = 1;
+    long long KA = 0, in_ch = 0;
+    for (int q = 0; q < A.c.nseg; ++q) {
+        KA += A.c.seg[q].nch;
+        bool seen = false;
+        for (int u = 0; u < q; ++u) seen = seen || A.sseg[u].hi == A.sseg[q].hi;
+        if (!seen) in_ch += A.c.seg[q].nch;
+    }
+    const long long KR = R.c.seg[0].nch, cols = (long long)g.B * g.T;
+    const long long Keff = KA + KR * R.c.M / std::max(1, A.c.M);
+    // every operand plane once (h, y, the gate written and read back, tanh / sigmoid where saved, h in and out of the residual) + the weights
+    const long long bytes = 4 * cols * (in_ch + (long long)A.c.M / 2 * (A.c.out1.p ? 4 : 2) + 2LL * R.c.M) + 4LL * A.c.M * KA + 4LL * R.c.M * KR;
+    TimerScope ts(WG_K_LAYER, cx.st, A.c.M, Keff, cols, bytes);
+    WG_LAUNCH(cx, convlayer16g_kernel, dim3(cus), dim3(512), 0, la);
+    g_layerg_launches.fetch_add(1, std::memory_order_relaxed);
+    return true;
+#endif
+}
+
 // (the counters are left at zero by every launch; a call that was cut short -- an error half way -- is the reason they are cleared
 // once at the start of every entry point that may use them)
 // (only where one of the one-launch layer kernels can run at all: they are opt-in through WG_LAYER_FUSION / WG_LAYER_FUSION_BIG; without them
@@ -1786,6 +1847,7 @@ void wn_forward(Ctx &cx, const WnRun &r)
                              so ? sref(g, ws + r.w.HS[hin], d.C) : snull());                                   // :45-46
             };
             // gate conv + residual product as ONE persistent launch where the gate conv fills the chip in whole rounds (wg_layer16q.h)
+            if (!last && so && !nb && run_convlayer_g(cx, gate_call, res_call)) continue;
             if (!last && so && !nb && run_convlayer_big(cx, ws, r.w.lsync, gate_call, res_call)) continue;
             gate_call();
             if (!last) res_call();
@@ -2290,6 +2352,7 @@ int wg_dbg_trace_read_cycles(unsigned long long *out, int n)
 #endif
 long long wg_stat_wgrad16t_launches(void) { return g_wgrad16t_launches.load(std::memory_order_relaxed); }
 long long wg_stat_layer_launches(void) { return g_layer_launches.load(std::memory_order_relaxed) + g_layerq_launches.load(std::memory_order_relaxed); }
+long long wg_stat_layerg_launches(void) { return g_layerg_launches.load(std::memory_order_relaxed); }
 void *wg_timer_create(int kernel_id, int capacity)
 {
     if (capacity < 1) return nullptr;

@@ -661,7 +661,11 @@ def test_coupling_block_on_flattened_column_tiles_vs_oracle(dev, precision, B, T
         sites[(int(info[5 * i]), nb.value.decode())] += 1
     L.wg_timer_destroy(timer)
     gate = {k[1]: v for k, v in sites.items() if k[0] == _lib.K_CONV_GATE}
-    assert gate.get("convgemm16g_kernel<EPI_GATE_SO>", 0) == 16, sites          # 8 layers, forward + the backward's recompute
+    layer = sum(v for k, v in sites.items() if k[0] == _lib.K_LAYER and k[1] == "convlayer16g_kernel")
+    if want_store:          # 256 column tiles, one per CU: 7 of the 8 layers run gate conv + residual product as ONE launch (convlayer16g_kernel)
+        assert layer == 14 and gate.get("convgemm16g_kernel<EPI_GATE_SO>", 0) == 2, sites
+    else:                   # 8 layers, forward + the backward's recompute
+        assert layer == 0 and gate.get("convgemm16g_kernel<EPI_GATE_SO>", 0) == 16, sites
     store = sum(v for k, v in sites.items() if k[0] == _lib.K_CONV_STORE and k[1] == "convgemm16g_kernel<EPI_STORE_SO>")
     assert (store >= 8) == want_store, sites                                     # the 8 data-gradient convs (K = 1536) of the backward
     assert np.abs(npy(z) - z_ref).max() < 1e-5 and np.abs(npy(ls) - ls_ref).max() < 1e-5
@@ -670,6 +674,42 @@ def test_coupling_block_on_flattened_column_tiles_vs_oracle(dev, precision, B, T
     named = dict(blk.named_parameters())
     for i, (n_, _, _) in enumerate(specs):
         assert relmax(npy(named[n_].grad), ref["grads"][i]) < GRAD_RTOL, n_
+
+
+@pytest.mark.gpu
+def test_layer_as_one_launch_on_flattened_tiles_vs_two_launches(dev, precision, monkeypatch):
+    """convlayer16g_kernel (csrc/wg_gemm16g.h): a layer's gate conv and residual product in ONE launch -- a workgroup owns whole 192-column
+    tiles, computes both 256-row gate tiles and then, from its own stores, the residual product.  A whole training step at the headline
+    columns (24 x 2000) must agree with the two-launch path (WG_LAYER_G=0) to rounding and repeat bit for bit, and the counter must show
+    the kernel ran: 7 of 8 layers of every flow in the forward and in the recompute of every flow but the one the forward kept."""
+    if precision != "bf16x3p":
+        pytest.skip("the LDS-DMA kernels exist in the S-plane mode only")
+    from constant_memory_waveglow_amd import _lib
+    from constant_memory_waveglow_amd.parallel import FlowTrainer
+    m, cfg, specs, P = build("c2", dev)
+    B, N, F = 24, 16000, 63
+    audio, h = fill.inputs("c2layerg", B, N, F, cfg["n_mels"])
+    x, ht = T(audio, dev), T(h, dev)
+    tr = FlowTrainer(m, fill.SIGMA)
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("WG_LAYER_G", fused)
+        before = _lib.lib().wg_stat_layerg_launches()
+        runs = []
+        for rep in range(2):
+            loss, z, logdet = tr.step(x, ht)
+            runs.append((loss.clone(), z.clone(), logdet.clone(), tr.fg.flat.clone()))
+        torch.cuda.synchronize()
+        n = _lib.lib().wg_stat_layerg_launches() - before
+        assert n == (2 * (cfg["flows"] * 7 + (cfg["flows"] - 1) * 7) if fused == "1" else 0), n
+        for a, b in zip(runs[0], runs[1]):
+            assert torch.equal(a, b)
+        res[fused] = runs[0]
+    (l1, z1, d1, g1), (l0, z0, d0, g0) = res["1"], res["0"]
+    # the same arithmetic in both forms (the residual product's K walk and accumulate-into value are unchanged): equal to the last bit
+    # of fp32 accumulation order, which IS the same; allow rounding in case a shape takes another tile order
+    assert abs(float(l1) - float(l0)) < 1e-6 and float((z1 - z0).abs().max()) < 2e-5 and float((d1 - d0).abs().max()) < 1e-2
+    assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max())
 
 
 def test_wn_forward_standalone(dev):

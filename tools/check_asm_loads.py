@@ -154,39 +154,69 @@ def check_dma_kernel(name, lines):
         if a and t.startswith("global_load_lds"):
             if n < 2 or not ins[n - 1][1].startswith("s_nop") or not re.match(r"s_mov_b32 m0, s\d+", ins[n - 2][1]):
                 errors.append("%s:%d: LDS-DMA without `s_mov_b32 m0, sN; s_nop 0` in front" % (name, no))
-    work, visited = [(0, 0, True)], set()
-    while work:
-        pc, cnt, drained = work.pop()
-        while pc < len(ins):
-            if (pc, cnt, drained) in visited:
+    # the state: the wave's hand-issued vector-memory instructions that may still be in flight, oldest first, as runs of one kind
+    # ('d' LDS-DMA, 'l' hand-issued register loads: the accumulate-into tile of convlayer16g_kernel's residual product); a wait for
+    # vmcnt(N) keeps the youngest N (the compiler's own loads and the epilogues' stores only make a wait retire MORE: ignored)
+    def trim(q, n):
+        out, left = [], n
+        for k, c in reversed(q):
+            if left <= 0:
                 break
-            visited.add((pc, cnt, drained))
+            t = min(c, left)
+            out.append((k, t))
+            left -= t
+        return tuple(reversed(out))
+
+    def push(q, k):
+        if q and q[-1][0] == k:
+            return q[:-1] + ((k, min(q[-1][1] + 1, 99)),)
+        return q + ((k, 1),)
+
+    def dmas(q):
+        return sum(c for k, c in q if k == "d")
+
+    work, visited = [(0, ())], set()
+    while work:
+        pc, q = work.pop()
+        while pc < len(ins):
+            if (pc, q) in visited:
+                break
+            visited.add((pc, q))
             no, t, inasm = ins[pc]
             ops = [o for o in re.split(r"[ ,]+", t) if o]
             op = ops[0]
             if inasm and op.startswith("global_load_lds"):
-                cnt, drained = min(cnt + 1, 99), False
+                q = push(q, "d")
+            elif inasm and op.startswith("global_load_dword"):
+                q = push(q, "l")
             elif inasm and op == "s_waitcnt" and "vmcnt" in t:
                 keep = int(re.search(r"vmcnt\((\d+)\)", t).group(1))
-                want = {10: 14, 3: 10}.get(keep)
-                if want is not None and cnt != want and (no, cnt) not in seen:
-                    seen.add((no, cnt))
-                    errors.append("%s:%d: `%s` with %d LDS-DMA instructions in flight (the immediate assumes %d)" % (name, no, t, cnt, want))
-                if keep not in (0, 3, 10) and no not in seen:
+                cnt = dmas(q)
+                # vmcnt(10): behind the prologue's two chunks, leaves B(0), A(1), B(1); vmcnt(3): at a chunk's barrier, 10 pieces in flight
+                # (or 7 when a tile change has drained everything since); vmcnt(14) / vmcnt(48): for the sake of the 48 accumulate-into
+                # loads (behind the residual product's 14 prologue pieces / right behind the gate product's last stores: nothing older stays)
+                want = {10: (14,), 3: (10, 7), 14: (14,)}.get(keep)
+                if want is not None and cnt not in want and (no, q) not in seen:
+                    seen.add((no, q))
+                    errors.append("%s:%d: `%s` with %d LDS-DMA instructions in flight (the immediate assumes %s)" % (name, no, t, cnt, want))
+                if keep not in (0, 3, 10, 14, 48) and no not in seen:
                     seen.add(no)
                     errors.append("%s:%d: unexpected hand-written wait `%s`" % (name, no, t))
-                cnt, drained = min(cnt, keep), keep == 0
+                q = trim(q, keep)
+                if keep == 48 and dmas(q) and (no, "48") not in seen:
+                    seen.add((no, "48"))
+                    errors.append("%s:%d: `%s` leaves LDS-DMA instructions in flight" % (name, no, t))
             elif op == "s_endpgm":
-                if not drained and ("end", no) not in seen:
+                if q and ("end", no) not in seen:
                     seen.add(("end", no))
-                    errors.append("%s:%d: wave ends with LDS-DMA instructions in flight" % (name, no))
+                    errors.append("%s:%d: wave ends with hand-issued loads / LDS-DMA instructions in flight" % (name, no))
                 break
             else:
                 if op == "s_branch":
                     pc = labels[ops[1]]
                     continue
                 if op.startswith("s_cbranch"):
-                    work.append((labels[ops[1]], cnt, drained))
+                    work.append((labels[ops[1]], q))
             pc += 1
     return ndma, nwait, errors
 
@@ -206,7 +236,7 @@ def main():
         print("no convgemm16w_kernel instantiation in the ISA")
         return 1
     bad = 0
-    for s in [i for i, l in enumerate(text) if re.match(r"^_Z\d+convgemm16g_kernel\w*:", l)]:
+    for s in [i for i, l in enumerate(text) if re.match(r"^_Z\d+(convgemm16g_kernel|convlayer16g_kernel)\w*:", l)]:
         e = next(i for i in range(s, len(text)) if ".amdhsa_kernel" in text[i] or text[i].startswith(".Lfunc_end"))
         kname = text[s].split(":")[0]
         ndma, nwait, errors = check_dma_kernel(kname, text[s:e])

@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 import constant_memory_waveglow_amd as cm          # noqa: E402
 from constant_memory_waveglow_amd import _lib      # noqa: E402
 
-NAMES = ["conv_store", "conv_gate", "conv_resskip", "conv_dgate", "wgrad"]
+NAMES = ["conv_store", "conv_gate", "conv_resskip", "conv_dgate", "wgrad", "layer"]
 
 
 def main():
@@ -38,7 +38,8 @@ def main():
     C_, Bt = a.ch, a.B * a.T
     flops = {  # algorithmic FLOPs per launch of the BIG instance of each class
         "conv_gate": 2.0 * (3 * C_ + 80) * 2 * C_ * Bt, "conv_resskip": 2.0 * C_ * 2 * C_ * Bt,
-        "conv_dgate": 2.0 * 2 * C_ * C_ * Bt, "conv_store": 2.0 * 3 * 2 * C_ * C_ * Bt, "wgrad": 2.0 * 2 * C_ * (3 * C_ + 80) * Bt}
+        "conv_dgate": 2.0 * 2 * C_ * C_ * Bt, "conv_store": 2.0 * 3 * 2 * C_ * C_ * Bt, "wgrad": 2.0 * 2 * C_ * (3 * C_ + 80) * Bt,
+        "layer": 2.0 * (3 * C_ + 80) * 2 * C_ * Bt + 2.0 * C_ * C_ * Bt}
 
     def run():
         xx = x.clone().requires_grad_(True)
