@@ -208,6 +208,7 @@ class FlowTrainer:
         self.n_buckets = len(self.fg.bucket_ranges)
         self.metrics = self.fg.tail       # [logdet.sum()/z.numel(), z.mean(), z.std(), loss] of the last step, reduced over the ranks
         self.optimizer = None             # a FlatAdam attaches itself here; step() then updates the weights as well
+        self.want_dh, self.last_dh = False, None      # want_dh: step() also keeps d loss / d h (wg_train_step's dh output) in last_dh
         self.events = None
         if self.table[0].is_cuda and (self.sync.world > 1 or self.sync._force):
             with torch.cuda.device(self.table[0].device):
@@ -230,13 +231,14 @@ class FlowTrainer:
             c = h.clamp_(-1.0, 1.0)
             h = E.wsr_cond(c, self.frontend[0].detach(), self.frontend[1].detach())
         loss, z, logdet, _, dh = eng.train_step(table, x, h, self.sigma, self.mean, need, grads_out=self.grad_views[:nflow],
-                                                need_dh=bool(self.frontend),
+                                                need_dh=bool(self.frontend) or self.want_dh,
                                                 flow_events=self.events[:self.n_flows + 1] if self.events else None,
                                                 keep=not self.model.mem_efficient, metrics=self.metrics)   # one C call: wg_train_step
         # buckets become final in the order backward retires the flows: last flow first (first flow first in reverse_mode), then the
         # upsampler, then (WSRGlow) the embedding tables, whose gradients come out of the conditioning gradient
         flows = range(self.n_flows) if self.model._reverse_mode else range(self.n_flows - 1, -1, -1)
         order = list(flows) + [self.n_flows]
+        self.last_dh = dh if self.want_dh else None      # d loss / d conditioning of this step (want_dh: off by default, nothing trains on it)
         if self.frontend:
             E.wsr_cond_backward(c, dh, out=(self.grad_views[nflow], self.grad_views[nflow + 1]))
             del dh

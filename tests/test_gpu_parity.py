@@ -412,7 +412,8 @@ def test_c2_full_batch_vs_oracle(dev, precision):
     walks, XCD rows, the one-product skip / conditioning gradient -- through FlowTrainer.step (wg_train_step, what bench.py times)
     against the float64 torch-CPU oracle (oracle/torch_cpu.py, pinned to the reference's goldens by tests/test_oracle_golden.py).
     Batch items are independent, so the oracle runs as one worker process per share of the batch (train_step_parallel).
-    Bars: z 1e-4, logdet rtol 1e-4, loss 1e-6, every one of the 459 gradients and dh within 1e-4 of its tensor's max."""
+    Bars: z 1e-4, logdet rtol 1e-4, loss 1e-6, every one of the 459 gradients and dh (from the same call: FlowTrainer.want_dh) within
+    1e-4 of its tensor's max; then the same for memory_efficient=False, the other benchmarked form, against the same oracle run."""
     if precision != "bf16x3p":
         pytest.skip("the headline shape is checked in the default arithmetic (CPU oracle time)")
     from oracle import torch_cpu
@@ -428,27 +429,29 @@ def test_c2_full_batch_vs_oracle(dev, precision):
     workers = max(1, min(B, cores // 8))
     ref = torch_cpu.train_step_parallel(cfg, fill.table(specs, P), audio, h, fill.SIGMA, workers=workers, threads=max(1, min(8, cores // workers)),
                                         need_dh=True, double=True)
-    tr = FlowTrainer(m, fill.SIGMA)
     x, ht = T(audio, dev), T(h, dev)
-    loss, z, logdet = tr.step(x, ht)
-    assert np.abs(npy(z) - ref["z"]).max() < Z_ATOL
-    assert logdet_close(npy(logdet), ref["logdet"], N)
-    assert abs(float(loss) - ref["loss"]) < LOSS_ATOL
-    named = dict(m.named_parameters())
-    worst = 0.0
-    for i, (n, _, _) in enumerate(specs):
-        e = relmax(npy(named[n].grad).astype(np.float64), ref["grads"][i])
-        worst = max(worst, e)
-        assert e < GRAD_RTOL, n
-    # dh through the autograd path of the same model (FlowTrainer does not return it for WaveGlow): same kernels, need_dh on
-    m.zero_grad(set_to_none=True)
-    hg = T(h, dev).requires_grad_(True)
-    z2, ld2 = m(T(audio, dev), hg)
-    cm.WaveGlowLoss(fill.SIGMA)(z2, ld2).backward()
-    assert torch.equal(z2.detach(), z) or float((z2.detach() - z).abs().max()) < 1e-6
-    assert relmax(npy(hg.grad).astype(np.float64), ref["dh"]) < GRAD_RTOL
-    print("headline shape vs float64 oracle: |dz| %.2e, worst gradient %.2e of its tensor's max (%d oracle workers)"
-          % (float(np.abs(npy(z) - ref["z"]).max()), worst, workers))
+    # both benchmarked forms of the step against the ONE oracle run: the constant-memory config (the headline) and the same network with
+    # stored activations (memory_efficient=False, configs/waveglow_LJ_speech_fast.json: `other_models.waveglow_memory_efficient_false`)
+    for mem_eff in (True, False):
+        if not mem_eff:
+            del tr
+            torch.cuda.empty_cache()
+            m, cfg, specs, P = build("c2", dev, mem_eff=False)
+        tr = FlowTrainer(m, fill.SIGMA)
+        tr.want_dh = True                                        # d loss / d h from the timed path itself (wg_train_step's dh output)
+        loss, z, logdet = tr.step(x, ht)
+        assert np.abs(npy(z) - ref["z"]).max() < Z_ATOL
+        assert logdet_close(npy(logdet), ref["logdet"], N)
+        assert abs(float(loss) - ref["loss"]) < LOSS_ATOL
+        named = dict(m.named_parameters())
+        worst = 0.0
+        for i, (n, _, _) in enumerate(specs):
+            e = relmax(npy(named[n].grad).astype(np.float64), ref["grads"][i])
+            worst = max(worst, e)
+            assert e < GRAD_RTOL, (mem_eff, n)
+        assert relmax(npy(tr.last_dh).astype(np.float64), ref["dh"]) < GRAD_RTOL, mem_eff
+        print("headline shape vs float64 oracle (memory_efficient=%s): |dz| %.2e, worst gradient %.2e of its tensor's max (%d oracle workers)"
+              % (mem_eff, float(np.abs(npy(z) - ref["z"]).max()), worst, workers))
 
 
 @pytest.mark.parametrize("c", [2, 4, 8])
