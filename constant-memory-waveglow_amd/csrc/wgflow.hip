@@ -1016,6 +1016,9 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                     cx.rec->add(epi == EPI_STORE ? WGS_CONV_STORE : epi == EPI_GATE ? WGS_CONV_GATE : WGS_CONV_RESSKIP, (int)gh.x).u.conv = as;
                     return;
                 }
+                // (measured slower in round 5: the same tiles with the operands by LDS-DMA into a ring of eight chunk buffers, seven chunks in
+                // flight, four waves that multiply and issue -- tools/experiments/wg_gemm16m.h: 2.70 against 2.46-2.52 ms per 0.7 s utterance,
+                // WaveFlow's row-by-row synthesis 96.6 against 86.7 ms: a CU's intake rate, not the depth of its prefetch, bounds these launches)
                 // (2 or 4 k-steps per chunk and barrier measured slower: tools/experiments/wg_gemm16hk.h)
                 switch (epi) {
                 case EPI_STORE: WG_LAUNCH(cx, convgemm16h_kernel<EPI_STORE>, gh, dim3(512), 0, as); break;
