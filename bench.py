@@ -99,7 +99,7 @@ def _traffic(kernel_prefix, prefix=""):
             continue
         for name, row in k.items():
             bare = name[5:] if name.startswith("void ") else name
-            if bare.startswith(kernel_prefix) and bare[len(kernel_prefix):len(kernel_prefix) + 1] in (",", ">", "("):
+            if bare.startswith(kernel_prefix) and bare[len(kernel_prefix):len(kernel_prefix) + 1] in ("", ",", ">", "("):
                 best = (row["hbm_bytes_per_launch"], os.path.relpath(f, ROOT), bare)
     return best
 
@@ -358,7 +358,7 @@ def other_models(dev):
 
 
 KCLASS = {0: "conv store / residual / data-gradient (EPI_STORE)", 1: "gate conv (EPI_GATE)", 2: "residual + skip conv (EPI_RESSKIP)",
-          3: "gate backward (EPI_DGATE)", 4: "weight gradient", 5: "layer launch: gate conv + residual product (opt-in)"}
+          3: "gate backward (EPI_DGATE)", 4: "weight gradient", 5: "layer launch: gate conv + residual product"}
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
@@ -744,7 +744,9 @@ def main(argv=None):
     comm = comm_report(wl, args, use_dist, world, rank, dev, dt_own, ms_per_step, barrier) if use_dist else None
     # the dominant kernel's launch duration: HIP events around every launch of its class over `args.steps` EXTRA steps (every rank runs
     # them: the collectives need all ranks), outside the timed region; the library reports which instantiation each launch ran
-    timer = L.wg_timer_create(_lib.K_CONV_GATE, per_step_gate * args.steps) if rank == 0 else None
+    # (every class is timed: the gate conv runs on its own -- class K_CONV_GATE -- or, at the training shapes since round 5, inside the
+    # one-launch layer -- K_LAYER: gate conv + residual product; the roofline describes whichever takes more of the step)
+    timer = L.wg_timer_create(-1, 4096 * args.steps) if rank == 0 else None
     barrier()
     if timer:
         L.wg_timer_attach(timer)
@@ -756,18 +758,28 @@ def main(argv=None):
 
     out = None
     if rank == 0:
-        n = L.wg_timer_count(timer)
-        buf = (C.c_float * n)()
-        L.wg_timer_read(timer, buf, n)
+        n_all = L.wg_timer_count(timer)
+        buf = (C.c_float * n_all)()
+        info = (C.c_longlong * (5 * n_all))()
+        L.wg_timer_read(timer, buf, n_all)
+        L.wg_timer_read_info(timer, info, n_all)
+        ms_all = np.frombuffer(buf, dtype=np.float32)
+        info = np.frombuffer(info, dtype=np.int64).reshape(n_all, 5)
+        per_class = {c: float(ms_all[info[:, 0] == c].sum()) for c in (_lib.K_CONV_GATE, _lib.K_LAYER)}
+        dom = max(per_class, key=per_class.get)
+        sel = np.nonzero(info[:, 0] == dom)[0]
         names = {}
         nb = C.create_string_buffer(256)
-        for i in range(n):
-            if L.wg_timer_read_name(timer, i, nb, 256) >= 0:
+        for i in sel:
+            if L.wg_timer_read_name(timer, int(i), nb, 256) >= 0:
                 names[nb.value.decode()] = names.get(nb.value.decode(), 0) + 1
         L.wg_timer_destroy(timer)
-        ms_all = np.frombuffer(buf, dtype=np.float32)
-        gate_ms = float(np.mean(ms_all)) if n else float("nan")
-        gate_flop = wl["gate_flop_per_launch"]                           # algorithmic FLOPs of one launch
+        n = int(sel.size)
+        gate_ms = float(np.mean(ms_all[sel])) if n else float("nan")
+        # algorithmic FLOPs of one launch: the gate conv's, or (layer launch) gate conv + residual product: 2 M K columns of what the
+        # library attaches to the launch (wg_timer_read_info: for the layer K counts the residual's channels scaled to the gate's rows)
+        gate_flop = wl["gate_flop_per_launch"] if dom == _lib.K_CONV_GATE or not n else float(2.0 * np.median(info[sel, 1] * info[sel, 2] * info[sel, 3]))
+        what = wl["gate_what"] if dom == _lib.K_CONV_GATE else wl["gate_what"] + ", then W_o's residual rows on the same workgroup (one launch per layer)"
         achieved = gate_flop / (gate_ms * 1e-3) / 1e12
         split = _lib.default_precision() != _lib.PREC_F32
         # bf16x3: every fp32 product costs three bf16 MFMAs; the roofline is the bf16 matrix pipe and only the
@@ -779,6 +791,13 @@ def main(argv=None):
         traffic, traffic_src, kfull = _traffic(kprefix, wl["profile_prefix"]) if kprefix else (None, None, None)
         if traffic_src:
             traffic_src += " (committed rocprofv3 --pmc summary of this command; not re-measured in this run)"
+        gate_alone = None
+        galone = np.nonzero(info[:, 0] == _lib.K_CONV_GATE)[0]
+        if dom == _lib.K_LAYER and galone.size:                          # the gate conv launches that run on their own (a WN's last layer)
+            g_ms = float(np.mean(ms_all[galone]))
+            g_ach = wl["gate_flop_per_launch"] / (g_ms * 1e-3) / 1e12
+            gate_alone = {"launch_ms": g_ms, "launches_timed": int(galone.size), "flop_per_launch": wl["gate_flop_per_launch"], "achieved": g_ach,
+                          "frac": g_ach / peak}
         STEP_FLOP = wl["step_flop_per_sample"]
         out = {
             "metric": wl["metric"],
@@ -791,8 +810,10 @@ def main(argv=None):
             "dtype": "f32 (contractions as split bf16x3 MFMA, fp32 accumulate)" if split else "f32", "data": "synthetic",
             "config": {"workload": wl["workload"] + (" + RCCL grad all-reduce" if world > 1 else ""),
                        "global_batch": B * world, "segment": SEGW, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "%s (EPI_GATE: %s)" % (kfull or (kprefix + ">" if "<" in kprefix else kprefix), wl["gate_what"]),
+            "roofline": {"bound": "mfma", "kernel": "%s (EPI_GATE: %s)" % (kfull or (kprefix + ">" if "<" in kprefix else kprefix), what),
                          "kernel_launch_sites": names,
+                         "class_ms_timed": {"gate conv on its own": per_class[_lib.K_CONV_GATE], "layer launch": per_class[_lib.K_LAYER]},
+                         **({"gate_conv_alone": gate_alone} if gate_alone else {}),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": gate_ms, "launches_timed": n, "launch_timing": "HIP events around every launch of the class over %d extra steps "
