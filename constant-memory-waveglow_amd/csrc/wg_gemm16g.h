@@ -421,7 +421,7 @@ __device__ __forceinline__ void wgg_stream(const ConvGemm16sArgs &aa, char *smem
     auto acc_start = [&](auto FIRST) __attribute__((always_inline)) {
         if (EPI == EPI_STORE_SO && aa.saux.hi) {
             if constexpr (PRE && decltype(FIRST)::value) {
-                // (in flight since the product in front finished; younger: the 14 pieces of chunks 0 and 1)
+                // (in flight since the product in front finished, and retired by the prologue's vmcnt(8) above: nothing left to wait for)
                 asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
                 wgg_init_tie(ih); wgg_init_tie(il);
             } else {
@@ -568,8 +568,29 @@ __device__ __forceinline__ void wgg_stream(const ConvGemm16sArgs &aa, char *smem
         if (++cc == nchunks) cc = 0;
     };
     WGG_TRACE(8);
-    issue(std::integral_constant<int, 0>(), 0);
-    issue(std::integral_constant<int, 1>(), 1);
+    if constexpr (PRE) {
+        // Behind another product of the same launch whose OUTPUT is this product's B operand (convlayer16g_kernel): the weight pieces of
+        // chunks 0 and 1 go out at once -- they depend on nothing -- then the wave waits for everything older than those eight (vmcnt(8):
+        // the stores of the product in front, its trailing fetches, the accumulate-into loads it issued for us), the barrier makes that
+        // true of every wave's stores, and only then the activation pieces are requested.  The table builds above and the weights' trip
+        // run under the store drain (4-9 us: this part acknowledges a store at memory speed) instead of behind it.
+        desc_request();
+        prep(0);
+        fire(WGG_IC(0), WGG_IC(0)); fire(WGG_IC(0), WGG_IC(1)); fire(WGG_IC(0), WGG_IC(2)); fire(WGG_IC(0), WGG_IC(3));
+        const void *sb0 = sbB;
+        const unsigned v0[3] = {vb[0], vb[1], vb[2]}, d0 = bd;
+        desc_request();
+        prep(1);
+        fire(WGG_IC(1), WGG_IC(0)); fire(WGG_IC(1), WGG_IC(1)); fire(WGG_IC(1), WGG_IC(2)); fire(WGG_IC(1), WGG_IC(3));
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        WGG_BAR();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wgg_glds16(sb0, v0[k], b_dst[k] + d0);
+        fire(WGG_IC(1), WGG_IC(4)); fire(WGG_IC(1), WGG_IC(5)); fire(WGG_IC(1), WGG_IC(6));
+    } else {
+        issue(std::integral_constant<int, 0>(), 0);
+        issue(std::integral_constant<int, 1>(), 1);
+    }
     acc_start(std::true_type());
     asm volatile("s_waitcnt vmcnt(10)" ::: "memory");        // the own pieces of A(0): younger are B(0), A(1), B(1)
     WGG_BAR();
@@ -585,8 +606,7 @@ __device__ __forceinline__ void wgg_stream(const ConvGemm16sArgs &aa, char *smem
     tile_done();
     if constexpr (NEXTI) {
         // the accumulate-into tile of the next product's first tile (the workgroup's first column tile, one row tile: its geometry is
-        // this product's), 48 loads per lane right behind the last stores; wait for everything in front of them -- the stores, the trailing
-        // fetches (they must not land in another product's LDS) -- and return with the loads in flight
+        // this product's), 48 loads per lane right behind the last stores; return with them in flight
         ck = 0;
         tile_at(0, ct, m0);
         block_pos();
@@ -594,7 +614,8 @@ __device__ __forceinline__ void wgg_stream(const ConvGemm16sArgs &aa, char *smem
         wgg_init_issue<0>(nxt->c, nxt->saux, ih, il, eb[0], et[0], mw, lane); wgg_init_issue<1>(nxt->c, nxt->saux, ih, il, eb[1], et[1], mw, lane);
         wgg_init_issue<2>(nxt->c, nxt->saux, ih, il, eb[2], et[2], mw, lane); wgg_init_issue<3>(nxt->c, nxt->saux, ih, il, eb[3], et[3], mw, lane);
         wgg_init_issue<4>(nxt->c, nxt->saux, ih, il, eb[4], et[4], mw, lane); wgg_init_issue<5>(nxt->c, nxt->saux, ih, il, eb[5], et[5], mw, lane);
-        asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+        // (no wait here: the next product waits for the stores, the trailing fetches and these loads behind its own first weight pieces;
+        // a trailing fetch lands in a ring slot before anything the same wave requests into it later -- the queue is in order)
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the trailing fetches must not land in another workgroup's LDS
     }
@@ -637,8 +658,8 @@ __global__ __launch_bounds__(512) void convlayer16g_kernel(const ConvLayer16gArg
     __shared__ __attribute__((aligned(1024))) char smem[WGG_LDS_ALL];
     u32x2 ih[4][6], il[4][6];                                 // the residual product's accumulate-into tile, in flight across the seam
     wgg_stream<EPI_GATE_SO, true, false, true>(la.p[0], smem, ih, il, &la.p[1]);
-    // every wave has waited for its own stores (the gate tiles are in L2, this CU's L1 never held those lines) and for its DMA; nobody
-    // may still be reading the rings or the tables when the next product's prologue overwrites them.  (The tile positions the gate
+    // nobody may still be reading the rings or the tables when the next product's prologue overwrites them (the gate tiles' stores are
+    // waited for inside the residual product, behind its first weight pieces; this CU's L1 never held those lines).  (The tile positions the gate
     // product's tail used for the loads are the residual product's own: same column tiles, same workgroup order, row tile 0.)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");

@@ -195,17 +195,19 @@ def check_dma_kernel(name, lines):
                 # vmcnt(10): behind the prologue's two chunks, leaves B(0), A(1), B(1); vmcnt(3): at a chunk's barrier, 10 pieces in flight
                 # (or 7 when a tile change has drained everything since); vmcnt(14) / vmcnt(48): for the sake of the 48 accumulate-into
                 # loads (behind the residual product's 14 prologue pieces / right behind the gate product's last stores: nothing older stays)
+                # vmcnt(8): the residual product of convlayer16g_kernel behind its first eight weight pieces (retires the gate product's stores,
+                # trailing fetches and the accumulate-into loads)
                 want = {10: (14,), 3: (10, 7), 14: (14,)}.get(keep)
+                if keep == 8 and (dmas(trim(q, 8)) != 8 or len(trim(q, 8)) != 1) and (no, q) not in seen:
+                    seen.add((no, q))
+                    errors.append("%s:%d: `%s` does not leave exactly the eight weight pieces in flight" % (name, no, t))
                 if want is not None and cnt not in want and (no, q) not in seen:
                     seen.add((no, q))
                     errors.append("%s:%d: `%s` with %d LDS-DMA instructions in flight (the immediate assumes %s)" % (name, no, t, cnt, want))
-                if keep not in (0, 3, 10, 14, 48) and no not in seen:
+                if keep not in (0, 3, 8, 10, 14) and no not in seen:
                     seen.add(no)
                     errors.append("%s:%d: unexpected hand-written wait `%s`" % (name, no, t))
                 q = trim(q, keep)
-                if keep == 48 and dmas(q) and (no, "48") not in seen:
-                    seen.add((no, "48"))
-                    errors.append("%s:%d: `%s` leaves LDS-DMA instructions in flight" % (name, no, t))
             elif op == "s_endpgm":
                 if q and ("end", no) not in seen:
                     seen.add(("end", no))
