@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "wg_nll_scratch_floats", "wg_train_scratch_floats",
     "wg_timer_create", "wg_timer_attach", "wg_timer_count", "wg_timer_read", "wg_timer_read_info", "wg_timer_destroy", "wg_stat_wgrad16t_launches",
     "wg_stat_layer_launches", "wg_layer_workspace_bytes", "wg_layer_apply", "wg_wf_wn_apply",
-    "wg_timer_read_name", "wg_box_probe_bytes", "wg_box_probe", "wg_stat_layerg_launches",
+    "wg_timer_read_name", "wg_box_probe_bytes", "wg_box_probe", "wg_stat_layerg_launches", "wg_stat_gate_split_launches",
 ]
 K_CONV_STORE, K_CONV_GATE, K_CONV_RESSKIP, K_CONV_DGATE, K_WGRAD, K_LAYER = range(6)
 
@@ -155,6 +155,7 @@ def lib():
     L.wg_box_probe_bytes.argtypes = []
     L.wg_box_probe.argtypes = [vp, i, vp, vp]
     L.wg_stat_layerg_launches.restype = C.c_longlong
+    L.wg_stat_gate_split_launches.restype = C.c_longlong
     _LIB = L
     return L
 

@@ -60,6 +60,14 @@ __device__ __forceinline__ void wgg_glds16(const void *sbase, unsigned voff, uns
 #endif
 }
 
+// Split K (xcd_items = 2, ntz = splits): a product whose tiles cannot fill the chip -- WSRGlow's gate conv, M = 512 x 6 144 columns = 64
+// tiles, K = 4 432 -- is cut along K into `ntz` parts per tile, one workgroup each; the parts leave their raw accumulators in a slab
+// ([part][tile][wave][block][lane] f32x4: every store a contiguous 1 KB) and gate_finish16g_kernel adds them and runs the gate epilogue.
+#define WGG_EPI_PART 8
+__device__ __forceinline__ void wgg_st16(const float *base, unsigned voff, const f32x4 &v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(base) : "memory");
+}
 // EPI_GATE_SO, column block NBI of the wave tile: 16 columns of plane row b from time step t0 on (the flattened columns of a tile may
 // belong to two plane rows, so every block has its own bases; otherwise as wgq_gate_nb)
 template <int NBI>
@@ -236,7 +244,7 @@ static_assert(sizeof(WggDesc) == 32 && sizeof(WggOffs) == 32 && WGG_LDS_ALL <= 1
 template <int EPI, bool LAYERK = false, bool PRE = false, bool NEXTI = false>
 __device__ __forceinline__ void wgg_stream(const ConvGemm16sArgs &aa, char *smem, u32x2 (&ih)[4][6], u32x2 (&il)[4][6], const ConvGemm16sArgs *nxt)
 {
-    static_assert(EPI == EPI_GATE_SO || EPI == EPI_STORE_SO || EPI == EPI_STORE_FO, "the hand-issued epilogues");
+    static_assert(EPI == EPI_GATE_SO || EPI == EPI_STORE_SO || EPI == EPI_STORE_FO || EPI == WGG_EPI_PART, "the hand-issued epilogues");
     const ConvGemmArgs &a = aa.c;
     const Geo g = a.g;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -245,17 +253,30 @@ __device__ __forceinline__ void wgg_stream(const ConvGemm16sArgs &aa, char *smem
     int nchunks = 0;
     for (int s = 0; s < a.nseg; ++s) nchunks += (a.seg[s].nch + WG16_BK - 1) / WG16_BK;
     const int nil = aa.tap_il * aa.tap_chunks;                // chunks walked interleaved over the taps (ConvGemm16sArgs::tap_il)
+    const bool splitk = aa.xcd_items == 2;                    // ONE (tile, K part) per workgroup: chunks [k0, k0 + nchunks) of the walk
+    int k0 = 0, part = 0;
     const int G = (int)gridDim.x, bid = (int)blockIdx.x;
     const bool xm = (G & 7) == 0;
     const int nx = xm ? 8 : 1, xid = xm ? (bid & 7) : 0, slot = xm ? (bid >> 3) : bid, xslots = xm ? (G >> 3) : G;
     const bool own = aa.xcd_items == 1;
     const int c_lo = xid * aa.ntx / nx, n_cols = (xid + 1) * aa.ntx / nx - c_lo, n_local = n_cols * aa.nty;
-    const int mine = own ? (slot < n_cols ? ((n_cols - 1 - slot) / xslots + 1) * aa.nty : 0) : (slot < n_local ? (n_local - 1 - slot) / xslots + 1 : 0);
+    int mine = own ? (slot < n_cols ? ((n_cols - 1 - slot) / xslots + 1) * aa.nty : 0) : (slot < n_local ? (n_local - 1 - slot) / xslots + 1 : 0);
+    int sk_tile = 0;                                          // split K: the XCD's (column tile, row tile) this workgroup works on
+    if (splitk) {
+        const int S = aa.ntz;
+        mine = slot < n_local * S ? 1 : 0;
+        part = slot % S; sk_tile = slot / S;
+        const int kb = (int)((long)part * nchunks / S), ke = (int)((long)(part + 1) * nchunks / S);
+        k0 = kb; nchunks = ke - kb;
+    }
     const int total = mine * nchunks;
     if (total == 0) return;
     auto tile_at = [&](int k, int &ct, int &m0) __attribute__((always_inline)) {
         const int kk = min(k, mine - 1);
-        if (own) {
+        if (splitk) {
+            const int cl = sk_tile / aa.nty;
+            ct = c_lo + cl; m0 = (sk_tile - cl * aa.nty) * WGG_BM;
+        } else if (own) {
             const int ci = kk / aa.nty;
             ct = c_lo + slot + ci * xslots; m0 = (kk - ci * aa.nty) * WGG_BM;
         } else {
@@ -267,7 +288,7 @@ __device__ __forceinline__ void wgg_stream(const ConvGemm16sArgs &aa, char *smem
 
     // ---------------------------------------------- the chunk table ----------------------------------------------
     if (tid < nchunks) {
-        const int v = tid;
+        const int v = k0 + tid;                               // (the walk's chunk this entry describes)
         int sg, ci, chi;
         if (v < nil) {
             sg = v % aa.tap_il;
@@ -291,7 +312,7 @@ __device__ __forceinline__ void wgg_stream(const ConvGemm16sArgs &aa, char *smem
         d.item_stride = (unsigned)(ss.Cp >> 3) * (unsigned)g.P * 16u;
         d.nq = (unsigned)min(4, (a.seg[sg].nch - ci + 7) >> 3);
         d.pad = 0;
-        *reinterpret_cast<WggDesc *>(smem + WGG_TAB + v * 32) = d;
+        *reinterpret_cast<WggDesc *>(smem + WGG_TAB + tid * 32) = d;
     }
     __syncthreads();
 
@@ -456,6 +477,15 @@ __device__ __forceinline__ void wgg_stream(const ConvGemm16sArgs &aa, char *smem
             wgg_gate_nb<0>(a, aa.s0, acc, eb[0], et[0], chb, lane); wgg_gate_nb<1>(a, aa.s0, acc, eb[1], et[1], chb, lane);
             wgg_gate_nb<2>(a, aa.s0, acc, eb[2], et[2], chb, lane); wgg_gate_nb<3>(a, aa.s0, acc, eb[3], et[3], chb, lane);
             wgg_gate_nb<4>(a, aa.s0, acc, eb[4], et[4], chb, lane); wgg_gate_nb<5>(a, aa.s0, acc, eb[5], et[5], chb, lane);
+        } else if constexpr (EPI == WGG_EPI_PART) {
+            // the raw accumulators, block by block, 1 KB per wave and store: slab[(part * tiles + tile) * 8 + wave][mb * 6 + nb][lane]
+            const int tile = ct * aa.nty + m0 / WGG_BM, ntiles = aa.ntx * aa.nty;
+            const float *sbase = a.out0.p + ((size_t)(part * ntiles + tile) * 8 + wave) * (24 * 64 * 4);
+            const unsigned vo = (unsigned)lane * 16u;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 6; ++nb) wgg_st16(sbase + (mb * 6 + nb) * 256, vo, acc[mb][nb]);
         } else if constexpr (EPI == EPI_STORE_FO) {
             const int mw = m0 + 64 * wr;
             wgg_store_fo_nb<0>(a, acc, eb[0], et[0], mw, lane); wgg_store_fo_nb<1>(a, acc, eb[1], et[1], mw, lane);
@@ -668,3 +698,28 @@ __global__ __launch_bounds__(512) void convlayer16g_kernel(const ConvLayer16gArg
     wgg_stream<EPI_STORE_SO, true, true, false>(la.p[1], smem, ih, il, nullptr);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (nothing the gate product's tail issued outlives the wave on any path)
 }
+
+// the K parts of a split product added up and gated: one workgroup per (tile, column block of the wave tiles), thread = (wave, lane) as in
+// the product; the epilogue is the product's own (wgg_gate_nb)
+__global__ __launch_bounds__(512) void gate_finish16g_kernel(const ConvGemm16sArgs aa, const float *slab, int splits)
+{
+    const ConvGemmArgs &a = aa.c;
+    const Geo g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = (int)blockIdx.x / 6, nb = (int)blockIdx.x - tile * 6, ntiles = aa.ntx * aa.nty;
+    const int ct = tile / aa.nty, m0 = (tile - ct * aa.nty) * WGG_BM, wr = wave >> 1, wc = wave & 1;
+    f32x4 acc[4][6];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < splits; ++p) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(slab + (((size_t)(p * ntiles + tile) * 8 + wave) * 24 + (mb * 6 + nb)) * 256 + lane * 4);
+            x += v;
+        }
+        acc[mb][0] = x;
+    }
+    const int cf = ct * WGG_BN + 96 * wc + 16 * nb, b = cf / g.Tt, t0 = cf - b * g.Tt;
+    wgg_gate_nb<0>(a, aa.s0, acc, b, t0, (m0 >> 1) + 32 * wr, lane);
+}
+

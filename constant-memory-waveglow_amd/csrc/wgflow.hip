@@ -40,6 +40,8 @@ struct Ctx {
     int prec;   // 0: exact fp32 MFMA; 1: bf16x3, operands split on the fly (wg_gemm16.h); 2: bf16x3 from pre-split S-planes (wg_gemm16s.h)
     int row_sel1;   // Geo::rows > 0 only: 0 = every plane row; r + 1 = the conv launches cover height row r of every item (WaveFlow's inverse)
     struct FinQueue *fq = nullptr;   // set inside wn_backward: weight-gradient slabs come from its arena, finalisations are batched
+    float *gslab = nullptr;          // set inside wn_forward when the workspace has a weight-gradient slab (idle during a forward pass):
+    size_t gslab_floats = 0;         // scratch for the K parts of a split gate conv (convgemm16g_kernel<WGG_EPI_PART>)
     struct StageRec *rec = nullptr;  // set while a launch sequence is RECORDED for the stage interpreter (wg_stage.h): nothing is launched
     struct BigCap *cap = nullptr;    // set while run_convgemm only DESCRIBES a chip-filling launch (run_convlayer_big): nothing is launched
 };
@@ -687,6 +689,25 @@ struct Bump {
     size_t take(size_t n) { size_t o = off; off += rupz(n, 64); return o; }
 };
 int device_cus();
+// Floats of scratch a WN's gate conv needs when it is cut along K (run_convgemm's split path: convgemm16g_kernel<WGG_EPI_PART>): 0 when
+// the shape does not qualify.  The same arithmetic as the launch site's, so that a workspace that was sized here always has the room.
+std::atomic<long long> g_gate_split_launches{0};             // diagnostics (wg_stat_gate_split_launches)
+static void gate_split_plan(int cols_padded, int M, int nc, int cus, int &nt, int &S)
+{
+    const int nct = (cols_padded + WGG_BN - 1) / WGG_BN, nrb = M / WGG_BM;
+    nt = nct * nrb; S = 0;
+    if (M % WGG_BM || cus % 8 || nt <= 0 || nct % 8) return;
+    const int s = cus / nt;
+    if (s >= 2 && s <= 8 && nt * s == cus && nc / s >= 8 && (nc + s - 1) / s <= WGG_MAXCHUNKS) S = s;
+}
+static size_t gate_split_floats(const WnD &d, const Geo &g)
+{
+    if (g.rows != 0 || g.H < 64) return 0;
+    const int nc = d.radix * ((d.C + WG16_BK - 1) / WG16_BK) + (d.aux + WG16_BK - 1) / WG16_BK + (d.bias ? 1 : 0);
+    int nt, S;
+    gate_split_plan(g.B * g.Tt, 2 * d.Cd, nc, device_cus(), nt, S);
+    return S ? (size_t)S * nt * 8 * 24 * 256 : 0;
+}
 void wn_ws_layout(Bump &bp, const WnD &d, int ic_max, const Geo &g, int mode, int prec, WnWs &w)
 {
     const size_t pC = (size_t)g.B * d.C * g.P, pD = (size_t)g.B * d.Cd * g.P, pS = (size_t)g.B * d.Cs * g.P;
@@ -753,8 +774,14 @@ void wn_ws_layout(Bump &bp, const WnD &d, int ic_max, const Geo &g, int mode, in
                                             + 2 * (wgth_part_floats(2 * device_cus(), std::max(16 * d.C, 32 * d.Cs)) + 64));
             }
         }
+        if (prec == 2) s = std::max(s, gate_split_floats(d, g));     // (the split gate conv's parts use the idle slab during a forward pass)
         w.slab_floats = s;
         w.slab = bp.take(s);
+    } else if (prec == 2) {
+        // forward / inverse workspaces get the split gate conv's scratch too: the forward of a training step (mode 1) and a plain
+        // forward then run the same arithmetic, K parts included
+        const size_t s = gate_split_floats(d, g);
+        if (s) { w.slab_floats = s; w.slab = bp.take(s); }
     }
 }
 
@@ -1054,6 +1081,27 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
             // store / data-gradient / skip products whose tiles deal out evenly over the CUs (env WG_G192=0 restores the 256 x 128 / 128 x 128 forms)
             // (products of fewer than 16 chunks -- the residual conv, K = 256: 36.6 against 35.3 us -- stay on the older kernel: a tile that
             // short is mostly this kernel's longer prologue; S-plane arrays and weight images beyond 4 GB: its 32-bit offsets)
+            // a gate conv whose tiles cannot fill the chip, cut along K (WSRGlow: 64 tiles, 139 chunks -> 4 parts of 35 on 256 workgroups) --
+            // the parts go to the workspace's slab (wn_ws_layout sizes it for this in every mode, so a plain forward and a training step's
+            // forward sum K in the same order; env WG_G192_SPLITK=0: off)
+            if (g192_on() && so_gate && g.rows == 0 && !cx.row_sel1 && !cx.rec && M % WGG_BM == 0 && g.H >= 64 && cus % 8 == 0 && cx.gslab &&
+                g192_fits(as, a16.img_stride, nseg)) {
+                const char *e = getenv("WG_G192_SPLITK");
+                const int nct = (g.B * g.Tt + WGG_BN - 1) / WGG_BN, nrb = M / WGG_BM;
+                int nt, S;
+                gate_split_plan(g.B * g.Tt, M, nc, cus, nt, S);
+                const size_t need = (size_t)S * nt * 8 * 24 * 256;
+                if (!(e && e[0] == '0') && S && need <= cx.gslab_floats) {
+                    ConvGemm16sArgs ap = as;
+                    ap.ntx = nct; ap.nty = nrb; ap.ntz = S; ap.xcd_items = 2;
+                    ap.c.out0.p = cx.gslab;
+                    WG_LAUNCH(cx, convgemm16g_kernel<WGG_EPI_PART>, dim3(cus), dim3(512), 0, ap);
+                    ap.c.out0 = a.out0;
+                    WG_LAUNCH(cx, gate_finish16g_kernel, dim3(nt * 6), dim3(512), 0, ap, (const float *)cx.gslab, S);
+                    g_gate_split_launches.fetch_add(1, std::memory_order_relaxed);
+                    return;
+                }
+            }
             const bool fo_g = fo_epi && !a.aux0.p;               // (the skip sum: fp32 plane out, nothing to accumulate into)
             if (g192_on() && !small && (so_gate || so_epi || fo_g) && g.rows == 0 && !cx.row_sel1 && !cx.rec && M % WGG_BM == 0 && g.H >= 64 && cus % 8 == 0 &&
                 nc >= 16 && nc <= WGG_MAXCHUNKS && g192_fits(as, a16.img_stride, nseg)) {
@@ -1780,6 +1828,13 @@ void wn_forward(Ctx &cx, const WnRun &r)
     const Geo &g = r.g;
     float *ws = r.ws;
     const bool sp = cx.prec == 2;
+    // the weight-gradient slab of a training workspace is idle while a WN runs forward (wn_backward's queue is flushed when it returns): scratch
+    // for a split gate conv's parts
+    struct GslabScope {
+        Ctx &c;
+        GslabScope(Ctx &cx_, float *p, size_t n) : c(cx_) { c.gslab = n ? p : nullptr; c.gslab_floats = n; }
+        ~GslabScope() { c.gslab = nullptr; c.gslab_floats = 0; }
+    } gslab_scope(cx, ws + r.w.slab, (r.w.slab_floats && !cx.fq) ? r.w.slab_floats : 0);
     const int nb = d.bias ? 1 : 0;
     const SegSpec sone = d.bias ? ones_seg(cx, r, true) : SegSpec{};
     const int cols0 = (cx.row_sel1 && g.rows > 0 ? g.B / g.rows : g.B) * g.Tt;
@@ -2356,6 +2411,7 @@ int wg_dbg_trace_read_cycles(unsigned long long *out, int n)
 long long wg_stat_wgrad16t_launches(void) { return g_wgrad16t_launches.load(std::memory_order_relaxed); }
 long long wg_stat_layer_launches(void) { return g_layer_launches.load(std::memory_order_relaxed) + g_layerq_launches.load(std::memory_order_relaxed); }
 long long wg_stat_layerg_launches(void) { return g_layerg_launches.load(std::memory_order_relaxed); }
+long long wg_stat_gate_split_launches(void) { return g_gate_split_launches.load(std::memory_order_relaxed); }
 void *wg_timer_create(int kernel_id, int capacity)
 {
     if (capacity < 1) return nullptr;

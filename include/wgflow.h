@@ -82,7 +82,7 @@ const char *wg_strerror(int code);
  * use_conv1x1, wg_wf_upsample; 4: wg_timer_create(-1, ..) times every kernel class, wg_timer_read_info, wg_stat_wgrad16t_launches,
  * wg_wf_* accept every WG_PREC_*; 5: wg_config and wg_wn_dims gained bias; 6: wg_stat_layer_launches, the workspaces carry the one-launch
  * layer's hand-off counters, wg_layer_apply / wg_layer_workspace_bytes, wg_wf_wn_apply; 7: wg_wf_config gained bias; 8: wg_timer_read_name,
- * wg_box_probe / wg_box_probe_bytes, wg_stat_layerg_launches).  A binding built against another revision must not pass its
+ * wg_box_probe / wg_box_probe_bytes, wg_stat_layerg_launches, wg_stat_gate_split_launches).  A binding built against another revision must not pass its
  * structs: the Python loader compares this with its own ABI_VERSION and refuses the library otherwise. */
 #define WG_ABI_VERSION 8
 int wg_abi_version(void);
@@ -126,6 +126,10 @@ long long wg_stat_layer_launches(void);
 /* diagnostics: launches of convlayer16g_kernel (csrc/wg_gemm16g.h: a layer's gate conv and residual product in one launch on 256 x 192 tiles of
  * flattened columns, a workgroup owning whole column tiles -- the training shapes; default on, env WG_LAYER_G=0 switches it off) */
 long long wg_stat_layerg_launches(void);
+/* diagnostics: gate convs that ran cut along K (convgemm16g_kernel<8> writes S partial 256 x 192 tiles per output tile into the workspace,
+ * gate_finish16g_kernel sums them in a fixed order and applies the gate): shapes whose column tiles fill a fraction 1/S of the CUs and
+ * whose K is long -- WSRGlow's 512 x 4432 gate conv at 12 x 512 columns; env WG_G192_SPLITK=0 switches it off */
+long long wg_stat_gate_split_launches(void);
 
 /* ---- sizes -------------------------------------------------------------------------------- */
 int    wg_param_count(const wg_config *cfg);                 /* entries of the parameter table */

@@ -1315,6 +1315,48 @@ def test_wsrglow_full_size_properties(dev, precision):
             assert torch.equal(p.grad, g_full[n]), n
 
 
+def test_wsrglow_gate_conv_cut_along_k_vs_uncut(dev, precision, monkeypatch):
+    """WSRGlow's gate conv at the timed shape (M 512, K 4432 = 139 chunks, 12 x 512 columns = 32 column tiles x 2 row tiles) fills a
+    quarter of the CUs, so run_convgemm cuts K in 4 (convgemm16g_kernel<8> + gate_finish16g_kernel, csrc/wg_gemm16g.h).  The cut changes
+    only the fp32 summation order: a step must agree with the uncut kernels (WG_G192_SPLITK=0) to rounding, repeat bit for bit, and
+    the counter must show the cut ran (every gate conv of the forward and of the recompute)."""
+    if precision != "bf16x3p":
+        pytest.skip("the LDS-DMA kernels exist in the S-plane mode only")
+    from constant_memory_waveglow_amd import _lib
+    from constant_memory_waveglow_amd.parallel import FlowTrainer
+    torch.manual_seed(0)
+    m = cm.WSRGlow(upsample_rate=2, memory_efficient=True, bias=False)
+    with torch.no_grad():
+        for blk in m.WNs:
+            blk.F.end.weight.normal_(0.0, 0.02)
+    m = m.to(dev)
+    B, N = 12, 8192
+    x = T(fill.uniform("wsrfull/x", (B, N), -1.0, 1.0), dev)
+    c = T(fill.uniform("wsrfull/c", (B, N // 2), -0.95, 0.95), dev)
+    tr = FlowTrainer(m, 1.0)
+    res = {}
+    for cut in ("1", "0"):
+        monkeypatch.setenv("WG_G192_SPLITK", cut)
+        before = _lib.lib().wg_stat_gate_split_launches()
+        runs = []
+        for rep in range(2):
+            loss, z, logdet = tr.step(x, c.clone())
+            runs.append((loss.clone(), z.clone(), logdet.clone(), tr.fg.flat.clone()))
+        torch.cuda.synchronize()
+        n = _lib.lib().wg_stat_gate_split_launches() - before
+        flows, layers = len(m.WNs), 8
+        assert n == (2 * (2 * flows - 1) * layers if cut == "1" else 0), n
+        for a, b in zip(runs[0][:3], runs[1][:3]):
+            assert torch.equal(a, b)
+        # (the two embedding tables' gradients go through LDS float atomics: equal to rounding; everything else repeats exactly)
+        assert float((runs[0][3] - runs[1][3]).abs().max()) <= 1e-5 * float(runs[0][3].abs().max())
+        res[cut] = runs[0]
+    (l1, z1, d1, g1), (l0, z0, d0, g0) = res["1"], res["0"]
+    assert abs(float(l1) - float(l0)) < 1e-6 and float((z1 - z0).abs().max()) < 2e-5
+    assert float((d1 - d0).abs().max()) <= 1e-6 * float(d0.abs().max()) + 1e-3
+    assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max())
+
+
 def test_waveflow_shipped_width_vs_oracle(dev, precision):
     """The shipped WaveFlow width (8 flows, 64 rows, 80 mels, 64 channels: one 128-row tile, K = 9*64 + 96) on a short segment."""
     from oracle import wf_oracle as wfo
