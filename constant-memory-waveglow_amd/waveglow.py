@@ -107,12 +107,43 @@ class WN(nn.Module):
         return self._table(self)
 
     def forward(self, x, y):
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            warnings.warn("WN.forward on its own runs without autograd; gradients flow through AffineCouplingBlock", stacklevel=2)
+        """(log_s, t) = WN(x, y) as waveglow.py:98-105 -- an ordinary differentiable module upstream, and here: called on its own with
+        autograd on, the call is a node whose backward is the coupling block's (wg_coupling_backward seeded with the gradients of
+        log_s and t, see _WNFn)."""
         if self._engine is None:
             from ._lib import WgWnDims, default_precision
             self._engine = engine.CouplingEngine(WgWnDims(*self.hip_dims(), default_precision(), int(self.has_bias)))
+        if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return _WNFn.apply(x, y, self, *self.parameters())
         return self._engine.wn([None if t is None else t.detach() for t in self.param_table()], x.detach(), y.detach())
+
+
+class _WNFn(Function):
+    """WN.forward on its own as an autograd node.  The backward is the coupling block's, unchanged: for z = cat(x, t) the block's
+    `x_b = (z_b - t) / exp(log_s)` is exactly zero (the recompute gives the same t), so the seeds efficient_modules.py:143-144 forms,
+    `d log_s = dz_b * x_b * exp(log_s) + dlog_s` and `d t = dz_b`, are the gradients handed in here when dz = cat(0, dt) and dlog_s is
+    the gradient of log_s; rows [0, ic) of the block's dx are the gradient of x."""
+
+    @staticmethod
+    def forward(ctx, x, y, wn, *weights):
+        table = wn.param_table()
+        log_s, t = wn._engine.wn([None if p is None else p.detach() for p in table], x.detach(), y.detach())
+        ctx.wn = wn
+        ctx.save_for_backward(x, y, t)
+        return log_s, t
+
+    @staticmethod
+    def backward(ctx, dlog_s, dt):
+        x, y, t = ctx.saved_tensors
+        wn = ctx.wn
+        table = wn.param_table()
+        need = [p is not None and p.requires_grad for p in table]
+        z = torch.cat((x.detach(), t), 1)
+        dz = torch.cat((torch.zeros_like(dt), dt), 1)
+        dx, dy, grads = wn._engine.backward([None if p is None else p.detach() for p in table], z, y.detach(), dz, dlog_s, False, need,
+                                            ctx.needs_input_grad[1], torch.empty_like(z))
+        by_id = {id(p): g for p, g in zip(table, grads) if p is not None}
+        return (dx[:, :x.size(1)] if ctx.needs_input_grad[0] else None, dy, None) + tuple(by_id.get(id(p)) for p in wn.parameters())
 
 
 class _WaveGlowFn(Function):

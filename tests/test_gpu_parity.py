@@ -5,6 +5,7 @@ Tolerances (BASELINE.json north_star: 1e-4 fp32):  z / x abs 1e-4;  loss 1e-6;  
 the reference's own fp32 logdet sits ~1e-4 from fp64);  every parameter gradient within 1e-4 of
 that tensor's max-abs.  Block-level tolerances follow the reference's tests/test_fwd_bwd.py."""
 import os
+import warnings
 
 import numpy as np
 import pytest
@@ -584,6 +585,48 @@ def test_coupling_block_with_bias_vs_torch_cpu(dev, rev):
         assert relmax(npy(named[n].grad), ref.grad.numpy()) < GRAD_RTOL, n
     ls_raw, t_raw = blk.F(T(x[:, :ic].copy(), dev), T(y, dev))                                  # WN.forward on its own (wg_wn_apply)
     assert np.abs(npy(ls_raw) - log_s.detach().numpy()).max() < 1e-5 and np.abs(npy(t_raw) - t.detach().numpy()).max() < 1e-5
+
+
+@pytest.mark.parametrize("bias", [False, True])
+def test_wn_on_its_own_is_differentiable_vs_torch_cpu(dev, precision, bias):
+    """WN is an ordinary differentiable module upstream (model/waveglow.py:49-105): `log_s, t = wn(x, y)` followed by any loss must give
+    gradients for x, y and every parameter.  Here the call is an autograd node (waveglow._WNFn) whose backward is wg_coupling_backward
+    seeded with (d log_s, d t); checked against plain torch autograd on the CPU over oracle/torch_cpu.py's WN."""
+    from oracle import torch_cpu
+    ic, aux, C, depth, B, Tn = 4, 20, 64, 4, 2, 333
+    specs = fill.wn_param_specs("", ic, aux, C, C, C, depth, 3, bias=bias)
+    tag = "wnalone/grad%d" % bias
+    P = fill.fill_params(specs, tag + "/")
+    x = fill.uniform(tag + "/x", (B, ic, Tn))
+    y = fill.normal(tag + "/y", (B, aux, Tn))
+    gls, gt = fill.normal(tag + "/gls", (B, ic, Tn)), fill.normal(tag + "/gt", (B, ic, Tn))
+    pt = [torch.from_numpy(P[n]).requires_grad_(True) for n, _, _ in specs]
+    xr, yr = torch.from_numpy(x).requires_grad_(True), torch.from_numpy(y).requires_grad_(True)
+    ls_r, t_r = torch_cpu._wn_forward(pt, xr, yr, depth, C, 3)
+    # a loss that is not linear in the outputs, so that the gradients handed to the node depend on them
+    ((ls_r * torch.from_numpy(gls)).sum() + (t_r * t_r * torch.from_numpy(gt)).sum()).backward()
+    wn = cm.WN(ic, aux, C, C, C, depth=depth, zero_init=False, bias=bias)
+    wn.load_state_dict({n: torch.from_numpy(v) for n, v in P.items()})
+    wn = wn.to(dev)
+    xt, yt = T(x, dev).requires_grad_(True), T(y, dev).requires_grad_(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                                          # (the "runs without autograd" warning is gone)
+        ls, t = wn(xt, yt)
+    assert ls.requires_grad and t.requires_grad
+    ((ls * T(gls, dev)).sum() + (t * t * T(gt, dev)).sum()).backward()
+    assert np.abs(npy(ls) - ls_r.detach().numpy()).max() < 1e-5 and np.abs(npy(t) - t_r.detach().numpy()).max() < 1e-5
+    assert relmax(npy(xt.grad), xr.grad.numpy()) < GRAD_RTOL and relmax(npy(yt.grad), yr.grad.numpy()) < GRAD_RTOL
+    named = dict(wn.named_parameters())
+    for (n, _, _), ref in zip(specs, pt):
+        assert relmax(npy(named[n].grad), ref.grad.numpy()) < GRAD_RTOL, n
+    # only t used, x not requiring a gradient: still a node (the parameters need theirs), and no gradient comes back for x
+    wn.zero_grad()
+    ls2, t2 = wn(T(x, dev), T(y, dev))
+    t2.sum().backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in wn.parameters())
+    with torch.no_grad():
+        ls3, t3 = wn(T(x, dev), T(y, dev))
+    assert not ls3.requires_grad and torch.equal(ls3, ls2) and torch.equal(t3, t2)
 
 
 def test_coupling_block_on_shared_b_tiles_vs_oracle(dev, precision):
