@@ -23,6 +23,7 @@ ABI_SYMBOLS = [
     "wg_timer_create", "wg_timer_attach", "wg_timer_count", "wg_timer_read", "wg_timer_read_info", "wg_timer_destroy", "wg_stat_wgrad16t_launches",
     "wg_stat_layer_launches", "wg_layer_workspace_bytes", "wg_layer_apply", "wg_wf_wn_apply",
     "wg_timer_read_name", "wg_box_probe_bytes", "wg_box_probe", "wg_stat_layerg_launches", "wg_stat_gate_split_launches",
+    "wg_wf_wn_backward",
 ]
 K_CONV_STORE, K_CONV_GATE, K_CONV_RESSKIP, K_CONV_DGATE, K_WGRAD, K_LAYER = range(6)
 
@@ -127,6 +128,7 @@ def lib():
     L.wg_wf_forward.argtypes = [wfp, vp, vp, vp, vp, i, i, i, vp, vp, vp, vp, sz, vp]
     L.wg_wf_inverse.argtypes = [wfp, vp, vp, vp, vp, i, i, i, vp, vp, vp, sz, vp]
     L.wg_wf_wn_apply.argtypes = [wfp, vp, vp, vp, vp, i, i, i, vp, vp, vp, sz, vp]
+    L.wg_wf_wn_backward.argtypes = [wfp, vp, vp, vp, vp, vp, vp, i, i, i, vp, vp, vp, vp, sz, vp]
     L.wg_wf_backward.argtypes = [wfp, vp, vp, vp, vp, vp, vp, i, i, i, vp, vp, vp, vp, sz, vp]
     L.wg_melspec_frames.argtypes = [i, i, i]
     L.wg_melspec.argtypes = [vp, i, i, i, i, i, C.c_double, C.c_double, i, vp, vp, vp]

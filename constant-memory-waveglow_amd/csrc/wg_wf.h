@@ -486,6 +486,27 @@ __global__ __launch_bounds__(256) void wf_rowsum_s_kernel(SRef in, Geo g, SRef o
     *reinterpret_cast<u32x4 *>(out.hi + out.lo_off + o) = ol;
 }
 
+// WN2D's backward on its own (wg_wf_wn_backward): the gradients of the returned (log_s, t), plain [items][rows_in][T], into the seed plane G
+// (channel 0 = d log_s, channel 1 = d t; zero for the rows that produced no output) and a zero gradient plane for x -- no coupling here,
+// WN2D's start conv adds its part in wn_backward
+__global__ void wf_seed_kernel(const float *__restrict__ dls, const float *__restrict__ dt, PRef G, PRef dX, Geo g, int rows_in)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
+    if (t >= g.T) return;
+    const int b = row / g.rows, r = row - b * g.rows;
+    const size_t o = ((size_t)b * rows_in + r) * g.T + t;
+    *paddr(G, g, row, 0, t) = r < rows_in ? dls[o] : 0.f;
+    *paddr(G, g, row, 1, t) = r < rows_in ? dt[o] : 0.f;
+    *paddr(dX, g, row, 0, t) = 0.f;
+}
+__global__ void wf_rows_out_kernel(PRef X, Geo g, int rows_out, float *__restrict__ x)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
+    if (t >= g.T) return;
+    const int b = row / g.rows, r = row - b * g.rows;
+    if (r < rows_out) x[((size_t)b * rows_out + r) * g.T + t] = *paddr(X, g, row, 0, t);
+}
+
 // WN2D.forward on its own: x[items][rows_in][T] (plain) into the n_group-row planes; the rows below it are zero (the convs are causal along
 // the height axis: they cannot reach the rows above them)
 __global__ void wf_rows_in_kernel(const float *__restrict__ x, PRef X, Geo g, int rows_in)

@@ -3049,6 +3049,43 @@ int wg_wf_wn_apply(const wg_wf_config *cf, const void *const *params, const void
     return cx.err;
 }
 
+// What autograd computes upstream for `log_s, t = wn2d(x, y)` (waveflow.py:128-135, an ordinary differentiable module): the recompute of
+// wg_wf_wn_apply with the layers kept, the gradients of (log_s, t) as the seeds of the WN backward, then wn_backward as inside wg_wf_backward.
+int wg_wf_wn_backward(const wg_wf_config *cf, const void *const *params, const void *packed, const float *x, const float *y,
+                      const float *dlog_s, const float *dt, int B, int rows, int Wd, float *dx, float *dy, void *const *grads,
+                      void *wsv, size_t ws_bytes, void *stream)
+{
+    int rc = wf_check(cf);
+    if (rc) return rc;
+    if (!params || !params[3 + 36] || !packed || !x || !y || !dlog_s || !dt || !grads || !wsv || B < 1 || Wd < 1 || rows < 1 || rows > cf->n_group)
+        return WG_EINVAL;
+    const WfWs W = wf_ws_layout(cf, B, Wd, 1);
+    if (W.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
+    Ctx cx = {(hipStream_t)stream, 0, cf->precision};
+    const float *const *p = (const float *const *)params;
+    float *const *gr = (float *const *)grads;
+    const float *pk = (const float *)packed;
+    const WfPack L = wf_pack_layout(cf);
+    float *ws = (float *)wsv;
+    const Geo g = W.g;
+    const dim3 rgrid((g.T + 255) / 256, g.B);
+    layer_sync_clear(cx, ws, W.wn.lsync);
+    WG_LAUNCH(cx, wf_rows_in_kernel, rgrid, dim3(256), 0, x, pref(ws + W.X[0], 1), g, rows);
+    WG_LAUNCH(cx, import_kernel, dim3((Wd + 255) / 256, cf->n_mels, B), dim3(256), 0, y, pref(ws + W.Y, W.auxp), W.gi, cf->n_mels);
+    if (cx.prec == 2) run_to_splane(cx, W.gi, pref(ws + W.Y, W.auxp), cf->n_mels, ws + W.YS, W.auxp);
+    if (cx.err == 0 && hipMemsetAsync(ws + W.dYrow, 0, (size_t)B * W.auxp * W.gi.P * sizeof(float), cx.st) != hipSuccess) cx.err = WG_ELAUNCH;
+    WnRun r;
+    r.d = wf_wn(cf); r.L = wn_pack_layout(r.d); r.g = g; r.ws = ws; r.w = W.wn; r.Y = ws + W.Y; r.YS = ws + W.YS; r.save = 1;
+    r.gi = W.gi; r.rs = ws + W.rs; r.rs_step = W.rs_step;
+    r.pk = pk + L.wn[0]; r.X = pref(ws + W.X[0], 1);
+    wn_forward(cx, r);
+    WG_LAUNCH(cx, wf_seed_kernel, rgrid, dim3(256), 0, dlog_s, dt, pref(ws + W.wn.G, r.L.kp_end), pref(ws + W.dX[0], 1), g, rows);
+    wn_backward(cx, r, p + 3, gr + 3, pref(ws + W.dX[0], 1), ws + W.dYrow);
+    if (dx) WG_LAUNCH(cx, wf_rows_out_kernel, rgrid, dim3(256), 0, pref(ws + W.dX[0], 1), g, rows, dx);
+    if (dy) WG_LAUNCH(cx, export_kernel, dim3((Wd + 255) / 256, cf->n_mels, B), dim3(256), 0, pref(ws + W.dYrow, W.auxp), dy, W.gi, cf->n_mels, 1.0f);
+    return cx.err;
+}
+
 // WaveFlow.reverse_computation (waveflow.py:210-253): per flow (last first) flip, then one height row at a time -- WN2D on row r
 // from rows <= r (what reverse_mode_forward's ring buffers hold), x[r+1] = (z[r+1] - t[r]) / exp(log_s[r]).
 int wg_wf_inverse(const wg_wf_config *cf, const void *const *params, const void *packed, const float *z, const float *mel,

@@ -653,6 +653,22 @@ class WN2DEngine(WaveFlowEngine):
                                         ws.numel(), _stream()), "wg_wf_wn_apply")
         return log_s, t
 
+    @on_device
+    def backward(self, wn_params, x, y, dlog_s, dt, need, need_dx, need_dy):
+        """wg_wf_wn_backward: gradients of x / y (None where not needed) and of the WN2D parameters (`need`: per table entry)."""
+        require_device(x, y, dlog_s, dt, *wn_params)
+        x, y, dlog_s, dt = x.contiguous(), y.contiguous(), dlog_s.contiguous(), dt.contiguous()
+        B, one, rows, W = x.shape
+        params = self.table(wn_params, x.device)
+        pk = self._pack(params, x.device)
+        ws = self._ws(B, W * self.cfg.n_group, 1, x.device)
+        grads = [None, None, None] + [torch.empty_like(p) if (p is not None and nd) else None for p, nd in zip(wn_params, need)]
+        dx = torch.empty_like(x) if need_dx else None
+        dy = torch.empty_like(y) if need_dy else None
+        check(_lib.lib().wg_wf_wn_backward(C.byref(self.cfg), _table(params), _p(pk), _p(x), _p(y), _p(dlog_s), _p(dt), B, rows, W, _p(dx), _p(dy),
+                                           _table(grads), _p(ws), ws.numel(), _stream()), "wg_wf_wn_backward")
+        return dx, dy, grads[3:]
+
 
 # ---- log-mel conditioner (include/wgflow.h: wg_melspec) -------------------------------------------------------------------------
 @on_device

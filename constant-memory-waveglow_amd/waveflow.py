@@ -98,15 +98,40 @@ class WN2D(nn.Module):
         return tab
 
     def forward(self, x, y):
-        """x [B, 1, rows <= n_group, W], y [B, aux, W] -> (log_s, t), each [B, 1, rows, W] (waveflow.py:128-135).  Forward only: inside
-        WaveFlow the gradients flow through wg_wf_backward."""
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            warnings.warn("WN2D.forward on its own runs without autograd; gradients flow through WaveFlow", stacklevel=2)
+        """x [B, 1, rows <= n_group, W], y [B, aux, W] -> (log_s, t), each [B, 1, rows, W] (waveflow.py:128-135).  Differentiable like
+        the module upstream: with autograd on the call is a node whose backward is wg_wf_wn_backward (_WN2DFn); inside WaveFlow the
+        gradients flow through wg_wf_backward."""
         if getattr(self, "_engine", None) is None:
             self._engine = engine.WN2DEngine(WgWfConfig(1, self.n_group, self.aux_chs, self.res_chs, self.dil_chs, self.skp_chs,
                                                          default_precision(), 0, int(self.has_bias)))
+        if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return _WN2DFn.apply(x.float(), y.float(), self, *self.parameters())
         with torch.no_grad():
             return self._engine.apply([None if p is None else p.detach() for p in self.param_table()], x.float(), y.float())
+
+
+class _WN2DFn(Function):
+    """WN2D.forward on its own as an autograd node: forward = wg_wf_wn_apply, backward = wg_wf_wn_backward (the recompute with the
+    layers kept, then the WN backward seeded with the gradients of log_s and t)."""
+
+    @staticmethod
+    def forward(ctx, x, y, wn, *weights):
+        table = wn.param_table()
+        log_s, t = wn._engine.apply([None if p is None else p.detach() for p in table], x.detach(), y.detach())
+        ctx.wn = wn
+        ctx.save_for_backward(x, y)
+        return log_s, t
+
+    @staticmethod
+    def backward(ctx, dlog_s, dt):
+        x, y = ctx.saved_tensors
+        wn = ctx.wn
+        table = wn.param_table()
+        need = [p is not None and p.requires_grad for p in table]
+        dx, dy, grads = wn._engine.backward([None if p is None else p.detach() for p in table], x.detach(), y.detach(), dlog_s, dt, need,
+                                            ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        by_id = {id(p): g for p, g in zip(table, grads) if p is not None}
+        return (dx, dy, None) + tuple(by_id.get(id(p)) for p in wn.parameters())
 
 
 class _WaveFlowFn(Function):

@@ -82,7 +82,8 @@ const char *wg_strerror(int code);
  * use_conv1x1, wg_wf_upsample; 4: wg_timer_create(-1, ..) times every kernel class, wg_timer_read_info, wg_stat_wgrad16t_launches,
  * wg_wf_* accept every WG_PREC_*; 5: wg_config and wg_wn_dims gained bias; 6: wg_stat_layer_launches, the workspaces carry the one-launch
  * layer's hand-off counters, wg_layer_apply / wg_layer_workspace_bytes, wg_wf_wn_apply; 7: wg_wf_config gained bias; 8: wg_timer_read_name,
- * wg_box_probe / wg_box_probe_bytes, wg_stat_layerg_launches, wg_stat_gate_split_launches).  A binding built against another revision must not pass its
+ * wg_box_probe / wg_box_probe_bytes, wg_stat_layerg_launches, wg_stat_gate_split_launches,
+ * wg_wf_wn_backward).  A binding built against another revision must not pass its
  * structs: the Python loader compares this with its own ABI_VERSION and refuses the library otherwise. */
 #define WG_ABI_VERSION 8
 int wg_abi_version(void);
@@ -288,6 +289,13 @@ int wg_wf_inverse(const wg_wf_config *cfg, const void *const *params, const void
  * WN2D entries are this module's parameters (the three upsampler entries are packed but not read here). */
 int wg_wf_wn_apply(const wg_wf_config *cfg, const void *const *params, const void *packed, const float *x, const float *y, int B, int rows, int W,
                    float *log_s, float *t, void *ws, size_t ws_bytes, void *stream);
+/* What autograd computes upstream for that call (WN2D is an ordinary differentiable module, waveflow.py:94-135): from the gradients of
+ * log_s and t, each [B,1,rows,W], the gradient of x (nullable, [B,1,rows,W]), of y (nullable, [B,n_mels,W]) and of every WN2D parameter
+ * (`grads`: the table layout of `params`, null entries skipped; the three upsampler entries are not touched).  Workspace:
+ * wg_wf_workspace_bytes(cfg, B, W * n_group, 1). */
+int wg_wf_wn_backward(const wg_wf_config *cfg, const void *const *params, const void *packed, const float *x, const float *y,
+                      const float *dlog_s, const float *dt, int B, int rows, int W, float *dx, float *dy, void *const *grads,
+                      void *ws, size_t ws_bytes, void *stream);
 /* What autograd computes upstream for z, logdet = model(x, mel) (the reference trains this model with memory_efficient=False):
  * every parameter gradient (table order), d mel (nullable), d audio (nullable), from the tape wg_wf_forward wrote. */
 int wg_wf_backward(const wg_wf_config *cfg, const void *const *params, const void *packed, const void *tape, const float *mel,

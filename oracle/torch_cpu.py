@@ -77,9 +77,16 @@ def noncausal_layer(Wg, Wv, Og, Ov, x, y, dilation, last_layer):
 def wn2d_forward(params, n_group, x, y):
     """WN2D.forward on its own (model/waveflow.py:70-135, layers :41-51): 3x3 convs dilated (h_dilation, 2^i), causal along the height axis
     (top padding only), the conditioning projection broadcast over the height axis.  params: [Vg, Vv, Sg, Sv, (Wg, Wv, Og, Ov) * 8, End] (+ the 19 biases, WN2D(bias=True))."""
-    hds = {8: [1] * 8, 16: [1] * 8, 32: [1, 2, 4] * 2 + [1, 2], 64: [1, 2, 4, 8, 16, 1, 2, 4], 128: [1, 2, 4, 8, 16, 32, 64, 1]}[n_group]
     p = [None if a is None else torch.from_numpy(np.ascontiguousarray(a, np.float32)) for a in params]
     xt, yt = torch.from_numpy(np.ascontiguousarray(x, np.float32)), torch.from_numpy(np.ascontiguousarray(y, np.float32))
+    with torch.no_grad():
+        ls, t = wn2d_forward_t(p, n_group, xt, yt)
+    return ls.numpy(), t.numpy()
+
+
+def wn2d_forward_t(p, n_group, xt, yt):
+    """wn2d_forward on torch tensors (differentiable: the checker of WN2D's gradients when the module is called on its own)."""
+    hds = {8: [1] * 8, 16: [1] * 8, 32: [1, 2, 4] * 2 + [1, 2], 64: [1, 2, 4, 8, 16, 1, 2, 4], 128: [1, 2, 4, 8, 16, 32, 64, 1]}[n_group]
     b = p[37:] if len(p) > 37 else [None] * 19          # bias=True: V.bias, start.bias, (W.bias, W_o.bias) x 8, end.bias behind end.weight
     h = Fn.conv2d(xt, _wn(p[2], p[3]), b[1])
     v = Fn.conv1d(yt, _wn(p[0], p[1]), b[0]).unsqueeze(2)
@@ -98,7 +105,7 @@ def wn2d_forward(params, n_group, x, y):
             sk = o
         skip = sk if skip is None else skip + sk
     out = Fn.conv2d(skip, p[36], b[18])
-    return out[:, :1].numpy(), out[:, 1:].numpy()
+    return out[:, :1], out[:, 1:]
 
 
 def set_threads(n):

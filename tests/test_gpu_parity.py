@@ -1448,6 +1448,51 @@ def test_wn2d_alone_vs_reference_golden(dev, golden_dir, precision, cname):
     assert np.abs(npy(ls) - gold[cname + "/log_s"]).max() < Z_ATOL and np.abs(npy(t) - gold[cname + "/t"]).max() < Z_ATOL
 
 
+@pytest.mark.parametrize("cname", ["wf8", "wf64_short", "wf8b"])
+def test_wn2d_on_its_own_is_differentiable_vs_reference_golden(dev, golden_dir, precision, cname):
+    """WN2D is an ordinary differentiable module upstream (model/waveflow.py:70-135): `log_s, t = wn2d(x, y)` followed by any loss gives
+    gradients for x, y and every parameter.  Here the call is an autograd node (waveflow._WN2DFn) whose backward is wg_wf_wn_backward;
+    checked against what the reference's own autograd gave (block_wn2d.npz: d x, d y in full, norm / head of every parameter gradient)
+    and, in full, against autograd over oracle/torch_cpu.py's restatement."""
+    from make_golden import wn2d_inputs, wn2d_seeds
+    from oracle import torch_cpu
+    cfg, P, x, y = wn2d_inputs(cname)
+    gold = np.load(os.path.join(golden_dir, "block_wn2d.npz"))
+    gls, gt = wn2d_seeds(cname, x.shape)
+    m = cm.waveflow.WN2D(cfg["n_group"], cfg["n_mels"], dilation_channels=cfg["dilation_channels"], residual_channels=cfg["residual_channels"],
+                         skip_channels=cfg["skip_channels"], bias=bool(cfg.get("bias")), zero_init=False)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    m = m.to(dev)
+    xt, yt = T(x, dev).requires_grad_(True), T(y, dev).requires_grad_(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        ls, t = m(xt, yt)
+    assert ls.requires_grad and t.requires_grad
+    ((ls * T(gls, dev)).sum() + (t * t * T(gt, dev)).sum()).backward()
+    assert np.abs(npy(ls) - gold[cname + "/log_s"]).max() < Z_ATOL and np.abs(npy(t) - gold[cname + "/t"]).max() < Z_ATOL
+    assert relmax(npy(xt.grad), gold[cname + "/dx"]) < GRAD_RTOL and relmax(npy(yt.grad), gold[cname + "/dy"]) < GRAD_RTOL
+    order = [n for n, _ in m.named_parameters()]
+    tab = m.param_table()
+    pt = [None if p is None else p.detach().cpu().clone().requires_grad_(True) for p in tab]
+    xr, yr = torch.from_numpy(x).requires_grad_(True), torch.from_numpy(y).requires_grad_(True)
+    ls_r, t_r = torch_cpu.wn2d_forward_t(pt, cfg["n_group"], xr, yr)
+    ((ls_r * torch.from_numpy(gls)).sum() + (t_r * t_r * torch.from_numpy(gt)).sum()).backward()
+    names = list(P)
+    named = dict(m.named_parameters())
+    by_id = {id(p): n for n, p in named.items()}
+    for p, q in zip(tab, pt):
+        n = by_id[id(p)]
+        g = npy(p.grad)
+        i = names.index(n)
+        if n == "start.weight_v":                              # Conv2d(1, C, 1) under weight norm: exactly zero; rounding noise on every side
+            assert np.abs(g).max() < 1e-5 * np.abs(npy(named["start.weight_g"].grad)).max(), n
+            continue
+        assert relmax(g, q.grad.numpy()) < GRAD_RTOL, n
+        nh = min(g.size, gold[cname + "/grad_head"].shape[1])
+        assert np.abs(g.ravel()[:nh] - gold[cname + "/grad_head"][i][:nh]).max() / max(float(gold[cname + "/grad_max"][i]), 1e-30) < GRAD_RTOL, n
+    assert len(order) == len(names)
+
+
 def test_waveflow_chip_filling_shape_vs_oracle(dev, precision):
     """The shipped WaveFlow width at a size that FILLS the chip -- batch 4 x 16000 samples = 256 plane rows x 250 columns -- against the
     C oracle: the launches the small fixtures never reach: 64-row tiles for the 64-row products (convgemm16q_kernel<.., M64>: the

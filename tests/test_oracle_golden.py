@@ -444,4 +444,25 @@ def test_wn2d_restatement_vs_reference_golden(golden_dir, cname):
         order += ["V.bias", "start.bias"] + [n for i in range(8) for n in ("layers.%d.W.bias" % i, "layers.%d.W_o.bias" % i)] + ["end.bias"]
     ls, t = torch_cpu.wn2d_forward([P[k] for k in order], cfg["n_group"], x, y)
     assert np.abs(ls - gold[cname + "/log_s"]).max() < 5e-6 and np.abs(t - gold[cname + "/t"]).max() < 5e-6
+    # ... and its gradients (autograd over the restatement) against what the reference's autograd gave for the same scalar
+    from make_golden import wn2d_seeds
+    import torch
+    gls, gt = wn2d_seeds(cname, x.shape)
+    pt = [torch.from_numpy(P[k]).requires_grad_(True) for k in order]
+    xt, yt = torch.from_numpy(x).requires_grad_(True), torch.from_numpy(y).requires_grad_(True)
+    lst, tt = torch_cpu.wn2d_forward_t(pt, cfg["n_group"], xt, yt)
+    ((lst * torch.from_numpy(gls)).sum() + (tt * tt * torch.from_numpy(gt)).sum()).backward()
+    assert np.abs(xt.grad.numpy() - gold[cname + "/dx"]).max() <= 1e-5 * np.abs(gold[cname + "/dx"]).max()
+    assert np.abs(yt.grad.numpy() - gold[cname + "/dy"]).max() <= 1e-5 * np.abs(gold[cname + "/dy"]).max()
+    names = list(P)                                            # the fixture's gradient rows follow the state-dict order of the inputs
+    for k, q in zip(order, pt):
+        i = names.index(k)
+        g = q.grad.numpy().ravel()
+        scale = max(float(gold[cname + "/grad_max"][i]), 1e-30)
+        if k == "start.weight_v":
+            assert np.abs(g).max() < 1e-5 * float(gold[cname + "/grad_max"][names.index("start.weight_g")])   # exact zero, rounding noise
+            continue
+        nh = min(g.size, 8)
+        assert np.abs(g[:nh] - gold[cname + "/grad_head"][i][:nh]).max() / scale < 1e-5, k
+        assert abs(float(np.sqrt((g.astype(np.float64) ** 2).sum())) - float(gold[cname + "/grad_norm"][i])) <= 1e-5 * float(gold[cname + "/grad_norm"][i]), k
 
