@@ -63,7 +63,7 @@ def build_model(dev, seed=0):
 
 
 EPI_NUM = {"EPI_STORE": 0, "EPI_GATE": 1, "EPI_RESSKIP": 2, "EPI_DGATE": 3, "EPI_STORE_SO": 4, "EPI_GATE_SO": 5, "EPI_DGATE_SO": 6,
-           "EPI_STORE_FO": 7}               # csrc/wg_gemm.h
+           "EPI_STORE_FO": 7, "WGG_EPI_PART": 8}               # csrc/wg_gemm.h, csrc/wg_gemm16g.h
 
 
 def launch_site_to_rocprof(expr):
@@ -102,6 +102,19 @@ def _traffic(kernel_prefix, prefix=""):
             if bare.startswith(kernel_prefix) and bare[len(kernel_prefix):len(kernel_prefix) + 1] in ("", ",", ">", "("):
                 best = (row["hbm_bytes_per_launch"], os.path.relpath(f, ROOT), bare)
     return best
+
+
+def site_traffic(site, prefix=""):
+    """_traffic for a launch site as the library names it.  A class entry that covers two launches is named "A + B" (the gate conv cut
+    along K: partial products + the kernel that sums them and applies the gate): the bytes of both, and both names; (None, None, None)
+    unless every part is in ONE summary."""
+    parts = [launch_site_to_rocprof(p) for p in site.split(" + ") if p.strip()]
+    if not parts:
+        return None, None, None
+    got = [_traffic(p, prefix) for p in parts]
+    if any(g[0] is None for g in got) or len({g[1] for g in got}) != 1:
+        return None, None, None
+    return sum(g[0] for g in got), got[0][1], " + ".join(g[2] for g in got)
 
 
 def box_probe(dev, ms=500):
@@ -787,8 +800,8 @@ def main(argv=None):
         peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
         # the instantiation most of the timed launches ran (a model may take more than one: small flows, other tile forms)
         site = max(names, key=names.get) if names else ""
-        kprefix = launch_site_to_rocprof(site)
-        traffic, traffic_src, kfull = _traffic(kprefix, wl["profile_prefix"]) if kprefix else (None, None, None)
+        kprefix = " + ".join(launch_site_to_rocprof(p) for p in site.split(" + ")) if site else ""
+        traffic, traffic_src, kfull = site_traffic(site, wl["profile_prefix"]) if site else (None, None, None)
         if traffic_src:
             traffic_src += " (committed rocprofv3 --pmc summary of this command; not re-measured in this run)"
         gate_alone = None
@@ -810,7 +823,7 @@ def main(argv=None):
             "dtype": "f32 (contractions as split bf16x3 MFMA, fp32 accumulate)" if split else "f32", "data": "synthetic",
             "config": {"workload": wl["workload"] + (" + RCCL grad all-reduce" if world > 1 else ""),
                        "global_batch": B * world, "segment": SEGW, "parallelism": "dp%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "%s (EPI_GATE: %s)" % (kfull or (kprefix + ">" if "<" in kprefix else kprefix), what),
+            "roofline": {"bound": "mfma", "kernel": "%s (EPI_GATE: %s)" % (kfull or " + ".join(p + ">" if "<" in p else p for p in kprefix.split(" + ")), what),
                          "kernel_launch_sites": names,
                          "class_ms_timed": {"gate conv on its own": per_class[_lib.K_CONV_GATE], "layer launch": per_class[_lib.K_LAYER]},
                          **({"gate_conv_alone": gate_alone} if gate_alone else {}),

@@ -1099,6 +1099,7 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                     ap.c.out0 = a.out0;
                     WG_LAUNCH(cx, gate_finish16g_kernel, dim3(nt * 6), dim3(512), 0, ap, (const float *)cx.gslab, S);
                     g_gate_split_launches.fetch_add(1, std::memory_order_relaxed);
+                    g_last_launch = "convgemm16g_kernel<WGG_EPI_PART> + gate_finish16g_kernel";      // (one timed class entry covers both)
                     return;
                 }
             }

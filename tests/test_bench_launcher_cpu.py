@@ -108,7 +108,9 @@ def test_launch_site_names_match_rocprof_names_by_prefix(tmp_path, monkeypatch):
         "void convgemm16g_kernel<5>(ConvGemm16sArgs)": {"hbm_bytes_per_launch": 1.9e8},
         "convlayer16g_kernel": {"hbm_bytes_per_launch": 4.1e8}}}))
     (prof / "r09a_wsr_hbm_traffic.json").write_text(json.dumps({"kernels": {
-        "void convgemm16q_kernel<5, 1, 1, false, false>(ConvGemm16sArgs)": {"hbm_bytes_per_launch": 3.0e8}}}))
+        "void convgemm16q_kernel<5, 1, 1, false, false>(ConvGemm16sArgs)": {"hbm_bytes_per_launch": 3.0e8},
+        "void convgemm16g_kernel<8>(ConvGemm16sArgs)": {"hbm_bytes_per_launch": 1.0e8},
+        "gate_finish16g_kernel": {"hbm_bytes_per_launch": 0.5e8}}}))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     t, src, full = bench._traffic("convgemm16q_kernel<5, 2, 2")
     assert t == 2.0e8 and src.endswith("r09a_hbm_traffic.json") and full.startswith("convgemm16q_kernel<5, 2, 2, false, false>")
@@ -117,3 +119,9 @@ def test_launch_site_names_match_rocprof_names_by_prefix(tmp_path, monkeypatch):
     assert bench._traffic("convlayer16g_kernel")[0] == 4.1e8                # (no template arguments: the whole name)
     assert bench._traffic("convgemm16q_kernel<1, 2, 2")[0] is None        # (a kernel no committed summary holds: nothing is cited)
     assert bench._traffic("convgemm16q_kernel<5, 1, 1", "_wsr_")[0] == 3.0e8
+    # one timed class entry that covers two launches (the gate conv cut along K and the kernel that finishes it): both names, both bytes
+    t, src, full = bench.site_traffic("convgemm16g_kernel<WGG_EPI_PART> + gate_finish16g_kernel", "_wsr_")
+    assert t == 1.5e8 and src.endswith("r09a_wsr_hbm_traffic.json")
+    assert full == "convgemm16g_kernel<8>(ConvGemm16sArgs) + gate_finish16g_kernel"
+    assert bench.site_traffic("convgemm16g_kernel<WGG_EPI_PART> + gate_finish16g_kernel")[0] is None      # (the WaveGlow summary holds neither)
+    assert bench.site_traffic("convlayer16g_kernel")[0] == 4.1e8
