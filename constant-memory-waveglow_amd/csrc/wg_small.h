@@ -1001,8 +1001,17 @@ __global__ __launch_bounds__(256) void layer_pack_kernel(const LayerPackArgs a)
             a.dst[(size_t)(tap * a.C + c) * a.ld + m] = vr[e] * scale;
         }
         if (tid == 0) a.dst[(size_t)(a.radix * a.C + row) * a.ld + m] = 1.0f;
-    } else {
+    } else if (a.kind == 1) {
         for (int e = tid; e < a.fan; e += 256) a.dst[(size_t)e * a.ld + row] = vr[e] * scale;
+    } else if (a.kind == 2) {
+        // the dilated conv's weight for its data gradient (wg_layer_backward): K = (tap, output row of the conv), M = input channel
+        for (int e = tid; e < a.fan; e += 256) {              // v[row][c][tap]
+            const int c = e / a.radix, tap = e - c * a.radix;
+            a.dst[(size_t)(tap * a.rows + row) * a.ld + c] = vr[e] * scale;
+        }
+    } else {
+        // W_o for the gate's gradient: K = W_o's output row, M = dilation channel -- the weight as it is, normalised
+        for (int e = tid; e < a.fan; e += 256) a.dst[(size_t)row * a.ld + e] = vr[e] * scale;
     }
 }
 // x[items][C][H][T] (the layout of a Conv2d activation) <-> planes with one plane row per (item, height row)

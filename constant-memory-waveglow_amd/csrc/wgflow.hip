@@ -3615,6 +3615,140 @@ int wg_layer_apply(const wg_layer_dims *d, const void *const *params, const floa
     return cx.err;
 }
 
+// What autograd computes upstream for `res, skip = layer(x, y)` (waveglow.py:41-46 / waveflow.py:41-51; the classes are ordinary
+// differentiable modules): the forward again with tanh / sigmoid kept, then the four products of a WN layer's backward as wn_backward
+// runs them in the exact-fp32 mode (W_o's weight gradient, the gate backward, W's weight gradient, the data gradient), on matrices
+// normalised from (g, v) by this call.
+struct LayerBwdWs {
+    LayerWs f;
+    size_t tw, sf, dO, dxy, dXp, rs, WT, WoN, slab, slab_floats, total;
+    int ldT, ldN;
+};
+static LayerBwdWs layer_bwd_ws_layout(const wg_layer_dims *d, int B, int T)
+{
+    LayerBwdWs w;
+    w.f = layer_ws_layout(d, B, T);
+    Bump bp;
+    bp.off = w.f.total;
+    const Geo &g = w.f.g;
+    const size_t cols = (size_t)g.B * g.P;
+    w.tw = bp.take(cols * w.f.Dp); w.sf = bp.take(cols * w.f.Dp);
+    w.dO = bp.take(cols * w.f.R);
+    w.dxy = bp.take(cols * 2 * d->dil_ch);
+    w.dXp = bp.take(cols * w.f.Cp);
+    w.rs = bp.take((size_t)B * 2 * d->dil_ch * w.f.gi.P);
+    w.ldT = rup(d->res_ch, WG_TILE); w.ldN = rup(d->dil_ch, WG_TILE);
+    w.WT = bp.take((size_t)w.f.taps * 2 * d->dil_ch * w.ldT);
+    w.WoN = bp.take((size_t)w.f.R * w.ldN);
+    const int MpW = rup(rup(2 * d->dil_ch, 32), WG_TILE), NpW = rup(w.f.taps * rup(d->res_ch, 32), WG_TILE);
+    const int MpO = rup(rup(d->res_ch, 32) + rup(d->skip_ch, 32), WG_TILE), NpO = rup(rup(d->dil_ch, 32), WG_TILE);
+    w.slab_floats = std::max(slab_floats(g, MpW, NpW), slab_floats(g, MpO, NpO));
+    w.slab = bp.take(w.slab_floats);
+    w.total = bp.off + 1024;
+    return w;
+}
+size_t wg_layer_backward_workspace_bytes(const wg_layer_dims *d, int B, int T)
+{
+    if (layer_check(d) || B < 1 || T < 1) return 0;
+    return layer_bwd_ws_layout(d, B, T).total * sizeof(float);
+}
+int wg_layer_backward(const wg_layer_dims *d, const void *const *params, const float *x, const float *y, const float *dres, const float *dskip,
+                      int B, int T, float *dx, float *dy, void *const *grads, void *wsv, size_t ws_bytes, void *stream)
+{
+    int rc = layer_check(d);
+    if (rc) return rc;
+    if (!params || !params[1] || !params[3] || !x || !y || !dskip || !grads || !wsv || B < 1 || T < 1) return WG_EINVAL;
+    const LayerBwdWs Wb = layer_bwd_ws_layout(d, B, T);
+    const LayerWs &W = Wb.f;
+    if (Wb.total * sizeof(float) > ws_bytes) return WG_EWORKSPACE;
+    Ctx cx = {(hipStream_t)stream, 0, 0};
+    float *ws = (float *)wsv;
+    const Geo g = W.g;
+    const int C = d->res_ch, Cd = d->dil_ch, Cs = d->skip_ch, last = d->last_layer ? 1 : 0;
+    const bool two_d = d->rows > 0;
+    const float *const *p = (const float *const *)params;
+    float *const *gr = (float *const *)grads;
+    if (hipMemsetAsync(ws, 0, Wb.total * sizeof(float), cx.st) != hipSuccess) return WG_ELAUNCH;
+    // the four matrices: the forward's two, W per tap transposed, W_o as it is
+    LayerPackArgs pa;
+    pa.g = p[0]; pa.v = p[1]; pa.dst = ws + W.Acat; pa.rows = 2 * Cd; pa.fan = C * W.taps; pa.ld = W.ldA; pa.kind = 0; pa.C = C; pa.Cd = Cd; pa.radix = W.taps;
+    WG_LAUNCH(cx, layer_pack_kernel, dim3(pa.rows), dim3(256), 0, pa);
+    pa.dst = ws + Wb.WT; pa.ld = Wb.ldT; pa.kind = 2;
+    WG_LAUNCH(cx, layer_pack_kernel, dim3(pa.rows), dim3(256), 0, pa);
+    pa.g = p[2]; pa.v = p[3]; pa.dst = ws + W.WoT; pa.rows = W.R; pa.fan = Cd; pa.ld = W.ldO; pa.kind = 1;
+    WG_LAUNCH(cx, layer_pack_kernel, dim3(pa.rows), dim3(256), 0, pa);
+    pa.dst = ws + Wb.WoN; pa.ld = Wb.ldN; pa.kind = 3;
+    WG_LAUNCH(cx, layer_pack_kernel, dim3(pa.rows), dim3(256), 0, pa);
+    PRef X = pref(ws + W.X, W.Cp), Y = pref(ws + W.Y, W.Yp), dO = pref(ws + Wb.dO, W.R);
+    const dim3 gx((T + 255) / 256, C, two_d ? g.B : B), gs((T + 255) / 256, Cs, two_d ? g.B : B);
+    PRef dOs = dO;
+    dOs.ch0 = last ? 0 : C;                                     // do = last ? dskip : cat(dres, dskip)
+    if (two_d) {
+        WG_LAUNCH(cx, import2d_kernel, gx, dim3(256), 0, x, X, g, C);
+        if (!last && dres) WG_LAUNCH(cx, import2d_kernel, gx, dim3(256), 0, dres, dO, g, C);
+        WG_LAUNCH(cx, import2d_kernel, gs, dim3(256), 0, dskip, dOs, g, Cs);
+    } else {
+        WG_LAUNCH(cx, import_kernel, gx, dim3(256), 0, x, X, g, C);
+        if (!last && dres) WG_LAUNCH(cx, import_kernel, gx, dim3(256), 0, dres, dO, g, C);
+        WG_LAUNCH(cx, import_kernel, gs, dim3(256), 0, dskip, dOs, g, Cs);
+    }
+    WG_LAUNCH(cx, import_kernel, dim3((T + 255) / 256, 2 * Cd, B), dim3(256), 0, y, Y, W.gi, 2 * Cd);
+    // forward gate conv, tanh and sigmoid kept (waveglow.py:42-44)
+    const int half = (d->radix - 1) / 2;
+    int ts[WG_MAX_SEG], ro[WG_MAX_SEG];
+    if (two_d) {
+        for (int kh = 0; kh < d->radix; ++kh)
+            for (int kw = 0; kw < d->radix; ++kw) { ts[kh * d->radix + kw] = (kw - half) * d->dilation; ro[kh * d->radix + kw] = (kh - (d->radix - 1)) * d->h_dilation; }
+    } else {
+        for (int kt = 0; kt < d->radix; ++kt) { ts[kt] = (kt - half) * d->dilation; ro[kt] = 0; }
+    }
+    SegSpec sg[WG_MAX_SEG];
+    int ns = 0;
+    for (int k = 0; k < W.taps; ++k) sg[ns++] = {ws + W.X, W.Cp, 0, C, ts[k], nullptr, 0, 0, ro[k], 0};
+    sg[ns++] = {ws + W.Y, W.Yp, 0, 2 * Cd, 0, nullptr, 0, 0, 0, two_d ? 1 : 0};
+    run_convgemm(cx, g, ws + W.Acat, W.ldA, 2 * Cd, sg, ns, EPI_GATE, pref(ws + W.gate, W.Dp), pref(ws + Wb.tw, W.Dp), pref(ws + Wb.sf, W.Dp), pnull(), pnull(), 0, 0);
+    float *slab = ws + Wb.slab;
+    // dW_o = sum do (x) gate
+    {
+        WSegSpec sa = {ws + Wb.dO, W.R, 0, W.R, 0, nullptr, W.R, 0};
+        WSegSpec sb = {ws + W.gate, W.Dp, 0, Cd, 0, nullptr, W.Dp, 0};
+        WgradOut wo = run_wgrad(cx, g, &sa, 1, &sb, 1, slab, Wb.slab_floats);
+        run_finalize(cx, slab, wo, 0, W.R, Cd, 1, 0, 1, 0, p[2], p[2] ? p[3] : nullptr, p[2] ? gr[2] : nullptr, gr[3]);
+    }
+    // dgate = W_o^T do -> dxy (gate backward, waveglow.py:13-15)
+    {
+        SegSpec s = {ws + Wb.dO, W.R, 0, W.R, 0, nullptr, 0, 0};
+        run_convgemm(cx, g, ws + Wb.WoN, Wb.ldN, Cd, &s, 1, EPI_DGATE, pref(ws + Wb.dxy, 2 * Cd), pnull(), pnull(), pref(ws + Wb.tw, W.Dp),
+                     pref(ws + Wb.sf, W.Dp), Cd, 0);
+    }
+    // dW = sum dxy (x) x[tap]
+    {
+        WSegSpec sa = {ws + Wb.dxy, 2 * Cd, 0, 2 * Cd, 0, nullptr, 2 * Cd, 0};
+        WSegSpec sb[WG_MAX_SEG];
+        for (int k = 0; k < W.taps; ++k) sb[k] = {ws + W.X, W.Cp, 0, C, ts[k], nullptr, W.Cp, 0, ro[k], 0};
+        WgradOut wo = run_wgrad(cx, g, &sa, 1, sb, W.taps, slab, Wb.slab_floats);
+        run_finalize(cx, slab, wo, 0, 2 * Cd, C, W.taps, 0, 1, rup(C, 32), p[0], p[0] ? p[1] : nullptr, p[0] ? gr[0] : nullptr, gr[1]);
+    }
+    // dx = sum_k W[:, :, k]^T dxy[t - shift_k] (+ dres: res = o[:C] + x)
+    if (dx) {
+        SegSpec s[WG_MAX_SEG];
+        for (int k = 0; k < W.taps; ++k) s[k] = {ws + Wb.dxy, 2 * Cd, 0, 2 * Cd, -ts[k], nullptr, 0, 0, -ro[k], 0};
+        run_convgemm(cx, g, ws + Wb.WT, Wb.ldT, C, s, W.taps, EPI_STORE, pref(ws + Wb.dXp, W.Cp), pnull(), pnull(),
+                     (!last && dres) ? pref(ws + Wb.dO, W.R) : pnull(), pnull(), 0, 0);
+        if (two_d) WG_LAUNCH(cx, export2d_kernel, gx, dim3(256), 0, pref(ws + Wb.dXp, W.Cp), dx, g, C);
+        else WG_LAUNCH(cx, export_kernel, gx, dim3(256), 0, pref(ws + Wb.dXp, W.Cp), dx, g, C, 1.0f);
+    }
+    // dy = dxy (2-D: summed over the height axis the conditioning was broadcast over)
+    if (dy) {
+        if (two_d) {
+            WG_LAUNCH(cx, wf_rowsum_kernel, dim3((T + 255) / 256, 2 * Cd, B), dim3(256), 0, pref(ws + Wb.dxy, 2 * Cd), g, pref(ws + Wb.rs, 2 * Cd), W.gi, 2 * Cd);
+            WG_LAUNCH(cx, export_kernel, dim3((T + 255) / 256, 2 * Cd, B), dim3(256), 0, pref(ws + Wb.rs, 2 * Cd), dy, W.gi, 2 * Cd, 1.0f);
+        } else
+            WG_LAUNCH(cx, export_kernel, dim3((T + 255) / 256, 2 * Cd, B), dim3(256), 0, pref(ws + Wb.dxy, 2 * Cd), dy, g, 2 * Cd, 1.0f);
+    }
+    return cx.err;
+}
+
 int wg_coupling_backward(const wg_wn_dims *dd, const void *const *params, const void *packed, const float *z, const float *y,
                          const float *dz, const float *dlog_s, int B, int T, int reverse, float *x, float *dx, float *dy,
                          void *const *grads, void *wsv, size_t ws_bytes, void *stream)

@@ -432,6 +432,49 @@ def layer_apply(dims, params, x, y):
 
 
 @on_device
+def layer_backward(dims, params, x, y, dres, dskip, need, need_dx, need_dy):
+    """wg_layer_backward: (dx, dy, [dW.g, dW.v, dW_o.g, dW_o.v]) of NonCausalLayer / NonCausalLayer2D called on its own; None where not needed."""
+    require_device(x, y, dskip, *params)
+    x, y, dskip = x.contiguous(), y.contiguous(), dskip.contiguous()
+    dres = None if dres is None else dres.contiguous()
+    B, T = x.shape[0], x.shape[-1]
+    nbytes = _lib.lib().wg_layer_backward_workspace_bytes(C.byref(dims), B, T)
+    if nbytes == 0:
+        raise WgError("NonCausalLayer shape not supported by the HIP kernels")
+    ws = _LAYER_BUFFERS.get((x.device, "bwd", dims.res_ch, dims.dil_ch, dims.skip_ch, dims.radix, dims.dilation, dims.h_dilation, dims.rows, B, T), nbytes, x.device)
+    params = [None if p is None else p.contiguous() for p in params]
+    grads = [torch.empty_like(p) if (p is not None and nd) else None for p, nd in zip(params, need)]
+    dx = torch.empty_like(x) if need_dx else None
+    dy = torch.empty_like(y) if need_dy else None
+    check(_lib.lib().wg_layer_backward(C.byref(dims), _table(params), _p(x), _p(y), _p(dres), _p(dskip), B, T, _p(dx), _p(dy), _table(grads),
+                                       _p(ws), ws.numel(), _stream()), "wg_layer_backward")
+    return dx, dy, grads
+
+
+class LayerFn(torch.autograd.Function):
+    """NonCausalLayer / NonCausalLayer2D forward on its own as an autograd node: wg_layer_apply / wg_layer_backward."""
+
+    @staticmethod
+    def forward(ctx, x, y, dims, *params):
+        res, skip = layer_apply(dims, [None if p is None else p.detach() for p in params], x.detach(), y.detach())
+        ctx.dims, ctx.n = dims, len(params)
+        ctx.save_for_backward(x, y, *[p for p in params if p is not None])
+        ctx.present = [p is not None for p in params]
+        return (skip,) if res is None else (res, skip)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        x, y = ctx.saved_tensors[:2]
+        it = iter(ctx.saved_tensors[2:])
+        params = [next(it) if here else None for here in ctx.present]
+        dres, dskip = (None, douts[0]) if len(douts) == 1 else douts
+        need = [p is not None and ctx.needs_input_grad[3 + k] for k, p in enumerate(params)]
+        dx, dy, grads = layer_backward(ctx.dims, [None if p is None else p.detach() for p in params], x.detach(), y.detach(), dres, dskip, need,
+                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return (dx, dy, None) + tuple(grads)
+
+
+@on_device
 def invconv_apply(W, x, reverse):
     require_device(W, x)
     x = x.contiguous()

@@ -43,14 +43,15 @@ class NonCausalLayer2D(nn.Module):
         forward only)."""
         if self.W.bias is not None or self.W_o.bias is not None:
             raise WgError("NonCausalLayer2D(bias=True) is not built into the HIP kernels")
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            warnings.warn("NonCausalLayer2D.forward on its own runs without autograd; gradients flow through WaveFlow", stacklevel=2)
         from ._lib import WgLayerDims
         last = len(self.chs_split) == 1
         dims = WgLayerDims(self.W.in_channels, self.W.out_channels // 2, self.chs_split[-1], self.W.kernel_size[0], self.W.dilation[1], int(last),
                            self.W.dilation[0], x.shape[2])
         wg_, wv = conv_gv(self.W)
         og, ov = conv_gv(self.W_o)
+        if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad or any(p.requires_grad for p in self.parameters())):
+            out = engine.LayerFn.apply(x.float(), y.float(), dims, wg_, wv, og, ov)    # differentiable like the module upstream (wg_layer_backward)
+            return (None, out[0]) if last else out
         with torch.no_grad():
             return engine.layer_apply(dims, [wg_, wv, og, ov], x.float(), y.float())
 

@@ -83,7 +83,7 @@ const char *wg_strerror(int code);
  * wg_wf_* accept every WG_PREC_*; 5: wg_config and wg_wn_dims gained bias; 6: wg_stat_layer_launches, the workspaces carry the one-launch
  * layer's hand-off counters, wg_layer_apply / wg_layer_workspace_bytes, wg_wf_wn_apply; 7: wg_wf_config gained bias; 8: wg_timer_read_name,
  * wg_box_probe / wg_box_probe_bytes, wg_stat_layerg_launches, wg_stat_gate_split_launches,
- * wg_wf_wn_backward).  A binding built against another revision must not pass its
+ * wg_wf_wn_backward, wg_layer_backward / wg_layer_backward_workspace_bytes).  A binding built against another revision must not pass its
  * structs: the Python loader compares this with its own ABI_VERSION and refuses the library otherwise. */
 #define WG_ABI_VERSION 8
 int wg_abi_version(void);
@@ -220,6 +220,13 @@ typedef struct wg_layer_dims {
 size_t wg_layer_workspace_bytes(const wg_layer_dims *d, int B, int T);
 int wg_layer_apply(const wg_layer_dims *d, const void *const *params, const float *x, const float *y, int B, int T,
                    float *res, float *skip, void *ws, size_t ws_bytes, void *stream);
+/* What autograd computes upstream for that call (NonCausalLayer / NonCausalLayer2D are ordinary differentiable modules): from d res
+ * (NULL: none -- the last layer, or an output nobody used) and d skip, the gradient of x (nullable), of y (nullable; [B,2 Cd,T] -- for the
+ * 2-D layer summed over the height axis y was broadcast over) and of the four parameters (`grads`: the layout of `params`; entries of a
+ * plain weight's g and entries nobody needs are NULL).  Workspace: wg_layer_backward_workspace_bytes. */
+size_t wg_layer_backward_workspace_bytes(const wg_layer_dims *d, int B, int T);
+int wg_layer_backward(const wg_layer_dims *d, const void *const *params, const float *x, const float *y, const float *dres, const float *dskip,
+                      int B, int T, float *dx, float *dy, void *const *grads, void *ws, size_t ws_bytes, void *stream);
 /* AffineCouplingFunc.backward / InvAffineCouplingFunc.backward (efficient_modules.py:118-154, 175-212):
  * from the block OUTPUT z, y, dz, dlog_s: rebuilt input x, dx, dy (nullable), parameter grads. */
 int wg_coupling_backward(const wg_wn_dims *d, const void *const *params, const void *packed,

@@ -327,6 +327,67 @@ def test_noncausal_layer2d_alone_vs_reference_golden(dev, golden_dir, precision,
         assert np.abs(npy(res) - gold["2d_" + cname + "/res"]).max() < 2e-5
 
 
+def _layer_grads_vs_golden(m, wn, last, x, y, tag, key, gold, dev):
+    from make_golden import layer_seeds
+    xt, yt = T(x, dev).requires_grad_(True), T(y, dev).requires_grad_(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                                          # (no "runs without autograd" warning any more)
+        res, skip = m(xt, yt)
+    assert skip.requires_grad and (res is None) == bool(last)
+    gr, gs = layer_seeds(tag, x.shape, tuple(skip.shape))
+    sc = (skip * skip * T(gs, dev)).sum()
+    if res is not None:
+        sc = sc + (res * T(gr, dev)).sum()
+    sc.backward()
+    assert relmax(npy(xt.grad), gold[key + "/dx"]) < GRAD_RTOL and relmax(npy(yt.grad), gold[key + "/dy"]) < GRAD_RTOL
+    for n, q in m.named_parameters():
+        assert relmax(npy(q.grad), gold[key + "/grad::" + (n if wn else n + "_v")]) < GRAD_RTOL, n
+    # an output nobody uses (d res absent), an input that needs no gradient
+    m.zero_grad()
+    res2, skip2 = m(T(x, dev), T(y, dev))
+    skip2.sum().backward()
+    assert all(q.grad is not None and bool(torch.isfinite(q.grad).all()) for q in m.parameters())
+
+
+@pytest.mark.parametrize("cname", ["d4", "last", "r5d3"])
+def test_noncausal_layer_alone_is_differentiable_vs_reference_golden(dev, golden_dir, precision, cname):
+    """NonCausalLayer is an ordinary differentiable module upstream (model/waveglow.py:18-46): `res, skip = layer(x, y)` followed by any
+    loss gives gradients for x, y, W and W_o (g and v under weight norm).  Here the call is an autograd node (engine.LayerFn) whose
+    backward is wg_layer_backward; every gradient against what the reference's own autograd gave (block_layer.npz)."""
+    if precision != "f32":
+        pytest.skip("the stand-alone layer always runs the exact-fp32 kernels")
+    from make_golden import LAYER_CASES, layer_inputs
+    C, Cd, Cs, radix, dil, last, wn, B, Tn = LAYER_CASES[cname]
+    P, x, y = layer_inputs(cname)
+    gold = np.load(os.path.join(golden_dir, "block_layer.npz"))
+    m = cm.NonCausalLayer(dil, Cd, C, Cs, radix, False, last_layer=last)
+    if wn:
+        m.apply(cm.add_weight_norms)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    else:
+        m.load_state_dict({"W.weight": torch.from_numpy(P["W.weight_v"]), "W_o.weight": torch.from_numpy(P["W_o.weight_v"])})
+    _layer_grads_vs_golden(m.to(dev), wn, last, x, y, "layer/" + cname, cname, gold, dev)
+
+
+@pytest.mark.parametrize("cname", ["hd2d4", "last"])
+def test_noncausal_layer2d_alone_is_differentiable_vs_reference_golden(dev, golden_dir, precision, cname):
+    """The same for NonCausalLayer2D (model/waveflow.py:14-51): nine taps with plane-row offsets in the weight gradient and the data
+    gradient, d y summed over the height axis the conditioning was broadcast over."""
+    if precision != "f32":
+        pytest.skip("the stand-alone layer always runs the exact-fp32 kernels")
+    from make_golden import LAYER2D_CASES, layer2d_inputs
+    C, Cd, Cs, hd, dil, last, wn, B, H, W = LAYER2D_CASES[cname]
+    P, x, y = layer2d_inputs(cname)
+    gold = np.load(os.path.join(golden_dir, "block_layer.npz"))
+    m = cm.waveflow.NonCausalLayer2D(hd, dil, Cd, C, Cs, 3, False, last_layer=last)
+    if wn:
+        m.apply(cm.add_weight_norms)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    else:
+        m.load_state_dict({"W.weight": torch.from_numpy(P["W.weight_v"]), "W_o.weight": torch.from_numpy(P["W_o.weight_v"])})
+    _layer_grads_vs_golden(m.to(dev), wn, last, x, y, "layer2d/" + cname, "2d_" + cname, gold, dev)
+
+
 @pytest.mark.parametrize("name", ["micro", "c1", "c2"])
 def test_one_launch_layer_vs_two_launches(dev, precision, monkeypatch, name):
     """convlayer16h_kernel (wg_layer16h.h): one launch per WN layer -- gate conv -> gate -> W_o -> residual / skip, model/waveglow.py:41-46 --
