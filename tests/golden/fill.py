@@ -161,6 +161,10 @@ WSR_KW = dict(dilation_channels=32, residual_channels=32, skip_channels=32, dept
 CONFIGS["wsr"] = dict(flows=12, n_group=16, n_early_every=4, n_early_size=2, hop_size=16, n_mels=8 * 400 + 51 * 9, **WSR_KW)
 # WSRGlow(upsample_rate=3, **WSR_KW) (configs/wsrglow_vctk_3x.json): 24 squeezed channels -> 1x1 convs of 24, 22 and 20 channels
 CONFIGS["wsr3"] = dict(flows=12, n_group=24, n_early_every=4, n_early_size=2, hop_size=24, n_mels=8 * 400 + 51 * 9, **WSR_KW)
+# WSRGlow(upsample_rate=2) at the shipped width (configs/wsrglow_vctk_2x.json: WN defaults 256 / 256 / 256, depth 8; 229.7 M parameters) and
+# its batch (12 x 8192): the timed workload of `bench.py --model wsrglow`, kept as a SUMMARY fixture (model_wsr_full.npz)
+WSR_KW_FULL = dict(dilation_channels=256, residual_channels=256, skip_channels=256, depth=8, radix=3)
+CONFIGS["wsr_full"] = dict(flows=12, n_group=16, n_early_every=4, n_early_size=2, hop_size=16, n_mels=8 * 400 + 51 * 9, **WSR_KW_FULL)
 WSR_TABLES = [("mu_enc.1.weight", (256, 400)), ("angle_embed.embed.weight", (120, 50))]
 SHAPES = {  # (batch, samples, mel frames)
     "micro": (2, 512, 8),
@@ -172,7 +176,8 @@ SHAPES = {  # (batch, samples, mel frames)
     "wsr": (2, 1024, 64),        # conditioning signal: [2, 512] low-rate samples -> 64 frames
     "wsr3": (2, 24 * 37, 37),    # rate 3: [2, 296] low-rate samples -> 37 frames (not a multiple of anything the kernels tile by)
 }
-WSR_RATE = {"wsr": 2, "wsr3": 3}
+SHAPES["wsr_full"] = (12, 8192, 512)
+WSR_RATE = {"wsr": 2, "wsr3": 3, "wsr_full": 2}
 # MelSpec cases (batch, samples): the conditioner every WaveGlow / WaveFlow config ships (sr 22050, n_fft 1024, hop 256, f_max 8000, 80 mels)
 MEL_CASES = {"short": (2, 4096), "segment": (1, 16000)}
 MEL_KW = dict(sr=22050, n_fft=1024, hop_length=256, f_max=8000, n_mels=80)

@@ -19,7 +19,10 @@ def test_make_golden_main_regenerates_every_fixture(tmp_path):
     env = dict(os.environ, WG_GOLDEN_OUT=str(tmp_path))
     r = subprocess.run([sys.executable, os.path.join(GOLD, "make_golden.py")], env=env, cwd=str(tmp_path), capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
-    committed = sorted(glob.glob(os.path.join(GOLD, "*.npz")))
+    # (the summary fixtures of the TIMED workloads -- one CPU training step of the reference at a benchmarked size -- are regenerated on
+    # request only: `python make_golden.py c2_full wf_full wsr_full`; main() does not write them)
+    on_request = {"model_wsr_full.npz", "model_c2_full.npz", "model_wf_full.npz"}
+    committed = sorted(f for f in glob.glob(os.path.join(GOLD, "*.npz")) if os.path.basename(f) not in on_request)
     assert len(committed) == 24
     for f in committed:
         g = os.path.join(str(tmp_path), os.path.basename(f))

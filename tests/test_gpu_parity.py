@@ -54,6 +54,26 @@ def logdet_close(a, b, N):
     return bool(np.all(np.abs(a - b) <= 1e-4 * np.abs(b) + 1e-7 * N))
 
 
+def _check_summary(gold, m, specs, z, logdet, loss, N):
+    """A summary fixture of a TIMED workload (tests/golden/make_golden.py: _summary -- one step of the reference at a benchmarked size):
+    both ends and the per-item norm of z, logdet, loss, norm and head of every gradient."""
+    zz = npy(z)
+    assert np.abs(zz[:, :256] - gold["z_head"]).max() < Z_ATOL and np.abs(zz[:, -256:] - gold["z_tail"]).max() < Z_ATOL
+    zn = np.sqrt((zz.astype(np.float64) ** 2).sum(1))
+    assert np.all(np.abs(zn - gold["z_item_norm"]) <= 1e-5 * gold["z_item_norm"])
+    assert logdet_close(npy(logdet), gold["logdet"], N)
+    assert abs(float(loss) - float(gold["loss"])) < LOSS_ATOL
+    named = dict(m.named_parameters())
+    for i, (n, _, _) in enumerate(specs):
+        if n.endswith("start.weight_v") and named[n].dim() == 4:
+            continue                                             # WN2D's Conv2d(1, C, 1) under weight norm: exactly zero, rounding noise
+        g = npy(named[n].grad)
+        nh = min(g.size, gold["grad_head"].shape[1])
+        assert np.abs(g.ravel()[:nh] - gold["grad_head"][i][:nh]).max() / max(float(gold["grad_max"][i]), 1e-30) < GRAD_RTOL, n
+        gn = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        assert abs(gn - float(gold["grad_norm"][i])) <= 1e-4 * float(gold["grad_norm"][i]) + 1e-12, n
+
+
 def build(name, dev, mem_eff=True, reverse_mode=False):
     cfg = fill.CONFIGS[name]
     specs = fill.model_param_specs(cfg)
@@ -492,6 +512,9 @@ def test_c2_full_batch_vs_oracle(dev, precision):
     ref = torch_cpu.train_step_parallel(cfg, fill.table(specs, P), audio, h, fill.SIGMA, workers=workers, threads=max(1, min(8, cores // workers)),
                                         need_dh=True, double=True)
     x, ht = T(audio, dev), T(h, dev)
+    # (model_c2_full.npz: one training step of the REFERENCE at this size on the CPU -- fp32, so looser than the float64 oracle, but the
+    # reference itself: a summary of z, logdet, loss, every gradient's norm / head, dh; tests/golden/make_golden.py c2_full)
+    gold_ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_c2_full.npz"))
     # both benchmarked forms of the step against the ONE oracle run: the constant-memory config (the headline) and the same network with
     # stored activations (memory_efficient=False, configs/waveglow_LJ_speech_fast.json: `other_models.waveglow_memory_efficient_false`)
     for mem_eff in (True, False):
@@ -512,6 +535,10 @@ def test_c2_full_batch_vs_oracle(dev, precision):
             worst = max(worst, e)
             assert e < GRAD_RTOL, (mem_eff, n)
         assert relmax(npy(tr.last_dh).astype(np.float64), ref["dh"]) < GRAD_RTOL, mem_eff
+        _check_summary(gold_ref, m, specs, z, logdet, loss, N)                      # ... and against the reference's own step at this size
+        dh = npy(tr.last_dh)
+        assert np.abs(dh[:, :, :4] - gold_ref["dh_head"]).max() <= GRAD_RTOL * float(gold_ref["dh_max"])
+        assert abs(float(np.sqrt((dh.astype(np.float64) ** 2).sum())) - float(gold_ref["dh_norm"])) <= 1e-4 * float(gold_ref["dh_norm"])
         print("headline shape vs float64 oracle (memory_efficient=%s): |dz| %.2e, worst gradient %.2e of its tensor's max (%d oracle workers)"
               % (mem_eff, float(np.abs(npy(z) - ref["z"]).max()), worst, workers))
 
@@ -1063,6 +1090,86 @@ def test_wsrglow_model_vs_reference_golden(dev, golden_dir, name):
     assert logdet_close(npy(ld), gold["logdet_inv"], N)
 
 
+def test_wsrglow_timed_workload_vs_reference_golden(dev, golden_dir, precision, monkeypatch):
+    """`bench.py --model wsrglow` at its own size -- WSRGlow(upsample_rate=2) as configs/wsrglow_vctk_2x.json ships it, 229.7 M parameters,
+    batch 12 x 8192 -- through the TIMED path (FlowTrainer.step = wg_train_step) against one training step of the reference itself on the
+    CPU (model_wsr_full.npz, a summary: loss, logdet, both ends and the per-item norm of z, norm / head of every gradient, the table
+    gradients in full, both index arrays of the conditioning).  This is the shape at which the gate conv is cut along K (the counter
+    must show it).
+
+    49 152 low-rate samples and 55 296 STFT bins are quantised on the way in; a decision whose pre-rounding value sits within float noise of
+    a bin edge may fall the other way on the GPU (here: ONE phase bin of item 0, frame 438).  The test finds such decisions from the
+    recorded indices, allows two, and hands the flow the reference's table rows at those frames -- what is compared is then the same function
+    -- skipping only the table-gradient rows the differing decisions themselves route to."""
+    if precision != "bf16x3p":
+        pytest.skip("the timed workload runs in the default arithmetic")
+    from constant_memory_waveglow_amd import _lib, engine
+    from constant_memory_waveglow_amd.parallel import FlowTrainer
+    name = "wsr_full"
+    cfg = fill.CONFIGS[name]
+    B, N, F = fill.SHAPES[name]
+    specs = fill.model_param_specs(cfg)
+    P = fill.fill_params(specs, name + "/")
+    P.update(fill.wsr_tables(name + "/"))
+    m = cm.WSRGlow(upsample_rate=2, memory_efficient=True, bias=False)
+    sd = {k: torch.from_numpy(v) for k, v in P.items()}
+    sd["window"] = torch.hann_window(16)
+    m.load_state_dict(sd)
+    mu_t, ang_t = P["mu_enc.1.weight"], P["angle_embed.embed.weight"]
+    del sd, P
+    m = m.to(dev)
+    audio, c = fill.wsr_inputs(name, B, N, 2)
+    gold = np.load(os.path.join(golden_dir, "model_%s.npz" % name))
+    # ---- the quantiser decisions
+    Fr = c.shape[1] // 8
+    real_cond = engine.wsr_cond
+    cond = npy(real_cond(T(np.clip(c, -1.0, 1.0), dev), m.mu_enc[1].weight.detach(), m.angle_embed.embed.weight.detach()))
+    ref_mu = mu_t[gold["mu_idx"].astype(np.int64)].reshape(B, Fr, 3200).transpose(0, 2, 1)
+    ref_ang = ang_t[gold["ang_idx"].astype(np.int64)].transpose(0, 1, 3, 2).reshape(B, 450, Fr)
+    bad_mu, bad_ang = np.argwhere((cond[:, :3200] != ref_mu).any(1)), np.argwhere((cond[:, 3209:] != ref_ang).any(1))
+    assert len(bad_mu) + len(bad_ang) <= 2, (bad_mu.tolist(), bad_ang.tolist())
+    skip_rows = {"mu_enc.1.weight": set(), "angle_embed.embed.weight": set()}
+    for b, f in bad_mu:
+        for s_ in range(8):
+            ours = cond[b, s_ * 400:(s_ + 1) * 400, f]
+            skip_rows["mu_enc.1.weight"] |= {int(gold["mu_idx"][b, 8 * f + s_]), int(np.argmin(np.abs(mu_t - ours).sum(1)))}
+    for b, f in bad_ang:
+        for k in range(9):
+            ours = cond[b, 3209 + k * 50:3209 + (k + 1) * 50, f]
+            skip_rows["angle_embed.embed.weight"] |= {int(gold["ang_idx"][b, k, f]), int(np.argmin(np.abs(ang_t - ours).sum(1)))}
+
+    def cond_with_reference_decisions(cc, mu_w, ang_w):
+        h = real_cond(cc, mu_w, ang_w)
+        for b, f in bad_mu:
+            h[b, :3200, f] = T(np.ascontiguousarray(ref_mu[b, :, f]), dev)
+        for b, f in bad_ang:
+            h[b, 3209:, f] = T(np.ascontiguousarray(ref_ang[b, :, f]), dev)
+        return h
+    monkeypatch.setattr(engine, "wsr_cond", cond_with_reference_decisions)
+    # ---- the timed step
+    tr = FlowTrainer(m, 1.0)
+    before = _lib.lib().wg_stat_gate_split_launches()
+    loss, z, logdet = tr.step(T(audio, dev), T(c, dev))
+    torch.cuda.synchronize()
+    assert _lib.lib().wg_stat_gate_split_launches() - before == (2 * len(m.WNs) - 1) * 8
+    zz = npy(z)
+    assert np.abs(zz[:, :256] - gold["z_head"]).max() < Z_ATOL and np.abs(zz[:, -256:] - gold["z_tail"]).max() < Z_ATOL
+    zn = np.sqrt((zz.astype(np.float64) ** 2).sum(1))
+    assert np.all(np.abs(zn - gold["z_item_norm"]) <= 1e-5 * gold["z_item_norm"])
+    assert logdet_close(npy(logdet), gold["logdet"], N)
+    assert abs(float(loss) - float(gold["loss"])) < LOSS_ATOL
+    named = dict(m.named_parameters())
+    for i, (n, _, _) in enumerate(specs):
+        g = npy(named[n].grad)
+        nh = min(g.size, gold["grad_head"].shape[1])
+        assert np.abs(g.ravel()[:nh] - gold["grad_head"][i][:nh]).max() / max(float(gold["grad_max"][i]), 1e-30) < GRAD_RTOL, n
+        gn = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        assert abs(gn - float(gold["grad_norm"][i])) <= 1e-4 * float(gold["grad_norm"][i]) + 1e-12, n
+    for n, _ in fill.WSR_TABLES:
+        keep = np.array([r for r in range(gold["grad::" + n].shape[0]) if r not in skip_rows[n]])
+        assert relmax(npy(named[n].grad)[keep], gold["grad::" + n][keep]) < GRAD_RTOL, n
+
+
 def test_wsrglow_full_width_vs_oracle(dev, precision):
     """The shipped WSRGlow width (WN 256 channels x 8 layers, 229.7 M parameters, V = 3659 -> 4096 per flow) on one short segment
     against the oracle: the conditioning GEMM segment with K = 3659 is the shape the small fixtures do not reach."""
@@ -1330,6 +1437,29 @@ def test_waveflow_two_forwards_before_backward(dev, precision):
     with torch.no_grad():                                      # no gradient wanted: no tape is kept
         _, _, tape = m._engine.forward([None if t is None else t.detach() for t in m.param_table()], T(audio, dev), T(mel, dev), False)
     assert tape is None
+
+
+def test_waveflow_timed_workload_vs_reference_golden(dev, golden_dir, precision):
+    """`bench.py --model waveflow` at its own size -- configs/waveflow_LJ_speech.json: 8 flows, 64 rows, 64 channels, batch 12 x 16000 --
+    against one training step of the reference itself on the CPU (model_wf_full.npz, a summary: both ends and the per-item norm of z,
+    logdet, loss, norm / head of every gradient, d mel in full)."""
+    if precision != "bf16x3p":
+        pytest.skip("the timed workload runs in the default arithmetic")
+    cfg = dict(flows=8, n_group=64, n_mels=80, dilation_channels=64, residual_channels=64, skip_channels=64)
+    B, N, F = 12, 16000, 63
+    specs = fill.waveflow_param_specs(cfg)
+    P = fill.fill_params(specs, "wf_full/")
+    m = cm.WaveFlow(use_conv1x1=False, memory_efficient=False, bias=False, **cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    m = m.to(dev)
+    audio, mel = fill.waveflow_inputs("wf_full", B, N, F, 80)
+    gold = np.load(os.path.join(golden_dir, "model_wf_full.npz"))
+    ht = T(mel, dev).requires_grad_(True)
+    z, logdet = m(T(audio, dev), ht)
+    loss = cm.WaveGlowLoss(fill.SIGMA)(z, logdet)
+    loss.backward()
+    _check_summary(gold, m, specs, z, logdet, loss, N)
+    assert relmax(npy(ht.grad), gold["dmel"]) < GRAD_RTOL
 
 
 def test_waveflow_full_size_properties(dev, precision):
