@@ -689,9 +689,11 @@ struct Bump {
     size_t take(size_t n) { size_t o = off; off += rupz(n, 64); return o; }
 };
 int device_cus();
-// Floats of scratch a WN's gate conv needs when it is cut along K (run_convgemm's split path: convgemm16g_kernel<WGG_EPI_PART>): 0 when
-// the shape does not qualify.  The same arithmetic as the launch site's, so that a workspace that was sized here always has the room.
 std::atomic<long long> g_gate_split_launches{0};             // diagnostics (wg_stat_gate_split_launches)
+// A gate conv cut along K (run_convgemm's split path: convgemm16g_kernel<WGG_EPI_PART> + gate_finish16g_kernel): nt = output tiles of
+// 256 x 192, S = parts per tile (0: the shape does not qualify) -- the tiles fill 1 / S of the CUs, the column tiles are a multiple of
+// 8 (XCD placement), every part holds at least 8 and at most WGG_MAXCHUNKS chunks.  ONE function for the launch site and for the
+// workspace layout, so that a workspace sized for the cut always has the room the launch asks for.
 static void gate_split_plan(int cols_padded, int M, int nc, int cus, int &nt, int &S)
 {
     const int nct = (cols_padded + WGG_BN - 1) / WGG_BN, nrb = M / WGG_BM;
@@ -700,6 +702,7 @@ static void gate_split_plan(int cols_padded, int M, int nc, int cus, int &nt, in
     const int s = cus / nt;
     if (s >= 2 && s <= 8 && nt * s == cus && nc / s >= 8 && (nc + s - 1) / s <= WGG_MAXCHUNKS) S = s;
 }
+// floats of scratch a WN's gate conv needs when it is cut (the parts' raw accumulators: 8 waves x 24 blocks x 256 floats per part)
 static size_t gate_split_floats(const WnD &d, const Geo &g)
 {
     if (g.rows != 0 || g.H < 64) return 0;
