@@ -11,30 +11,14 @@
 // (lane l: row l&31, k = 8*(l>>5) .. +7) is one conflict-free ds_read_b128.
 #pragma once
 #include "wg_gemm.h"
+#include "wg_splane.h"
 #include <type_traits>
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define WG16_BK 32                    // k per chunk (two MFMA k-steps)
 #define WG16_ROWB 80                  // bytes per LDS row (32 bf16 + 16 B pad)
 #define WG16_IMG (WG_TILE * WG16_ROWB)  // one 128-row image
-
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-// two floats -> packed bf16 pair (round to nearest even): one v_cvt_pk_bf16_f32
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b)
-{
-    f32x2_t v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-}
-// split two floats: packed hi pair and packed lo pair (element 0 in the low half)
-__device__ __forceinline__ void split2(float a, float b, unsigned &hi, unsigned &lo)
-{
-    hi = cvt_pk_bf16(a, b);
-    lo = cvt_pk_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
-}
 
 // one k-step of 16: acc[mi][ni] += A(rows wr*64+mi*32..) x B(rows wc*64+ni*32..)
 __device__ __forceinline__ void mma16_step(const char *Ahi, const char *Alo, const char *Bhi, const char *Blo,

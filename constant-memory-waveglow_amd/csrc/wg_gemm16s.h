@@ -14,16 +14,6 @@
 #pragma once
 #include "wg_gemm16.h"
 
-struct SRef {
-    unsigned short *hi;   // lo array at hi + lo_off
-    size_t lo_off;        // = B * Cp * P elements
-    int Cp, ch0;          // channel rows per item (multiple of 8), first channel (multiple of 8)
-};
-__device__ __forceinline__ size_t s_index(const SRef &r, const Geo &g, int b, int c, int t)
-{
-    const int cc = r.ch0 + c;
-    return (((size_t)b * (r.Cp >> 3) + (cc >> 3)) * g.P + g.H + t) * 8 + (cc & 7);
-}
 // 4 consecutive channels (c multiple of 4) of one time step
 // EXPERIMENT -DWG_OPT_NT_S=<mask>: S-plane stores of the conv epilogues with the non-temporal policy (1: store / residual, 2: gate
 // backward, 4: gate conv)

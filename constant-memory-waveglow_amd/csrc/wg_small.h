@@ -2,6 +2,7 @@
 // WN.end + affine coupling (+ its backward seed), upsampler, loss, weight packing, gradient finalisation.
 #pragma once
 #include "wg_gemm.h"
+#include "wg_splane.h"       // SRef / s_index / split2: the seam form of end_affine_kernel writes the next WN's h_0 as an S-plane
 
 #define WG_MAXC 32   // largest invertible-1x1 / end-conv row count handled by the small kernels
 
@@ -204,13 +205,22 @@ struct AffineArgs {
     float *partial;         // [B][gridDim.x] per-block sums of +-log_s (FWD/REV), nullable
     Geo g;
     int mode;
+    // SEAM instantiation only (synthesis: the inverse direction between two WNs, one launch instead of three): after the inverse affine the
+    // inverse 1x1 conv on the flow's c = 2 ic channels (mixM: W^-1, c x c, row major), then WN.start of the NEXT flow visited on its
+    // xa = plane channels [n_rel, n_rel + n_ic) relative to X's first channel (negative where an early output re-enters, waveglow.py:204-205)
+    const float *mixM;
+    const float *nW;        // next start conv, fp32 effective weights [n_C][n_ldw]
+    int n_ldw, n_C, n_ic, n_rel;
+    PRef nH;                // next WN's h_0, fp32 plane (p == nullptr: none)
+    SRef nHS;               // ... and its S-plane
 };
 
 #define WG_AFF_T 64          // time steps per workgroup
+#define WG_SEAM_MAXW 2048    // floats of the next start conv's weights a SEAM launch stages (n_C x n_ic)
 #define WG_AFF_LD 64         // skip-channel loads a lane keeps in flight
 // NR = accumulator rows kept per lane: 8 where 2 * ic <= 8 (WaveGlow: n_group 8), 32 otherwise.  (With 32 accumulators next to the 64
 // loads in flight the kernel needed 250 VGPRs and 41 KB of LDS: two workgroups per CU, 38 us per launch at the training shape.)
-template <int NR>
+template <int NR, bool SEAM = false>
 __global__ __launch_bounds__(256) void end_affine_kernel(const AffineArgs a)
 {
     // out[m][t] = sum_k W_end[m][k] S[k][t] for the 2*ic <= 32 rows of the end conv: far too few rows for a matrix tile to pay, and
@@ -229,6 +239,19 @@ __global__ __launch_bounds__(256) void end_affine_kernel(const AffineArgs a)
     float acc[NR];
 #pragma unroll
     for (int m = 0; m < NR; ++m) acc[m] = 0.f;
+    // SEAM: what the tail needs from memory is requested here, in front of the end conv's reduction, and used behind it -- the next
+    // start conv's weights, W^-1, the flow's channels of this lane's time step (wave 0)
+    float pre_sw[SEAM ? WG_SEAM_MAXW / 256 : 1], pre_mw = 0.f, pre_x[SEAM ? 8 : 1];
+    if constexpr (SEAM) {
+#pragma unroll
+        for (int q = 0; q < WG_SEAM_MAXW / 256; ++q) {
+            const int e = tid + 256 * q;
+            pre_sw[q] = e < a.n_C * a.n_ic ? a.nW[(size_t)(e / a.n_ic) * a.n_ldw + (e % a.n_ic)] : 0.f;
+        }
+        if (tid < 4 * a.ic * a.ic) pre_mw = a.mixM[tid];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pre_x[i] = (wave == 0 && i < 2 * a.ic && t < g.T) ? *paddr(a.X, g, b, i, t) : 0.f;
+    }
     {
         const int kq = (a.Cs + 3) / 4, k0 = wave * kq, k1 = min(a.Cs, k0 + kq);
         const float *sp = paddr(a.S, g, b, 0, min(t, g.Tt - 1));        // columns in [T, Tt) read the zero padding; beyond Tt is clamped
@@ -278,6 +301,84 @@ __global__ __launch_bounds__(256) void end_affine_kernel(const AffineArgs a)
 
     const int ic = a.ic;
     float lsum = 0.f;
+    if constexpr (SEAM) {
+        // AFF_REV for the flow, W^-1 on its channels, the next WN's start conv -- three dependent ~5 us launches per flow of a synthesis
+        // call otherwise (end_affine_kernel, mix_kernel, start_fwd_kernel: their arithmetic, expression for expression)
+        __shared__ float xs[8][WG_AFF_T];                                // the flow's channels after the mix
+        __shared__ float mw[64];
+        __shared__ float sw[WG_SEAM_MAXW];
+        const int c = 2 * ic;
+        if (tid < c * c) mw[tid] = pre_mw;
+#pragma unroll
+        for (int q = 0; q < WG_SEAM_MAXW / 256; ++q) sw[tid + 256 * q] = pre_sw[q];
+        __syncthreads();
+        const bool live = t < g.T;
+        if (wave == 0) {
+            float x[8], y[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = pre_x[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < ic) {
+                    const float ls = tile[j][lane], tt = tile[ic + j][lane];
+                    // (x[ic + j] with a run-time ic: select, the array stays in registers)
+                    float xb = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) xb = (i == ic + j) ? x[i] : xb;
+                    const float xr = (xb - tt) / expf(ls);                 // efficient_modules.py:94 / :167
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x[i] = (i == ic + j) ? xr : x[i];
+                    if (live) lsum -= ls;
+                }
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (i < c && o < c) sacc += mw[o * c + i] * x[i];      // mix_kernel's sum
+                y[o] = sacc;
+            }
+#pragma unroll
+            for (int o = 0; o < 8; ++o)
+                if (o < c) {
+                    if (live) *paddr(a.X, g, b, o, t) = y[o];
+                    xs[o][lane] = y[o];
+                }
+        }
+        __syncthreads();
+        if (live) {
+            float xa[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int rel = a.n_rel + j;
+                xa[j] = 0.f;
+                if (j < a.n_ic) xa[j] = (rel >= 0 && rel < c) ? xs[rel][lane] : *paddr(a.X, g, b, rel, t);
+            }
+            for (int cg = wave; cg < a.n_C / 8; cg += 4) {                 // start_fwd_kernel's thread: one time step, 8 output channels
+                float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j < a.n_ic) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = fmaf(sw[(cg * 8 + e) * a.n_ic + j], xa[j], o[e]);
+                    }
+                if (a.nH.p) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) *paddr(a.nH, g, b, cg * 8 + e, t) = o[e];
+                }
+                u32x4 h, l;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsigned hh, ll;
+                    split2(o[2 * e], o[2 * e + 1], hh, ll);
+                    h[e] = hh; l[e] = ll;
+                }
+                const size_t si = s_index(a.nHS, g, b, cg * 8, t);
+                *reinterpret_cast<u32x4 *>(a.nHS.hi + si) = h;
+                *reinterpret_cast<u32x4 *>(a.nHS.hi + a.nHS.lo_off + si) = l;
+            }
+        }
+    } else
     for (int e = tid; e < ic * WG_AFF_T; e += 256) {
         const int j = e / WG_AFF_T, tl = e - j * WG_AFF_T;
         const int t = blockIdx.x * WG_AFF_T + tl;

@@ -846,6 +846,25 @@ def test_layer_as_one_launch_on_flattened_tiles_vs_two_launches(dev, precision, 
     assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max())
 
 
+def test_inverse_seam_launch_vs_three_launches(dev, precision, monkeypatch):
+    """Synthesis between two WNs: the inverse affine, the inverse 1x1 conv and the next WN's start conv as ONE launch
+    (end_affine_kernel<8, true>, opt-in WG_INV_SEAM=1: measured no faster, csrc/wgflow.hip run_inv_seam) against the three launches: the
+    same expressions in the same order, so x must be equal bit for bit (logdet: the per-block sums of log_s are added in another order)."""
+    if precision != "bf16x3p":
+        pytest.skip("the seam kernel writes S-planes: the default arithmetic only")
+    m, cfg, specs, P = build("c2", dev)
+    for B, F in ((1, 63), (3, 20)):
+        h = T(fill.normal("seam/h%d" % B, (B, cfg["n_mels"], F)), dev)
+        z = T(fill.normal("seam/z%d" % B, (B, F * 256), 0.6), dev)
+        out = {}
+        for sw in ("1", "0"):
+            monkeypatch.setenv("WG_INV_SEAM", sw)
+            with torch.no_grad():
+                out[sw] = m.reverse(z.clone(), h)
+        assert torch.equal(out["1"][0], out["0"][0])
+        assert float((out["1"][1] - out["0"][1]).abs().max()) <= 1e-6 * float(out["0"][1].abs().max())
+
+
 def test_wn_forward_standalone(dev):
     wn = cm.WN(4, 80, 64, 64, 64, depth=4, zero_init=False).to(dev)
     specs = fill.wn_param_specs("", 4, 80, 64, 64, 64, 4, 3)
