@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "wg_timer_create", "wg_timer_attach", "wg_timer_count", "wg_timer_read", "wg_timer_read_info", "wg_timer_destroy", "wg_stat_wgrad16t_launches",
     "wg_stat_layer_launches", "wg_layer_workspace_bytes", "wg_layer_apply", "wg_wf_wn_apply",
     "wg_timer_read_name", "wg_box_probe_bytes", "wg_box_probe", "wg_stat_layerg_launches", "wg_stat_gate_split_launches",
-    "wg_wf_wn_backward", "wg_layer_backward_workspace_bytes", "wg_layer_backward",
+    "wg_wf_wn_backward", "wg_layer_backward_workspace_bytes", "wg_layer_backward", "wg_affine_apply", "wg_affine_backward",
 ]
 K_CONV_STORE, K_CONV_GATE, K_CONV_RESSKIP, K_CONV_DGATE, K_WGRAD, K_LAYER = range(6)
 
@@ -153,6 +153,8 @@ def lib():
     L.wg_layer_backward_workspace_bytes.restype = C.c_size_t
     L.wg_layer_backward_workspace_bytes.argtypes = [C.POINTER(WgLayerDims), i, i]
     L.wg_layer_backward.argtypes = [C.POINTER(WgLayerDims), vp, vp, vp, vp, vp, i, i, vp, vp, vp, vp, sz, vp]
+    L.wg_affine_apply.argtypes = [vp, vp, vp, sz, i, vp, vp]
+    L.wg_affine_backward.argtypes = [vp, vp, vp, vp, vp, sz, i, vp, vp, vp, vp, vp]
     L.wg_timer_destroy.argtypes = [vp]
     L.wg_timer_destroy.restype = None
     L.wg_timer_read_name.argtypes = [vp, i, C.c_char_p, i]

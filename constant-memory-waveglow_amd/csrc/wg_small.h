@@ -435,6 +435,44 @@ __global__ __launch_bounds__(256) void end_affine_kernel(const AffineArgs a)
     }
 }
 
+// The affine coupling on plain arrays, for an AffineCouplingBlock whose transform is NOT this package's WN (efficient_modules.py:58-62
+// takes any `transform_type`): the transform runs as the caller's torch module, this is the block's own arithmetic.
+//   apply:     out = reverse ? (in - t) / exp(log_s) : in * exp(log_s) + t                                     (:81 / :94)
+//   backward:  the block input rebuilt from its output, the seeds of the transform's backward (gradients w.r.t. ITS outputs log_s, t)
+//              and the gradient of the passed-through half: AffineCouplingFunc.backward :132-148 / InvAffineCouplingFunc.backward :194-206
+struct AffinePlainArgs {
+    const float *in, *log_s, *t;       // [n]
+    const float *dout, *dls;           // backward: gradient of the block output's second half; of the returned log_s (nullable)
+    float *out;                        // apply: the output half; backward: the rebuilt input half
+    float *g_ls, *g_t, *din;           // backward
+    size_t n;
+    int reverse, backward;
+};
+__global__ void affine_plain_kernel(const AffinePlainArgs a)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const float ls = a.log_s[i], tt = a.t[i], sc = expf(ls), v = a.in[i];
+    if (!a.backward) {
+        a.out[i] = a.reverse ? (v - tt) / sc : v * sc + tt;
+        return;
+    }
+    const float d = a.dout[i], gl = a.dls ? a.dls[i] : 0.f;
+    if (!a.reverse) {                                          // v = zb
+        const float xr = (v - tt) / sc;
+        a.out[i] = xr;
+        a.g_ls[i] = d * xr * sc + gl;
+        a.g_t[i] = d;
+        a.din[i] = d * sc;
+    } else {                                                   // v = xb (the block's output), the returned log_s was -ls
+        const float zb = v * sc + tt;
+        a.out[i] = zb;
+        a.g_ls[i] = -(d * zb / sc + gl) + d * tt / sc;
+        a.g_t[i] = -d / sc;
+        a.din[i] = d / sc;
+    }
+}
+
 // logdet[b] = sum_k coef * T * logdetW_k + sum_k sum_tiles partial[k][b][tile]      (waveglow.py:175 / :202)
 __global__ void logdet_finalize_kernel(const float *__restrict__ lu, int ostride, int n_flows, float coef_T,
                                        const float *__restrict__ partial, int ntile, int B, float *__restrict__ logdet)

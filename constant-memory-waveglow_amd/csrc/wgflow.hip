@@ -3810,6 +3810,29 @@ int wg_layer_backward(const wg_layer_dims *d, const void *const *params, const f
     return cx.err;
 }
 
+int wg_affine_apply(const float *in, const float *log_s, const float *t, size_t n, int reverse, float *out, void *stream)
+{
+    if (!in || !log_s || !t || !out || n < 1) return WG_EINVAL;
+    Ctx cx = {(hipStream_t)stream, 0, 0};
+    AffinePlainArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in; a.log_s = log_s; a.t = t; a.out = out; a.n = n; a.reverse = reverse;
+    WG_LAUNCH(cx, affine_plain_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, a);
+    return cx.err;
+}
+int wg_affine_backward(const float *out_half, const float *log_s, const float *t, const float *dout, const float *dlog_s, size_t n, int reverse,
+                       float *in_rebuilt, float *g_log_s, float *g_t, float *din, void *stream)
+{
+    if (!out_half || !log_s || !t || !dout || !in_rebuilt || !g_log_s || !g_t || !din || n < 1) return WG_EINVAL;
+    Ctx cx = {(hipStream_t)stream, 0, 0};
+    AffinePlainArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = out_half; a.log_s = log_s; a.t = t; a.dout = dout; a.dls = dlog_s; a.out = in_rebuilt; a.g_ls = g_log_s; a.g_t = g_t; a.din = din;
+    a.n = n; a.reverse = reverse; a.backward = 1;
+    WG_LAUNCH(cx, affine_plain_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, a);
+    return cx.err;
+}
+
 int wg_coupling_backward(const wg_wn_dims *dd, const void *const *params, const void *packed, const float *z, const float *y,
                          const float *dz, const float *dlog_s, int B, int T, int reverse, float *x, float *dx, float *dy,
                          void *const *grads, void *wsv, size_t ws_bytes, void *stream)

@@ -100,21 +100,61 @@ class _Coupling(Function):
         return (dx, dy, None, None) + tuple(by_id.get(id(p)) for p in plist)
 
 
+class _GenericCoupling(Function):
+    """AffineCouplingFunc / InvAffineCouplingFunc (efficient_modules.py:99-212) around ANY transform module F(x_a, y) -> (log_s, t): the
+    transform runs as the caller's torch module (no graph kept in forward; recomputed with autograd on in backward, as upstream :127-130),
+    the block's own arithmetic -- the affine map, the input rebuilt from the output, the seeds of the transform's backward -- runs in the
+    library (wg_affine_apply / wg_affine_backward)."""
+
+    @staticmethod
+    def forward(ctx, x, y, block, reverse, *weights):
+        ic = x.size(1) // 2
+        xa, xb = x[:, :ic].contiguous(), x[:, ic:].contiguous()
+        with torch.no_grad():
+            log_s, t = block.F(xa, y)
+            zb = engine.affine_apply(xb, log_s, t, reverse)
+            z = torch.cat((xa, zb), 1)
+        ctx.block, ctx.reverse = block, reverse
+        ctx.save_for_backward(x.data, y, z)
+        return z, (-log_s if reverse else log_s)
+
+    @staticmethod
+    def backward(ctx, dz, dlog_s):
+        x, y, z = ctx.saved_tensors
+        F, reverse = ctx.block.F, ctx.reverse
+        ic = z.size(1) // 2
+        za = z[:, :ic].detach().contiguous().requires_grad_(True)
+        ya = y.detach().requires_grad_(True) if ctx.needs_input_grad[1] else y.detach()
+        with torch.enable_grad():
+            log_s, t = F(za, ya)                                                       # recompute :127-130 / :189-192
+        rebuilt, g_ls, g_t, din = engine.affine_backward(z[:, ic:], log_s.detach(), t.detach(), dz[:, ic:], dlog_s, reverse)
+        with torch.no_grad():
+            torch.cat((za.detach(), rebuilt), 1, out=_rematerialise(x, z))             # the freed input, in place (:135-136 / :197-198)
+        plist = [p for p in F.parameters() if p.requires_grad]
+        inputs = [za] + plist + ([ya] if ctx.needs_input_grad[1] else [])
+        grads = torch.autograd.grad([log_s, t], inputs, [g_ls, g_t], allow_unused=True)  # :140-144 / :200-204
+        da = dz[:, :ic] + (grads[0] if grads[0] is not None else 0)
+        dy = grads[-1] if ctx.needs_input_grad[1] else None
+        by_id = {id(p): g for p, g in zip(plist, grads[1:1 + len(plist)])}
+        return (torch.cat((da, din), 1), dy, None, None) + tuple(by_id.get(id(p)) for p in F.parameters())
+
+
 class AffineCouplingBlock(Reversible):
     """Affine coupling z_a = x_a, z_b = x_b * exp(log_s) + t with (log_s, t) = F(x_a, y)  (efficient_modules.py:57-96).
-    `transform_type` must be this package's WN (the fused HIP transform net)."""
+    With `transform_type` = this package's WN the whole block is the fused HIP path (wg_coupling_*); any other transform module runs as
+    it is and the block's own arithmetic goes through wg_affine_apply / wg_affine_backward (_GenericCoupling)."""
 
     def __init__(self, transform_type, memory_efficient=True, reverse_mode=False, **kwargs):
         super().__init__(reverse_mode)
         self.F = transform_type(**kwargs)
-        if not hasattr(self.F, "hip_dims"):
-            raise WgError("AffineCouplingBlock runs on the fused HIP WN kernels; transform_type must be "
-                          "constant_memory_waveglow_amd.WN (got %r)" % (transform_type,))
         self._memory_efficient = bool(memory_efficient)
-        self._engine = engine.CouplingEngine(WgWnDims(*self.F.hip_dims(), _default_precision(), int(getattr(self.F, "has_bias", False))))
+        self._fn = _Coupling if hasattr(self.F, "hip_dims") else _GenericCoupling
+        self._engine = None
+        if self._fn is _Coupling:
+            self._engine = engine.CouplingEngine(WgWnDims(*self.F.hip_dims(), _default_precision(), int(getattr(self.F, "has_bias", False))))
 
     def _run(self, x: Tensor, y: Tensor, reverse: bool) -> Tuple[Tensor, Tensor]:
-        z, log_s = _Coupling.apply(x, y, self, reverse, *self.F.parameters())
+        z, log_s = self._fn.apply(x, y, self, reverse, *self.F.parameters())
         if self._memory_efficient:
             _free(x)
         return z, log_s

@@ -432,6 +432,31 @@ def layer_apply(dims, params, x, y):
 
 
 @on_device
+def affine_apply(xb, log_s, t, reverse):
+    """The coupling's own arithmetic on plain tensors (wg_affine_apply): xb * exp(log_s) + t, or (reverse) (xb - t) / exp(log_s)."""
+    require_device(xb, log_s, t)
+    xb, log_s, t = xb.contiguous(), log_s.contiguous(), t.contiguous()
+    if not (xb.shape == log_s.shape == t.shape) or xb.dtype != torch.float32 or log_s.dtype != torch.float32 or t.dtype != torch.float32:
+        raise WgError("affine coupling: the transform must return float32 (log_s, t) of the shape of the passed half, got %s / %s for %s"
+                      % (tuple(log_s.shape), tuple(t.shape), tuple(xb.shape)))
+    out = torch.empty_like(xb)
+    check(_lib.lib().wg_affine_apply(_p(xb), _p(log_s), _p(t), xb.numel(), int(reverse), _p(out), _stream()), "wg_affine_apply")
+    return out
+
+
+@on_device
+def affine_backward(out_half, log_s, t, dout, dlog_s, reverse):
+    """wg_affine_backward -> (input half rebuilt, d/d log_s, d/d t of the transform's outputs, gradient of the input half)."""
+    require_device(out_half, log_s, t, dout)
+    out_half, log_s, t, dout = out_half.contiguous(), log_s.contiguous(), t.contiguous(), dout.contiguous()
+    dlog_s = None if dlog_s is None else dlog_s.contiguous()
+    rebuilt, g_ls, g_t, din = (torch.empty_like(out_half) for _ in range(4))
+    check(_lib.lib().wg_affine_backward(_p(out_half), _p(log_s), _p(t), _p(dout), _p(dlog_s), out_half.numel(), int(reverse), _p(rebuilt),
+                                        _p(g_ls), _p(g_t), _p(din), _stream()), "wg_affine_backward")
+    return rebuilt, g_ls, g_t, din
+
+
+@on_device
 def layer_backward(dims, params, x, y, dres, dskip, need, need_dx, need_dy):
     """wg_layer_backward: (dx, dy, [dW.g, dW.v, dW_o.g, dW_o.v]) of NonCausalLayer / NonCausalLayer2D called on its own; None where not needed."""
     require_device(x, y, dskip, *params)

@@ -83,7 +83,7 @@ const char *wg_strerror(int code);
  * wg_wf_* accept every WG_PREC_*; 5: wg_config and wg_wn_dims gained bias; 6: wg_stat_layer_launches, the workspaces carry the one-launch
  * layer's hand-off counters, wg_layer_apply / wg_layer_workspace_bytes, wg_wf_wn_apply; 7: wg_wf_config gained bias; 8: wg_timer_read_name,
  * wg_box_probe / wg_box_probe_bytes, wg_stat_layerg_launches, wg_stat_gate_split_launches,
- * wg_wf_wn_backward, wg_layer_backward / wg_layer_backward_workspace_bytes).  A binding built against another revision must not pass its
+ * wg_wf_wn_backward, wg_layer_backward / wg_layer_backward_workspace_bytes, wg_affine_apply / wg_affine_backward).  A binding built against another revision must not pass its
  * structs: the Python loader compares this with its own ABI_VERSION and refuses the library otherwise. */
 #define WG_ABI_VERSION 8
 int wg_abi_version(void);
@@ -336,6 +336,16 @@ int wg_lowpass(const float *x, int B, int T, int n_fft, int hop, int cut_bins, i
  * Hyper-parameters are doubles (Python floats upstream): 1 - beta is formed in double before it is rounded to fp32. */
 int wg_adam_step(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, size_t n, double lr, double beta1, double beta2,
                  double eps, double weight_decay, int step, void *stream);
+
+/* The affine coupling by itself, on plain arrays of n = B * ic * T floats: what AffineCouplingBlock computes around a transform that is
+ * NOT this library's WN (efficient_modules.py:58-62 accepts any `transform_type`; the transform then runs as the caller's module).
+ * apply: out = in * exp(log_s) + t, or (reverse) (in - t) / exp(log_s)  (:81 / :94).
+ * backward (AffineCouplingFunc.backward :132-148 / InvAffineCouplingFunc.backward :194-206): from the block output's second half, the
+ * recomputed log_s and t, the gradient of that half and of the returned log_s (nullable): the block input's second half rebuilt, the
+ * gradients w.r.t. the transform's outputs (g_log_s, g_t: the seeds of its backward) and the gradient of the input half. */
+int wg_affine_apply(const float *in, const float *log_s, const float *t, size_t n, int reverse, float *out, void *stream);
+int wg_affine_backward(const float *out_half, const float *log_s, const float *t, const float *dout, const float *dlog_s, size_t n, int reverse,
+                       float *in_rebuilt, float *g_log_s, float *g_t, float *din, void *stream);
 
 #ifdef __cplusplus
 }

@@ -717,6 +717,55 @@ def test_wn_on_its_own_is_differentiable_vs_torch_cpu(dev, precision, bias):
     assert not ls3.requires_grad and torch.equal(ls3, ls2) and torch.equal(t3, t2)
 
 
+class _TinyTransform(torch.nn.Module):
+    """a transform that is not WN: (log_s, t) = chunk(tanh(conv3(x_a) + conv1(y)))"""
+
+    def __init__(self, in_channels, aux_channels, hidden=24):
+        super().__init__()
+        self.a = torch.nn.Conv1d(in_channels, hidden, 3, padding=1)
+        self.b = torch.nn.Conv1d(aux_channels, hidden, 1)
+        self.o = torch.nn.Conv1d(hidden, 2 * in_channels, 1)
+
+    def forward(self, xa, y):
+        ls, t = self.o(torch.tanh(self.a(xa) + self.b(y))).chunk(2, 1)
+        return 0.5 * torch.tanh(ls), t
+
+
+@pytest.mark.parametrize("rev", [False, True])
+def test_coupling_block_with_any_transform_vs_plain_autograd(dev, rev):
+    """AffineCouplingBlock takes any `transform_type` upstream (model/efficient_modules.py:58-62).  With a transform that is not this
+    package's WN the module runs as it is and the block's own arithmetic goes through wg_affine_apply / wg_affine_backward
+    (efficient_modules._GenericCoupling): outputs, the freed-and-rebuilt input and every gradient against the plain composition
+    `zb = xb * exp(log_s) + t` (or its inverse) under torch autograd, both directions."""
+    ic, aux, B, Tn = 3, 10, 2, 157
+    torch.manual_seed(3)
+    blk = cm.AffineCouplingBlock(_TinyTransform, True, in_channels=ic, aux_channels=aux).to(dev)
+    x = T(fill.uniform("anyF/x", (B, 2 * ic, Tn)), dev)
+    y = T(fill.normal("anyF/y", (B, aux, Tn)), dev)
+    gz, gls = T(fill.normal("anyF/gz", (B, 2 * ic, Tn)), dev), T(fill.normal("anyF/gls", (B, ic, Tn)), dev)
+    # plain composition
+    xr, yr = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    ls, t = blk.F(xr[:, :ic], yr)
+    if rev:
+        zr, lsr = torch.cat((xr[:, :ic], (xr[:, ic:] - t) / torch.exp(ls)), 1), -ls
+    else:
+        zr, lsr = torch.cat((xr[:, :ic], xr[:, ic:] * torch.exp(ls) + t), 1), ls
+    ((zr * gz).sum() + (lsr * gls).sum()).backward()
+    want = {n: p.grad.clone() for n, p in blk.F.named_parameters()}
+    blk.zero_grad()
+    # the block
+    xt, yt = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    xin = xt.clone()
+    z, lo = blk.reverse(xin, yt) if rev else blk(xin, yt)
+    assert xin.untyped_storage().size() == 0                                    # memory_efficient: the input was freed (:75 / :88)
+    ((z * gz).sum() + (lo * gls).sum()).backward()
+    assert xin.untyped_storage().size() > 0 and float((xin - x).abs().max()) < 1e-5      # ... and rebuilt in place by the backward
+    assert float((z - zr).abs().max()) < 1e-5 and float((lo - lsr).abs().max()) < 1e-6
+    assert relmax(npy(xt.grad), npy(xr.grad)) < 1e-5 and relmax(npy(yt.grad), npy(yr.grad)) < 1e-5
+    for n, p in blk.F.named_parameters():
+        assert relmax(npy(p.grad), npy(want[n])) < 1e-5, n
+
+
 def test_coupling_block_on_shared_b_tiles_vs_oracle(dev, precision):
     """One coupling block at the shipped WN width (256 channels, so the gate conv has 512 rows) on 2 x 16 384 columns: 1 024 gate-conv
     tiles = 2 per CU, the shape at which the engine runs the 256 x 128 form of the conv kernel (two compute groups sharing one B image,
