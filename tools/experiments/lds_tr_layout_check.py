@@ -57,3 +57,31 @@ if __name__ == "__main__":
     assert r == 1 and w == 1
     # data check: every (t, ch) maps to a distinct unit
     assert len({off(t, ch) for t in range(32) for ch in range(16)}) == 512
+
+
+# ---- round 5: the image LDS-DMA would write for the weight-gradient product (next step for wgrad16t) ----
+# global_load_lds_dwordx4 copies 1 KB lane-linear: 64 consecutive time steps of ONE 8-channel group of an S-plane ([c/8][p][8]).  The
+# image is therefore [channel group][t 0..63][8 channels], a plane of 1 024 bytes per group -- no swizzle inside a piece, but the planes'
+# bases are free.  The transposing read of the 16-channel block mb touches the planes 2 mb and 2 mb + 1 at 8 time steps per 32-lane half:
+# conflict free iff the two planes are 64 (mod 128) bytes apart, e.g. a plane stride of 1 088 bytes.
+def dma_off(t, cg, stride):
+    return stride * cg + 16 * t
+
+
+def dma_tr_read(mb, second, kstep, stride):
+    groups = []
+    for half in range(2):
+        addrs = []
+        for l in range(32 * half, 32 * half + 32):
+            g, q, p = l >> 4, (l & 15) >> 2, l & 3
+            t = 32 * kstep + 8 * g + q + (4 if second else 0)
+            addrs.append(dma_off(t, 2 * mb + (p >> 1), stride) + 8 * (p & 1))
+        groups.append(addrs)
+    return groups
+
+
+if __name__ == "__main__":
+    for stride in (1024, 1024 + 32, 1024 + 64, 1024 + 128):
+        r = max(worst(dma_tr_read(mb, s, ks, stride), 64, 8) for mb in range(16) for s in (0, 1) for ks in (0, 1))
+        print("LDS-DMA image [cg][t][8], plane stride %4d bytes: transposing read %d-way" % (stride, r))
+    assert max(worst(dma_tr_read(mb, s, ks, 1088), 64, 8) for mb in range(16) for s in (0, 1) for ks in (0, 1)) == 1
