@@ -46,16 +46,32 @@ sys.path.insert(0, ROOT)
 C2 = dict(flows=12, n_group=8, n_early_every=4, n_early_size=2, hop_size=256, n_mels=80,
           dilation_channels=256, residual_channels=256, skip_channels=256, depth=8, radix=3)   # configs/waveglow_LJ_speech.json:6-19
 SEG, FRAMES, SIGMA = 16000, 63, 0.7
+# the config behind the ONLY speed the reference publishes ("around 470 kHz on a 1080ti", README.md:64-67): configs/musicnet_config.json:7-20
+MUSICNET = dict(flows=18, n_group=8, n_early_every=6, n_early_size=2, hop_size=512, n_mels=80,
+                dilation_channels=256, residual_channels=256, skip_channels=256, depth=4, radix=3)
+MUSICNET_PUBLISHED_KHZ = 470.0            # /root/reference/README.md:67 (GTX 1080 Ti)
 FP32_MFMA_PEAK_TFLOPS = 157.3            # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0           # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA" (dense)
 FWD_FLOP_PER_SAMPLE = 13_376_372         # SURVEY.md 2.1 (forward = inverse)
 STEP_FLOP_PER_SAMPLE = 40_129_116        # fwd + dgrad + wgrad (algorithmic; the recompute is not credited)
 
 
-def build_model(dev, seed=0):
+def fwd_flop_per_sample(cfg):
+    """Multiply-adds x 2 of one forward (= inverse) pass per audio sample, from the architecture (SURVEY.md 2.1 / 8d's count: start,
+    conditioning, the dilated convs, W_o, end and the 1x1 conv of every flow; c = channels left after the early outputs)."""
+    C, Cd, Cs, D, R = cfg["residual_channels"], cfg["dilation_channels"], cfg["skip_channels"], cfg["depth"], cfg["radix"]
+    total, c = 0, cfg["n_group"]
+    for k in range(cfg["flows"]):
+        if k and k % cfg["n_early_every"] == 0:
+            c -= cfg["n_early_size"]
+        total += 2 * (c // 2) * C + D * 2 * cfg["n_mels"] * 2 * Cd + D * 2 * R * C * 2 * Cd + (D - 1) * 2 * Cd * (C + Cs) + 2 * Cd * Cs + 2 * Cs * c + 2 * c * c
+    return total / cfg["n_group"]
+
+
+def build_model(dev, seed=0, cfg=None):
     import constant_memory_waveglow_amd as cm
     torch.manual_seed(seed)
-    model = cm.WaveGlow(memory_efficient=True, bias=False, **C2)
+    model = cm.WaveGlow(memory_efficient=True, bias=False, **(cfg or C2))
     with torch.no_grad():                 # the reference zero-inits WN.end (log_s = t = 0); make the flow non-trivial
         for blk in model.WNs:
             blk.F.end.weight.normal_(0.0, 0.02)
@@ -81,13 +97,34 @@ def launch_site_to_rocprof(expr):
     return "%s<%s" % (name.strip(), ", ".join(parts))
 
 
+# template arguments a launch site may leave out, as the kernels declare them (csrc/wg_gemm16q.h convgemm16q_kernel<EPI, NI, MG = 1,
+# M64 = false, CG2 = false>, csrc/wg_small.h end_affine_kernel<NR, SEAM = false>): (number of parameters, the trailing defaults)
+TEMPLATE_DEFAULTS = {"convgemm16q_kernel": (5, ["1", "false", "false"]), "end_affine_kernel": (2, ["false"])}
+
+
+def full_instantiation(site_prefix):
+    """launch_site_to_rocprof's prefix padded with the kernel's declared defaults and closed: "convgemm16q_kernel<5, 2, 2" ->
+    "convgemm16q_kernel<5, 2, 2, false, false>" -- the name rocprofv3 prints up to its argument list, to be matched EXACTLY (a bare
+    prefix also matched "convgemm16q_kernel<5, 2, 2, false, true>", another instantiation launched from another site)."""
+    if "<" not in site_prefix:
+        return site_prefix
+    name, targs = site_prefix.split("<", 1)
+    parts = [a.strip() for a in targs.split(",")]
+    n, tail = TEMPLATE_DEFAULTS.get(name, (len(parts), []))
+    if len(parts) < n:
+        parts += tail[len(tail) - (n - len(parts)):]
+    return "%s<%s>" % (name, ", ".join(parts))
+
+
 def _traffic(kernel_prefix, prefix=""):
     """(HBM bytes per launch of the dominant kernel, the file it was read from, the kernel's full name there).  NOT measured in this
     run: the bytes come from the newest committed PMC summary (profiles/*_hbm_traffic.json, produced by tools/profile_summary.py from
     separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes)
-    whose kernel table holds a name that STARTS with `kernel_prefix` (launch_site_to_rocprof of the instantiation that ran in THIS run: a
-    summary of another kernel is never cited); (None, None, None) if there is none."""
+    whose kernel table holds EXACTLY ONE name that is the instantiation `kernel_prefix` stands for (launch_site_to_rocprof of the
+    instantiation that ran in THIS run, defaulted template arguments filled in from the kernel's declaration: a summary of another
+    kernel or of another instantiation is never cited); (None, None, None) if there is none, or if a summary is ambiguous."""
     import glob
+    want = full_instantiation(kernel_prefix)
     best = (None, None, None)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
         tag = os.path.basename(f)
@@ -97,10 +134,15 @@ def _traffic(kernel_prefix, prefix=""):
             k = json.load(open(f))["kernels"]
         except Exception:
             continue
+        hits = []
         for name, row in k.items():
             bare = name[5:] if name.startswith("void ") else name
-            if bare.startswith(kernel_prefix) and bare[len(kernel_prefix):len(kernel_prefix) + 1] in ("", ",", ">", "("):
-                best = (row["hbm_bytes_per_launch"], os.path.relpath(f, ROOT), bare)
+            if bare == want or (bare.startswith(want) and bare[len(want):len(want) + 1] == "("):
+                hits.append((row["hbm_bytes_per_launch"], os.path.relpath(f, ROOT), bare))
+        if len(hits) == 1:
+            best = hits[0]
+        elif len(hits) > 1:
+            best = (None, None, None)                          # (the newest summary is ambiguous: cite nothing rather than an older one)
     return best
 
 
@@ -375,7 +417,7 @@ KCLASS = {0: "conv store / residual / data-gradient (EPI_STORE)", 1: "gate conv 
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
-def kernel_rooflines(trainer, x, h, split, steps=2, top=12, step_fn=None):
+def kernel_rooflines(trainer, x, h, split, steps=2, top=12, step_fn=None, box_tflops=None):
     """Per-SHAPE rooflines of the conv / weight-gradient launches of the training step: every such launch of `steps` extra steps is
     bracketed with HIP events on the launch stream (wg_timer_create(-1, ..): all classes) and reported with the shape the library
     attaches to it (wg_timer_read_info): class, M x K, columns, algorithmic HBM bytes.  Grouped by (class, M, K); per group: launches per
@@ -418,7 +460,8 @@ def kernel_rooflines(trainer, x, h, split, steps=2, top=12, step_fn=None):
         rows.append({"kernel": KCLASS.get(cls, str(cls)), "M": M, "K": K, "columns": cols, "launches_per_step": len(v) / steps,
                      "avg_us": us, "ms_per_step": us * len(v) / steps / 1e3, "flop_per_launch": flop, "bytes_per_launch": by,
                      "tflops_algorithmic": tf, "gbs_algorithmic": gbs, "bound": "mfma" if f_m >= f_h else "hbm", "frac": max(f_m, f_h),
-                     "frac_mfma": f_m, "frac_hbm": f_h})
+                     "frac_mfma": f_m, "frac_hbm": f_h,
+                     **({"frac_of_box": 3.0 * tf / box_tflops} if (box_tflops and split) else {})})
     rows.sort(key=lambda r: -r["ms_per_step"])
     return {"timed_ms_per_step": total_ms, "mfma_peak_tflops_algorithmic": peak_tf, "hbm_peak_gbs": HBM_PEAK_GBS,
             "note": "HIP events around every conv / weight-gradient launch of %d extra steps (the events cost a few per cent; the headline "
@@ -737,7 +780,6 @@ def main(argv=None):
     for _ in range(args.warmup):
         step()
     L = _lib.lib()
-    box = box_probe(dev) if rank == 0 and not args.no_box else None
     per_step_gate = wl["gate_launches_per_step"]
     barrier()
     t0 = time.perf_counter()
@@ -755,6 +797,9 @@ def main(argv=None):
     ms_per_step = dt / args.steps * 1e3
     value = world * B * SEGW * args.steps / dt
     comm = comm_report(wl, args, use_dist, world, rank, dev, dt_own, ms_per_step, barrier) if use_dist else None
+    # (behind the timed steps: half a second of full-power matrix work on ONE rank in front of a max-reduced multi-rank headline would
+    # heat that rank's GPU alone; the other ranks wait at the barrier below)
+    box = box_probe(dev) if rank == 0 and not args.no_box else None
     # the dominant kernel's launch duration: HIP events around every launch of its class over `args.steps` EXTRA steps (every rank runs
     # them: the collectives need all ranks), outside the timed region; the library reports which instantiation each launch ran
     # (every class is timed: the gate conv runs on its own -- class K_CONV_GATE -- or, at the training shapes since round 5, inside the
@@ -833,6 +878,9 @@ def main(argv=None):
                                                                                     "behind the timed ones (nothing is attached while the headline runs)" % args.steps,
                          "flop_per_launch": gate_flop,
                          "mfma_tflops_issued": achieved * (3 if split else 1),
+                         # issued TFLOP/s of the dominant launch over what THIS GPU sustains on the library's fixed matrix-pipe + LDS loop
+                         # without global traffic (`box`): separates a slow box from a slow kernel in one number
+                         **({"frac_of_box": achieved * (3 if split else 1) / box["tflops_issued"]} if (box and box.get("tflops_issued") and split) else {}),
                          "x_fp32_mfma_peak": achieved / FP32_MFMA_PEAK_TFLOPS},
             "step_flop_per_sample": STEP_FLOP,
             "step_tflops_algorithmic": value * STEP_FLOP / 1e12 / world,
@@ -851,7 +899,8 @@ def main(argv=None):
             args.no_inverse = args.no_extra = args.no_cpu = True         # the secondary legs belong to the headline workload
             if world == 1:
                 try:
-                    out["roofline"]["kernels"] = kernel_rooflines(trainer, x, h, split, step_fn=step if trainer is None else None)
+                    out["roofline"]["kernels"] = kernel_rooflines(trainer, x, h, split, step_fn=step if trainer is None else None,
+                                                                      box_tflops=(box or {}).get("tflops_issued"))
                 except Exception as e:                                    # noqa: BLE001
                     out["roofline"]["kernels"] = {"error": repr(e)}
             if args.model == "waveflow" and world == 1 and not wl.get("no_inverse"):
@@ -895,6 +944,21 @@ def main(argv=None):
                     torch.cuda.synchronize()
                     costs.append(time.perf_counter() - t1)
             out["inverse_khz_batch8x16128"] = xs.numel() / sorted(costs)[2] / 1000.0
+            # the reference's published configuration (musicnet: 18 flows, early outputs every 6, WN depth 4, hop 512): 10 s of audio
+            mus = build_model(dev, cfg=MUSICNET)
+            hm = torch.randn(1, MUSICNET["n_mels"], 431, device=dev, generator=g)
+            with torch.no_grad():
+                mus.infer(hm, 0.6)
+                costs = []
+                for _ in range(5):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    xm = mus.infer(hm, 0.6)
+                    torch.cuda.synchronize()
+                    costs.append(time.perf_counter() - t1)
+            mus_khz = xm.numel() / sorted(costs)[2] / 1000.0
+            out["inverse_khz_musicnet_%d" % xm.numel()] = mus_khz
+            del mus
             # synthesis is the forward's FLOPs (13.38 MFLOP per sample) on the same matrix pipe: 2.5 PF bf16, three issued per product
             peak = BF16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
             out["inverse_roofline"] = {
@@ -903,6 +967,13 @@ def main(argv=None):
                                        "frac": out["inverse_khz_%d" % nn] * 1e3 * FWD_FLOP_PER_SAMPLE / 1e12 / peak} for nn in (63 * 256, 862 * 256)},
                           "8x16128": {"khz": out["inverse_khz_batch8x16128"], "achieved": out["inverse_khz_batch8x16128"] * 1e3 * FWD_FLOP_PER_SAMPLE / 1e12,
                                       "frac": out["inverse_khz_batch8x16128"] * 1e3 * FWD_FLOP_PER_SAMPLE / 1e12 / peak}},
+                "musicnet": {"config": "configs/musicnet_config.json: 18 flows, n_early_every 6, WN depth 4, hop 512, 80 mels; %d samples" % xm.numel(),
+                             "khz": mus_khz, "flop_per_sample": fwd_flop_per_sample(MUSICNET),
+                             "achieved": mus_khz * 1e3 * fwd_flop_per_sample(MUSICNET) / 1e12,
+                             "frac": mus_khz * 1e3 * fwd_flop_per_sample(MUSICNET) / 1e12 / peak,
+                             "reference_published_khz": MUSICNET_PUBLISHED_KHZ,
+                             "reference_published_on": "GTX 1080 Ti (README.md:64-67 of the reference: 'around 470kHz'); other hardware, quoted for scale",
+                             "x_reference_published": mus_khz / MUSICNET_PUBLISHED_KHZ},
                 "note": "one call between two synchronisations as inference.py:50-56; a 16 128-sample utterance is a chain of ~250 small "
                         "launches (64 x 64 tiles on every CU, DESIGN.md section 4a iii), the 10 s utterance fills the chip"}
         if world == 1 and args.model == "waveglow":
@@ -919,7 +990,7 @@ def main(argv=None):
             out["adam_step_ms"] = (time.perf_counter() - t1) / 5 * 1e3
         if world == 1 and args.model == "waveglow":                   # (extra steps on one rank only would wait for collectives forever)
             try:
-                out["roofline"]["kernels"] = kernel_rooflines(trainer, x, h, split)
+                out["roofline"]["kernels"] = kernel_rooflines(trainer, x, h, split, box_tflops=(box or {}).get("tflops_issued"))
             except Exception as e:                                    # noqa: BLE001 -- diagnostics never touch the headline line
                 out["roofline"]["kernels"] = {"error": repr(e)}
         if world == 1 and not args.no_extra:

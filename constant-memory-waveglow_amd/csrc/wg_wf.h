@@ -94,27 +94,28 @@ __global__ __launch_bounds__(256) void wf_upsample_bwd_kernel(const WfUpBwdArgs 
         for (int b = 0; b < a.B; ++b) {
             const float *mb = a.mel + ((size_t)b * a.M + c) * a.F, *gb = a.gp + ((size_t)b * a.M + o) * a.W;
             // eight frames at a time, their sixteen loads issued together (one load pair per fma, each behind the other, was a chain of
-            // B * (F + 1) round trips: 466 us per step at the shipped shape).  Terms outside the row are multiplied by zero instead of
-            // skipped: the sum keeps its order, and acc + 0 * g is acc.
+            // B * (F + 1) round trips: 466 us per step at the shipped shape).  A term outside the row is loaded from a clamped, valid
+            // address and then NOT added (a select on the product's sum, not a zero factor: 0 * Inf would be NaN): the sum keeps its order.
             for (int i0 = 0; i0 <= a.F; i0 += 8) {
                 float mv[8], gv[8];
+                bool ok[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int i = i0 + u, j = a.s * i + k - a.pad;
-                    const bool ok = i <= a.F && j >= 0 && j < a.W;
-                    const float m = mb[min(i, a.F - 1)];
-                    mv[u] = ok ? m : 0.f;
+                    ok[u] = i <= a.F && j >= 0 && j < a.W;
+                    mv[u] = mb[min(i, a.F - 1)];
                     gv[u] = gb[min(max(j, 0), a.W - 1)];
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc = fmaf(mv[u], gv[u], acc);
+                for (int u = 0; u < 8; ++u) acc = ok[u] ? fmaf(mv[u], gv[u], acc) : acc;
             }
         }
         a.dw[(size_t)c * a.M * a.K + e] = acc;
     }
     if (a.dbias && blockIdx.y == 0) {
         // dbias[c]: block (c, 0) sums its own channel -- every thread a strided share of the B * W terms, then a fixed tree over the block
-        // (80 threads of block 0 walking 3000 terms each, one load behind the other, was 300 us)
+        // (80 threads of block 0 walking 3000 terms each, one load behind the other, was 300 us).  The tree below is written for the
+        // launch shape wf_upsample_bwd uses: blockDim.x == 256, gridDim.x == M (one block column per channel).
         __shared__ float red[256];
         float acc = 0.f;
         for (int b = 0; b < a.B; ++b)

@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -30,6 +31,49 @@ namespace {
 
 inline int rup(int x, int m) { return (x + m - 1) / m * m; }
 inline size_t rupz(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------------
+// developer switches from the environment
+// ------------------------------------------------------------------------------------------------
+// Read ONCE per process (first use) and again only when the caller asks (wg_reload_env: what a test or an A/B run calls after it has
+// changed a variable).  getenv() on every launch raced with setenv / os.environ writes from other threads of the process (undefined
+// behaviour in libc) and put several scans of the environment in front of each of the ~250 launches of a synthesis call.
+struct EnvSw {
+    bool g192 = true;            // WG_G192=0: the conv products never take the 256 x 192-tile kernel of wg_gemm16g.h
+    bool g192_splitk = true;     // WG_G192_SPLITK=0: a gate conv whose tiles cannot fill the chip is not cut along K
+    bool g192_own = false;       // WG_G192_OWN=1: experiment, column ownership for stand-alone products
+    bool g192_rem = true;        // WG_G192_REM=0: a ragged last round of tiles is not cut along K (run_convgemm)
+    bool layer_fusion = false;   // WG_LAYER_FUSION=1: the one-launch layer for small grids (wg_layer16h.h), opt-in
+    bool layer_fusion_big = false;   // WG_LAYER_FUSION_BIG=1: the one-launch layer on 256 x 128 tiles (wg_layer16q.h), opt-in
+    bool layer_g = true;         // WG_LAYER_G=0: gate conv and residual product as two launches
+    bool inv_seam = false;       // WG_INV_SEAM=1: end conv + affine + inverse 1x1 + next start conv as one launch, opt-in
+};
+static std::atomic<const EnvSw *> g_env{nullptr};
+static const EnvSw *env_load()
+{
+    auto is = [](const char *name, char c) { const char *e = getenv(name); return e && e[0] == c; };
+    EnvSw *n = new EnvSw;        // (a reload leaks the table it replaces: 16 bytes per call of a test-only entry point, never freed under a reader)
+    n->g192 = !is("WG_G192", '0');
+    n->g192_splitk = !is("WG_G192_SPLITK", '0');
+    { const char *e = getenv("WG_G192_OWN"); n->g192_own = e && atoi(e) != 0; }
+    n->g192_rem = !is("WG_G192_REM", '0');
+    n->layer_fusion = is("WG_LAYER_FUSION", '1');
+    n->layer_fusion_big = is("WG_LAYER_FUSION_BIG", '1');
+    n->layer_g = !is("WG_LAYER_G", '0');
+    n->inv_seam = is("WG_INV_SEAM", '1');
+    return n;
+}
+static const EnvSw &env_sw()
+{
+    const EnvSw *e = g_env.load(std::memory_order_acquire);
+    if (!e) {
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lk(mu);
+        e = g_env.load(std::memory_order_acquire);
+        if (!e) { e = env_load(); g_env.store(e, std::memory_order_release); }
+    }
+    return *e;
+}
 
 // ------------------------------------------------------------------------------------------------
 // launch bookkeeping
@@ -690,6 +734,7 @@ struct Bump {
 };
 int device_cus();
 std::atomic<long long> g_gate_split_launches{0};             // diagnostics (wg_stat_gate_split_launches)
+std::atomic<long long> g_gate_rem_launches{0};               // diagnostics (wg_stat_gate_rem_launches)
 // A gate conv cut along K (run_convgemm's split path: convgemm16g_kernel<WGG_EPI_PART> + gate_finish16g_kernel): nt = output tiles of
 // 256 x 192, S = parts per tile (0: the shape does not qualify) -- the tiles fill 1 / S of the CUs, the column tiles are a multiple of
 // 8 (XCD placement), every part holds at least 8 and at most WGG_MAXCHUNKS chunks.  ONE function for the launch site and for the
@@ -911,12 +956,8 @@ static bool g192_fits(const ConvGemm16sArgs &as, size_t img_stride, int nseg)
     return true;
 }
 
-// env WG_G192 (read once): 0 = the conv products never take the 256 x 192-tile kernel of wg_gemm16g.h (A/B runs in one build)
-static bool g192_on()
-{
-    const char *e = getenv("WG_G192");                       // (per call: tests and A/B runs switch it inside one process)
-    return !(e && e[0] == '0');
-}
+// env WG_G192=0: the conv products never take the 256 x 192-tile kernel of wg_gemm16g.h (A/B runs in one build; EnvSw)
+static bool g192_on() { return env_sw().g192; }
 
 void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const SegSpec *segs, int nseg, int epi,
                   PRef out0, PRef out1, PRef out2, PRef aux0, PRef aux1, int nsplit, int accumulate, SRef s0 = snull(), SRef saux = snull())
@@ -1089,12 +1130,11 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
             // forward sum K in the same order; env WG_G192_SPLITK=0: off)
             if (g192_on() && so_gate && g.rows == 0 && !cx.row_sel1 && !cx.rec && M % WGG_BM == 0 && g.H >= 64 && cus % 8 == 0 && cx.gslab &&
                 g192_fits(as, a16.img_stride, nseg)) {
-                const char *e = getenv("WG_G192_SPLITK");
                 const int nct = (g.B * g.Tt + WGG_BN - 1) / WGG_BN, nrb = M / WGG_BM;
                 int nt, S;
                 gate_split_plan(g.B * g.Tt, M, nc, cus, nt, S);
                 const size_t need = (size_t)S * nt * 8 * 24 * 256;
-                if (!(e && e[0] == '0') && S && need <= cx.gslab_floats) {
+                if (env_sw().g192_splitk && S && need <= cx.gslab_floats) {
                     ConvGemm16sArgs ap = as;
                     ap.ntx = nct; ap.nty = nrb; ap.ntz = S; ap.xcd_items = 2;
                     ap.c.out0.p = cx.gslab;
@@ -1113,7 +1153,7 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                 const int rounds = (nt + cus - 1) / cus;
                 if (nt >= cus && (double)(rounds * cus - nt) <= 0.1 * rounds * cus) {
                     as.ntx = nct; as.nty = nrb; as.ntz = 1; as.xcd_items = 0;
-                    { static const int own = [] { const char *e = getenv("WG_G192_OWN"); return e ? atoi(e) : 0; }(); if (own) as.xcd_items = 1; }   // experiment: column ownership
+                    if (env_sw().g192_own) as.xcd_items = 1;                                   // experiment: column ownership
                     if (so_gate) WG_LAUNCH(cx, convgemm16g_kernel<EPI_GATE_SO>, dim3(cus), dim3(512), 0, as);
                     else if (fo_g) WG_LAUNCH(cx, convgemm16g_kernel<EPI_STORE_FO>, dim3(cus), dim3(512), 0, as);
                     else WG_LAUNCH(cx, convgemm16g_kernel<EPI_STORE_SO>, dim3(cus), dim3(512), 0, as);
@@ -1672,8 +1712,7 @@ bool run_convlayer(Ctx &cx, float *ws, size_t lsync, FA &&gate_call, FB &&wo_cal
         // identical, and no faster than the two launches it replaces -- 2.72 against 2.65-2.76 ms per 0.7 s utterance, 95.7 against 95.8 ms
         // for WaveFlow's row-by-row synthesis: the in-launch hand-off (write-through drain, arrival, poll, first sc1 loads) costs what
         // the kernel boundary did.  Kept for the test that pins it and as the starting point should the hand-off get cheaper.
-        const char *e = getenv("WG_LAYER_FUSION");
-        if (!e || e[0] != '1') return false;
+        if (!env_sw().layer_fusion) return false;
     }
     StageRec rec;
     cx.rec = &rec;
@@ -1718,8 +1757,7 @@ bool run_convlayer_big(Ctx &cx, float *ws, size_t lsync, FA &&gate_call, FB &&re
         // parity identical, 166-169 us per layer against 117.7 + 34.8 = 152.5 us for the two launches (step 65.9 against 64.3 ms).  The R tiles
         // cost 42 us of the launch -- twice their share of chunks: an 8-chunk tile is half overhead (the accumulate-into tile's round trip,
         // the epilogue, the poll), exactly as in the stand-alone residual launch -- and the G tiles run 8 % slower in the two-shape loop.
-        const char *e = getenv("WG_LAYER_FUSION_BIG");
-        if (!e || e[0] != '1') return false;
+        if (!env_sw().layer_fusion_big) return false;
     }
     BigCap cg, cr;
     cg.ok = cr.ok = false;
@@ -1768,10 +1806,8 @@ bool run_convlayer_g(Ctx &cx, FA &&gate_call, FB &&res_call)
 #if defined(WG_OPT_NO_G192) || defined(WG_OPT_NO_LAYERG)
     return false;
 #else
-    {   // (read per call: tests switch it inside one process; WG_LAYER_FUSION_BIG=1 asks for the older one-launch layer instead)
-        const char *e = getenv("WG_LAYER_G"), *big = getenv("WG_LAYER_FUSION_BIG");
-        if ((e && e[0] == '0') || (big && big[0] == '1')) return false;
-    }
+    // (WG_LAYER_FUSION_BIG=1 asks for the older one-launch layer instead)
+    if (!env_sw().layer_g || env_sw().layer_fusion_big) return false;
     if (!g192_on() || cx.prec != 2 || cx.rec || cx.cap || cx.err) return false;
     BigCap cg, cr;
     cg.ok = cr.ok = false;
@@ -1822,8 +1858,10 @@ bool run_convlayer_g(Ctx &cx, FA &&gate_call, FB &&res_call)
 // every forward / inverse call paid a 64 KB memset for counters nobody reads)
 void layer_sync_clear(Ctx &cx, float *ws, size_t lsync)
 {
-    const char *e0 = getenv("WG_LAYER_FUSION"), *e1 = getenv("WG_LAYER_FUSION_BIG");
-    if (!((e0 && e0[0] == '1') || (e1 && e1[0] == '1'))) return;
+    // the hand-off counters of the opt-in one-launch layers: cleared whenever a call may use them.  (A call that ended in an error left them
+    // wherever it stopped; the next call clears them here before anything reads them -- and a process that switched the opt-in off in
+    // between does not read them at all.)
+    if (!(env_sw().layer_fusion || env_sw().layer_fusion_big)) return;
     if (cx.prec == 2 && !cx.err && hipMemsetAsync(ws + lsync, 0, WGL_SYNC_WORDS * sizeof(unsigned), cx.st) != hipSuccess) cx.err = WG_ELAUNCH;
 }
 
@@ -1956,8 +1994,7 @@ void run_end_affine(Ctx &cx, const WnRun &r, int mode, PRef dX, float *log_s_out
 // `nxt` is the next WN's run (its X already re-based); returns false where the shapes are outside the seam kernel's.
 bool run_inv_seam(Ctx &cx, const WnRun &r, const float *Winv, float *partial, const WnRun &nxt)
 {
-    const char *e = getenv("WG_INV_SEAM");
-    if (!(e && e[0] == '1')) return false;
+    if (!env_sw().inv_seam) return false;
     const WnD &d = r.d, &n = nxt.d;
     const Geo &g = r.g;
     const int rel = nxt.X.ch0 - r.X.ch0;
@@ -2438,6 +2475,7 @@ const char *wg_strerror(int code)
     return "unknown error";
 }
 int wg_abi_version(void) { return WG_ABI_VERSION; }
+void wg_reload_env(void) { g_env.store(env_load(), std::memory_order_release); }
 
 #if defined(WG_DBG_TRACE)
 int wg_dbg_trace_read(unsigned long long *out, int n)
@@ -2453,6 +2491,7 @@ long long wg_stat_wgrad16t_launches(void) { return g_wgrad16t_launches.load(std:
 long long wg_stat_layer_launches(void) { return g_layer_launches.load(std::memory_order_relaxed) + g_layerq_launches.load(std::memory_order_relaxed); }
 long long wg_stat_layerg_launches(void) { return g_layerg_launches.load(std::memory_order_relaxed); }
 long long wg_stat_gate_split_launches(void) { return g_gate_split_launches.load(std::memory_order_relaxed); }
+long long wg_stat_gate_rem_launches(void) { return g_gate_rem_launches.load(std::memory_order_relaxed); }
 void *wg_timer_create(int kernel_id, int capacity)
 {
     if (capacity < 1) return nullptr;
@@ -2521,24 +2560,36 @@ int wg_box_probe(void *scratch, int ms, double *out, void *stream)
     u32x4 *rnd = (u32x4 *)base;
     float *res = (float *)(base + (size_t)65536 * 16);
     unsigned long long *stamps = (unsigned long long *)(base + (size_t)65536 * 16 + (size_t)256 * 512 * 4);
+    struct Events {                                           // destroyed on every way out
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        bool ok() { return hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess; }
+        ~Events() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+    } ev;
+    if (!ev.ok()) return WG_ELAUNCH;
+    // (the clock stamps start from zero: after a launch that failed they must not read as a clock)
+    if (hipMemsetAsync(stamps, 0, 512 * sizeof(unsigned long long), st) != hipSuccess) return WG_ELAUNCH;
     hipLaunchKernelGGL(box_fill_kernel, dim3(256), dim3(256), 0, st, rnd);
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return WG_ELAUNCH;
+    if (hipGetLastError() != hipSuccess) return WG_ELAUNCH;
     float one = 0.f, last = 0.f;
-    (void)hipEventRecord(e0, st);
+    (void)hipEventRecord(ev.e0, st);
     hipLaunchKernelGGL(box_probe_kernel, dim3(256), dim3(512), 0, st, rnd, res, stamps);
-    (void)hipEventRecord(e1, st);
-    if (hipStreamSynchronize(st) != hipSuccess || hipEventElapsedTime(&one, e0, e1) != hipSuccess) return WG_ELAUNCH;
+    if (hipGetLastError() != hipSuccess) return WG_ELAUNCH;
+    (void)hipEventRecord(ev.e1, st);
+    if (hipStreamSynchronize(st) != hipSuccess || hipEventElapsedTime(&one, ev.e0, ev.e1) != hipSuccess) return WG_ELAUNCH;
     const int batch = 8, rounds = std::max(1, (int)((double)ms / (std::max(one, 0.05f) * batch)));
     for (int r = 0; r < rounds; ++r) {
-        (void)hipEventRecord(e0, st);
-        for (int i = 0; i < batch; ++i) hipLaunchKernelGGL(box_probe_kernel, dim3(256), dim3(512), 0, st, rnd, res, stamps);
-        (void)hipEventRecord(e1, st);
-        if (hipStreamSynchronize(st) != hipSuccess || hipEventElapsedTime(&last, e0, e1) != hipSuccess) return WG_ELAUNCH;
+        (void)hipEventRecord(ev.e0, st);
+        for (int i = 0; i < batch; ++i) {
+            hipLaunchKernelGGL(box_probe_kernel, dim3(256), dim3(512), 0, st, rnd, res, stamps);
+            if (hipGetLastError() != hipSuccess) return WG_ELAUNCH;
+        }
+        (void)hipEventRecord(ev.e1, st);
+        if (hipStreamSynchronize(st) != hipSuccess || hipEventElapsedTime(&last, ev.e0, ev.e1) != hipSuccess) return WG_ELAUNCH;
     }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     std::vector<unsigned long long> h(512);
-    if (hipMemcpy(h.data(), stamps, 512 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return WG_ELAUNCH;
+    if (hipMemcpyAsync(h.data(), stamps, 512 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return WG_ELAUNCH;
     std::vector<double> ghz;
     for (int b = 0; b < 256; ++b) ghz.push_back(h[2 * b + 1] ? (double)h[2 * b] / (double)h[2 * b + 1] / 10.0 : 0.0);
     std::sort(ghz.begin(), ghz.end());

@@ -27,3 +27,14 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _library_rereads_its_switches(request):
+    """The library reads its developer switches (WG_LAYER_G, WG_G192_SPLITK, ...) from the environment once per process and again
+    when asked (include/wgflow.h wg_reload_env).  A test that set one with monkeypatch has had it restored by now: start every GPU test
+    from the environment as it stands."""
+    if "gpu" in request.keywords:
+        import constant_memory_waveglow_amd as pkg
+        pkg._lib.lib().wg_reload_env()
+    yield

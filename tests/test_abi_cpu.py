@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(L, s), "libwgflow.so lacks %s" % s
     assert sorted(_lib.ABI_SYMBOLS) == declared
-    assert L.wg_abi_version() == _lib.ABI_VERSION == 8
+    assert L.wg_abi_version() == _lib.ABI_VERSION == 9
     header = open(os.path.join(ROOT, "include", "wgflow.h")).read()
     assert "#define WG_ABI_VERSION %d" % _lib.ABI_VERSION in header
     # the ctypes mirror of wg_config has exactly the fields the header declares, in order

@@ -105,6 +105,7 @@ def test_launch_site_names_match_rocprof_names_by_prefix(tmp_path, monkeypatch):
     (prof / "r09a_hbm_traffic.json").write_text(json.dumps({"kernels": {
         "void convgemm16q_kernel<5, 2, 2, false, false>(ConvGemm16sArgs)": {"hbm_bytes_per_launch": 2.0e8},
         "void convgemm16q_kernel<5, 2, 1, false, false>(ConvGemm16sArgs)": {"hbm_bytes_per_launch": 9.0e8},
+        "void convgemm16q_kernel<5, 2, 2, false, true>(ConvGemm16sArgs)": {"hbm_bytes_per_launch": 7.0e8},
         "void convgemm16g_kernel<5>(ConvGemm16sArgs)": {"hbm_bytes_per_launch": 1.9e8},
         "convlayer16g_kernel": {"hbm_bytes_per_launch": 4.1e8}}}))
     (prof / "r09a_wsr_hbm_traffic.json").write_text(json.dumps({"kernels": {
@@ -116,6 +117,10 @@ def test_launch_site_names_match_rocprof_names_by_prefix(tmp_path, monkeypatch):
     assert t == 2.0e8 and src.endswith("r09a_hbm_traffic.json") and full.startswith("convgemm16q_kernel<5, 2, 2, false, false>")
     t, src, full = bench._traffic("convgemm16g_kernel<5")
     assert t == 1.9e8 and full == "convgemm16g_kernel<5>(ConvGemm16sArgs)"
+    # (the site that leaves out `false, false` must not be served the `false, true` instantiation's bytes, whichever comes last)
+    assert bench.full_instantiation("convgemm16q_kernel<5, 2, 2") == "convgemm16q_kernel<5, 2, 2, false, false>"
+    assert bench.full_instantiation("convgemm16q_kernel<5, 2") == "convgemm16q_kernel<5, 2, 1, false, false>"
+    assert bench._traffic("convgemm16q_kernel<5, 2, 2, false, true")[0] == 7.0e8
     assert bench._traffic("convlayer16g_kernel")[0] == 4.1e8                # (no template arguments: the whole name)
     assert bench._traffic("convgemm16q_kernel<1, 2, 2")[0] is None        # (a kernel no committed summary holds: nothing is cited)
     assert bench._traffic("convgemm16q_kernel<5, 1, 1", "_wsr_")[0] == 3.0e8

@@ -425,6 +425,7 @@ def test_one_launch_layer_vs_two_launches(dev, precision, monkeypatch, name):
     res = {}
     for fused in ("1", "0"):
         monkeypatch.setenv("WG_LAYER_FUSION", fused)
+        _lib.lib().wg_reload_env()
         before = _lib.lib().wg_stat_layer_launches()
         runs = []
         with torch.no_grad():
@@ -467,6 +468,7 @@ def test_layer_launch_of_the_training_shapes_vs_two_launches(dev, precision, mon
     res = {}
     for fused in ("1", "0"):
         monkeypatch.setenv("WG_LAYER_FUSION_BIG", fused)
+        _lib.lib().wg_reload_env()
         before = _lib.lib().wg_stat_layer_launches()
         runs = []
         for rep in range(3):
@@ -877,6 +879,7 @@ def test_layer_as_one_launch_on_flattened_tiles_vs_two_launches(dev, precision, 
     res = {}
     for fused in ("1", "0"):
         monkeypatch.setenv("WG_LAYER_G", fused)
+        _lib.lib().wg_reload_env()
         before = _lib.lib().wg_stat_layerg_launches()
         runs = []
         for rep in range(2):
@@ -908,6 +911,7 @@ def test_inverse_seam_launch_vs_three_launches(dev, precision, monkeypatch):
         out = {}
         for sw in ("1", "0"):
             monkeypatch.setenv("WG_INV_SEAM", sw)
+            _lib.lib().wg_reload_env()
             with torch.no_grad():
                 out[sw] = m.reverse(z.clone(), h)
         assert torch.equal(out["1"][0], out["0"][0])
@@ -1327,14 +1331,17 @@ SWEEP = [
     dict(flows=2, n_group=8, n_early_every=4, n_early_size=2, hop_size=64, n_mels=20, ch=(64, 64, 64), depth=2, radix=1, B=2, F=4),
     # 37 time tiles x 7 items: 518 tiles (128x128 gate conv, 128x64 elsewhere) for 512 persistent workgroups -> some walk two tiles
     dict(flows=1, n_group=8, n_early_every=4, n_early_size=2, hop_size=64, n_mels=20, ch=(128, 128, 128), depth=2, radix=3, B=7, F=592),
+    # the architecture behind the one speed the reference publishes (configs/musicnet_config.json:7-20, README.md:64-67): 18 flows, early
+    # outputs every 6, WN depth 4, hop 512 (an upsampler of stride 64, 129 taps); bench.py's `inverse_khz_musicnet_*` leg times it
+    dict(flows=18, n_group=8, n_early_every=6, n_early_size=2, hop_size=512, n_mels=80, ch=(256, 256, 256), depth=4, radix=3, B=1, F=6),
 ]
 
 
 @pytest.mark.parametrize("case", range(len(SWEEP)))
 def test_shape_sweep_vs_oracle(dev, case):
     """Odd channel mixes (dilation != residual != skip), depth 1 and 9 (dilation 256 > T), n_group 4..32, early outputs every flow,
-    radix 1, a time axis shorter than one tile and one that is not a multiple of it, batch 1..7, and a launch with a few more tiles
-    than persistent workgroups."""
+    radix 1, a time axis shorter than one tile and one that is not a multiple of it, batch 1..7, a launch with a few more tiles
+    than persistent workgroups, and the reference's musicnet architecture (18 flows of depth 4, hop 512)."""
     c = SWEEP[case]
     cfg = dict(flows=c["flows"], n_group=c["n_group"], n_early_every=c["n_early_every"], n_early_size=c["n_early_size"],
                hop_size=c["hop_size"], n_mels=c["n_mels"], dilation_channels=c["ch"][0], residual_channels=c["ch"][1],
@@ -1639,6 +1646,7 @@ def test_wsrglow_gate_conv_cut_along_k_vs_uncut(dev, precision, monkeypatch):
     res = {}
     for cut in ("1", "0"):
         monkeypatch.setenv("WG_G192_SPLITK", cut)
+        _lib.lib().wg_reload_env()
         before = _lib.lib().wg_stat_gate_split_launches()
         runs = []
         for rep in range(2):
