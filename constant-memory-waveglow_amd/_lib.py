@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "wg_stat_layer_launches", "wg_layer_workspace_bytes", "wg_layer_apply", "wg_wf_wn_apply",
     "wg_timer_read_name", "wg_box_probe_bytes", "wg_box_probe", "wg_stat_layerg_launches", "wg_stat_gate_split_launches",
     "wg_wf_wn_backward", "wg_layer_backward_workspace_bytes", "wg_layer_backward", "wg_affine_apply", "wg_affine_backward",
-    "wg_reload_env", "wg_stat_gate_rem_launches",
+    "wg_reload_env", "wg_stat_gate_rem_launches", "wg_wsr_cond_pre",
 ]
 K_CONV_STORE, K_CONV_GATE, K_CONV_RESSKIP, K_CONV_DGATE, K_WGRAD, K_LAYER = range(6)
 
@@ -115,6 +115,7 @@ def lib():
     L.wg_wn_apply.argtypes = [wnp, vp, vp, vp, i, i, vp, vp, vp, sz, vp]
     L.wg_wsr_cond.argtypes = [vp, i, i, vp, vp, vp, vp]
     L.wg_wsr_cond_backward.argtypes = [vp, i, i, vp, vp, vp, vp]
+    L.wg_wsr_cond_pre.argtypes = [vp, i, i, vp, vp, vp]
     L.wg_adam_step.argtypes = [vp, vp, vp, vp, sz, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, i, vp]
     wfp = C.POINTER(WgWfConfig)
     L.wg_wf_param_count.argtypes = [wfp]

@@ -26,19 +26,20 @@
 
 __device__ __forceinline__ float wsr_clip(float x) { return fminf(fmaxf(x, -1.f), 1.f); }
 
-// torchaudio.functional.mu_law_encoding with 256 channels, float32 step by step
-__device__ __forceinline__ int wsr_mu_index(float x)
+// torchaudio.functional.mu_law_encoding with 256 channels, float32 step by step.  The value that is truncated is a function of its own
+// (wsr_mu_pre / wsr_angle_pre): wg_wsr_cond_pre hands exactly these to a test, which can then tell a decision that fell on the other
+// side of a bin edge within float noise from an indexing bug.
+__device__ __forceinline__ float wsr_mu_pre(float x)
 {
     const float mu = 255.f;
     const float sgn = (float)((x > 0.f) - (x < 0.f));
     const float x_mu = sgn * log1pf(mu * fabsf(x)) / log1pf(mu);
-    return (int)((x_mu + 1.f) / 2.f * mu + 0.5f);
+    return (x_mu + 1.f) / 2.f * mu + 0.5f;
 }
+__device__ __forceinline__ int wsr_mu_index(float x) { return (int)wsr_mu_pre(x); }
 // AngleEmbedding.forward (wsrglow.py:16-17): ((angle / pi + 1) * 0.5 * (embed_num - 1)).long()
-__device__ __forceinline__ int wsr_angle_index(float ang)
-{
-    return (int)((ang / 3.14159274101257324f + 1.f) * 0.5f * (float)(WSR_ANG - 1));
-}
+__device__ __forceinline__ float wsr_angle_pre(float ang) { return (ang / 3.14159274101257324f + 1.f) * 0.5f * (float)(WSR_ANG - 1); }
+__device__ __forceinline__ int wsr_angle_index(float ang) { return (int)wsr_angle_pre(ang); }
 __device__ __forceinline__ float wsr_padded(const float *c, int L, int i)
 {
     int j = i - 4;
@@ -118,6 +119,25 @@ __global__ __launch_bounds__(256) void wsr_cond_kernel(const float *c, int L, co
             v = ang_w[(int)s_ang[k][tx] * WSR_ANG_DIM + e];
         }
         ob[(size_t)ch * F] = v;
+    }
+}
+
+// Diagnostics (wg_wsr_cond_pre): the two quantisers' values BEFORE truncation, computed by the very functions wsr_cond_kernel truncates:
+// mu_pre[b][i] for every low-rate sample, ang_pre[b][k][f] for every STFT bin.  One thread per frame.
+__global__ __launch_bounds__(256) void wsr_cond_pre_kernel(const float *c, int L, float *mu_pre, float *ang_pre)
+{
+    const int F = L >> 3, b = blockIdx.y, f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    const float *cb = c + (size_t)b * L;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mu_pre[(size_t)b * L + 8 * f + j] = wsr_mu_pre(wsr_clip(cb[8 * f + j]));
+    float x[16];
+    wsr_window(cb, L, f, x);
+#pragma unroll
+    for (int k = 0; k < WSR_BINS; ++k) {
+        float re, im;
+        wsr_bin(x, k, re, im);
+        ang_pre[((size_t)b * WSR_BINS + k) * F + f] = wsr_angle_pre(atan2f(im, re));
     }
 }
 

@@ -3450,6 +3450,15 @@ int wg_wsr_cond(const float *c, int B, int L, const float *mu_table, const float
     return cx.err;
 }
 
+int wg_wsr_cond_pre(const float *c, int B, int L, float *mu_pre, float *ang_pre, void *stream)
+{
+    if (!c || !mu_pre || !ang_pre || B < 1 || L < 8) return WG_EINVAL;
+    if (L % 8) return WG_ESHAPE;
+    Ctx cx = {(hipStream_t)stream, 0, 0};
+    WG_LAUNCH(cx, wsr_cond_pre_kernel, dim3((L / 8 + 255) / 256, B), dim3(256), 0, c, L, mu_pre, ang_pre);
+    return cx.err;
+}
+
 int wg_wsr_cond_backward(const float *c, int B, int L, const float *dcond, float *dmu_table, float *dang_table, void *stream)
 {
     if (!c || !dcond || !dmu_table || !dang_table || B < 1 || L < 8) return WG_EINVAL;

@@ -112,8 +112,10 @@ class _GenericCoupling(Function):
         xa, xb = x[:, :ic].contiguous(), x[:, ic:].contiguous()
         with torch.no_grad():
             log_s, t = block.F(xa, y)
-            zb = engine.affine_apply(xb, log_s, t, reverse)
-            z = torch.cat((xa, zb), 1)
+            # (a transform under autocast may return half precision: the block's arithmetic is float32, as upstream's custom_fwd leaves it)
+            log_s, t = log_s.float(), t.float()
+            zb = engine.affine_apply(xb.float(), log_s, t, reverse)
+            z = torch.cat((xa.float(), zb), 1)
         ctx.block, ctx.reverse = block, reverse
         ctx.save_for_backward(x.data, y, z)
         return z, (-log_s if reverse else log_s)
@@ -127,16 +129,38 @@ class _GenericCoupling(Function):
         ya = y.detach().requires_grad_(True) if ctx.needs_input_grad[1] else y.detach()
         with torch.enable_grad():
             log_s, t = F(za, ya)                                                       # recompute :127-130 / :189-192
-        rebuilt, g_ls, g_t, din = engine.affine_backward(z[:, ic:], log_s.detach(), t.detach(), dz[:, ic:], dlog_s, reverse)
+        rebuilt, g_ls, g_t, din = engine.affine_backward(z[:, ic:], log_s.detach().float(), t.detach().float(), dz[:, ic:].float(),
+                                                         None if dlog_s is None else dlog_s.float(), reverse)
         with torch.no_grad():
             torch.cat((za.detach(), rebuilt), 1, out=_rematerialise(x, z))             # the freed input, in place (:135-136 / :197-198)
         plist = [p for p in F.parameters() if p.requires_grad]
         inputs = [za] + plist + ([ya] if ctx.needs_input_grad[1] else [])
-        grads = torch.autograd.grad([log_s, t], inputs, [g_ls, g_t], allow_unused=True)  # :140-144 / :200-204
+        grads = torch.autograd.grad([log_s, t], inputs, [g_ls.to(log_s.dtype), g_t.to(t.dtype)], allow_unused=True)  # :140-144 / :200-204
         da = dz[:, :ic] + (grads[0] if grads[0] is not None else 0)
         dy = grads[-1] if ctx.needs_input_grad[1] else None
         by_id = {id(p): g for p, g in zip(plist, grads[1:1 + len(plist)])}
         return (torch.cat((da, din), 1), dy, None, None) + tuple(by_id.get(id(p)) for p in F.parameters())
+
+
+class _AffineMap(Function):
+    """The affine map of a coupling block on its own, for a block that keeps its graph (memory_efficient=False with a transform that is
+    not this package's WN): (half, log_s, t) -> (half * exp(log_s) + t, log_s), or reversed ((half - t) / exp(log_s), -log_s)
+    (efficient_modules.py:77-82 / :91-96).  Same kernels as _GenericCoupling (wg_affine_apply / wg_affine_backward); nothing is freed,
+    nothing is written in place -- upstream runs this case under plain autograd and never touches the caller's x."""
+
+    @staticmethod
+    def forward(ctx, half, log_s, t, reverse):
+        half, log_s, t = half.float(), log_s.float(), t.float()
+        out = engine.affine_apply(half, log_s, t, reverse)
+        ctx.reverse = reverse
+        ctx.save_for_backward(out, log_s, t)
+        return out, (-log_s if reverse else log_s)
+
+    @staticmethod
+    def backward(ctx, dout, dret):
+        out, log_s, t = ctx.saved_tensors
+        _, g_ls, g_t, din = engine.affine_backward(out, log_s, t, dout.float(), None if dret is None else dret.float(), ctx.reverse)
+        return din, g_ls, g_t, None
 
 
 class AffineCouplingBlock(Reversible):
@@ -154,6 +178,13 @@ class AffineCouplingBlock(Reversible):
             self._engine = engine.CouplingEngine(WgWnDims(*self.F.hip_dims(), _default_precision(), int(getattr(self.F, "has_bias", False))))
 
     def _run(self, x: Tensor, y: Tensor, reverse: bool) -> Tuple[Tensor, Tensor]:
+        if self._fn is _GenericCoupling and not self._memory_efficient:
+            # the graph is kept, as upstream :77-82 / :91-96: the transform under plain autograd, the map as its own node, x left alone
+            ic = x.size(1) // 2
+            xa, xb = x[:, :ic], x[:, ic:]
+            log_s, t = self.F(xa, y)
+            zb, ret = _AffineMap.apply(xb.contiguous(), log_s, t, reverse)
+            return torch.cat((xa.to(zb.dtype), zb), 1), ret
         z, log_s = self._fn.apply(x, y, self, reverse, *self.F.parameters())
         if self._memory_efficient:
             _free(x)

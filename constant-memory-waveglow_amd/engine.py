@@ -582,6 +582,18 @@ def wsr_cond(c, mu_table, ang_table):
 
 
 @on_device
+def wsr_cond_pre(c):
+    """Diagnostics (wg_wsr_cond_pre): the quantisers' float32 values before truncation -> (mu_pre[B,L], ang_pre[B,9,L/8])."""
+    require_device(c)
+    c = c.contiguous()
+    B, L = c.shape
+    mu_pre = torch.empty(B, L, dtype=torch.float32, device=c.device)
+    ang_pre = torch.empty(B, 9, L // 8, dtype=torch.float32, device=c.device)
+    check(_lib.lib().wg_wsr_cond_pre(_p(c), B, L, _p(mu_pre), _p(ang_pre), _stream()), "wg_wsr_cond_pre")
+    return mu_pre, ang_pre
+
+
+@on_device
 def wsr_cond_backward(c, dcond, out=None):
     """-> (d mu_table [256,400], d ang_table [120,50]) from dcond[B,3659,L/8]; out: optional pair of contiguous tensors to fill."""
     require_device(c, dcond)

@@ -84,7 +84,7 @@ const char *wg_strerror(int code);
  * layer's hand-off counters, wg_layer_apply / wg_layer_workspace_bytes, wg_wf_wn_apply; 7: wg_wf_config gained bias; 8: wg_timer_read_name,
  * wg_box_probe / wg_box_probe_bytes, wg_stat_layerg_launches, wg_stat_gate_split_launches,
  * wg_wf_wn_backward, wg_layer_backward / wg_layer_backward_workspace_bytes, wg_affine_apply / wg_affine_backward; 9: wg_reload_env,
- * wg_stat_gate_rem_launches).  A binding built against another revision must not pass its
+ * wg_stat_gate_rem_launches, wg_wsr_cond_pre).  A binding built against another revision must not pass its
  * structs: the Python loader compares this with its own ABI_VERSION and refuses the library otherwise. */
 #define WG_ABI_VERSION 9
 int wg_abi_version(void);
@@ -255,6 +255,10 @@ int wg_upsample(const wg_config *cfg, const void *packed, const float *h, int B,
  * the Python mirror does that).  The result feeds wg_forward / wg_inverse as `h` of a WaveGlow with n_mels = 3659. */
 #define WG_WSR_COND_CHANNELS 3659
 int wg_wsr_cond(const float *c, int B, int L, const float *mu_table, const float *ang_table, float *cond, void *stream);
+/* Diagnostics: the two quantisers' float32 values BEFORE truncation, from the functions wg_wsr_cond truncates: mu_pre[B][L] (the mu-law
+ * value (x_mu + 1) / 2 * 255 + 0.5 of every clipped low-rate sample, wsrglow.py:39) and ang_pre[B][9][L/8] ((angle / pi + 1) * 0.5 * 119 of
+ * every STFT bin, wsrglow.py:15-18).  A parity test uses them to forgive ONLY decisions that sit within float noise of a bin edge. */
+int wg_wsr_cond_pre(const float *c, int B, int L, float *mu_pre, float *ang_pre, void *stream);
 /* Its backward: the two nn.Embedding weight gradients from dcond[B,3659,L/8] (c has no gradient path: wsrglow.py:39,48 go
  * through integer indices, :47 has no parameters).  Outputs are overwritten. */
 int wg_wsr_cond_backward(const float *c, int B, int L, const float *dcond, float *dmu_table, float *dang_table, void *stream);

@@ -733,15 +733,17 @@ class _TinyTransform(torch.nn.Module):
         return 0.5 * torch.tanh(ls), t
 
 
+@pytest.mark.parametrize("mem_eff", [True, False])
 @pytest.mark.parametrize("rev", [False, True])
-def test_coupling_block_with_any_transform_vs_plain_autograd(dev, rev):
+def test_coupling_block_with_any_transform_vs_plain_autograd(dev, rev, mem_eff):
     """AffineCouplingBlock takes any `transform_type` upstream (model/efficient_modules.py:58-62).  With a transform that is not this
     package's WN the module runs as it is and the block's own arithmetic goes through wg_affine_apply / wg_affine_backward
     (efficient_modules._GenericCoupling): outputs, the freed-and-rebuilt input and every gradient against the plain composition
-    `zb = xb * exp(log_s) + t` (or its inverse) under torch autograd, both directions."""
+    `zb = xb * exp(log_s) + t` (or its inverse) under torch autograd, both directions.  memory_efficient=False keeps the graph as
+    upstream :77-82 / :91-96 does: the caller's x is neither freed nor rewritten (efficient_modules._AffineMap)."""
     ic, aux, B, Tn = 3, 10, 2, 157
     torch.manual_seed(3)
-    blk = cm.AffineCouplingBlock(_TinyTransform, True, in_channels=ic, aux_channels=aux).to(dev)
+    blk = cm.AffineCouplingBlock(_TinyTransform, mem_eff, in_channels=ic, aux_channels=aux).to(dev)
     x = T(fill.uniform("anyF/x", (B, 2 * ic, Tn)), dev)
     y = T(fill.normal("anyF/y", (B, aux, Tn)), dev)
     gz, gls = T(fill.normal("anyF/gz", (B, 2 * ic, Tn)), dev), T(fill.normal("anyF/gls", (B, ic, Tn)), dev)
@@ -759,13 +761,40 @@ def test_coupling_block_with_any_transform_vs_plain_autograd(dev, rev):
     xt, yt = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
     xin = xt.clone()
     z, lo = blk.reverse(xin, yt) if rev else blk(xin, yt)
-    assert xin.untyped_storage().size() == 0                                    # memory_efficient: the input was freed (:75 / :88)
+    if mem_eff:
+        assert xin.untyped_storage().size() == 0                                # memory_efficient: the input was freed (:75 / :88)
+    else:
+        keep = xin.detach().clone()
     ((z * gz).sum() + (lo * gls).sum()).backward()
-    assert xin.untyped_storage().size() > 0 and float((xin - x).abs().max()) < 1e-5      # ... and rebuilt in place by the backward
+    if mem_eff:
+        assert xin.untyped_storage().size() > 0 and float((xin - x).abs().max()) < 1e-5      # ... and rebuilt in place by the backward
+    else:
+        assert torch.equal(xin.detach(), keep)                                  # the caller's live input: never written
     assert float((z - zr).abs().max()) < 1e-5 and float((lo - lsr).abs().max()) < 1e-6
     assert relmax(npy(xt.grad), npy(xr.grad)) < 1e-5 and relmax(npy(yt.grad), npy(yr.grad)) < 1e-5
     for n, p in blk.F.named_parameters():
         assert relmax(npy(p.grad), npy(want[n])) < 1e-5, n
+
+
+@pytest.mark.parametrize("mem_eff", [True, False])
+def test_coupling_block_with_any_transform_under_autocast(dev, mem_eff):
+    """A transform that returns half-precision (log_s, t) -- any module under torch.autocast -- must not make the block's own float32
+    arithmetic refuse them (upstream wraps its Functions in custom_fwd / custom_bwd, efficient_modules.py:101,117): outputs are float32
+    and close to the float32 run, and a backward goes through."""
+    ic, aux, B, Tn = 3, 10, 2, 96
+    torch.manual_seed(4)
+    blk = cm.AffineCouplingBlock(_TinyTransform, mem_eff, in_channels=ic, aux_channels=aux).to(dev)
+    x = T(fill.uniform("acF/x", (B, 2 * ic, Tn)), dev)
+    y = T(fill.normal("acF/y", (B, aux, Tn)), dev)
+    z32, ls32 = blk(x.clone(), y)
+    xt = x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.float16):
+        z, ls = blk(xt.clone(), y)
+    assert z.dtype == torch.float32 and ls.dtype == torch.float32
+    assert float((z - z32).abs().max()) < 2e-2 and float((ls - ls32).abs().max()) < 2e-2
+    (z.sum() + ls.sum()).backward()
+    assert xt.grad is not None and bool(torch.isfinite(xt.grad).all())
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in blk.F.parameters())
 
 
 def test_coupling_block_on_shared_b_tiles_vs_oracle(dev, precision):
@@ -1200,6 +1229,23 @@ def test_wsrglow_timed_workload_vs_reference_golden(dev, golden_dir, precision, 
     ref_ang = ang_t[gold["ang_idx"].astype(np.int64)].transpose(0, 1, 3, 2).reshape(B, 450, Fr)
     bad_mu, bad_ang = np.argwhere((cond[:, :3200] != ref_mu).any(1)), np.argwhere((cond[:, 3209:] != ref_ang).any(1))
     assert len(bad_mu) + len(bad_ang) <= 2, (bad_mu.tolist(), bad_ang.tolist())
+    # only a genuine tie is forgiven: at every differing decision the value the GPU truncates (wg_wsr_cond_pre: the functions
+    # wsr_cond_kernel itself truncates) must sit within 1e-4 of an integer -- a bin edge -- and the two decisions must be the two sides of it
+    mu_pre, ang_pre = (npy(t) for t in engine.wsr_cond_pre(T(np.clip(c, -1.0, 1.0), dev)))
+    for b, f in bad_mu:
+        for s_ in range(8):
+            ref_i, pre = int(gold["mu_idx"][b, 8 * f + s_]), float(mu_pre[b, 8 * f + s_])
+            if int(np.floor(pre)) != ref_i:
+                assert abs(pre - round(pre)) < 1e-4 and abs(int(np.floor(pre)) - ref_i) == 1, (b, f, s_, pre, ref_i)
+    for b, f in bad_ang:
+        for k in range(9):
+            ref_i, pre = int(gold["ang_idx"][b, k, f]), float(ang_pre[b, k, f])
+            if int(pre) != ref_i:
+                assert abs(pre - round(pre)) < 1e-4 and abs(int(pre) - ref_i) == 1, (b, k, f, pre, ref_i)
+    # and the debug output is what the kernel used: truncating it reproduces the kernel's own choice of table row everywhere
+    mu_rows = np.floor(mu_pre).astype(np.int64).reshape(B, Fr, 8)
+    assert np.array_equal(cond[:, :3200].reshape(B, 8, 400, Fr), mu_t[mu_rows].transpose(0, 2, 3, 1))
+    assert np.array_equal(cond[:, 3209:].reshape(B, 9, 50, Fr), ang_t[ang_pre.astype(np.int64)].transpose(0, 1, 3, 2))
     skip_rows = {"mu_enc.1.weight": set(), "angle_embed.embed.weight": set()}
     for b, f in bad_mu:
         for s_ in range(8):
