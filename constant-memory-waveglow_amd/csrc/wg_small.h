@@ -213,6 +213,12 @@ struct AffineArgs {
     int n_ldw, n_C, n_ic, n_rel;
     PRef nH;                // next WN's h_0, fp32 plane (p == nullptr: none)
     SRef nHS;               // ... and its S-plane
+    // FROMG instantiation: out = sum_l Weff_l gate_l straight from the layers' gate S-planes -- Weff_l = W_end Wskip_l (2 ic x Cd per layer:
+    // weff_kernel below), endT = Weff^T stacked along K, [nl * Cd][32] -- instead of W_end (sum_l Wskip_l gate_l): the 256-row skip sum
+    // exists only to be contracted to these 2 ic rows again (model/waveglow.py:104-105), so it is neither computed nor read
+    const unsigned short *gS[16];   // hi array of layer l's gate S-plane (Cd channels per item; lo at + g_lo_off)
+    size_t g_lo_off;
+    int Cd, nl;
 };
 
 #define WG_AFF_T 64          // time steps per workgroup
@@ -220,7 +226,7 @@ struct AffineArgs {
 #define WG_AFF_LD 64         // skip-channel loads a lane keeps in flight
 // NR = accumulator rows kept per lane: 8 where 2 * ic <= 8 (WaveGlow: n_group 8), 32 otherwise.  (With 32 accumulators next to the 64
 // loads in flight the kernel needed 250 VGPRs and 41 KB of LDS: two workgroups per CU, 38 us per launch at the training shape.)
-template <int NR, bool SEAM = false>
+template <int NR, bool SEAM = false, bool FROMG = false>
 __global__ __launch_bounds__(256) void end_affine_kernel(const AffineArgs a)
 {
     // out[m][t] = sum_k W_end[m][k] S[k][t] for the 2*ic <= 32 rows of the end conv: far too few rows for a matrix tile to pay, and
@@ -252,6 +258,54 @@ __global__ __launch_bounds__(256) void end_affine_kernel(const AffineArgs a)
 #pragma unroll
         for (int i = 0; i < 8; ++i) pre_x[i] = (wave == 0 && i < 2 * a.ic && t < g.T) ? *paddr(a.X, g, b, i, t) : 0.f;
     }
+    if constexpr (FROMG) {
+        // K = nl * Cd gate channels, 8 per 16-byte unit of an S-plane ([c / 8][p][8] bf16, hi and lo arrays): a lane reads the units of
+        // its time step -- consecutive lanes, consecutive units: 1 KB per wave instruction -- 8 units x (hi, lo) in flight, and rebuilds
+        // gate = hi + lo (the operand the matrix kernels multiply: nothing is lost against the skip sum's own input)
+        const int K = a.Cd * a.nl;
+        const int kq = ((K / 8 + 3) / 4) * 8, k0 = wave * kq, k1 = min(K, k0 + kq);
+        const size_t ti = (size_t)(g.H + min(t, g.Tt - 1)) * 8;
+        const size_t gstride = (size_t)g.P * 8, item = (size_t)b * (a.Cd >> 3) * gstride;
+        float *wl = stage + wave * (WG_AFF_LD * NR);
+        for (int kk = 0; kk < kq; kk += WG_AFF_LD) {                     // (same trip count in every wave: barriers inside)
+            const int k = k0 + kk;
+            u32x4 vh[8], vl[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ku = k + 8 * u;
+                vh[u] = u32x4{0u, 0u, 0u, 0u}; vl[u] = vh[u];
+                if (ku < k1) {
+                    const int l = ku / a.Cd, ch = ku - l * a.Cd;         // (wave uniform: a unit never straddles two layers, Cd % 8 == 0)
+                    const unsigned short *q = a.gS[l] + item + (size_t)(ch >> 3) * gstride + ti;
+                    vh[u] = *reinterpret_cast<const u32x4 *>(q);
+                    vl[u] = *reinterpret_cast<const u32x4 *>(q + a.g_lo_off);
+                }
+            }
+            if (kk) __syncthreads();                                     // the previous block has been consumed
+            for (int i = lane; i < WG_AFF_LD * (NR / 4); i += 64) {      // columns [0, NR) of rows k .. k+63 of endT ([K][32])
+                const int u = i / (NR / 4), q = i - u * (NR / 4);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k + u < k1) v = reinterpret_cast<const float4 *>(a.endT + (size_t)(k + u) * 32)[q];
+                reinterpret_cast<float4 *>(wl)[i] = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const unsigned wh = vh[u][e >> 1], wlo = vl[u][e >> 1];
+                    const float sv = (e & 1) ? __uint_as_float(wh & 0xffff0000u) + __uint_as_float(wlo & 0xffff0000u)
+                                             : __uint_as_float(wh << 16) + __uint_as_float(wlo << 16);
+                    const float4 *w = reinterpret_cast<const float4 *>(wl + (8 * u + e) * NR);      // same address in every lane: LDS broadcast
+#pragma unroll
+                    for (int q = 0; q < NR / 4; ++q) {
+                        const float4 wq = w[q];
+                        acc[4 * q] = fmaf(wq.x, sv, acc[4 * q]);         acc[4 * q + 1] = fmaf(wq.y, sv, acc[4 * q + 1]);
+                        acc[4 * q + 2] = fmaf(wq.z, sv, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(wq.w, sv, acc[4 * q + 3]);
+                    }
+                }
+        }
+    } else
     {
         const int kq = (a.Cs + 3) / 4, k0 = wave * kq, k1 = min(a.Cs, k0 + kq);
         const float *sp = paddr(a.S, g, b, 0, min(t, g.Tt - 1));        // columns in [T, Tt) read the zero padding; beyond Tt is clamped
@@ -684,6 +738,49 @@ __global__ void nll_loss_bwd_kernel(const float *__restrict__ z, int B, int N, f
     if (elementwise_mean) sc /= (float)N;
     if (i < (size_t)B * N) dz[i] = z[i] * inv_sigma2 * sc;
     if (i < (size_t)B) dlogdet[i] = -sc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weff_l = W_end Wskip_l  (2 ic x Cd per layer).  WN ends with out = W_end (sum_l Wskip_l gate_l) (model/waveglow.py:104-105): the skip
+// sum's Cs rows are contracted to 2 ic <= 32 again at once, and so is everything that flows back through it -- dS = W_end^T G has rank
+// 2 ic.  With Weff the engine never forms the skip sum or its gradient:
+//   forward / inverse   out = sum_l Weff_l gate_l                 (end_affine_kernel<.., FROMG>: one pass over the gate planes)
+//   gate backward       Wskip_l^T dS = Weff_l^T G                 (a K segment of 2 ic -> 32 channels instead of Cs; image rows from effN)
+//   weight gradients    dWskip_l = W_end^T P_l,  dW_end = sum_l P_l Wskip_l^T   with  P_l = G gate_l^T  (2 ic x Cd: pgate_kernel, wg_thin.h)
+// One thread per gate channel j of a layer: effT[(l Cd + j)][m] (the [K][32] layout of endT) and effN[l][m][j] (32 rows of Cd floats, the
+// source of the gate backward's image rows), m < 2 ic, zero beyond.  Runs between the row norms and the pack jobs of a weight pack.
+// ------------------------------------------------------------------------------------------------
+struct EffJob {
+    const float *wE;        // end.weight [2 ic][Cs] (plain weight)
+    const float *v;         // W_o.weight_v of the layer, first SKIP row: [Cs][Cd]
+    const float *scale;     // g / |v| of those rows [Cs]
+    float *effT, *effN;     // [Cd][32] rows of the WN's effT ; [32][Cd]
+    int ic2, Cs, Cd;
+};
+#define WG_EFF_JOBS 64
+struct EffArgs {
+    int n;
+    EffJob job[WG_EFF_JOBS];
+};
+__global__ __launch_bounds__(256) void weff_kernel(const EffArgs a)
+{
+    const EffJob j = a.job[blockIdx.y];
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= j.Cd) return;
+    float acc[32];
+#pragma unroll
+    for (int m = 0; m < 32; ++m) acc[m] = 0.f;
+    for (int s = 0; s < j.Cs; ++s) {
+        const float w = j.scale[s] * j.v[(size_t)s * j.Cd + c];          // the effective skip weight, as the pack jobs form it
+#pragma unroll
+        for (int m = 0; m < 32; ++m)
+            if (m < j.ic2) acc[m] = fmaf(j.wE[(size_t)m * j.Cs + s], w, acc[m]);
+    }
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {
+        j.effT[(size_t)c * 32 + m] = acc[m];
+        j.effN[(size_t)m * j.Cd + c] = acc[m];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

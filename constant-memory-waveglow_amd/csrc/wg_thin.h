@@ -339,3 +339,134 @@ __global__ __launch_bounds__(256) void start_fwd_kernel(const StartFwdArgs a)
     *reinterpret_cast<u32x4 *>(a.HS.hi + a.HS.lo_off + i) = l;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The rank-2ic form of the skip path's gradients (wg_small.h, weff_kernel): with G = (d/d log_s, d/d t) the seed of WN's backward
+// (efficient_modules.py:139-144) and dS = W_end^T G,
+//     dWskip_l = sum_{b,t} dS (x) gate_l = W_end^T P_l ,    dW_end = sum_{b,t} G (x) S = sum_l P_l Wskip_l^T ,    P_l = sum_{b,t} G (x) gate_l
+// so ONE pass over the layers' gate planes (what the skip sum of the recompute pass read, without writing a Cs-row plane, and without
+// the 2 x Cs rows dS costs every layer's weight-gradient and gate-backward product) yields every gradient that went through S.
+// pgate_kernel: a wave owns 8 gate channels (one 16-byte unit row of a layer's S-plane) and a range of 64-column blocks; lane = time step:
+// coalesced unit loads (1 KB per wave instruction), G's rows of that block (coalesced fp32 rows, L2-resident: G is 2 ic x B T), 64 sums
+// per lane; at the end a butterfly over the lanes and ONE partial per (range, unit row).  thin_fold_kernel adds the ranges in a fixed order.
+// ------------------------------------------------------------------------------------------------
+struct PGateArgs {
+    const unsigned short *gS[16];  // hi array of layer l's gate S-plane (Cd channels per item)
+    size_t g_lo_off;
+    PRef G;                        // fp32 plane, rows [0, ic2)
+    int Cd, nl, ic2, mrows;        // mrows = ic2 rounded up to 8: rows of P per layer
+    Geo g;
+    int nblk, per;                 // 64-column blocks in all (B * Tt / 64), per range
+    float *part;                   // [gridDim.y][nl][mrows][Cd]
+};
+__global__ __launch_bounds__(256) void pgate_kernel(const PGateArgs a)
+{
+    const Geo g = a.g;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ug = (int)blockIdx.x * 4 + wave;                  // unit row over all layers
+    const int upl = a.Cd >> 3, l = ug / upl, cg = ug - l * upl;
+    if (l >= a.nl) return;
+    const int m0 = (int)blockIdx.z * 8;
+    const int tb0 = (int)blockIdx.y * a.per, tb1 = min(a.nblk, tb0 + a.per), bpi = g.Tt / 64;
+    const unsigned short *base = a.gS[l] + (size_t)cg * g.P * 8;
+    const size_t item = (size_t)upl * g.P * 8;
+    float acc[8][8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[m][e] = 0.f;
+    constexpr int DEPTH = 4;                                     // 64-column blocks in flight per wave
+    for (int tb = tb0; tb < tb1; tb += DEPTH) {
+        u32x4 vh[DEPTH], vl[DEPTH];
+        float gm[DEPTH][8];
+        bool ok[DEPTH];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int tbb = min(tb + d, tb1 - 1), b = tbb / bpi, t = (tbb - b * bpi) * 64 + lane;
+            ok[d] = tb + d < tb1 && t < g.T;
+            const unsigned short *q = base + (size_t)b * item + (size_t)(g.H + t) * 8;
+            vh[d] = *reinterpret_cast<const u32x4 *>(q);
+            vl[d] = *reinterpret_cast<const u32x4 *>(q + a.g_lo_off);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) gm[d][m] = (m0 + m < a.ic2) ? *paddr(a.G, g, b, m0 + m, t) : 0.f;
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const unsigned wh = vh[d][e >> 1], wl = vl[d][e >> 1];
+                float x = (e & 1) ? __uint_as_float(wh & 0xffff0000u) + __uint_as_float(wl & 0xffff0000u)
+                                  : __uint_as_float(wh << 16) + __uint_as_float(wl << 16);
+                x = ok[d] ? x : 0.f;                             // (columns beyond T hold whatever the last pass left: never multiplied)
+#pragma unroll
+                for (int m = 0; m < 8; ++m) acc[m][e] = fmaf(ok[d] ? gm[d][m] : 0.f, x, acc[m][e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float s = acc[m][e];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            acc[m][e] = s;
+        }
+    // lane m writes row m0 + m of this unit row: 8 consecutive floats
+    float *out = a.part + (((size_t)blockIdx.y * a.nl + l) * a.mrows + m0) * a.Cd + cg * 8;
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+        if (lane == m) {
+            f32x4 lo4 = {acc[m][0], acc[m][1], acc[m][2], acc[m][3]}, hi4 = {acc[m][4], acc[m][5], acc[m][6], acc[m][7]};
+            *reinterpret_cast<f32x4 *>(out + (size_t)m * a.Cd) = lo4;
+            *reinterpret_cast<f32x4 *>(out + (size_t)m * a.Cd + 4) = hi4;
+        }
+}
+
+// from P ([nl][mrows][Cd], folded): dWskip_l = W_end^T P_l as [Cs][Cd] matrices (the effective-weight gradient run_finalize takes), and
+// dW_end = sum_l P_l Wskip_l^T as [32][Cs] (Wskip_l = scale (x) v: the effective skip rows, as the pack jobs form them)
+struct LrFinArgs {
+    const float *P, *wE;           // wE: end.weight [ic2][Cs]
+    const float *v[16], *scale[16];   // per layer: W_o.weight_v at its first skip row [Cs][Cd], g / |v| of those rows
+    float *dWsk, *dWend;           // [nl][Cs][Cd] ; [32][Cs]
+    int nl, Cs, Cd, ic2, mrows;
+};
+__global__ __launch_bounds__(256) void lr_dwsk_kernel(const LrFinArgs a)
+{
+    const int l = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= a.Cs * a.Cd) return;
+    const int s = e / a.Cd, k = e - s * a.Cd;
+    const float *Pl = a.P + (size_t)l * a.mrows * a.Cd;
+    float acc = 0.f;
+    for (int m = 0; m < a.ic2; ++m) acc = fmaf(a.wE[(size_t)m * a.Cs + s], Pl[(size_t)m * a.Cd + k], acc);
+    a.dWsk[((size_t)l * a.Cs + s) * a.Cd + k] = acc;
+}
+// one block per skip row s: thread k-slices, 32 sums per thread, a fixed tree over the block
+__global__ __launch_bounds__(256) void lr_dwend_kernel(const LrFinArgs a)
+{
+    __shared__ float red[32][257];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    float acc[32];
+#pragma unroll
+    for (int m = 0; m < 32; ++m) acc[m] = 0.f;
+    for (int l = 0; l < a.nl; ++l) {
+        const float sc = a.scale[l][s];
+        const float *vr = a.v[l] + (size_t)s * a.Cd, *Pl = a.P + (size_t)l * a.mrows * a.Cd;
+        for (int k = tid; k < a.Cd; k += 256) {
+            const float w = sc * vr[k];
+#pragma unroll
+            for (int m = 0; m < 32; ++m)
+                if (m < a.ic2) acc[m] = fmaf(Pl[(size_t)m * a.Cd + k], w, acc[m]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 32; ++m) red[m][tid] = acc[m];
+    __syncthreads();
+    for (int q = 128; q > 0; q >>= 1) {
+        if (tid < q)
+#pragma unroll
+            for (int m = 0; m < 32; ++m) red[m][tid] += red[m][tid + q];
+        __syncthreads();
+    }
+    if (tid < 32) a.dWend[(size_t)tid * a.Cs + s] = tid < a.ic2 ? red[tid][0] : 0.f;
+}

@@ -47,6 +47,7 @@ struct EnvSw {
     bool layer_fusion_big = false;   // WG_LAYER_FUSION_BIG=1: the one-launch layer on 256 x 128 tiles (wg_layer16q.h), opt-in
     bool layer_g = true;         // WG_LAYER_G=0: gate conv and residual product as two launches
     bool inv_seam = false;       // WG_INV_SEAM=1: end conv + affine + inverse 1x1 + next start conv as one launch, opt-in
+    bool lowrank = true;         // WG_LOWRANK=0: the skip sum and its gradient are formed as planes again (lowrank_skip below)
 };
 static std::atomic<const EnvSw *> g_env{nullptr};
 static const EnvSw *env_load()
@@ -61,6 +62,7 @@ static const EnvSw *env_load()
     n->layer_fusion_big = is("WG_LAYER_FUSION_BIG", '1');
     n->layer_g = !is("WG_LAYER_G", '0');
     n->inv_seam = is("WG_INV_SEAM", '1');
+    n->lowrank = !is("WG_LOWRANK", '0');
     return n;
 }
 static const EnvSw &env_sw()
@@ -232,6 +234,17 @@ inline bool fused_dy(const WnD &d)
 }
 
 
+// The skip sum S = sum_l Wskip_l gate_l and its gradient dS = W_end^T G never formed (Weff_l = W_end Wskip_l, wg_small.h weff_kernel):
+// S-plane mode, 1-D WN without biases (a skip bias would enter `out` through W_end as well), every layer's gate kept (fused_skip).
+inline bool lowrank_shape(const WnD &d)
+{
+#if defined(WG_OPT_NO_LOWRANK)
+    (void)d; return false;
+#else
+    return d.prec == 2 && !d.mode2d && !d.bias && fused_skip(d) && d.Cd % 64 == 0 && d.Cs <= 1024;
+#endif
+}
+
 Geo make_geo(int B, int T, int halo_need)
 {
     Geo g;
@@ -262,6 +275,7 @@ struct WnPack {
     size_t scale_V, scale_start, scale_W[16], scale_Wo[16];
     size_t startT, startN, endT, endN, bias_end;
     size_t Acat[16], WoT[16], WoN[16], WT[16], VN[16], WskT, VNall;
+    size_t effT = 0, effN = 0, WoG[16] = {0};                // lowrank_shape: Weff^T [depth Cd][32]; Weff per layer [depth][32][Cd]; [Wres_l^T | Weff_l^T] k-major
     int ld_startT, ld_startN, ld_endN, ld_Acat, ld_WoT[16], ld_WoN, ld_WT, ld_VN, ld_WskT;
     int kp_start, kp_end, kcat;
     size_t total;
@@ -310,6 +324,13 @@ WnPack wn_pack_layout(const WnD &d)
     L.bias_end = take(32);
     // V^T of every layer stacked along K: dy = sum_i V_i^T dxy_i as ONE product over all the layers' dxy (fused_dy)
     L.VNall = take_mat(d.depth * 2 * d.Cd, L.ld_VN);
+    if (lowrank_shape(d)) {
+        L.effT = take((size_t)d.depth * d.Cd * 32);
+        L.effN = take((size_t)d.depth * 32 * d.Cd);
+        // the gate backward's weights with the skip rows replaced by Weff_l: K = [C residual rows (none on the last layer) | 32 rows of G]
+        // (kp_end rows, as the G plane has them: run_convgemm finds a matrix's image behind K = the segments' channels)
+        for (int i = 0; i < d.depth; ++i) L.WoG[i] = take_mat((i == d.depth - 1 ? 0 : d.C) + L.kp_end, L.ld_WoN);
+    }
     L.total = off;
     return L;
 }
@@ -371,6 +392,40 @@ struct JobBatch {
     }
 };
 
+struct EffBatch {
+    Ctx *ctx;
+    EffArgs ea;
+    int maxcd = 0;
+    EffBatch(Ctx *c) : ctx(c) { ea.n = 0; }
+    void flush()
+    {
+        if (!ea.n) return;
+        WG_LAUNCH(*ctx, weff_kernel, dim3((maxcd + 255) / 256, ea.n), dim3(256), 0, ea);
+        ea.n = 0; maxcd = 0;
+    }
+    void add(const EffJob &j)
+    {
+        if (ea.n == WG_EFF_JOBS) flush();
+        ea.job[ea.n++] = j;
+        maxcd = std::max(maxcd, j.Cd);
+    }
+};
+// Weff of every layer (lowrank_shape): behind the row norms (it reads W_o's scales), in front of the pack jobs (they read effN)
+void wn_pack_eff(EffBatch &eb, const WnD &d, const WnPack &L, const float *const *p, float *pk)
+{
+    if (!lowrank_shape(d)) return;
+    for (int i = 0; i < d.depth; ++i) {
+        const int r0 = d.wo_rows(i) - d.Cs;
+        EffJob j;
+        j.wE = p[4 + 4 * d.depth];
+        j.v = p[7 + 4 * i] + (size_t)r0 * d.Cd;
+        j.scale = pk + L.scale_Wo[i] + r0;
+        j.effT = pk + L.effT + (size_t)i * d.Cd * 32;
+        j.effN = pk + L.effN + (size_t)i * 32 * d.Cd;
+        j.ic2 = 2 * d.ic; j.Cs = d.Cs; j.Cd = d.Cd;
+        eb.add(j);
+    }
+}
 // params: WN table (nparams entries).  Two passes over the stream: all row norms, then all packs.
 void wn_pack_norms(JobBatch &jb, const WnD &d, const WnPack &L, const float *const *p, float *pk)
 {
@@ -412,6 +467,12 @@ void wn_pack_mats(JobBatch &jb, const WnD &d, const WnPack &L, const float *cons
                       pk + L.scale_Wo[i] + r0, d.Cd, 1, 0);
         }
         jb.pack_m(fuse, pk + L.WoN[i], rows, L.ld_WoN, 0, f32, rows, 1, rows, d.Cd, 0, vWo, pk + L.scale_Wo[i], d.Cd, 1, 0);
+        if (lowrank_shape(d)) {                                  // [Wres_i^T | Weff_i^T]: the residual rows as in WoN, then Weff_i's 2 ic rows (of kp_end)
+            const int rr = rows - d.Cs;
+            if (rr) jb.pack_m(fuse, pk + L.WoG[i], rr + L.kp_end, L.ld_WoN, 0, false, rr, 1, rr, d.Cd, 0, vWo, pk + L.scale_Wo[i], d.Cd, 1, 0);
+            jb.pack_m(fuse, pk + L.WoG[i], rr + L.kp_end, L.ld_WoN, rr, false, L.kp_end, 1, 2 * d.ic, d.Cd, 0, pk + L.effN + (size_t)i * 32 * d.Cd, ones,
+                      d.Cd, 1, 0);
+        }
         for (int kt = 0; kt < d.radix; ++kt)   // A[kt*2Cd + o][c] = W[o][c][kt]
             jb.pack_m(fuse, pk + L.WT[i], d.radix * 2 * d.Cd, L.ld_WT, kt * 2 * d.Cd, f32, 2 * d.Cd, 1, 2 * d.Cd, d.C, 0, vW,
                       pk + L.scale_W[i], d.C * d.radix, d.radix, kt);
@@ -1865,6 +1926,44 @@ void layer_sync_clear(Ctx &cx, float *ws, size_t lsync)
     if (cx.prec == 2 && !cx.err && hipMemsetAsync(ws + lsync, 0, WGL_SYNC_WORDS * sizeof(unsigned), cx.st) != hipSuccess) cx.err = WG_ELAUNCH;
 }
 
+// The WN runs in the rank-2ic form of its skip path (lowrank_shape; wg_small.h weff_kernel): no skip sum, no dS.  One predicate for the
+// forward, the recompute pass and the backward of a shape, so that a kept flow and a recomputed one produce the same bits: the shapes
+// whose forward keeps every layer's gate anyway (the one-product skip sum's, fs below).
+static bool lowrank_on(const Ctx &cx, const WnRun &r)
+{
+    const Geo &g = r.g;
+    return env_sw().lowrank && cx.prec == 2 && lowrank_shape(r.d) && r.L.effT && !cx.rec && !cx.row_sel1 && g.rows == 0 &&
+           g.B * g.Tt >= WG_FUSED_SKIP_MIN_COLS;
+}
+// where end_affine_kernel takes `out` from: W_end . S (the skip plane), or sum_l Weff_l gate_l straight from the gate planes
+static bool affine_source(const Ctx &cx, const WnRun &r, AffineArgs &a)
+{
+    a.bias = r.d.bias ? r.pk + r.L.bias_end : nullptr;
+    a.Cs = r.d.Cs; a.ic = r.d.ic;
+    if (!lowrank_on(cx, r)) {
+        a.endT = r.pk + r.L.endT;
+        a.S = pref(r.ws + r.w.skip, r.d.Cs);
+        return false;
+    }
+    a.endT = r.pk + r.L.effT;
+    a.S = pnull();
+    for (int i = 0; i < r.d.depth; ++i) a.gS[i] = (const unsigned short *)(r.ws + r.w.gateS[i]);
+    a.g_lo_off = (size_t)r.g.B * r.d.Cd * r.g.P;
+    a.Cd = r.d.Cd; a.nl = r.d.depth;
+    return true;
+}
+static void launch_end_affine(Ctx &cx, const AffineArgs &a, bool fromg)
+{
+    const dim3 grid(a.g.Tt / WG_AFF_T, a.g.B);
+    if (fromg) {
+        if (2 * a.ic <= 8) WG_LAUNCH(cx, (end_affine_kernel<8, false, true>), grid, dim3(256), 0, a);
+        else WG_LAUNCH(cx, (end_affine_kernel<32, false, true>), grid, dim3(256), 0, a);
+    } else {
+        if (2 * a.ic <= 8) WG_LAUNCH(cx, end_affine_kernel<8>, grid, dim3(256), 0, a);
+        else WG_LAUNCH(cx, end_affine_kernel<32>, grid, dim3(256), 0, a);
+    }
+}
+
 void wn_forward(Ctx &cx, const WnRun &r)
 {
     const WnD &d = r.d;
@@ -1959,6 +2058,7 @@ void wn_forward(Ctx &cx, const WnRun &r)
         gate_call();
         wo_call();
     }
+    if (fs && lowrank_on(cx, r)) return;                      // (the end conv reads the gate planes themselves: affine_source)
     if (fs) {                                                 // cum_skip = sum_i skip_i (waveglow.py:104) = [Wskip_0 .. Wskip_{d-1}] [gate_0; ..; gate_{d-1}]
         SegSpec sk[WG_MAX_SEG];
         for (int i = 0; i < d.depth; ++i) sk[i] = {ws + r.w.gate[i], d.Cd, 0, d.Cd, 0, ws + r.w.gateS[i], d.Cd, 0};
@@ -1974,16 +2074,12 @@ void run_end_affine(Ctx &cx, const WnRun &r, int mode, PRef dX, float *log_s_out
 {
     AffineArgs a;
     memset(&a, 0, sizeof(a));
-    a.endT = r.pk + r.L.endT;
-    a.bias = r.d.bias ? r.pk + r.L.bias_end : nullptr;
-    a.S = pref(r.ws + r.w.skip, r.d.Cs);
-    a.Cs = r.d.Cs; a.ic = r.d.ic;
+    const bool fromg = affine_source(cx, r, a);
     a.X = r.X; a.dX = dX;
     a.Gp = pref(r.ws + r.w.G, r.L.kp_end);
     a.log_s_out = log_s_out; a.dls_plain = dls_plain; a.dld = dld; a.partial = partial;
     a.g = r.g; a.mode = mode;
-    if (2 * a.ic <= 8) WG_LAUNCH(cx, end_affine_kernel<8>, dim3(r.g.Tt / WG_AFF_T, r.g.B), dim3(256), 0, a);
-    else WG_LAUNCH(cx, end_affine_kernel<32>, dim3(r.g.Tt / WG_AFF_T, r.g.B), dim3(256), 0, a);
+    launch_end_affine(cx, a, fromg);
 }
 
 // Synthesis, between two WNs of the inverse direction: AFF_REV of flow k, its inverse 1x1 conv and WN.start of the flow visited next as
@@ -1994,7 +2090,7 @@ void run_end_affine(Ctx &cx, const WnRun &r, int mode, PRef dX, float *log_s_out
 // `nxt` is the next WN's run (its X already re-based); returns false where the shapes are outside the seam kernel's.
 bool run_inv_seam(Ctx &cx, const WnRun &r, const float *Winv, float *partial, const WnRun &nxt)
 {
-    if (!env_sw().inv_seam) return false;
+    if (!env_sw().inv_seam || lowrank_on(cx, r)) return false;
     const WnD &d = r.d, &n = nxt.d;
     const Geo &g = r.g;
     const int rel = nxt.X.ch0 - r.X.ch0;
@@ -2094,6 +2190,48 @@ void run_thin_end(Ctx &cx, const WnRun &r, float *G, int Gc, float *skip, float 
     run_finalize(cx, out, wo, 0, k2, d.Cs, 1, 0, 1, 0, nullptr, nullptr, nullptr, dW);
 }
 
+// The skip path's gradients in their rank-2ic form (wg_thin.h pgate_kernel): P_l = sum G (x) gate_l for every layer in one pass over the
+// gate planes, then dWskip_l = W_end^T P_l (returned: [depth][Cs][Cd] in the finalisation queue's arena, for the caller's run_finalize of
+// W_o's skip rows) and dW_end = sum_l P_l Wskip_l^T (finalised here).
+static const float *run_lowrank_end(Ctx &cx, const WnRun &r, const float *const *p, float *dWend)
+{
+    const WnD &d = r.d;
+    const Geo &g = r.g;
+    const int ic2 = 2 * d.ic, mrows = rup(ic2, 8), nblk = g.B * (g.Tt / 64);
+    const int ncr = std::max(1, std::min(8, nblk / 4)), per = (nblk + ncr - 1) / ncr;
+    const size_t n = (size_t)d.depth * mrows * d.Cd;
+    PGateArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int i = 0; i < d.depth; ++i) a.gS[i] = (const unsigned short *)(r.ws + r.w.gateS[i]);
+    a.g_lo_off = (size_t)g.B * d.Cd * g.P;
+    a.G = pref(r.ws + r.w.G, r.L.kp_end);
+    a.Cd = d.Cd; a.nl = d.depth; a.ic2 = ic2; a.mrows = mrows;
+    a.g = g; a.nblk = nblk; a.per = per;
+    // partials, P, the dWskip matrices and dW_end: ONE reservation (nothing of it may be recycled before the queued finalisations ran)
+    const size_t fl = wgth_part_floats(ncr, (int)n) + rupz((size_t)d.depth * d.Cs * d.Cd, 64) + (size_t)32 * d.Cs;
+    a.part = cx.fq->reserve(fl);
+    if (cx.err) return nullptr;
+    float *P = a.part + (size_t)ncr * n, *dWsk = P + rupz(n, 64), *dWe = dWsk + rupz((size_t)d.depth * d.Cs * d.Cd, 64);
+    WG_LAUNCH(cx, pgate_kernel, dim3((d.depth * (d.Cd / 8) + 3) / 4, ncr, mrows / 8), dim3(256), 0, a);
+    WG_LAUNCH(cx, thin_fold_kernel, dim3((unsigned)(n / 32)), dim3(256), 0, (const float *)a.part, ncr, (int)n, P);
+    LrFinArgs f;
+    memset(&f, 0, sizeof(f));
+    f.P = P; f.wE = p[4 + 4 * d.depth];
+    for (int i = 0; i < d.depth; ++i) {
+        const int r0 = d.wo_rows(i) - d.Cs;
+        f.v[i] = p[7 + 4 * i] + (size_t)r0 * d.Cd;
+        f.scale[i] = r.pk + r.L.scale_Wo[i] + r0;
+    }
+    f.dWsk = dWsk; f.dWend = dWe;
+    f.nl = d.depth; f.Cs = d.Cs; f.Cd = d.Cd; f.ic2 = ic2; f.mrows = mrows;
+    WG_LAUNCH(cx, lr_dwsk_kernel, dim3((d.Cs * d.Cd + 255) / 256, d.depth), dim3(256), 0, f);
+    WG_LAUNCH(cx, lr_dwend_kernel, dim3(d.Cs), dim3(256), 0, f);
+    WgradOut wo;
+    wo.nsplit = 1; wo.Mp = 32; wo.Np = d.Cs; wo.slab = dWe;
+    run_finalize(cx, dWe, wo, 0, ic2, d.Cs, 1, 0, 1, 0, nullptr, nullptr, nullptr, dWend);
+    return dWsk;
+}
+
 // backward through WN given the G plane (what autograd.grad at efficient_modules.py:143 evaluates).
 // p/grads: this WN's parameter / gradient tables.  dX: gradient plane at the same ch0 as r.X (dxa accumulates into it).
 void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *grads, PRef dX, float *dY)
@@ -2132,8 +2270,24 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
 #if !defined(WG_OPT_NO_FIN_BATCH)
     FinQueue fq(cx, slab, cap);                               // flushed when it goes out of scope: before the caller's next launch
 #endif
+    // the rank-2ic form of the skip path (lowrank_on): neither S nor dS = W_end^T G exists; G itself (as an S-plane of kp_end channels)
+    // is the K segment that stands for dS in every gate backward, and the skip rows' weight gradients come from P_l = G gate_l^T
+    const bool lr = lowrank_on(cx, r);
+    const float *dWsk = nullptr;
     // end: dW_end = sum G (x) S ; dS = W_end^T G
-    {
+    if (lr) {
+        run_to_splane(cx, g, pref(G, Gc), Gc, ws + r.w.GS, Gc);
+        dWsk = run_lowrank_end(cx, r, p, grads[4 + 4 * nd]);
+        // W_o's skip rows: dWskip_i = W_end^T P_i, [Cs][Cd] at dWsk + i Cs Cd; parameter rows [wo_rows - Cs, wo_rows).  Queued at once:
+        // the matrices live in the finalisation queue's arena, and a later reservation that wraps it flushes what is queued first
+        for (int i = 0; i < nd && dWsk; ++i) {
+            const int r0 = d.wo_rows(i) - d.Cs;
+            WgradOut wk;
+            wk.nsplit = 1; wk.Mp = d.Cs; wk.Np = d.Cd; wk.slab = const_cast<float *>(dWsk) + (size_t)i * d.Cs * d.Cd;
+            run_finalize(cx, wk.slab, wk, 0, d.Cs, d.Cd, 1, 0, 1, 0, p[6 + 4 * i] ? p[6 + 4 * i] + r0 : nullptr, p[7 + 4 * i] + (size_t)r0 * d.Cd,
+                         grads[6 + 4 * i] ? grads[6 + 4 * i] + r0 : nullptr, grads[7 + 4 * i] ? grads[7 + 4 * i] + (size_t)r0 * d.Cd : nullptr);
+        }
+    } else {
         // skip (fp32 only: it feeds the fp32 end conv) has no S-plane -> this small product runs on the on-the-fly kernel
         if (thin_ok(cx, d)) run_thin_end(cx, r, G, Gc, skip, ws + r.w.dSS, grads[4 + 4 * nd]);      // both in one pass over skip (wg_thin.h)
         else {
@@ -2156,9 +2310,16 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
         // dW_o = sum do (x) gate,  do = last ? dS : cat(dh_{i+1}, dS)
         if (gw) {                                                              // (the last layer's group has no dh rows: zero, skipped by row0)
             gsO[i].sa[0] = {nullptr, d.C, 0, d.C, 0, last ? nullptr : dHSp(i + 1), d.C, 0};
-            gsO[i].sa[1] = {nullptr, d.Cs, 0, d.Cs, 0, ws + r.w.dSS, d.Cs, 0};
+            gsO[i].sa[1] = {nullptr, d.Cs, 0, d.Cs, 0, ws + r.w.dSS, d.Cs, 0};          // (lowrank: the group has its dh rows only, nsa = 1 below)
             gsO[i].sb[0] = {nullptr, d.Cd, 0, d.Cd, 0, ws + r.w.gateS[i], d.Cd, 0};
             if (nb) gsO[i].sb[1] = wone;
+        } else if (lr) {
+            if (!last) {                                                         // the residual rows' product; the skip rows come from P
+                WSegSpec sa = {dH, d.C, 0, d.C, 0, dHSp(i + 1), d.C, 0};
+                WSegSpec sb = {gate, d.Cd, 0, d.Cd, 0, ws + r.w.gateS[i], d.Cd, 0};
+                WgradOut wo = run_wgrad(cx, g, &sa, 1, &sb, 1, slab, cap);
+                run_finalize(cx, slab, wo, 0, d.C, d.Cd, 1, 0, 1, 0, p[6 + 4 * i], p[7 + 4 * i], grads[6 + 4 * i], grads[7 + 4 * i]);
+            }
         } else {
             WSegSpec sa[2];
             int nsa = 0;
@@ -2174,8 +2335,9 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
             SegSpec s[2];
             int ns = 0;
             if (!last) s[ns++] = {dH, d.C, 0, d.C, 0, dHSp(i + 1), d.C, 0};
-            s[ns++] = {dS, d.Cs, 0, d.Cs, 0, ws + r.w.dSS, d.Cs, 0};
-            run_convgemm(cx, g, r.pk + r.L.WoN[i], r.L.ld_WoN, d.Cd, s, ns, EPI_DGATE, sp ? pnull() : pref(dxy, 2 * d.Cd), pnull(), pnull(),
+            if (lr) s[ns++] = {G, Gc, 0, Gc, 0, ws + r.w.GS, Gc, 0};          // Wskip_i^T dS = Weff_i^T G: 2 ic channels (of kp_end) instead of Cs
+            else s[ns++] = {dS, d.Cs, 0, d.Cs, 0, ws + r.w.dSS, d.Cs, 0};
+            run_convgemm(cx, g, r.pk + (lr ? r.L.WoG[i] : r.L.WoN[i]), r.L.ld_WoN, d.Cd, s, ns, EPI_DGATE, sp ? pnull() : pref(dxy, 2 * d.Cd), pnull(), pnull(),
                          pref(ws + r.w.tw[i], d.Cd), pref(ws + r.w.sf[i], d.Cd), d.Cd, 0, sp ? sref(g, dxyS, 2 * d.Cd) : snull());
         }
         // dW (taps) and dV (conditioning) in one wgrad
@@ -2254,7 +2416,7 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
 #endif
         // (one after the other, each finalisation queued behind its own launch: the second product's slabs may then reuse the arena)
         const int nsbT = d.radix + (hv ? 0 : 1) + nb;
-        if (pair) run_wgrad_group_pair(cx, g, gsT, 1, nsbT, wo, gsO, 2, 1 + nb, woO, nd, ws + r.w.dSS);
+        if (pair) run_wgrad_group_pair(cx, g, gsT, 1, nsbT, wo, gsO, lr ? 1 : 2, 1 + nb, woO, nd, ws + r.w.dSS);
         else run_wgrad_group(cx, g, gsT, nd, 1, nsbT, ws + r.w.dSS, wo);
         for (int i = 0; i < nd && !cx.err; ++i) {
             run_finalize(cx, slab, wo[i], 0, 2 * d.Cd, d.C, d.radix, 0, 1, C32, p[4 + 4 * i], p[5 + 4 * i], grads[4 + 4 * i], grads[5 + 4 * i]);
@@ -2265,7 +2427,7 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
             fin_bias(slab, wo[i], 0, 2 * d.Cd, d.radix * C32 + rup(d.aux, 32), gb(2 + 2 * i));
             fin_bias(slab, wo[i], 0, 2 * d.Cd, d.radix * C32 + rup(d.aux, 32), gb(0) ? gb(0) + ro : nullptr);
         }
-        if (!pair) run_wgrad_group(cx, g, gsO, nd, 2, 1 + nb, ws + r.w.dSS, woO);
+        if (!pair) run_wgrad_group(cx, g, gsO, nd, lr ? 1 : 2, 1 + nb, ws + r.w.dSS, woO);
         if (hv) {                                             // dV of every layer: items x T columns against the conditioning itself
             WgradOut woV[WG_GRP_MAX];
             run_wgrad_group(cx, r.gi, gsV, nd, 1, 1, ws + r.w.dSS, woV);
@@ -2277,6 +2439,10 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
         }
         for (int i = 0; i < nd && !cx.err; ++i) {
             const int last = i == nd - 1;
+            if (lr) {                                         // the product holds the C residual rows (none on the last layer); the skip rows from P
+                if (!last) run_finalize(cx, slab, woO[i], 0, d.C, d.Cd, 1, 0, 1, 0, p[6 + 4 * i], p[7 + 4 * i], grads[6 + 4 * i], grads[7 + 4 * i]);
+                continue;
+            }
             run_finalize(cx, slab, woO[i], last ? d.C : 0, d.wo_rows(i), d.Cd, 1, 0, 1, 0, p[6 + 4 * i], p[7 + 4 * i], grads[6 + 4 * i], grads[7 + 4 * i]);
             fin_bias(slab, woO[i], last ? d.C : 0, d.wo_rows(i), rup(d.Cd, 32), gb(3 + 2 * i));
         }
@@ -2640,6 +2806,9 @@ int wg_wn_pack_weights(const wg_wn_dims *dd, const void *const *params, void *pa
     JobBatch jb(&cx);
     wn_pack_norms(jb, d, L, (const float *const *)params, wn);
     jb.flush_norm();
+    EffBatch eb(&cx);
+    wn_pack_eff(eb, d, L, (const float *const *)params, wn);
+    eb.flush();
     wn_pack_mats(jb, d, L, (const float *const *)params, wn, ones);
     jb.flush_pack();
     ImgBatch ib(&cx);
@@ -2675,6 +2844,12 @@ int wg_pack_weights(const wg_config *cf, const void *const *params, void *packed
         wn_pack_norms(jb, d, wn_pack_layout(d), p + wn_table_off(cf, k), pk + M.wn[k]);
     }
     jb.flush_norm();
+    EffBatch eb(&cx);
+    for (int k = 0; k < cf->n_flows; ++k) {
+        const WnD d = flow_wn(cf, k);
+        wn_pack_eff(eb, d, wn_pack_layout(d), p + wn_table_off(cf, k), pk + M.wn[k]);
+    }
+    eb.flush();
     jb.pack(pk + M.up_w, cf->up_kernel, cf->n_mels, cf->up_kernel, 1, cf->n_mels, cf->up_kernel, 0, p[2], pk + M.up_scale, cf->up_kernel, 1, 0);
     jb.pack(pk + M.up_bias, cf->n_mels, 1, cf->n_mels, 1, 1, cf->n_mels, 0, p[0], ones, cf->n_mels, 1, 0);
     for (int k = 0; k < cf->n_flows; ++k) {
@@ -3634,11 +3809,10 @@ int wg_wn_apply(const wg_wn_dims *dd, const void *packed, const float *x, const 
     wn_forward(cx, r);
     AffineArgs a;
     memset(&a, 0, sizeof(a));
-    a.endT = r.pk + r.L.endT; a.S = pref(ws + W.wn.skip, d.Cs); a.Cs = d.Cs; a.ic = d.ic; a.X = X;
-    a.bias = d.bias ? r.pk + r.L.bias_end : nullptr;
+    const bool fromg = affine_source(cx, r, a);
+    a.X = X;
     a.log_s_out = log_s; a.t_out = t; a.g = g; a.mode = AFF_RAW;
-    if (2 * a.ic <= 8) WG_LAUNCH(cx, end_affine_kernel<8>, dim3(g.Tt / WG_AFF_T, g.B), dim3(256), 0, a);
-    else WG_LAUNCH(cx, end_affine_kernel<32>, dim3(g.Tt / WG_AFF_T, g.B), dim3(256), 0, a);
+    launch_end_affine(cx, a, fromg);
     return cx.err;
 }
 

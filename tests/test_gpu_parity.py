@@ -425,7 +425,7 @@ def test_one_launch_layer_vs_two_launches(dev, precision, monkeypatch, name):
     res = {}
     for fused in ("1", "0"):
         monkeypatch.setenv("WG_LAYER_FUSION", fused)
-        _lib.lib().wg_reload_env()
+        cm._lib.lib().wg_reload_env()
         before = _lib.lib().wg_stat_layer_launches()
         runs = []
         with torch.no_grad():
@@ -468,7 +468,7 @@ def test_layer_launch_of_the_training_shapes_vs_two_launches(dev, precision, mon
     res = {}
     for fused in ("1", "0"):
         monkeypatch.setenv("WG_LAYER_FUSION_BIG", fused)
-        _lib.lib().wg_reload_env()
+        cm._lib.lib().wg_reload_env()
         before = _lib.lib().wg_stat_layer_launches()
         runs = []
         for rep in range(3):
@@ -908,7 +908,7 @@ def test_layer_as_one_launch_on_flattened_tiles_vs_two_launches(dev, precision, 
     res = {}
     for fused in ("1", "0"):
         monkeypatch.setenv("WG_LAYER_G", fused)
-        _lib.lib().wg_reload_env()
+        cm._lib.lib().wg_reload_env()
         before = _lib.lib().wg_stat_layerg_launches()
         runs = []
         for rep in range(2):
@@ -940,7 +940,7 @@ def test_inverse_seam_launch_vs_three_launches(dev, precision, monkeypatch):
         out = {}
         for sw in ("1", "0"):
             monkeypatch.setenv("WG_INV_SEAM", sw)
-            _lib.lib().wg_reload_env()
+            cm._lib.lib().wg_reload_env()
             with torch.no_grad():
                 out[sw] = m.reverse(z.clone(), h)
         assert torch.equal(out["1"][0], out["0"][0])
@@ -1692,7 +1692,7 @@ def test_wsrglow_gate_conv_cut_along_k_vs_uncut(dev, precision, monkeypatch):
     res = {}
     for cut in ("1", "0"):
         monkeypatch.setenv("WG_G192_SPLITK", cut)
-        _lib.lib().wg_reload_env()
+        cm._lib.lib().wg_reload_env()
         before = _lib.lib().wg_stat_gate_split_launches()
         runs = []
         for rep in range(2):
