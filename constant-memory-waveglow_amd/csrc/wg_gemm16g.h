@@ -70,8 +70,15 @@ __device__ __forceinline__ void wgg_st16(const float *base, unsigned voff, const
 }
 // EPI_GATE_SO, column block NBI of the wave tile: 16 columns of plane row b from time step t0 on (the flattened columns of a tile may
 // belong to two plane rows, so every block has its own bases; otherwise as wgq_gate_nb)
+// with `part`: the block's 8 x 16 share of WN's `out`, Weff (2 ic <= 8 rows x the wave's 32 gate channels) . gate (32 x 16), goes to
+// part[slot][b][t][8].  It is ONE more 16x16x32 product per column block on the split operands the epilogue holds anyway: the lane's
+// eight gate values, packed to bf16 for the S-plane store, ARE the B fragment (lane = column l & 15, k-group l >> 4; the channel order
+// inside the wave's 32 -- j < 4: 4 q + j, j >= 4: 16 + 4 q + j - 4 -- is a permutation of K, and the Weff fragments eah / eal are packed
+// in the same order: weff_kernel), and rows 0-7 of the result lie in lanes 0-31 as four rows per lane: one 16-byte store.  (As 64 FMAs +
+// 16 cross-lane adds per block on the vector ALU this cost 4.3 us per tile: 147 against 138 us per layer launch.)
 template <int NBI>
-__device__ __forceinline__ void wgg_gate_nb(const ConvGemmArgs &a, const SRef &s0, f32x4 (&acc)[4][6], int b, int t0, int chb, int lane)
+__device__ __forceinline__ void wgg_gate_nb(const ConvGemmArgs &a, const SRef &s0, f32x4 (&acc)[4][6], int b, int t0, int chb, int lane,
+                                            float *part = nullptr, int slot = 0, bf16x8 eah = bf16x8{}, bf16x8 eal = bf16x8{})
 {
     const Geo g = a.g;
     const int col = lane & 15, rq = lane >> 4;
@@ -86,6 +93,23 @@ __device__ __forceinline__ void wgg_gate_nb(const ConvGemmArgs &a, const SRef &s
         gv[i] = tw[i] * sf[i];
     }
     const int bb = min(b, g.B - 1);
+    u32x2 gh[2], gl[2];                                       // the gate as packed bf16 pairs: [16-channel block][pair]
+#pragma unroll
+    for (int mbp = 0; mbp < 2; ++mbp) {
+        unsigned hh, ll;
+        split2(gv[4 * mbp], gv[4 * mbp + 1], hh, ll); gh[mbp][0] = hh; gl[mbp][0] = ll;
+        split2(gv[4 * mbp + 2], gv[4 * mbp + 3], hh, ll); gh[mbp][1] = hh; gl[mbp][1] = ll;
+    }
+    if (part) {
+        const u32x4 bh4 = {gh[0][0], gh[0][1], gh[1][0], gh[1][1]}, bl4 = {gl[0][0], gl[0][1], gl[1][0], gl[1][1]};
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, bh4), bl = __builtin_bit_cast(bf16x8, bl4);
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eal, bh, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eah, bl, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eah, bh, o, 0, 0, 0);
+        const float *pb = part + (((size_t)slot * g.B + bb) * g.Tt + t0) * 8;
+        if (live && rq < 2) wgg_st16(pb, (unsigned)(col * 32 + rq * 16), o);      // rows 4 rq .. 4 rq + 3 of column col
+    }
 #pragma unroll
     for (int mbp = 0; mbp < 2; ++mbp) {
         const float *bt = has_ts ? paddr4(a.out1, g, bb, chb + mbp * 16, t0) : nullptr;
@@ -94,10 +118,7 @@ __device__ __forceinline__ void wgg_gate_nb(const ConvGemmArgs &a, const SRef &s
         f32x4 vt, vs;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { vt[e] = tw[4 * mbp + e]; vs[e] = sf[4 * mbp + e]; }
-        u32x2 vh, vl;
-        unsigned hh, ll;
-        split2(gv[4 * mbp], gv[4 * mbp + 1], hh, ll); vh[0] = hh; vl[0] = ll;
-        split2(gv[4 * mbp + 2], gv[4 * mbp + 3], hh, ll); vh[1] = hh; vl[1] = ll;
+        const u32x2 vh = gh[mbp], vl = gl[mbp];
 #if defined(WGG_DBG_NOSTORE)                              // timing build: the epilogue's arithmetic without its stores
         if (live && vh[0] == 0x12345u && vl[1] == 0x54321u) {
 #else
@@ -222,10 +243,12 @@ struct WggDesc {
     unsigned pad;
 };
 struct WggOffs { unsigned a[4], b[3], pad; };             // a: bytes from the weight image, b: bytes from the chunk's b_base
-#define WGG_MAXCHUNKS 64
+#define WGG_MAXCHUNKS 56                                  // (the longest product that runs here: the data-gradient conv, 48 chunks)
 #define WGG_TAB WGG_LDS                                   // the tables sit behind the rings
 #define WGG_WTAB (WGG_TAB + WGG_MAXCHUNKS * 32)
-#define WGG_LDS_ALL (WGG_WTAB + 8 * WGG_MAXCHUNKS * 32)   // 157 696 bytes
+#define WGG_EFF (WGG_WTAB + 8 * WGG_MAXCHUNKS * 32)       // EPI_GATE_SO with ConvGemm16sArgs::part: Weff of the layer, [8][M / 2] fp32
+#define WGG_EFF_BYTES 8192
+#define WGG_LDS_ALL (WGG_EFF + WGG_EFF_BYTES)             // 163 584 bytes
 static_assert(sizeof(WggDesc) == 32 && sizeof(WggOffs) == 32 && WGG_LDS_ALL <= 160 * 1024, "LDS budget");
 
 // ConvGemm16sArgs as for convgemm16q_kernel, with ntx = column tiles of 192 flattened columns (ceil(B * Tt / 192)), nty = 256-row tiles,
@@ -286,6 +309,13 @@ __device__ __forceinline__ void wgg_stream(const ConvGemm16sArgs &aa, char *smem
     };
     const int ncols = g.B * g.Tt;
 
+    if constexpr (EPI == EPI_GATE_SO) {
+        if (aa.part) {                                        // Weff of this layer as fragments: 1 KB per 32 gate channels (at most WGG_EFF_BYTES: the launch site checks)
+            const int n4 = (a.M >> 6) * 1024 / 16;
+            for (int i = tid; i < n4; i += 512)
+                reinterpret_cast<u32x4 *>(smem + WGG_EFF)[i] = reinterpret_cast<const u32x4 *>(aa.eff)[i];
+        }
+    }
     // ---------------------------------------------- the chunk table ----------------------------------------------
     if (tid < nchunks) {
         const int v = k0 + tid;                               // (the walk's chunk this entry describes)
@@ -474,9 +504,17 @@ __device__ __forceinline__ void wgg_stream(const ConvGemm16sArgs &aa, char *smem
         block_pos();
         if constexpr (EPI == EPI_GATE_SO) {
             const int chb = (m0 >> 1) + 32 * wr;                 // the wave's 64 rows = [32 tanh | 32 sigmoid] of 32 gate channels
-            wgg_gate_nb<0>(a, aa.s0, acc, eb[0], et[0], chb, lane); wgg_gate_nb<1>(a, aa.s0, acc, eb[1], et[1], chb, lane);
-            wgg_gate_nb<2>(a, aa.s0, acc, eb[2], et[2], chb, lane); wgg_gate_nb<3>(a, aa.s0, acc, eb[3], et[3], chb, lane);
-            wgg_gate_nb<4>(a, aa.s0, acc, eb[4], et[4], chb, lane); wgg_gate_nb<5>(a, aa.s0, acc, eb[5], et[5], chb, lane);
+            // the wave's Weff fragments (hi, lo): slice = (row tile, wave row) of the staged image, [slice][hi | lo][k-group][8 rows][16 B];
+            // A rows 8-15 are zero
+            const int slot = (m0 >> 8) * 4 + wr;
+            bf16x8 eah = bf16x8{}, eal = bf16x8{};
+            if (aa.part && (lane & 15) < 8) {
+                const char *ef = smem + WGG_EFF + slot * 1024 + ((lane >> 4) * 8 + (lane & 15)) * 16;
+                eah = *reinterpret_cast<const bf16x8 *>(ef); eal = *reinterpret_cast<const bf16x8 *>(ef + 512);
+            }
+            wgg_gate_nb<0>(a, aa.s0, acc, eb[0], et[0], chb, lane, aa.part, slot, eah, eal); wgg_gate_nb<1>(a, aa.s0, acc, eb[1], et[1], chb, lane, aa.part, slot, eah, eal);
+            wgg_gate_nb<2>(a, aa.s0, acc, eb[2], et[2], chb, lane, aa.part, slot, eah, eal); wgg_gate_nb<3>(a, aa.s0, acc, eb[3], et[3], chb, lane, aa.part, slot, eah, eal);
+            wgg_gate_nb<4>(a, aa.s0, acc, eb[4], et[4], chb, lane, aa.part, slot, eah, eal); wgg_gate_nb<5>(a, aa.s0, acc, eb[5], et[5], chb, lane, aa.part, slot, eah, eal);
         } else if constexpr (EPI == WGG_EPI_PART) {
             // the raw accumulators, block by block, 1 KB per wave and store: slab[(part * tiles + tile) * 8 + wave][mb * 6 + nb][lane]
             const int tile = ct * aa.nty + m0 / WGG_BM, ntiles = aa.ntx * aa.nty;

@@ -111,6 +111,12 @@ struct ConvGemm16sArgs {
                                   // tap's window, which is a neighbouring time tile's centre window, is requested within a few chunks of that
                                   // neighbour's own request and still sits in the XCD's L2 (tap after tap they are 16 chunks = tens of
                                   // microseconds apart: the data-gradient conv fetched every window from HBM again, 388 MB for 147 MB)
+    // convgemm16g_kernel / convlayer16g_kernel, EPI_GATE_SO only (wg_gemm16g.h, wgg_gate_nb): with `part` the epilogue also leaves
+    // Weff (gate tile) -- the tile's share of WN's `out` = sum_l Weff_l gate_l (wg_small.h weff_kernel) -- as [slot][b][t][8] fp32, slot =
+    // 4 x row tile + the wave's row block: the end conv then adds nl x slots rows of 32 bytes per column instead of reading every gate
+    // plane again.  eff: Weff_l as MFMA fragments, [M / 64 slices of 32 gate channels][hi | lo][k-group][8 rows][8 bf16] (weff_kernel)
+    const float *eff;
+    float *part;
     int xcd_items;                // convgemm16q, persistent launches: > 0 = plane rows per XCD (ntz / 8): XCD x (workgroup id & 7) owns the plane
                                   // rows x, x + 8, ... and walks their tiles row by row -- all time tiles of a row are then in flight on ONE
                                   // XCD, so a dilation tap's window (another tile's centre window) and the other row tiles' copy of the same

@@ -219,6 +219,10 @@ struct AffineArgs {
     const unsigned short *gS[16];   // hi array of layer l's gate S-plane (Cd channels per item; lo at + g_lo_off)
     size_t g_lo_off;
     int Cd, nl;
+    // SRC == 2: out = the sum of `nsrc` partial rows of 8 floats per column, [src][b][t][8] fp32 (src = layer x slot: what the gate convs'
+    // epilogues left, wg_gemm16g.h wgg_gate_nb): 2 ic <= 8 only
+    const float *part;
+    int nsrc;
 };
 
 #define WG_AFF_T 64          // time steps per workgroup
@@ -226,7 +230,7 @@ struct AffineArgs {
 #define WG_AFF_LD 64         // skip-channel loads a lane keeps in flight
 // NR = accumulator rows kept per lane: 8 where 2 * ic <= 8 (WaveGlow: n_group 8), 32 otherwise.  (With 32 accumulators next to the 64
 // loads in flight the kernel needed 250 VGPRs and 41 KB of LDS: two workgroups per CU, 38 us per launch at the training shape.)
-template <int NR, bool SEAM = false, bool FROMG = false>
+template <int NR, bool SEAM = false, int SRC = 0>       // SRC: 0 = W_end . S, 1 = sum_l Weff_l gate_l from the gate planes, 2 = the gate convs' partial rows
 __global__ __launch_bounds__(256) void end_affine_kernel(const AffineArgs a)
 {
     // out[m][t] = sum_k W_end[m][k] S[k][t] for the 2*ic <= 32 rows of the end conv: far too few rows for a matrix tile to pay, and
@@ -258,7 +262,28 @@ __global__ __launch_bounds__(256) void end_affine_kernel(const AffineArgs a)
 #pragma unroll
         for (int i = 0; i < 8; ++i) pre_x[i] = (wave == 0 && i < 2 * a.ic && t < g.T) ? *paddr(a.X, g, b, i, t) : 0.f;
     }
-    if constexpr (FROMG) {
+    if constexpr (SRC == 2) {
+        // wave w adds its quarter of the sources in source order, sixteen 16-byte loads in flight; lanes = time steps, 32 bytes apart
+        static_assert(SRC != 2 || NR == 8, "partial rows hold 8 floats");
+        const int nq = (a.nsrc + 3) / 4, s0 = wave * nq, s1 = min(a.nsrc, s0 + nq);
+        const size_t stride = (size_t)g.B * g.Tt * 8;
+        const float *p0 = a.part + ((size_t)b * g.Tt + min(t, g.Tt - 1)) * 8;
+        for (int sb = s0; sb < s1; sb += 8) {
+            f32x4 v0[8], v1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float *q = p0 + (size_t)min(sb + u, s1 - 1) * stride;
+                v0[u] = *reinterpret_cast<const f32x4 *>(q);
+                v1[u] = *reinterpret_cast<const f32x4 *>(q + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (sb + u < s1) {
+                    acc[0] += v0[u][0]; acc[1] += v0[u][1]; acc[2] += v0[u][2]; acc[3] += v0[u][3];
+                    acc[4] += v1[u][0]; acc[5] += v1[u][1]; acc[6] += v1[u][2]; acc[7] += v1[u][3];
+                }
+        }
+    } else if constexpr (SRC == 1) {
         // K = nl * Cd gate channels, 8 per 16-byte unit of an S-plane ([c / 8][p][8] bf16, hi and lo arrays): a lane reads the units of
         // its time step -- consecutive lanes, consecutive units: 1 KB per wave instruction -- 8 units x (hi, lo) in flight, and rebuilds
         // gate = hi + lo (the operand the matrix kernels multiply: nothing is lost against the skip sum's own input)
@@ -755,6 +780,8 @@ struct EffJob {
     const float *v;         // W_o.weight_v of the layer, first SKIP row: [Cs][Cd]
     const float *scale;     // g / |v| of those rows [Cs]
     float *effT, *effN;     // [Cd][32] rows of the WN's effT ; [32][Cd]
+    unsigned short *effA;   // nullable: rows 0-7 as 16x16x32 A fragments for the gate conv's epilogue (wg_gemm16g.h wgg_gate_nb):
+                            // [Cd / 32 slices][hi | lo][k-group q][row m][8 bf16], element j of k-group q = channel 4 q + j (j < 4) or 16 + 4 q + j - 4
     int ic2, Cs, Cd;
 };
 #define WG_EFF_JOBS 64
@@ -762,24 +789,56 @@ struct EffArgs {
     int n;
     EffJob job[WG_EFF_JOBS];
 };
+// block (x, job): 64 gate channels; thread (c = tid & 63, q = tid >> 6) walks quarter q of the Cs skip rows, eight loads in flight (one
+// thread per channel walking all Cs rows was a chain of Cs round trips: 190 us per launch for 4 MFLOP); W_end sits in LDS (broadcast
+// reads); the four quarters are added in a fixed order
 __global__ __launch_bounds__(256) void weff_kernel(const EffArgs a)
 {
     const EffJob j = a.job[blockIdx.y];
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= j.Cd) return;
+    if ((int)blockIdx.x * 64 >= j.Cd) return;
+    extern __shared__ float weff_lds[];                       // wE [ic2][Cs], then part [3][32][64]
+    float *we = weff_lds, *part = weff_lds + j.ic2 * j.Cs;
+    const int tid = threadIdx.x, cl = tid & 63, q = tid >> 6, c = blockIdx.x * 64 + cl;
+    for (int i = tid; i < j.ic2 * j.Cs; i += 256) we[i] = j.wE[i];
+    __syncthreads();
     float acc[32];
 #pragma unroll
     for (int m = 0; m < 32; ++m) acc[m] = 0.f;
-    for (int s = 0; s < j.Cs; ++s) {
-        const float w = j.scale[s] * j.v[(size_t)s * j.Cd + c];          // the effective skip weight, as the pack jobs form it
+    const int sq = (j.Cs + 3) / 4, s0 = q * sq, s1 = min(j.Cs, s0 + sq);
+    const int cc = min(c, j.Cd - 1);
+    for (int s = s0; s < s1; s += 8) {
+        float w[8];
 #pragma unroll
-        for (int m = 0; m < 32; ++m)
-            if (m < j.ic2) acc[m] = fmaf(j.wE[(size_t)m * j.Cs + s], w, acc[m]);
+        for (int u = 0; u < 8; ++u) {
+            const int ss = min(s + u, s1 - 1);
+            w[u] = j.scale[ss] * j.v[(size_t)ss * j.Cd + cc];           // the effective skip weight, as the pack jobs form it
+            if (s + u >= s1) w[u] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int m = 0; m < 32; ++m)
+                if (m < j.ic2) acc[m] = fmaf(we[m * j.Cs + min(s + u, s1 - 1)], w[u], acc[m]);
     }
+    if (q)
 #pragma unroll
-    for (int m = 0; m < 32; ++m) {
-        j.effT[(size_t)c * 32 + m] = acc[m];
-        j.effN[(size_t)m * j.Cd + c] = acc[m];
+        for (int m = 0; m < 32; ++m) part[((q - 1) * 32 + m) * 64 + cl] = acc[m];
+    __syncthreads();
+    if (q == 0 && c < j.Cd) {
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+            const float x = m < j.ic2 ? (acc[m] + part[m * 64 + cl]) + (part[(32 + m) * 64 + cl] + part[(64 + m) * 64 + cl]) : 0.f;
+            j.effT[(size_t)c * 32 + m] = x;
+            j.effN[(size_t)m * j.Cd + c] = x;
+            if (j.effA && m < 8) {
+                const int sl = c >> 5, cc = c & 31, qq = (cc & 15) >> 2, jj = (cc & 3) + (cc >= 16 ? 4 : 0);
+                unsigned hh, ll;
+                split2(x, 0.f, hh, ll);
+                unsigned short *e = j.effA + ((size_t)(sl * 2) * 32 + qq * 8 + m) * 8 + jj;
+                e[0] = (unsigned short)(hh & 0xffffu);
+                e[32 * 8] = (unsigned short)(ll & 0xffffu);
+            }
+        }
     }
 }
 

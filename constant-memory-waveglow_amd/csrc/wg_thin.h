@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void lr_dwsk_kernel(const LrFinArgs a)
 // one block per skip row s: thread k-slices, 32 sums per thread, a fixed tree over the block
 __global__ __launch_bounds__(256) void lr_dwend_kernel(const LrFinArgs a)
 {
-    __shared__ float red[32][257];
+    __shared__ float red[32][4];
     const int s = blockIdx.x, tid = threadIdx.x;
     float acc[32];
 #pragma unroll
@@ -459,14 +459,15 @@ __global__ __launch_bounds__(256) void lr_dwend_kernel(const LrFinArgs a)
                 if (m < a.ic2) acc[m] = fmaf(Pl[(size_t)m * a.Cd + k], w, acc[m]);
         }
     }
+    // a butterfly over the lanes, then the four waves' sums in wave order: a fixed order
 #pragma unroll
-    for (int m = 0; m < 32; ++m) red[m][tid] = acc[m];
+    for (int m = 0; m < 32; ++m)
+        if (m < a.ic2) {
+            float x = acc[m];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+            if ((tid & 63) == 0) red[m][tid >> 6] = x;
+        }
     __syncthreads();
-    for (int q = 128; q > 0; q >>= 1) {
-        if (tid < q)
-#pragma unroll
-            for (int m = 0; m < 32; ++m) red[m][tid] += red[m][tid + q];
-        __syncthreads();
-    }
-    if (tid < 32) a.dWend[(size_t)tid * a.Cs + s] = tid < a.ic2 ? red[tid][0] : 0.f;
+    if (tid < 32) a.dWend[(size_t)tid * a.Cs + s] = tid < a.ic2 ? (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]) : 0.f;
 }

@@ -90,6 +90,11 @@ struct Ctx {
     size_t gslab_floats = 0;         // scratch for the K parts of a split gate conv (convgemm16g_kernel<WGG_EPI_PART>)
     struct StageRec *rec = nullptr;  // set while a launch sequence is RECORDED for the stage interpreter (wg_stage.h): nothing is launched
     struct BigCap *cap = nullptr;    // set while run_convgemm only DESCRIBES a chip-filling launch (run_convlayer_big): nothing is launched
+    // the gate conv's share of WN's `out` from its own epilogue (ConvGemm16sArgs::part; wn_forward sets these around a layer's gate conv):
+    const float *gate_eff = nullptr; // Weff of the layer as A fragments (WnPack::effA)
+    float *gate_part = nullptr;      // that layer's partial rows
+    int part_written = 0;            // gate convs of this call that were launched with them
+    int *probe = nullptr;            // set while run_convgemm only REPORTS whether a gate conv would take the kernel that writes them (1) or not (0)
 };
 // a launch of the 256 x 128-tile conv kernel as its argument block (ntx x nty x ntz tiles of 256 rows), instead of the launch
 struct BigCap {
@@ -118,6 +123,7 @@ thread_local const char *g_last_launch = "";
 #define WG_LAUNCH(ctx, kern, grid, block, shmem, ...)                         \
     do {                                                                      \
         if ((ctx).rec) (ctx).rec->ok = false;   /* not a recordable launch */ \
+        else if ((ctx).probe) { }               /* a route is being asked for, nothing runs */ \
         else if ((ctx).err == 0) {                                            \
             g_last_launch = #kern;                                            \
             hipLaunchKernelGGL(kern, grid, block, shmem, (ctx).st, __VA_ARGS__); \
@@ -241,9 +247,20 @@ inline bool lowrank_shape(const WnD &d)
 #if defined(WG_OPT_NO_LOWRANK)
     (void)d; return false;
 #else
-    return d.prec == 2 && !d.mode2d && !d.bias && fused_skip(d) && d.Cd % 64 == 0 && d.Cs <= 1024;
+    return d.prec == 2 && !d.mode2d && !d.bias && fused_skip(d) && d.Cd % 64 == 0 && 2 * d.ic * d.Cs <= 8192;                           // (W_end in weff_kernel's LDS)
 #endif
 }
+
+// ... and the gate convs leave their share of `out` themselves (ConvGemm16sArgs::part): 8 floats per column and (row tile, wave row)
+inline bool gate_parts_shape(const WnD &d)
+{
+#if defined(WG_OPT_NO_GATE_PARTS)
+    (void)d; return false;
+#else
+    return lowrank_shape(d) && 2 * d.ic <= 8 && (2 * d.Cd) % 256 == 0 && 8 * d.Cd * sizeof(float) <= 8192;
+#endif
+}
+inline int gate_part_slots(const WnD &d) { return (2 * d.Cd / 256) * 4; }
 
 Geo make_geo(int B, int T, int halo_need)
 {
@@ -275,6 +292,7 @@ struct WnPack {
     size_t scale_V, scale_start, scale_W[16], scale_Wo[16];
     size_t startT, startN, endT, endN, bias_end;
     size_t Acat[16], WoT[16], WoN[16], WT[16], VN[16], WskT, VNall;
+    size_t effA = 0;                                          // gate_parts_shape: Weff as A fragments for the gate conv's epilogue, Cd / 32 KB per layer
     size_t effT = 0, effN = 0, WoG[16] = {0};                // lowrank_shape: Weff^T [depth Cd][32]; Weff per layer [depth][32][Cd]; [Wres_l^T | Weff_l^T] k-major
     int ld_startT, ld_startN, ld_endN, ld_Acat, ld_WoT[16], ld_WoN, ld_WT, ld_VN, ld_WskT;
     int kp_start, kp_end, kcat;
@@ -327,6 +345,7 @@ WnPack wn_pack_layout(const WnD &d)
     if (lowrank_shape(d)) {
         L.effT = take((size_t)d.depth * d.Cd * 32);
         L.effN = take((size_t)d.depth * 32 * d.Cd);
+        if (gate_parts_shape(d)) L.effA = take((size_t)d.depth * (d.Cd / 32) * 256);
         // the gate backward's weights with the skip rows replaced by Weff_l: K = [C residual rows (none on the last layer) | 32 rows of G]
         // (kp_end rows, as the G plane has them: run_convgemm finds a matrix's image behind K = the segments' channels)
         for (int i = 0; i < d.depth; ++i) L.WoG[i] = take_mat((i == d.depth - 1 ? 0 : d.C) + L.kp_end, L.ld_WoN);
@@ -396,18 +415,20 @@ struct EffBatch {
     Ctx *ctx;
     EffArgs ea;
     int maxcd = 0;
+    size_t lds = 0;
     EffBatch(Ctx *c) : ctx(c) { ea.n = 0; }
     void flush()
     {
         if (!ea.n) return;
-        WG_LAUNCH(*ctx, weff_kernel, dim3((maxcd + 255) / 256, ea.n), dim3(256), 0, ea);
-        ea.n = 0; maxcd = 0;
+        WG_LAUNCH(*ctx, weff_kernel, dim3((maxcd + 63) / 64, ea.n), dim3(256), lds, ea);
+        ea.n = 0; maxcd = 0; lds = 0;
     }
     void add(const EffJob &j)
     {
         if (ea.n == WG_EFF_JOBS) flush();
         ea.job[ea.n++] = j;
         maxcd = std::max(maxcd, j.Cd);
+        lds = std::max(lds, ((size_t)j.ic2 * j.Cs + 3 * 32 * 64) * sizeof(float));      // (lowrank_shape: 2 ic Cs <= 8192 floats -> at most 56 KB)
     }
 };
 // Weff of every layer (lowrank_shape): behind the row norms (it reads W_o's scales), in front of the pack jobs (they read effN)
@@ -422,6 +443,7 @@ void wn_pack_eff(EffBatch &eb, const WnD &d, const WnPack &L, const float *const
         j.scale = pk + L.scale_Wo[i] + r0;
         j.effT = pk + L.effT + (size_t)i * d.Cd * 32;
         j.effN = pk + L.effN + (size_t)i * 32 * d.Cd;
+        j.effA = L.effA ? (unsigned short *)(pk + L.effA + (size_t)i * (d.Cd / 32) * 256) : nullptr;
         j.ic2 = 2 * d.ic; j.Cs = d.Cs; j.Cd = d.Cd;
         eb.add(j);
     }
@@ -784,6 +806,7 @@ struct WnWs {               // plane bases (float offsets) of one WN's activatio
     size_t dxy_step = 0, dxyS_step = 0;                  // fused_dy: layer i's dxy at dxy + i * step (0: one buffer for all layers)
     size_t dHS_step = 0;                                 // grouped_wgrad: dh_i at dHS + i * step (0: accumulated in place in one plane)
     size_t ones = 0, onesS = 0;                          // WnD::bias: 32 channels of ones on [0, T) (fp32 plane, S-plane), filled by every WN pass
+    size_t gpart = 0, gpart_step = 0;                    // lowrank_shape, 2 ic <= 8: the gate convs' partial rows of `out`, [depth][slots][B][Tt][8] fp32
     size_t lsync = 0;                                    // precision 2: the one-launch layer's hand-off counters (wg_layer16h.h), WGL_SYNC_WORDS words, zero between launches
     int nH;                 // 2 (ping-pong) or depth
     size_t slab_floats;
@@ -826,6 +849,10 @@ void wn_ws_layout(Bump &bp, const WnD &d, int ic_max, const Geo &g, int mode, in
         for (int i = 0; i < d.depth; ++i) w.gateS[i] = (mode || i == 0 || fused_skip(d)) ? bp.take(pD) : w.gateS[0];
         w.XaS = bp.take((size_t)g.B * rup(ic_max, WG_BK) * g.P);
         w.lsync = bp.take(WGL_SYNC_WORDS);
+        if (gate_parts_shape(d) && g.rows == 0) {
+            w.gpart_step = rupz((size_t)gate_part_slots(d) * g.B * g.Tt * 8, 64);
+            w.gpart = bp.take(w.gpart_step * d.depth);
+        }
         if (mode) {
             w.GS = bp.take((size_t)g.B * rup(2 * ic_max, WG_BK) * g.P);
             w.dSS = bp.take(pS);
@@ -902,6 +929,10 @@ void wn_ws_layout_kept(Bump &bp, const WnD &d, int ic_max, const Geo &g, int pre
     if (prec == 2) {
         for (int i = 0; i < d.depth; ++i) { w.HS[i] = bp.take(pC); w.gateS[i] = bp.take(pD); }
         w.XaS = bp.take((size_t)g.B * rup(ic_max, WG_BK) * g.P);
+        if (gate_parts_shape(d) && g.rows == 0) {                // (every flow keeps its own: the backward's end conv reads them again)
+            w.gpart_step = rupz((size_t)gate_part_slots(d) * g.B * g.Tt * 8, 64);
+            w.gpart = bp.take(w.gpart_step * d.depth);
+        }
     } else {
         for (int i = 0; i < d.depth; ++i) { w.H[i] = bp.take(pC); w.gate[i] = bp.take(pD); }
     }
@@ -1057,7 +1088,8 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
     else out_ch = (long long)M * ((out0.p ? 1 : 0) + (s0.hi ? 1 : 0) + (aux0.p ? 1 : 0) + (saux.hi ? 1 : 0));
     const long long alg_bytes = 4 * cols * (in_ch + out_ch) + 4LL * M * Ksum;
     if (cx.cap && cx.prec != 2) { cx.cap->ok = false; return; }
-    TimerScope ts((cx.rec || cx.cap) ? -1000 : WG_K_CONV_STORE + epi, cx.st, M, Ksum, cols, alg_bytes);      // (nothing is launched while recording)
+    if (cx.probe) *cx.probe = 0;
+    TimerScope ts((cx.rec || cx.cap || cx.probe) ? -1000 : WG_K_CONV_STORE + epi, cx.st, M, Ksum, cols, alg_bytes);      // (nothing is launched while recording)
     if (cx.prec) {
         ConvGemm16Args a16;
         int K = 0, nc = 0;
@@ -1077,6 +1109,8 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
             }
 #endif
             as.img = a16.img; as.img_stride = a16.img_stride; as.c = a; as.s0 = s0; as.saux = saux;
+            as.eff = nullptr; as.part = nullptr;
+            if (epi == EPI_GATE && cx.gate_part && (size_t)(M / 64) * 1024 <= WGG_EFF_BYTES) { as.eff = cx.gate_eff; as.part = cx.gate_part; }
             for (int s = 0; s < nseg; ++s) {
                 as.sseg[s].hi = (const unsigned short *)segs[s].s;
                 as.sseg[s].lo_off = (size_t)(segs[s].per_item ? g.B / g.rows : g.B) * segs[s].sCp * g.P;
@@ -1196,7 +1230,9 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                 gate_split_plan(g.B * g.Tt, M, nc, cus, nt, S);
                 const size_t need = (size_t)S * nt * 8 * 24 * 256;
                 if (env_sw().g192_splitk && S && need <= cx.gslab_floats) {
+                    if (cx.probe) { *cx.probe = 0; return; }  // (the cut gate conv does not write the partial rows)
                     ConvGemm16sArgs ap = as;
+                    ap.eff = nullptr; ap.part = nullptr;
                     ap.ntx = nct; ap.nty = nrb; ap.ntz = S; ap.xcd_items = 2;
                     ap.c.out0.p = cx.gslab;
                     WG_LAUNCH(cx, convgemm16g_kernel<WGG_EPI_PART>, dim3(cus), dim3(512), 0, ap);
@@ -1215,6 +1251,8 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                 if (nt >= cus && (double)(rounds * cus - nt) <= 0.1 * rounds * cus) {
                     as.ntx = nct; as.nty = nrb; as.ntz = 1; as.xcd_items = 0;
                     if (env_sw().g192_own) as.xcd_items = 1;                                   // experiment: column ownership
+                    if (cx.probe) { *cx.probe = so_gate ? 1 : 0; return; }
+                    if (so_gate && as.part) ++cx.part_written;
                     if (so_gate) WG_LAUNCH(cx, convgemm16g_kernel<EPI_GATE_SO>, dim3(cus), dim3(512), 0, as);
                     else if (fo_g) WG_LAUNCH(cx, convgemm16g_kernel<EPI_STORE_FO>, dim3(cus), dim3(512), 0, as);
                     else WG_LAUNCH(cx, convgemm16g_kernel<EPI_STORE_SO>, dim3(cus), dim3(512), 0, as);
@@ -1907,6 +1945,7 @@ bool run_convlayer_g(Ctx &cx, FA &&gate_call, FB &&res_call)
     // every operand plane once (h, y, the gate written and read back, tanh / sigmoid where saved, h in and out of the residual) + the weights
     const long long bytes = 4 * cols * (in_ch + (long long)A.c.M / 2 * (A.c.out1.p ? 4 : 2) + 2LL * R.c.M) + 4LL * A.c.M * KA + 4LL * R.c.M * KR;
     TimerScope ts(WG_K_LAYER, cx.st, A.c.M, Keff, cols, bytes);
+    if (A.part) ++cx.part_written;
     WG_LAUNCH(cx, convlayer16g_kernel, dim3(cus), dim3(512), 0, la);
     g_layerg_launches.fetch_add(1, std::memory_order_relaxed);
     return true;
@@ -1926,6 +1965,10 @@ void layer_sync_clear(Ctx &cx, float *ws, size_t lsync)
     if (cx.prec == 2 && !cx.err && hipMemsetAsync(ws + lsync, 0, WGL_SYNC_WORDS * sizeof(unsigned), cx.st) != hipSuccess) cx.err = WG_ELAUNCH;
 }
 
+struct WnRun;
+// layer i's gate conv (model/waveglow.py:42-44): dilated taps of h_i (plane / S-plane `hin`) + the conditioning -> gate (tanh, sigmoid
+// kept where the pass saves them); keepg: every layer's gate has its own plane
+static void wn_gate_conv(Ctx &cx, const WnRun &r, int i, int hin, bool keepg);
 // The WN runs in the rank-2ic form of its skip path (lowrank_shape; wg_small.h weff_kernel): no skip sum, no dS.  One predicate for the
 // forward, the recompute pass and the backward of a shape, so that a kept flow and a recomputed one produce the same bits: the shapes
 // whose forward keeps every layer's gate anyway (the one-product skip sum's, fs below).
@@ -1935,33 +1978,82 @@ static bool lowrank_on(const Ctx &cx, const WnRun &r)
     return env_sw().lowrank && cx.prec == 2 && lowrank_shape(r.d) && r.L.effT && !cx.rec && !cx.row_sel1 && g.rows == 0 &&
            g.B * g.Tt >= WG_FUSED_SKIP_MIN_COLS;
 }
-// where end_affine_kernel takes `out` from: W_end . S (the skip plane), or sum_l Weff_l gate_l straight from the gate planes
-static bool affine_source(const Ctx &cx, const WnRun &r, AffineArgs &a)
+// Do this WN's gate convs leave their share of `out` (ConvGemm16sArgs::part)?  Asked of run_convgemm itself (Ctx::probe: the launch is
+// described, routed, and not run), so that the answer cannot drift from the routing: 1 = the kernel that writes the partial rows.
+static bool gate_parts_on(Ctx &cx, const WnRun &r);
+// where end_affine_kernel takes `out` from: 0 = W_end . S (the skip plane), 1 = sum_l Weff_l gate_l straight from the gate planes,
+// 2 = the partial rows the gate convs left
+static int affine_source(Ctx &cx, const WnRun &r, AffineArgs &a)
 {
     a.bias = r.d.bias ? r.pk + r.L.bias_end : nullptr;
     a.Cs = r.d.Cs; a.ic = r.d.ic;
     if (!lowrank_on(cx, r)) {
         a.endT = r.pk + r.L.endT;
         a.S = pref(r.ws + r.w.skip, r.d.Cs);
-        return false;
+        return 0;
     }
     a.endT = r.pk + r.L.effT;
     a.S = pnull();
+    if (gate_parts_on(cx, r)) {
+        a.part = r.ws + r.w.gpart;
+        a.nsrc = r.d.depth * gate_part_slots(r.d);
+        if (r.w.gpart_step != (size_t)gate_part_slots(r.d) * r.g.B * r.g.Tt * 8 && !cx.err) cx.err = WG_EINVAL;      // (the sources are one array)
+        return 2;
+    }
     for (int i = 0; i < r.d.depth; ++i) a.gS[i] = (const unsigned short *)(r.ws + r.w.gateS[i]);
     a.g_lo_off = (size_t)r.g.B * r.d.Cd * r.g.P;
     a.Cd = r.d.Cd; a.nl = r.d.depth;
-    return true;
+    return 1;
 }
-static void launch_end_affine(Ctx &cx, const AffineArgs &a, bool fromg)
+static void launch_end_affine(Ctx &cx, const AffineArgs &a, int src)
 {
     const dim3 grid(a.g.Tt / WG_AFF_T, a.g.B);
-    if (fromg) {
-        if (2 * a.ic <= 8) WG_LAUNCH(cx, (end_affine_kernel<8, false, true>), grid, dim3(256), 0, a);
-        else WG_LAUNCH(cx, (end_affine_kernel<32, false, true>), grid, dim3(256), 0, a);
+    if (src == 2) {
+        WG_LAUNCH(cx, (end_affine_kernel<8, false, 2>), grid, dim3(256), 0, a);
+    } else if (src == 1) {
+        if (2 * a.ic <= 8) WG_LAUNCH(cx, (end_affine_kernel<8, false, 1>), grid, dim3(256), 0, a);
+        else WG_LAUNCH(cx, (end_affine_kernel<32, false, 1>), grid, dim3(256), 0, a);
     } else {
         if (2 * a.ic <= 8) WG_LAUNCH(cx, end_affine_kernel<8>, grid, dim3(256), 0, a);
         else WG_LAUNCH(cx, end_affine_kernel<32>, grid, dim3(256), 0, a);
     }
+}
+
+static void wn_gate_conv(Ctx &cx, const WnRun &r, int i, int hin, bool keepg)
+{
+    const WnD &d = r.d;
+    const Geo &g = r.g;
+    float *ws = r.ws;
+    const bool sp = cx.prec == 2;
+    const int nb = d.bias ? 1 : 0;
+    float *Hin = ws + r.w.H[hin];
+    float *gate = ws + r.w.gate[keepg ? i : 0];
+    const float *gateS = ws + r.w.gateS[keepg ? i : 0];
+    SegSpec sg[WG_MAX_SEG];
+    int ns = 0;
+    for (int kt = 0; kt < d.radix; ++kt) {
+        int ts, ro;
+        d.tap(i, kt, ts, ro);
+        sg[ns++] = {Hin, d.C, 0, d.C, ts, ws + r.w.HS[hin], d.C, 0, ro, 0};
+    }
+#if defined(WG_DBG_NOCOND)      // timing experiment only (results are garbage): the gate conv without its conditioning segment
+    if (false)
+#endif
+    sg[ns++] = {r.Y, d.auxp(), 0, d.auxp(), 0, r.YS, d.auxp(), 0, 0, d.mode2d};
+    if (nb) sg[ns++] = ones_seg(cx, r, false);               // (wn_forward filled the plane of ones at the start of the pass)
+    run_convgemm(cx, g, r.pk + r.L.Acat[i], r.L.ld_Acat, 2 * d.Cd, sg, ns, EPI_GATE, sp ? pnull() : pref(gate, d.Cd),
+                 r.save ? pref(ws + r.w.tw[i], d.Cd) : pnull(), r.save ? pref(ws + r.w.sf[i], d.Cd) : pnull(),
+                 pnull(), pnull(), 0, 0, sp ? sref(g, gateS, d.Cd) : snull());             // waveglow.py:42-44
+}
+static bool gate_parts_on(Ctx &cx, const WnRun &r)
+{
+    if (!lowrank_on(cx, r) || !gate_parts_shape(r.d) || !r.w.gpart_step || !r.L.effA || cx.probe) return false;
+    int route = 0;
+    cx.probe = &route;
+    cx.gate_eff = r.pk + r.L.effA; cx.gate_part = r.ws + r.w.gpart;
+    wn_gate_conv(cx, r, 0, 0, true);
+    cx.probe = nullptr; cx.gate_eff = nullptr; cx.gate_part = nullptr;
+    return route == 1;
 }
 
 void wn_forward(Ctx &cx, const WnRun &r)
@@ -2009,28 +2101,19 @@ void wn_forward(Ctx &cx, const WnRun &r)
     // single-utterance synthesis (2 048 columns) lost 9 % with it, the training shapes gain 2.5 % per step
     const int cols = (cx.row_sel1 && g.rows > 0 ? g.B / g.rows : g.B) * g.Tt;
     const bool fs = fused_skip(d) && cols >= WG_FUSED_SKIP_MIN_COLS;
+    // (lowrank) the gate convs leave their share of `out` themselves: asked once per pass; every layer must then have written its rows
+    const bool gparts = fs && gate_parts_on(cx, r);
+    const int written0 = cx.part_written;
     for (int i = 0; i < d.depth; ++i) {
         const int hin = r.save ? i : (i & 1), hout = r.save ? std::min(i + 1, d.depth - 1) : ((i + 1) & 1);
         float *Hin = ws + r.w.H[hin], *Hout = ws + r.w.H[hout];
         float *gate = ws + r.w.gate[(r.save || fs) ? i : 0];
         const float *gateS = ws + r.w.gateS[(r.save || fs) ? i : 0];
-        SegSpec sg[WG_MAX_SEG];
-        int ns = 0;
-        for (int kt = 0; kt < d.radix; ++kt) {
-            int ts, ro;
-            d.tap(i, kt, ts, ro);
-            sg[ns++] = {Hin, d.C, 0, d.C, ts, ws + r.w.HS[hin], d.C, 0, ro, 0};
-        }
-#if defined(WG_DBG_NOCOND)      // timing experiment only (results are garbage): the gate conv without its conditioning segment
-        if (false)
-#endif
-        sg[ns++] = {r.Y, d.auxp(), 0, d.auxp(), 0, r.YS, d.auxp(), 0, 0, d.mode2d};
-        if (nb) sg[ns++] = sone;
         // fp32 gate plane: only the on-the-fly weight-gradient kernel still reads it (backward); the S-plane feeds W_o
         auto gate_call = [&]() {
-            run_convgemm(cx, g, r.pk + r.L.Acat[i], r.L.ld_Acat, 2 * d.Cd, sg, ns, EPI_GATE, sp ? pnull() : pref(gate, d.Cd),
-                         r.save ? pref(ws + r.w.tw[i], d.Cd) : pnull(), r.save ? pref(ws + r.w.sf[i], d.Cd) : pnull(),
-                         pnull(), pnull(), 0, 0, sp ? sref(g, gateS, d.Cd) : snull());             // waveglow.py:42-44
+            if (gparts) { cx.gate_eff = r.pk + r.L.effA + (size_t)i * (d.Cd / 32) * 256; cx.gate_part = ws + r.w.gpart + (size_t)i * r.w.gpart_step; }
+            wn_gate_conv(cx, r, i, hin, r.save || fs);
+            cx.gate_eff = nullptr; cx.gate_part = nullptr;
         };
         SegSpec sgt[2] = {{gate, d.Cd, 0, d.Cd, 0, gateS, d.Cd, 0}, sone};
         const int last = i == d.depth - 1;
@@ -2058,7 +2141,8 @@ void wn_forward(Ctx &cx, const WnRun &r)
         gate_call();
         wo_call();
     }
-    if (fs && lowrank_on(cx, r)) return;                      // (the end conv reads the gate planes themselves: affine_source)
+    if (gparts && cx.part_written - written0 != d.depth && !cx.err) cx.err = WG_ELAUNCH;      // (a gate conv took another kernel than the probe said)
+    if (fs && lowrank_on(cx, r)) return;                      // (the end conv reads the gate planes or the partial rows: affine_source)
     if (fs) {                                                 // cum_skip = sum_i skip_i (waveglow.py:104) = [Wskip_0 .. Wskip_{d-1}] [gate_0; ..; gate_{d-1}]
         SegSpec sk[WG_MAX_SEG];
         for (int i = 0; i < d.depth; ++i) sk[i] = {ws + r.w.gate[i], d.Cd, 0, d.Cd, 0, ws + r.w.gateS[i], d.Cd, 0};
@@ -2074,7 +2158,7 @@ void run_end_affine(Ctx &cx, const WnRun &r, int mode, PRef dX, float *log_s_out
 {
     AffineArgs a;
     memset(&a, 0, sizeof(a));
-    const bool fromg = affine_source(cx, r, a);
+    const int fromg = affine_source(cx, r, a);
     a.X = r.X; a.dX = dX;
     a.Gp = pref(r.ws + r.w.G, r.L.kp_end);
     a.log_s_out = log_s_out; a.dls_plain = dls_plain; a.dld = dld; a.partial = partial;
@@ -3809,7 +3893,7 @@ int wg_wn_apply(const wg_wn_dims *dd, const void *packed, const float *x, const 
     wn_forward(cx, r);
     AffineArgs a;
     memset(&a, 0, sizeof(a));
-    const bool fromg = affine_source(cx, r, a);
+    const int fromg = affine_source(cx, r, a);
     a.X = X;
     a.log_s_out = log_s; a.t_out = t; a.g = g; a.mode = AFF_RAW;
     launch_end_affine(cx, a, fromg);
