@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WGFLOW_LIB") or os.path.join(_HERE, "csrc", "libwgflow.so")   # WGFLOW_LIB: developer A/B builds
 _LIB = None
 
-ABI_VERSION = 9          # include/wgflow.h WG_ABI_VERSION (9: wg_reload_env, wg_stat_gate_rem_launches)
+ABI_VERSION = 9          # include/wgflow.h WG_ABI_VERSION (9: wg_reload_env, wg_stat_gate_part_launches)
 ABI_SYMBOLS = [
     "wg_strerror", "wg_abi_version", "wg_param_count", "wg_packed_bytes", "wg_workspace_bytes",
     "wg_wn_param_count", "wg_wn_packed_bytes", "wg_coupling_workspace_bytes", "wg_invconv_workspace_bytes",
@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "wg_stat_layer_launches", "wg_layer_workspace_bytes", "wg_layer_apply", "wg_wf_wn_apply",
     "wg_timer_read_name", "wg_box_probe_bytes", "wg_box_probe", "wg_stat_layerg_launches", "wg_stat_gate_split_launches",
     "wg_wf_wn_backward", "wg_layer_backward_workspace_bytes", "wg_layer_backward", "wg_affine_apply", "wg_affine_backward",
-    "wg_reload_env", "wg_stat_gate_rem_launches", "wg_wsr_cond_pre",
+    "wg_reload_env", "wg_stat_gate_part_launches", "wg_wsr_cond_pre",
 ]
 K_CONV_STORE, K_CONV_GATE, K_CONV_RESSKIP, K_CONV_DGATE, K_WGRAD, K_LAYER = range(6)
 
@@ -165,7 +165,7 @@ def lib():
     L.wg_box_probe.argtypes = [vp, i, vp, vp]
     L.wg_stat_layerg_launches.restype = C.c_longlong
     L.wg_stat_gate_split_launches.restype = C.c_longlong
-    L.wg_stat_gate_rem_launches.restype = C.c_longlong
+    L.wg_stat_gate_part_launches.restype = C.c_longlong
     L.wg_reload_env.restype = None
     L.wg_reload_env.argtypes = []
     _LIB = L

@@ -156,7 +156,7 @@ __device__ __forceinline__ void mfma12(const Frags16 &f, f32x16 (&acc)[2][2])
 }
 
 // ------------------------------------------------------------------------------------------------
-// staging registers of the loader waves (convgemm16q / convgemm16h; protocol: tools/experiments/wg_gemm16_superseded.h, convgemm16w)
+// staging registers of the loader waves (convgemm16q / convgemm16h; protocol: convgemm16w, removed in round 6 -- git show 4c099e9:tools/experiments/wg_gemm16_superseded.h)
 // ------------------------------------------------------------------------------------------------
 struct Stage8 {
     u32x4 ah[2], al[2], bh[2], bl[2];
@@ -190,7 +190,7 @@ __device__ unsigned long long wg_dbg_trace_cyc[512 * 16];   // shader cycles (s_
 #define WG16W_BAR() __syncthreads()
 #endif
 #if defined(WG_OPT_MFMA32) || defined(WG_OPT_NO_WSPEC) || defined(WG_OPT_DMA)
-#include "../../tools/experiments/wg_gemm16_superseded.h"      // A/B builds only: the superseded conv kernels
+#error "the superseded conv kernels (convgemm16w / 16d / 16p) left the tree in round 6: git show 4c099e9:tools/experiments/wg_gemm16_superseded.h"
 #endif
 
 // ------------------------------------------------------------------------------------------------

@@ -42,12 +42,12 @@ struct EnvSw {
     bool g192 = true;            // WG_G192=0: the conv products never take the 256 x 192-tile kernel of wg_gemm16g.h
     bool g192_splitk = true;     // WG_G192_SPLITK=0: a gate conv whose tiles cannot fill the chip is not cut along K
     bool g192_own = false;       // WG_G192_OWN=1: experiment, column ownership for stand-alone products
-    bool g192_rem = true;        // WG_G192_REM=0: a ragged last round of tiles is not cut along K (run_convgemm)
     bool layer_fusion = false;   // WG_LAYER_FUSION=1: the one-launch layer for small grids (wg_layer16h.h), opt-in
     bool layer_fusion_big = false;   // WG_LAYER_FUSION_BIG=1: the one-launch layer on 256 x 128 tiles (wg_layer16q.h), opt-in
     bool layer_g = true;         // WG_LAYER_G=0: gate conv and residual product as two launches
     bool inv_seam = false;       // WG_INV_SEAM=1: end conv + affine + inverse 1x1 + next start conv as one launch, opt-in
-    bool lowrank = true;         // WG_LOWRANK=0: the skip sum and its gradient are formed as planes again (lowrank_skip below)
+    bool lowrank = true;         // WG_LOWRANK=0: the skip sum and its gradient are formed as planes again (lowrank_on below)
+    bool lowrank_all = false;    // WG_LOWRANK=2: also where it was measured slower (2 ic > 8: WSRGlow) -- tests of those instantiations
 };
 static std::atomic<const EnvSw *> g_env{nullptr};
 static const EnvSw *env_load()
@@ -57,12 +57,12 @@ static const EnvSw *env_load()
     n->g192 = !is("WG_G192", '0');
     n->g192_splitk = !is("WG_G192_SPLITK", '0');
     { const char *e = getenv("WG_G192_OWN"); n->g192_own = e && atoi(e) != 0; }
-    n->g192_rem = !is("WG_G192_REM", '0');
     n->layer_fusion = is("WG_LAYER_FUSION", '1');
     n->layer_fusion_big = is("WG_LAYER_FUSION_BIG", '1');
     n->layer_g = !is("WG_LAYER_G", '0');
     n->inv_seam = is("WG_INV_SEAM", '1');
     n->lowrank = !is("WG_LOWRANK", '0');
+    n->lowrank_all = is("WG_LOWRANK", '2');
     return n;
 }
 static const EnvSw &env_sw()
@@ -818,7 +818,7 @@ struct Bump {
 };
 int device_cus();
 std::atomic<long long> g_gate_split_launches{0};             // diagnostics (wg_stat_gate_split_launches)
-std::atomic<long long> g_gate_rem_launches{0};               // diagnostics (wg_stat_gate_rem_launches)
+std::atomic<long long> g_gate_part_launches{0};              // diagnostics (wg_stat_gate_part_launches)
 // A gate conv cut along K (run_convgemm's split path: convgemm16g_kernel<WGG_EPI_PART> + gate_finish16g_kernel): nt = output tiles of
 // 256 x 192, S = parts per tile (0: the shape does not qualify) -- the tiles fill 1 / S of the CUs, the column tiles are a multiple of
 // 8 (XCD placement), every part holds at least 8 and at most WGG_MAXCHUNKS chunks.  ONE function for the launch site and for the
@@ -1183,9 +1183,9 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                     return;
                 }
                 // (measured slower in round 5: the same tiles with the operands by LDS-DMA into a ring of eight chunk buffers, seven chunks in
-                // flight, four waves that multiply and issue -- tools/experiments/wg_gemm16m.h: 2.70 against 2.46-2.52 ms per 0.7 s utterance,
+                // flight, four waves that multiply and issue -- git show 4c099e9:tools/experiments/wg_gemm16m.h: 2.70 against 2.46-2.52 ms per 0.7 s utterance,
                 // WaveFlow's row-by-row synthesis 96.6 against 86.7 ms: a CU's intake rate, not the depth of its prefetch, bounds these launches)
-                // (2 or 4 k-steps per chunk and barrier measured slower: tools/experiments/wg_gemm16hk.h)
+                // (2 or 4 k-steps per chunk and barrier measured slower: git show 4c099e9:tools/experiments/wg_gemm16hk.h)
                 switch (epi) {
                 case EPI_STORE: WG_LAUNCH(cx, convgemm16h_kernel<EPI_STORE>, gh, dim3(512), 0, as); break;
                 case EPI_GATE: WG_LAUNCH(cx, convgemm16h_kernel<EPI_GATE>, gh, dim3(512), 0, as); break;
@@ -1252,7 +1252,7 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                     as.ntx = nct; as.nty = nrb; as.ntz = 1; as.xcd_items = 0;
                     if (env_sw().g192_own) as.xcd_items = 1;                                   // experiment: column ownership
                     if (cx.probe) { *cx.probe = so_gate ? 1 : 0; return; }
-                    if (so_gate && as.part) ++cx.part_written;
+                    if (so_gate && as.part) { ++cx.part_written; g_gate_part_launches.fetch_add(1, std::memory_order_relaxed); }
                     if (so_gate) WG_LAUNCH(cx, convgemm16g_kernel<EPI_GATE_SO>, dim3(cus), dim3(512), 0, as);
                     else if (fo_g) WG_LAUNCH(cx, convgemm16g_kernel<EPI_STORE_FO>, dim3(cus), dim3(512), 0, as);
                     else WG_LAUNCH(cx, convgemm16g_kernel<EPI_STORE_SO>, dim3(cus), dim3(512), 0, as);
@@ -1335,7 +1335,7 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
             case EPI_DGATE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_DGATE, 2>), gp, dim3(512), 0, as); break;
             }
             return;
-#else                                             // A/B build -DWG_OPT_MFMA32: the 32x32x16 kernel (tools/experiments/wg_gemm16_superseded.h)
+#else                                             // A/B build -DWG_OPT_MFMA32: the 32x32x16 kernel (git show 4c099e9:tools/experiments/wg_gemm16_superseded.h)
             if (small) {
                 switch (epi) {
                 case EPI_STORE: WG_LAUNCH(cx, (convgemm16w_kernel<EPI_STORE, 1>), gp, dim3(512), 0, as); break;
@@ -1945,7 +1945,7 @@ bool run_convlayer_g(Ctx &cx, FA &&gate_call, FB &&res_call)
     // every operand plane once (h, y, the gate written and read back, tanh / sigmoid where saved, h in and out of the residual) + the weights
     const long long bytes = 4 * cols * (in_ch + (long long)A.c.M / 2 * (A.c.out1.p ? 4 : 2) + 2LL * R.c.M) + 4LL * A.c.M * KA + 4LL * R.c.M * KR;
     TimerScope ts(WG_K_LAYER, cx.st, A.c.M, Keff, cols, bytes);
-    if (A.part) ++cx.part_written;
+    if (A.part) { ++cx.part_written; g_gate_part_launches.fetch_add(1, std::memory_order_relaxed); }
     WG_LAUNCH(cx, convlayer16g_kernel, dim3(cus), dim3(512), 0, la);
     g_layerg_launches.fetch_add(1, std::memory_order_relaxed);
     return true;
@@ -1975,8 +1975,10 @@ static void wn_gate_conv(Ctx &cx, const WnRun &r, int i, int hin, bool keepg);
 static bool lowrank_on(const Ctx &cx, const WnRun &r)
 {
     const Geo &g = r.g;
-    return env_sw().lowrank && cx.prec == 2 && lowrank_shape(r.d) && r.L.effT && !cx.rec && !cx.row_sel1 && g.rows == 0 &&
-           g.B * g.Tt >= WG_FUSED_SKIP_MIN_COLS;
+    // (2 ic <= 8: where the gate convs can leave their share of `out` themselves.  WSRGlow -- 2 ic = 16, 6 144 columns per launch -- runs
+    // the form that reads the gate planes, on 96 workgroups: measured 41.9 against 40.7 ms per step, gpurun_out/r06j_wsr_ab.txt)
+    return env_sw().lowrank && cx.prec == 2 && lowrank_shape(r.d) && (2 * r.d.ic <= 8 || env_sw().lowrank_all) && r.L.effT && !cx.rec &&
+           !cx.row_sel1 && g.rows == 0 && g.B * g.Tt >= WG_FUSED_SKIP_MIN_COLS;
 }
 // Do this WN's gate convs leave their share of `out` (ConvGemm16sArgs::part)?  Asked of run_convgemm itself (Ctx::probe: the launch is
 // described, routed, and not run), so that the answer cannot drift from the routing: 1 = the kernel that writes the partial rows.
@@ -2048,6 +2050,7 @@ static void wn_gate_conv(Ctx &cx, const WnRun &r, int i, int hin, bool keepg)
 static bool gate_parts_on(Ctx &cx, const WnRun &r)
 {
     if (!lowrank_on(cx, r) || !gate_parts_shape(r.d) || !r.w.gpart_step || !r.L.effA || cx.probe) return false;
+    if (env_sw().layer_fusion_big) return false;              // (the opt-in one-launch layer on 256 x 128 tiles has its own gate epilogue)
     int route = 0;
     cx.probe = &route;
     cx.gate_eff = r.pk + r.L.effA; cx.gate_part = r.ws + r.w.gpart;
@@ -2741,7 +2744,7 @@ long long wg_stat_wgrad16t_launches(void) { return g_wgrad16t_launches.load(std:
 long long wg_stat_layer_launches(void) { return g_layer_launches.load(std::memory_order_relaxed) + g_layerq_launches.load(std::memory_order_relaxed); }
 long long wg_stat_layerg_launches(void) { return g_layerg_launches.load(std::memory_order_relaxed); }
 long long wg_stat_gate_split_launches(void) { return g_gate_split_launches.load(std::memory_order_relaxed); }
-long long wg_stat_gate_rem_launches(void) { return g_gate_rem_launches.load(std::memory_order_relaxed); }
+long long wg_stat_gate_part_launches(void) { return g_gate_part_launches.load(std::memory_order_relaxed); }
 void *wg_timer_create(int kernel_id, int capacity)
 {
     if (capacity < 1) return nullptr;

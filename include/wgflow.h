@@ -84,11 +84,11 @@ const char *wg_strerror(int code);
  * layer's hand-off counters, wg_layer_apply / wg_layer_workspace_bytes, wg_wf_wn_apply; 7: wg_wf_config gained bias; 8: wg_timer_read_name,
  * wg_box_probe / wg_box_probe_bytes, wg_stat_layerg_launches, wg_stat_gate_split_launches,
  * wg_wf_wn_backward, wg_layer_backward / wg_layer_backward_workspace_bytes, wg_affine_apply / wg_affine_backward; 9: wg_reload_env,
- * wg_stat_gate_rem_launches, wg_wsr_cond_pre).  A binding built against another revision must not pass its
+ * wg_stat_gate_part_launches, wg_wsr_cond_pre).  A binding built against another revision must not pass its
  * structs: the Python loader compares this with its own ABI_VERSION and refuses the library otherwise. */
 #define WG_ABI_VERSION 9
 int wg_abi_version(void);
-/* Developer switches (WG_G192, WG_G192_SPLITK, WG_G192_REM, WG_LAYER_G, WG_LAYER_FUSION, WG_LAYER_FUSION_BIG, WG_INV_SEAM: A/B switches between
+/* Developer switches (WG_G192, WG_G192_SPLITK, WG_LOWRANK, WG_LAYER_G, WG_LAYER_FUSION, WG_LAYER_FUSION_BIG, WG_INV_SEAM: A/B switches between
  * kernels that compute the same thing, csrc/wgflow.hip EnvSw) are read from the environment ONCE per process, at the first call that needs
  * one; a caller that changes one afterwards -- a test, an A/B run -- calls this to have them read again.  Not to be called while
  * another thread is inside the library.  No counterpart upstream. */
@@ -137,10 +137,9 @@ long long wg_stat_layerg_launches(void);
  * gate_finish16g_kernel sums them in a fixed order and applies the gate): shapes whose column tiles fill a fraction 1/S of the CUs and
  * whose K is long -- WSRGlow's 512 x 4432 gate conv at 12 x 512 columns; env WG_G192_SPLITK=0 switches it off */
 long long wg_stat_gate_split_launches(void);
-/* diagnostics: conv products whose tiles fill the chip a whole number of rounds plus a ragged remainder, launched as full rounds + the
- * remainder tiles cut along K over all CUs (csrc/wgflow.hip run_convgemm: the 10 s synthesis shapes, 288 tiles on 256 CUs; env
- * WG_G192_REM=0 switches it off) */
-long long wg_stat_gate_rem_launches(void);
+/* diagnostics: gate convs launched with the partial rows of WN's `out` (csrc/wg_gemm16g.h, wgg_gate_nb: the rank-2ic form of the skip
+ * path, csrc/wgflow.hip lowrank_on / gate_parts_on; env WG_LOWRANK=0 switches the form off) -- lets a test assert that a shape took it */
+long long wg_stat_gate_part_launches(void);
 
 /* ---- sizes -------------------------------------------------------------------------------- */
 int    wg_param_count(const wg_config *cfg);                 /* entries of the parameter table */

@@ -108,6 +108,81 @@ def wn2d_forward_t(p, n_group, xt, yt):
     return out[:, :1], out[:, 1:]
 
 
+def waveflow_train_step(cfg, params, audio, mel, sigma, need_dh=False, double=False):
+    """One training step of WaveFlow(use_conv1x1=False) (model/waveflow.py:196-223: replication pad + full ConvTranspose1d + LeakyReLU(0.4)
+    upsampler :169-175; squeeze to [B, 1, n_group, W]; per flow (log_s, t) = WN2D(x[:, :, :-1], y), rows 1.. mapped affinely, the rows flipped
+    with row 0 at the end :206-218) and the NLL of model/loss.py:10-15.  params in tests/golden/fill.waveflow_param_specs order (no 1x1 convs).
+    The graph is held for ONE flow at a time: the forward keeps every flow's input (n_group x W values per item), the backward re-runs a
+    flow under autograd from its input -- plain autograd in effect (the shipped config has memory_efficient=false), at an eighth of the memory.
+    Returns dict(z, logdet, loss, grads, dh) like train_step; double: float64 arithmetic on the same float32 inputs."""
+    flows, H, M = cfg["flows"], cfg["n_group"], cfg["n_mels"]
+    dt = torch.float64 if double else torch.float32
+    P = [None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dt) for a in params]
+    per = 37 + (19 if cfg.get("bias") else 0)
+    wn_p = [P[3 + k * per: 3 + (k + 1) * per] for k in range(flows)]
+    x_in = torch.from_numpy(np.ascontiguousarray(audio, np.float32)).to(dt)
+    hm = torch.from_numpy(np.ascontiguousarray(mel, np.float32)).to(dt)
+    B, N = x_in.shape
+    W = N // H
+    s = 256 // H
+
+    def upsample(bias, g, v, hh):
+        y = Fn.conv_transpose1d(Fn.pad(hh, [0, 1], mode="replicate"), _wn(g, v), bias, stride=s, padding=s // 2)
+        return Fn.leaky_relu(y, 0.4)[..., :W]
+
+    def flow(p, x, y):
+        log_s, t = wn2d_forward_t(p, H, x[:, :, :-1], y)
+        xout = x[:, :, 1:] * torch.exp(log_s) + t
+        return torch.cat((xout.flip(2), x[:, :, :1]), 2), log_s.sum((1, 2, 3))
+
+    with torch.no_grad():
+        y = upsample(P[0], P[1], P[2], hm)
+        x = x_in.view(B, 1, W, H).transpose(2, 3).contiguous()
+        logdet = torch.zeros(B, dtype=dt)
+        xs = []
+        for k in range(flows):
+            xs.append(x)
+            x, ld = flow(wn_p[k], x, y)
+            logdet = logdet + ld
+        z = x.squeeze(1).transpose(1, 2).contiguous().view(B, N)
+        loss = (0.5 * (z * z).sum(1) / sigma ** 2 - logdet).mean() / N
+        dx = (z / (sigma ** 2 * B * N)).view(B, 1, W, H).transpose(2, 3).contiguous()
+    dld = torch.full((B,), -1.0 / (B * N), dtype=dt)
+    grads = [None if p is None else torch.zeros_like(p) for p in P]
+    dy = torch.zeros_like(y)
+    for k in range(flows - 1, -1, -1):
+        with torch.enable_grad():
+            xi = xs[k].detach().requires_grad_(True)
+            y_ = y.detach().requires_grad_(True)
+            live = [q.detach().requires_grad_(True) if q is not None else None for q in wn_p[k]]
+            xo, ld = flow(live, xi, y_)
+            wanted = [xi, y_] + [q for q in live if q is not None]
+            got = torch.autograd.grad([xo, ld], wanted, [dx, dld])
+        dx = got[0]
+        dy += got[1]
+        it = iter(got[2:])
+        for j, q in enumerate(live):
+            if q is not None:
+                grads[3 + k * per + j] = next(it)
+    with torch.enable_grad():
+        live = [q.detach().requires_grad_(True) if q is not None else None for q in P[:3]]
+        h_ = hm.detach().requires_grad_(need_dh)
+        yy = upsample(live[0], live[1], live[2], h_)
+        wanted = [q for q in live if q is not None] + ([h_] if need_dh else [])
+        got = torch.autograd.grad(yy, wanted, dy)
+    it = iter(got)
+    for j, q in enumerate(live):
+        if q is not None:
+            grads[j] = next(it)
+    dh = next(it).numpy() if need_dh else None
+    return dict(z=z.numpy(), logdet=logdet.numpy(), loss=float(loss), grads=[None if g is None else g.numpy() for g in grads], dh=dh)
+
+
+def _step_of(cfg):
+    """the training step a job's cfg asks for: cfg['model'] == 'waveflow' -> waveflow_train_step, else train_step (WaveGlow)"""
+    return waveflow_train_step if cfg.get("model") == "waveflow" else train_step
+
+
 def set_threads(n):
     torch.set_num_threads(max(1, int(n)))
     return torch.get_num_threads()
@@ -298,8 +373,8 @@ def _shares(B, workers):
 
 
 def train_step_parallel(cfg, params, audio, h, sigma, workers, threads=8, need_dh=False, double=False):
-    """train_step over the batch cut into `workers` shares, one process each (see above).  Same return value as train_step
-    (arrays in float64 when double)."""
+    """train_step (or, with cfg['model'] == 'waveflow', waveflow_train_step) over the batch cut into `workers` shares, one process each
+    (see above).  Same return value as train_step (arrays in float64 when double)."""
     import os
     import shutil
     B, N = audio.shape
@@ -378,20 +453,21 @@ def _worker_main(workdir, index):
     b0, b1 = job["shares"][index]
     audio = np.array(np.load(os.path.join(workdir, "audio.npy"), mmap_mode="r")[b0:b1])      # (copies: torch wants writable arrays)
     h = np.array(np.load(os.path.join(workdir, "h.npy"), mmap_mode="r")[b0:b1])
+    train_step_ = _step_of(job["cfg"])
     if job["runs"]:                                          # timing worker
-        train_step(job["cfg"], params, audio, h, job["sigma"])
+        train_step_(job["cfg"], params, audio, h, job["sigma"])
         open(os.path.join(workdir, "ready%d" % index), "w").close()
         while not os.path.exists(os.path.join(workdir, "go")):
             time.sleep(0.005)
         steps, start = [], time.time()
         for _ in range(job["runs"]):
             t0 = time.time()
-            train_step(job["cfg"], params, audio, h, job["sigma"])
+            train_step_(job["cfg"], params, audio, h, job["sigma"])
             steps.append(time.time() - t0)
         with open(os.path.join(workdir, "time%d.json" % index), "w") as f:
             json.dump({"start": start, "end": time.time(), "steps": steps}, f)
         return
-    r = train_step(job["cfg"], params, audio, h, job["sigma"], need_dh=job["need_dh"], double=job["double"])
+    r = train_step_(job["cfg"], params, audio, h, job["sigma"], need_dh=job["need_dh"], double=job["double"])
     out = {"z": r["z"], "logdet": r["logdet"], "loss": np.float64(r["loss"])}
     for j, g in enumerate(r["grads"]):
         if g is not None:

@@ -135,6 +135,33 @@ def test_wide_batch_step_vs_oracle(dev):
     assert np.abs(npy(xr) - audio).max() < Z_ATOL
 
 
+def test_rank_form_of_the_skip_path_with_sixteen_rows_vs_oracle(dev, monkeypatch):
+    """The skip path in its rank-2ic form (csrc/wgflow.hip lowrank_on: no skip sum, no dS; the end conv contracts the gate planes with
+    W_end Wskip_l, the gate backward takes G as a K segment, W_o's skip rows and dW_end come from P_l = G gate_l^T) runs by default where
+    2 ic <= 8; the instantiations for more rows -- `end_affine_kernel<32, false, 1>`, two row slices of `pgate_kernel` -- are forced here
+    (WG_LOWRANK=2) on the scaled-down WSRGlow core (n_group 16: 2 ic = 16, 14) at 11 x 384 columns, against the float64 oracle."""
+    monkeypatch.setenv("WG_LOWRANK", "2")
+    cm._lib.lib().wg_reload_env()
+    m, cfg, specs, P = build("wsr_like", dev)
+    B, (_, N, F) = 11, fill.SHAPES["wsr_like"]
+    audio, h = fill.inputs("wsr_like_x11", B, N, F, cfg["n_mels"])
+    ref = orc.train_step(orc.make_config(**cfg), fill.table(specs, P), audio, h, fill.SIGMA, need_dh=True, double=True)
+    x, ht = T(audio, dev), T(h, dev).requires_grad_(True)
+    z, logdet = m(x, ht)
+    loss = cm.WaveGlowLoss(fill.SIGMA)(z, logdet)
+    loss.backward()
+    assert np.abs(npy(z) - ref["z"]).max() < Z_ATOL
+    assert logdet_close(npy(logdet), ref["logdet"], N)
+    assert abs(float(loss) - ref["loss"]) < LOSS_ATOL
+    assert relmax(npy(ht.grad), ref["dh"]) < GRAD_RTOL
+    named = dict(m.named_parameters())
+    for i, (n, _, _) in enumerate(specs):
+        assert relmax(npy(named[n].grad), ref["grads"][i]) < GRAD_RTOL, n
+    with torch.no_grad():
+        xr, _ = m.reverse(z.detach(), ht.detach())
+    assert np.abs(npy(xr) - audio).max() < Z_ATOL
+
+
 def test_bias_wide_batch_step_vs_oracle(dev):
     """WN(bias=True) (model/waveglow.py:58) at 4 608 columns per launch: the one-product skip sum (its bias rows: one per layer), the
     S-plane-only residual stream and the grouped weight-gradient launch with the ones segment.  Against the float64 oracle."""
@@ -526,7 +553,11 @@ def test_c2_full_batch_vs_oracle(dev, precision):
             m, cfg, specs, P = build("c2", dev, mem_eff=False)
         tr = FlowTrainer(m, fill.SIGMA)
         tr.want_dh = True                                        # d loss / d h from the timed path itself (wg_train_step's dh output)
+        parts0 = cm._lib.lib().wg_stat_gate_part_launches()
         loss, z, logdet = tr.step(x, ht)
+        # the timed shape runs the rank-2ic form of the skip path with the gate convs writing their share of `out`: 8 per WN pass --
+        # 12 forward + 11 recompute passes in the constant-memory form, 12 forward passes with stored activations
+        assert cm._lib.lib().wg_stat_gate_part_launches() - parts0 == 8 * (23 if mem_eff else 12)
         assert np.abs(npy(z) - ref["z"]).max() < Z_ATOL
         assert logdet_close(npy(logdet), ref["logdet"], N)
         assert abs(float(loss) - ref["loss"]) < LOSS_ATOL
@@ -1581,6 +1612,51 @@ def test_waveflow_timed_workload_vs_reference_golden(dev, golden_dir, precision)
     loss.backward()
     _check_summary(gold, m, specs, z, logdet, loss, N)
     assert relmax(npy(ht.grad), gold["dmel"]) < GRAD_RTOL
+
+
+def test_waveflow_timed_workload_vs_float64_oracle(dev, precision):
+    """`bench.py --model waveflow` at its own size (configs/waveflow_LJ_speech.json: 8 flows, 64 rows, 64 channels, batch 12 x 16000) against
+    the float64 torch-CPU oracle IN FULL -- every element of z, logdet, loss, d loss / d mel and every one of the 299 gradients -- where the
+    reference's own step at this size is kept as a summary only (test_waveflow_timed_workload_vs_reference_golden).  The oracle
+    (oracle/torch_cpu.waveflow_train_step, pinned to the reference's goldens by tests/test_oracle_golden.py) runs one worker process per
+    share of the batch.  Bars: z 1e-4, logdet rtol 1e-4, loss 1e-6, every gradient within 1e-4 of its tensor's max."""
+    if precision != "bf16x3p":
+        pytest.skip("the timed workload runs in the default arithmetic (CPU oracle time)")
+    from oracle import torch_cpu
+    cfg = dict(flows=8, n_group=64, n_mels=80, dilation_channels=64, residual_channels=64, skip_channels=64)
+    B, N, F = 12, 16000, 63
+    specs = fill.waveflow_param_specs(cfg)
+    P = fill.fill_params(specs, "wf_full/")
+    audio, mel = fill.waveflow_inputs("wf_full", B, N, F, 80)
+    n_allowed, quota, firsts = torch_cpu.host_cpu_budget()      # (what this process may really use: a container may grant a fraction of what it shows)
+    cores = max(1, int(quota) if quota else len(firsts))
+    workers = max(1, min(B, cores // 2))
+    ref = torch_cpu.train_step_parallel(dict(cfg, model="waveflow"), fill.table(specs, P), audio, mel, fill.SIGMA, workers=workers,
+                                        threads=max(1, min(4, cores // workers)), need_dh=True, double=True)
+    m = cm.WaveFlow(use_conv1x1=False, memory_efficient=False, bias=False, **cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+    m = m.to(dev)
+    ht = T(mel, dev).requires_grad_(True)
+    z, logdet = m(T(audio, dev), ht)
+    loss = cm.WaveGlowLoss(fill.SIGMA)(z, logdet)
+    loss.backward()
+    assert np.abs(npy(z) - ref["z"]).max() < Z_ATOL
+    assert logdet_close(npy(logdet), ref["logdet"], N)
+    assert abs(float(loss) - ref["loss"]) < LOSS_ATOL
+    assert relmax(npy(ht.grad).astype(np.float64), ref["dh"]) < GRAD_RTOL
+    named = dict(m.named_parameters())
+    worst = 0.0
+    for i, (n, _, _) in enumerate(specs):
+        g = npy(named[n].grad).astype(np.float64)
+        if n.endswith("start.weight_v"):
+            # Conv2d(1, C, 1) under weight norm: w = g sign(v), the exact gradient w.r.t. v is zero; both sides hold rounding noise
+            assert np.abs(g).max() < 1e-5 * np.abs(npy(named[n[:-1] + "g"].grad)).max(), n
+            continue
+        e = relmax(g, ref["grads"][i])
+        worst = max(worst, e)
+        assert e < GRAD_RTOL, n
+    print("WaveFlow 12 x 16000 vs float64 oracle: |dz| %.2e, worst gradient %.2e of its tensor's max (%d oracle workers)"
+          % (float(np.abs(npy(z) - ref["z"]).max()), worst, workers))
 
 
 def test_waveflow_full_size_properties(dev, precision):

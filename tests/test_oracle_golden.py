@@ -297,6 +297,44 @@ def test_waveflow_matches_reference(golden_dir, name, double):
     assert _logdet_close(ld, G["logdet_inv"], N)
 
 
+@pytest.mark.parametrize("name", ["wf8", "wf64", "wf8b"])
+@pytest.mark.parametrize("double", [False, True])
+def test_waveflow_torch_cpu_matches_reference(golden_dir, name, double):
+    """oracle/torch_cpu.waveflow_train_step -- the float64-capable checker of the WaveFlow workload at its full size
+    (tests/test_gpu_parity.py::test_waveflow_timed_workload_vs_float64_oracle) -- pinned to the reference's own step
+    (make_golden.waveflow_fixture): z, logdet, loss, d loss / d mel, every gradient's norm / head, and the batch cut into two worker
+    processes giving the same numbers (train_step_parallel with cfg['model'] = 'waveflow')."""
+    from oracle import torch_cpu as tc
+    cfg = dict(fill.WF_CONFIGS[name], model="waveflow")
+    B, N, F = fill.WF_SHAPES[name]
+    specs = fill.waveflow_param_specs(cfg)
+    P = fill.fill_params(specs, name + "/")
+    audio, mel = fill.waveflow_inputs(name, B, N, F, cfg["n_mels"])
+    G = np.load(os.path.join(golden_dir, "model_%s.npz" % name))
+    tab = fill.table(specs, P)
+    r = tc.waveflow_train_step(cfg, tab, audio, mel, fill.SIGMA, need_dh=True, double=double)
+
+    def check(r):
+        assert np.abs(r["z"] - G["z"]).max() < 2e-6
+        assert _logdet_close(r["logdet"], G["logdet"], N)
+        assert abs(r["loss"] - float(G["loss"])) < 1e-6
+        assert np.abs(r["dh"] - G["dmel"]).max() < 1e-5 * np.abs(G["dmel"]).max()
+        for i, (n, shape, _) in enumerate(specs):
+            g = r["grads"][i]
+            if n.endswith("start.weight_v"):
+                assert np.abs(g).max() < 1e-6 * np.abs(r["grads"][i - 1]).max(), n
+                continue
+            gn = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
+            assert abs(gn - float(G["grad_norm"][i])) <= 2e-5 * float(G["grad_norm"][i]) + 1e-12, n
+            nh = min(g.size, G["grad_head"].shape[1])
+            assert np.abs(g.ravel()[:nh] - G["grad_head"][i][:nh]).max() <= 2e-5 * float(G["grad_max"][i]) + 1e-12, n
+            if "grad::" + n in G:
+                assert np.abs(g - G["grad::" + n]).max() <= 2e-5 * np.abs(G["grad::" + n]).max(), n
+    check(r)
+    if name == "wf8" and double:
+        check(tc.train_step_parallel(cfg, tab, audio, mel, fill.SIGMA, workers=2, threads=1, need_dh=True, double=True))
+
+
 # ---- log-mel conditioner (SURVEY.md 8f rank 3) ----------------------------------------------------------------------------
 
 @pytest.mark.parametrize("tag", list(fill.MEL_CASES))
