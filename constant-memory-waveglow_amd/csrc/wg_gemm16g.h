@@ -110,6 +110,33 @@ __device__ __forceinline__ void wgg_gate_nb(const ConvGemmArgs &a, const SRef &s
         const float *pb = part + (((size_t)slot * g.B + bb) * g.Tt + t0) * 8;
         if (live && rq < 2) wgg_st16(pb, (unsigned)(col * 32 + rq * 16), o);      // rows 4 rq .. 4 rq + 3 of column col
     }
+#if defined(WGG_OPT_UNIT16)
+    // A/B (measured, parity green, NOT adopted: 57.10 / 57.15 against 57.16 / 57.19 ms per step, layer launch 148.5 / 147.7 against
+    // 147.1 / 147.4 us -- gpurun_out/r06l: the width of the S-plane stores is not what the store drain costs, as round 2 found for the
+    // older kernel): the gate's S-plane as 16-byte stores.  Lanes l and l + 16 hold the two halves of one unit; v_permlane16_swap trades the odd
+    // 16-lane rows of the first 16-channel block's registers for the even rows of the second's: even rows then hold a whole unit of
+    // block 0, odd rows one of block 1 -- two 16-byte stores per column block instead of four 8-byte ones
+    {
+        u32x4 uh = {gh[0][0], gh[0][1], gh[1][0], gh[1][1]}, ul = {gl[0][0], gl[0][1], gl[1][0], gl[1][1]};
+        swap16_unit(uh); swap16_unit(ul);
+        const int mbp = rq & 1;                               // the block this lane's unit belongs to
+        const unsigned short *sh = s0.hi + s_index(s0, g, bb, chb, t0), *sl = sh + s0.lo_off;
+        const unsigned vo_u = (unsigned)(((2 * mbp + (rq >> 1)) * g.P + col) * 16);
+        if (live) {
+            asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(vo_u), "v"(uh), "s"(sh) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(vo_u), "v"(ul), "s"(sl) : "memory");
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float *bt = has_ts ? paddr4(a.out1, g, bb, chb + q * 16, t0) : nullptr;
+            const float *bs = has_ts ? paddr4(a.out2, g, bb, chb + q * 16, t0) : nullptr;
+            f32x4 vt, vs;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { vt[e] = tw[4 * q + e]; vs[e] = sf[4 * q + e]; }
+            if (live && has_ts) { wgq_st16nt<0>(bt, vo_t, vt); wgq_st16nt<0>(bs, vo_t, vs); }
+        }
+    }
+#else
 #pragma unroll
     for (int mbp = 0; mbp < 2; ++mbp) {
         const float *bt = has_ts ? paddr4(a.out1, g, bb, chb + mbp * 16, t0) : nullptr;
@@ -137,6 +164,7 @@ __device__ __forceinline__ void wgg_gate_nb(const ConvGemmArgs &a, const SRef &s
 #endif
         }
     }
+#endif
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -149,6 +177,23 @@ __device__ __forceinline__ void wgg_store_nb(const ConvGemmArgs &a, const SRef &
     const bool live = b < g.B && t0 + col < g.T;
     const int bb = min(b, g.B - 1);
     const unsigned vo = (unsigned)(((rq >> 1) * g.P + col) * 16 + 8 * (rq & 1));
+#if defined(WGG_OPT_UNIT16)
+#pragma unroll
+    for (int mb = 0; mb < 4; mb += 2) {                       // (M is a multiple of 256 here: every row exists)
+        unsigned h0, l0, h1, l1, h2, l2, h3, l3;
+        split2(acc[mb][NBI][0], acc[mb][NBI][1], h0, l0); split2(acc[mb][NBI][2], acc[mb][NBI][3], h1, l1);
+        split2(acc[mb + 1][NBI][0], acc[mb + 1][NBI][1], h2, l2); split2(acc[mb + 1][NBI][2], acc[mb + 1][NBI][3], h3, l3);
+        u32x4 uh = {h0, h1, h2, h3}, ul = {l0, l1, l2, l3};
+        swap16_unit(uh); swap16_unit(ul);
+        const unsigned short *hb = s0.hi + s_index(s0, g, bb, mw + mb * 16, t0), *lb = hb + s0.lo_off;
+        const unsigned vo_u = (unsigned)(((2 * (rq & 1) + (rq >> 1)) * g.P + col) * 16);
+        if (live) {
+            asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(vo_u), "v"(uh), "s"(hb) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(vo_u), "v"(ul), "s"(lb) : "memory");
+        }
+    }
+}
+#else
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
         const int mbase = mw + mb * 16;
@@ -160,6 +205,7 @@ __device__ __forceinline__ void wgg_store_nb(const ConvGemmArgs &a, const SRef &
         if (live && mbase + 4 * rq < a.M) { wgq_st8<0>(hb, vo, ph); wgq_st8<0>(lb, vo, pl); }
     }
 }
+#endif
 // EPI_STORE_FO, column block NBI: an fp32 plane as the only output (skip sum): the lane's 4 rows of every 16-row block are four rows of the
 // plane, 4 bytes each (a wave instruction covers 4 x 64 contiguous bytes)
 template <int NBI>
