@@ -413,7 +413,8 @@ def other_models(dev):
 
 
 KCLASS = {0: "conv store / residual / data-gradient (EPI_STORE)", 1: "gate conv (EPI_GATE)", 2: "residual + skip conv (EPI_RESSKIP)",
-          3: "gate backward (EPI_DGATE)", 4: "weight gradient", 5: "layer launch: gate conv + residual product"}
+          3: "gate backward (EPI_DGATE)", 4: "weight gradient", 5: "layer launch: gate conv + residual product",
+          6: "rank-2ic skip path: end conv from partial rows / gate planes, P = G gate^T"}
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "wg_wf_wn_backward", "wg_layer_backward_workspace_bytes", "wg_layer_backward", "wg_affine_apply", "wg_affine_backward",
     "wg_reload_env", "wg_stat_gate_part_launches", "wg_wsr_cond_pre",
 ]
-K_CONV_STORE, K_CONV_GATE, K_CONV_RESSKIP, K_CONV_DGATE, K_WGRAD, K_LAYER = range(6)
+K_CONV_STORE, K_CONV_GATE, K_CONV_RESSKIP, K_CONV_DGATE, K_WGRAD, K_LAYER, K_THIN = range(7)
 
 
 class WgConfig(C.Structure):

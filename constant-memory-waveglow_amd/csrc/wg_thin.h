@@ -359,7 +359,7 @@ struct PGateArgs {
     int nblk, per;                 // 64-column blocks in all (B * Tt / 64), per range
     float *part;                   // [gridDim.y][nl][mrows][Cd]
 };
-__global__ __launch_bounds__(256) void pgate_kernel(const PGateArgs a)
+__global__ __launch_bounds__(256, 3) void pgate_kernel(const PGateArgs a)      // (three workgroups per CU: <= 168 registers)
 {
     const Geo g = a.g;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -2010,6 +2010,9 @@ static int affine_source(Ctx &cx, const WnRun &r, AffineArgs &a)
 static void launch_end_affine(Ctx &cx, const AffineArgs &a, int src)
 {
     const dim3 grid(a.g.Tt / WG_AFF_T, a.g.B);
+    // (timed as its own class where it replaces the skip sum: what it adds per column, and the bytes of that + the flow's channels in and out)
+    const long long cols = (long long)a.g.B * a.g.T, kk = src == 2 ? 8LL * a.nsrc : src == 1 ? (long long)a.Cd * a.nl : a.Cs;
+    TimerScope ts(src ? WG_K_THIN : -1000, cx.st, 2 * a.ic, kk, cols, 4 * cols * (kk + 4 * a.ic));
     if (src == 2) {
         WG_LAUNCH(cx, (end_affine_kernel<8, false, 2>), grid, dim3(256), 0, a);
     } else if (src == 1) {
@@ -2285,7 +2288,7 @@ static const float *run_lowrank_end(Ctx &cx, const WnRun &r, const float *const 
     const WnD &d = r.d;
     const Geo &g = r.g;
     const int ic2 = 2 * d.ic, mrows = rup(ic2, 8), nblk = g.B * (g.Tt / 64);
-    const int ncr = std::max(1, std::min(8, nblk / 4)), per = (nblk + ncr - 1) / ncr;
+    const int ncr = std::max(1, std::min(12, nblk / 4)), per = (nblk + ncr - 1) / ncr;      // (64 x 12 workgroups: three per CU)
     const size_t n = (size_t)d.depth * mrows * d.Cd;
     PGateArgs a;
     memset(&a, 0, sizeof(a));
@@ -2299,7 +2302,11 @@ static const float *run_lowrank_end(Ctx &cx, const WnRun &r, const float *const 
     a.part = cx.fq->reserve(fl);
     if (cx.err) return nullptr;
     float *P = a.part + (size_t)ncr * n, *dWsk = P + rupz(n, 64), *dWe = dWsk + rupz((size_t)d.depth * d.Cs * d.Cd, 64);
-    WG_LAUNCH(cx, pgate_kernel, dim3((d.depth * (d.Cd / 8) + 3) / 4, ncr, mrows / 8), dim3(256), 0, a);
+    {
+        const long long cols = (long long)g.B * g.T, kk = (long long)d.depth * d.Cd;
+        TimerScope ts(WG_K_THIN, cx.st, ic2, kk, cols, 4 * cols * (kk + ic2));
+        WG_LAUNCH(cx, pgate_kernel, dim3((d.depth * (d.Cd / 8) + 3) / 4, ncr, mrows / 8), dim3(256), 0, a);
+    }
     WG_LAUNCH(cx, thin_fold_kernel, dim3((unsigned)(n / 32)), dim3(256), 0, (const float *)a.part, ncr, (int)n, P);
     LrFinArgs f;
     memset(&f, 0, sizeof(f));

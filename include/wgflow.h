@@ -105,6 +105,8 @@ void wg_reload_env(void);
 #define WG_K_WGRAD 4         /* weight-gradient kernel */
 #define WG_K_LAYER 5         /* convlayer16q_kernel: a layer's gate conv + residual product in one persistent launch (reported as M = gate rows,
                               * K = gate K + residual K * residual rows / gate rows, so that 2 M K columns = the launch's FLOPs) */
+#define WG_K_THIN 6          /* the byte-bound passes of the rank-2ic skip path: WN's end conv from the gate planes or from the gate convs' partial rows
+                              * (M = 2 ic, K = the channels or rows it adds), and P_l = G gate_l^T over the gate planes (M = 2 ic, K = depth x dil_ch) */
 void *wg_timer_create(int kernel_id, int capacity);   /* kernel_id < 0: every class above */
 void  wg_timer_attach(void *timer);
 int   wg_timer_count(void *timer);
