@@ -359,7 +359,8 @@ struct PGateArgs {
     int nblk, per;                 // 64-column blocks in all (B * Tt / 64), per range
     float *part;                   // [gridDim.y][nl][mrows][Cd]
 };
-__global__ __launch_bounds__(256, 3) void pgate_kernel(const PGateArgs a)      // (three workgroups per CU: <= 168 registers)
+// (three workgroups per CU -- __launch_bounds__(256, 3), 168 registers, 12 column ranges -- measured slower: 110.5 against 105-107 us)
+__global__ __launch_bounds__(256) void pgate_kernel(const PGateArgs a)
 {
     const Geo g = a.g;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -449,7 +450,6 @@ __global__ __launch_bounds__(256) void lr_dwend_kernel(const LrFinArgs a)
     float acc[32];
 #pragma unroll
     for (int m = 0; m < 32; ++m) acc[m] = 0.f;
-#pragma unroll 4                                          // (the layers' loads in flight together: 26 -> ~12 us per launch)
     for (int l = 0; l < a.nl; ++l) {
         const float sc = a.scale[l][s];
         const float *vr = a.v[l] + (size_t)s * a.Cd, *Pl = a.P + (size_t)l * a.mrows * a.Cd;

@@ -2288,7 +2288,7 @@ static const float *run_lowrank_end(Ctx &cx, const WnRun &r, const float *const 
     const WnD &d = r.d;
     const Geo &g = r.g;
     const int ic2 = 2 * d.ic, mrows = rup(ic2, 8), nblk = g.B * (g.Tt / 64);
-    const int ncr = std::max(1, std::min(12, nblk / 4)), per = (nblk + ncr - 1) / ncr;      // (64 x 12 workgroups: three per CU)
+    const int ncr = std::max(1, std::min(8, nblk / 4)), per = (nblk + ncr - 1) / ncr;
     const size_t n = (size_t)d.depth * mrows * d.Cd;
     PGateArgs a;
     memset(&a, 0, sizeof(a));
