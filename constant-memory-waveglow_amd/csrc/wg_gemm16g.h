@@ -83,7 +83,9 @@ __device__ __forceinline__ void wgg_gate_nb(const ConvGemmArgs &a, const SRef &s
     const Geo g = a.g;
     const int col = lane & 15, rq = lane >> 4;
     const bool live = b < g.B && t0 + col < g.T;
-    const bool has_ts = a.out1.p != nullptr;
+    // (the saved planes: sigmoid always when the pass keeps them; tanh only where the gate backward still reads it -- in the S-plane mode it
+    // takes tanh = gate / sigmoid from the gate's own S-plane: ConvGemmArgs::out1 is then null)
+    const bool has_ts = a.out2.p != nullptr, has_t = a.out1.p != nullptr;
     const unsigned vo_t = (unsigned)((rq * g.P + col) * 16), vo_s = (unsigned)(((rq >> 1) * g.P + col) * 16 + 8 * (rq & 1));
     float tw[8], sf[8], gv[8];
 #pragma unroll
@@ -128,18 +130,19 @@ __device__ __forceinline__ void wgg_gate_nb(const ConvGemmArgs &a, const SRef &s
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const float *bt = has_ts ? paddr4(a.out1, g, bb, chb + q * 16, t0) : nullptr;
+            const float *bt = has_t ? paddr4(a.out1, g, bb, chb + q * 16, t0) : nullptr;
             const float *bs = has_ts ? paddr4(a.out2, g, bb, chb + q * 16, t0) : nullptr;
             f32x4 vt, vs;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { vt[e] = tw[4 * q + e]; vs[e] = sf[4 * q + e]; }
-            if (live && has_ts) { wgq_st16nt<0>(bt, vo_t, vt); wgq_st16nt<0>(bs, vo_t, vs); }
+            if (live && has_t) wgq_st16nt<0>(bt, vo_t, vt);
+            if (live && has_ts) wgq_st16nt<0>(bs, vo_t, vs);
         }
     }
 #else
 #pragma unroll
     for (int mbp = 0; mbp < 2; ++mbp) {
-        const float *bt = has_ts ? paddr4(a.out1, g, bb, chb + mbp * 16, t0) : nullptr;
+        const float *bt = has_t ? paddr4(a.out1, g, bb, chb + mbp * 16, t0) : nullptr;
         const float *bs = has_ts ? paddr4(a.out2, g, bb, chb + mbp * 16, t0) : nullptr;
         const unsigned short *sh = s0.hi + s_index(s0, g, bb, chb + mbp * 16, t0), *sl = sh + s0.lo_off;
         f32x4 vt, vs;
@@ -151,7 +154,8 @@ __device__ __forceinline__ void wgg_gate_nb(const ConvGemmArgs &a, const SRef &s
 #else
         if (live) {
 #endif
-            if (has_ts) { wgq_st16nt<0>(bt, vo_t, vt); wgq_st16nt<0>(bs, vo_t, vs); }
+            if (has_t) wgq_st16nt<0>(bt, vo_t, vt);
+            if (has_ts) wgq_st16nt<0>(bs, vo_t, vs);
 #if defined(WGG_OPT_ST_SC1)                               // experiment: write-through stores (no dirty lines left for the end-of-kernel write-back)
             asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(vo_s), "v"(vh), "s"(sh) : "memory");
             asm volatile("global_store_dwordx2 %0, %1, %2 sc1" ::"v"(vo_s), "v"(vl), "s"(sl) : "memory");

@@ -193,7 +193,8 @@ __device__ __forceinline__ void wgq_gate_nb(f32x4 (&acc)[4][NB], bool live, cons
         split2(gv[4 * mbp], gv[4 * mbp + 1], hh, ll); vh[0] = hh; vl[0] = ll;
         split2(gv[4 * mbp + 2], gv[4 * mbp + 3], hh, ll); vh[1] = hh; vl[1] = ll;
         if (live) {
-            if (has_ts) { wgq_st16nt<256 * NBI>(bt[mbp], vo_t, vt); wgq_st16nt<256 * NBI>(bs[mbp], vo_t, vs); }
+            if (has_ts && bt[mbp]) wgq_st16nt<256 * NBI>(bt[mbp], vo_t, vt);      // (tanh: only where something still reads it, see conv_epilogue_q)
+            if (has_ts) wgq_st16nt<256 * NBI>(bs[mbp], vo_t, vs);
             wgq_st8<256 * NBI>(sh[mbp], vo_s, vh);
             wgq_st8<256 * NBI>(sl[mbp], vo_s, vl);
         }
@@ -209,6 +210,29 @@ template <int OFF>
 __device__ __forceinline__ void wgq_ld16nt(f32x4 &v, const float *base, unsigned voff)
 {
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(v) : "v"(voff), "s"(base), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void wgq_ld8(u32x2 &v, const unsigned short *base, unsigned voff)
+{
+    asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(base), "n"(OFF) : "memory");
+}
+// tanh of a gate element from what the S-plane mode keeps of it: gate = tanh . sigmoid (the S-plane's hi + lo) and the saved sigmoid.
+// sigmoid == 0 (the pre-activation underflowed): gate is 0 too and the factor sigmoid (1 - tanh^2) the caller forms is 0 whatever tanh is.
+__device__ __forceinline__ float wg_tanh_from_gate(float gate, float sf)
+{
+    const float t = __fdividef(gate, sf);
+    return sf > 0.f ? fminf(fmaxf(t, -1.f), 1.f) : 0.f;
+}
+template <int NB>
+__device__ __forceinline__ void wgq_wait_loads8(u32x2 (&x)[NB], u32x2 (&y)[NB], f32x4 (&z)[NB])
+{
+    if constexpr (NB == 4)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]),
+                                            "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3])::"memory");
+    else if constexpr (NB == 2)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(y[0]), "+v"(y[1]), "+v"(z[0]), "+v"(z[1])::"memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(y[0]), "+v"(z[0])::"memory");
 }
 // every hand-issued load has landed (names the registers so that nothing that reads them moves above the wait)
 template <int NB>
@@ -232,7 +256,7 @@ __device__ __forceinline__ void wgq_store_row(const unsigned short *hb, const un
 }
 template <int EPI, int NB>
 __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRef &s0, f32x4 (&acc)[4][NB], int t0, int m0, int b,
-                                                int wr, int wc, int lane)
+                                                int wr, int wc, int lane, const SRef &saux = SRef{nullptr, 0, 8, 0})
 {
     const Geo g = a.g;
     const int col = lane & 15, rq = lane >> 4;
@@ -241,13 +265,15 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
         // (the fp32 tanh / sigmoid planes [c / 4][t][4]: 16 bytes per lane; the gate's S-plane: 8 bytes), column blocks as immediates
         const int chb = (m0 >> 1) + wr * 32;
         if (2 * chb >= a.M) return;
-        const bool has_ts = a.out1.p != nullptr;
+        // the saved planes: sigmoid (out2) whenever the pass keeps them, tanh (out1) only where the gate backward still reads it -- in the
+        // S-plane mode it takes tanh = gate / sigmoid from the gate's own S-plane, and out1 is null
+        const bool has_ts = a.out2.p != nullptr;
         const int tl0 = wc * (16 * NB);
         const float *bt[2], *bs[2];
         const unsigned short *sh[2], *sl[2];
 #pragma unroll
         for (int mbp = 0; mbp < 2; ++mbp) {
-            bt[mbp] = has_ts ? paddr4(a.out1, g, b, chb + mbp * 16, t0 + tl0) : nullptr;
+            bt[mbp] = (has_ts && a.out1.p) ? paddr4(a.out1, g, b, chb + mbp * 16, t0 + tl0) : nullptr;
             bs[mbp] = has_ts ? paddr4(a.out2, g, b, chb + mbp * 16, t0 + tl0) : nullptr;
             sh[mbp] = s0.hi + s_index(s0, g, b, chb + mbp * 16, t0 + tl0);
             sl[mbp] = sh[mbp] + s0.lo_off;
@@ -267,7 +293,7 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
         if (2 * chb >= a.M) return;                              // (2 Cd is a multiple of 64: a wave's 32 gate channels are all valid or none)
         float *b0 = a.out0.p ? paddr(a.out0, g, b, chb, t0) : nullptr;
         float *b1 = a.out1.p ? paddr(a.out1, g, b, chb, t0) : nullptr;
-        float *b2 = a.out1.p ? paddr(a.out2, g, b, chb, t0) : nullptr;
+        float *b2 = a.out2.p ? paddr(a.out2, g, b, chb, t0) : nullptr;
         unsigned short *sh = s0.hi + s_index(s0, g, b, chb, t0);
         unsigned short *sl = sh + s0.lo_off;
         const unsigned s_grp = (unsigned)g.P * 8u;
@@ -289,20 +315,20 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
 #pragma unroll
                     for (int e = 0; e < 4; ++e) b0[off + (unsigned)e * (unsigned)g.P] = gv[4 * mbp + e];
                 }
-                if (b1) {
+                if (b2) {
                     // (non-temporal: the saved tanh / sigmoid planes are read once, by the gate backward of this layer, 15 layer
-                    // launches later: kept out of L2's way, -0.45 ms per training step)
+                    // launches later: kept out of L2's way, -0.45 ms per training step; tanh only where out1 is given)
 #if WG_TS_INTERLEAVED
                     const int chq = chb + mbp * 16 + 4 * rq;
                     f32x4 vt, vs;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { vt[e] = tw[4 * mbp + e]; vs[e] = sf[4 * mbp + e]; }
-                    __builtin_nontemporal_store(vt, reinterpret_cast<f32x4 *>(paddr4(a.out1, g, b, chq, t0 + (int)tl)));
+                    if (b1) __builtin_nontemporal_store(vt, reinterpret_cast<f32x4 *>(paddr4(a.out1, g, b, chq, t0 + (int)tl)));
                     __builtin_nontemporal_store(vs, reinterpret_cast<f32x4 *>(paddr4(a.out2, g, b, chq, t0 + (int)tl)));
 #else
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        __builtin_nontemporal_store(tw[4 * mbp + e], &b1[off + (unsigned)e * (unsigned)g.P]);
+                        if (b1) __builtin_nontemporal_store(tw[4 * mbp + e], &b1[off + (unsigned)e * (unsigned)g.P]);
                         __builtin_nontemporal_store(sf[4 * mbp + e], &b2[off + (unsigned)e * (unsigned)g.P]);
                     }
 #endif
@@ -332,19 +358,47 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
         // S-plane stores likewise (see EPI_STORE_SO).
         const unsigned vo_t = (unsigned)((rq * g.P + col) * 16), vo_s = (unsigned)(((rq >> 1) * g.P + col) * 16 + 8 * (rq & 1));
         const int tl0 = wc * (16 * NB), tw0 = t0 + tl0 + col;
+        const bool twg = a.aux0.p == nullptr;                   // tanh from the gate's S-plane (saux) instead of a saved plane
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             const int mbase = m0 + wr * 64 + mb * 16;
             if (mbase >= a.M) continue;                         // (wave uniform; M is a multiple of 16 on this path)
-            const float *px = paddr4(a.aux0, g, b, mbase, t0 + tl0), *py = paddr4(a.aux1, g, b, mbase, t0 + tl0);
-            f32x4 ax[NB], ay[NB];
-            wgq_ld16nt<0>(ax[0], px, vo_t); wgq_ld16nt<0>(ay[0], py, vo_t);
-            if constexpr (NB > 1) { wgq_ld16nt<256>(ax[1], px, vo_t); wgq_ld16nt<256>(ay[1], py, vo_t); }
-            if constexpr (NB > 2) { wgq_ld16nt<512>(ax[2], px, vo_t); wgq_ld16nt<512>(ay[2], py, vo_t); }
-            if constexpr (NB > 3) { wgq_ld16nt<768>(ax[3], px, vo_t); wgq_ld16nt<768>(ay[3], py, vo_t); }
+            const float *py = paddr4(a.aux1, g, b, mbase, t0 + tl0);
             const unsigned short *hb = s0.hi + s_index(s0, g, b, mbase, t0 + tl0), *lb = hb + s0.lo_off;
             const unsigned short *hb2 = s0.hi + s_index(s0, g, b, a.nsplit + mbase, t0 + tl0), *lb2 = hb2 + s0.lo_off;
-            wgq_wait_loads<NB>(ax, ay);
+            f32x4 ax[NB], ay[NB];
+            // (each form issues, waits and finishes its values INSIDE its branch: registers of loads in flight must not meet at a join --
+            // the compiler would copy them there before the wait, tools/check_asm_loads.py)
+            if (twg) {
+                // tanh is not kept in the S-plane mode: the gate's own S-plane (saux: hi + lo, 2^-17 relative) and the saved sigmoid give
+                // tanh = gate / sigmoid -- the same bytes read, 4 bytes per element less written by every gate conv that keeps its planes
+                const unsigned short *gb = saux.hi + s_index(saux, g, b, mbase, t0 + tl0), *gbl = gb + saux.lo_off;
+                u32x2 gh_[NB], gl_[NB];
+                f32x4 sy[NB];
+                wgq_ld8<0>(gh_[0], gb, vo_s); wgq_ld8<0>(gl_[0], gbl, vo_s); wgq_ld16nt<0>(sy[0], py, vo_t);
+                if constexpr (NB > 1) { wgq_ld8<256>(gh_[1], gb, vo_s); wgq_ld8<256>(gl_[1], gbl, vo_s); wgq_ld16nt<256>(sy[1], py, vo_t); }
+                if constexpr (NB > 2) { wgq_ld8<512>(gh_[2], gb, vo_s); wgq_ld8<512>(gl_[2], gbl, vo_s); wgq_ld16nt<512>(sy[2], py, vo_t); }
+                if constexpr (NB > 3) { wgq_ld8<768>(gh_[3], gb, vo_s); wgq_ld8<768>(gl_[3], gbl, vo_s); wgq_ld16nt<768>(sy[3], py, vo_t); }
+                wgq_wait_loads8<NB>(gh_, gl_, sy);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    ay[nb] = sy[nb];
+                    ax[nb][0] = wg_tanh_from_gate(__uint_as_float(gh_[nb][0] << 16) + __uint_as_float(gl_[nb][0] << 16), sy[nb][0]);
+                    ax[nb][1] = wg_tanh_from_gate(__uint_as_float(gh_[nb][0] & 0xffff0000u) + __uint_as_float(gl_[nb][0] & 0xffff0000u), sy[nb][1]);
+                    ax[nb][2] = wg_tanh_from_gate(__uint_as_float(gh_[nb][1] << 16) + __uint_as_float(gl_[nb][1] << 16), sy[nb][2]);
+                    ax[nb][3] = wg_tanh_from_gate(__uint_as_float(gh_[nb][1] & 0xffff0000u) + __uint_as_float(gl_[nb][1] & 0xffff0000u), sy[nb][3]);
+                }
+            } else {
+                const float *px = paddr4(a.aux0, g, b, mbase, t0 + tl0);
+                f32x4 tx[NB], ty[NB];
+                wgq_ld16nt<0>(tx[0], px, vo_t); wgq_ld16nt<0>(ty[0], py, vo_t);
+                if constexpr (NB > 1) { wgq_ld16nt<256>(tx[1], px, vo_t); wgq_ld16nt<256>(ty[1], py, vo_t); }
+                if constexpr (NB > 2) { wgq_ld16nt<512>(tx[2], px, vo_t); wgq_ld16nt<512>(ty[2], py, vo_t); }
+                if constexpr (NB > 3) { wgq_ld16nt<768>(tx[3], px, vo_t); wgq_ld16nt<768>(ty[3], py, vo_t); }
+                wgq_wait_loads<NB>(tx, ty);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) { ax[nb] = tx[nb]; ay[nb] = ty[nb]; }
+            }
             u32x2 ph[NB], pl[NB], qh[NB], ql[NB];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
@@ -388,8 +442,16 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
                     // (non-temporal, like the stores that saved them: this is their only use; M is a multiple of 4 here)
                     f32x4 vx = {0.f, 0.f, 0.f, 0.f}, vy = {0.f, 0.f, 0.f, 0.f};
                     if (t0 + tl < g.T && mbase + 4 * rq < a.M) {
-                        vx = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(paddr4(a.aux0, g, b, mbase + 4 * rq, t0 + tl)));
                         vy = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(paddr4(a.aux1, g, b, mbase + 4 * rq, t0 + tl)));
+                        if (a.aux0.p) vx = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(paddr4(a.aux0, g, b, mbase + 4 * rq, t0 + tl)));
+                        else {                                  // tanh = gate / sigmoid from the gate's S-plane (see EPI_DGATE_SO)
+                            const size_t gi = s_index(saux, g, b, mbase + 4 * rq, t0 + tl);
+                            const u32x2 uh = *reinterpret_cast<const u32x2 *>(saux.hi + gi), ul = *reinterpret_cast<const u32x2 *>(saux.hi + saux.lo_off + gi);
+                            vx[0] = wg_tanh_from_gate(__uint_as_float(uh[0] << 16) + __uint_as_float(ul[0] << 16), vy[0]);
+                            vx[1] = wg_tanh_from_gate(__uint_as_float(uh[0] & 0xffff0000u) + __uint_as_float(ul[0] & 0xffff0000u), vy[1]);
+                            vx[2] = wg_tanh_from_gate(__uint_as_float(uh[1] << 16) + __uint_as_float(ul[1] << 16), vy[2]);
+                            vx[3] = wg_tanh_from_gate(__uint_as_float(uh[1] & 0xffff0000u) + __uint_as_float(ul[1] & 0xffff0000u), vy[3]);
+                        }
                     }
                     ax[q][nb] = vx; ay[q][nb] = vy;
                     (void)p0; (void)p1;
@@ -833,7 +895,7 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
 #if defined(WG_OPT_EPI_PRIO)
         __builtin_amdgcn_s_setprio(WG_OPT_EPI_PRIO);         // experiment: the epilogue's VALU / store issue ahead of the co-resident workgroup's waves
 #endif
-        conv_epilogue_q<EPI, NB>(a, aa.s0, acc, t0, m0, b, wr, wc, le);
+        conv_epilogue_q<EPI, NB>(a, aa.s0, acc, t0, m0, b, wr, wc, le, aa.saux);
 #if defined(WG_OPT_EPI_PRIO)
         __builtin_amdgcn_s_setprio(0);
 #endif

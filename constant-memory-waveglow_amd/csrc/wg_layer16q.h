@@ -67,7 +67,8 @@ __device__ __forceinline__ void wglq_gate_nb(f32x4 (&acc)[4][NB], bool live, con
         split2(gv[4 * mbp], gv[4 * mbp + 1], hh, ll); vh[0] = hh; vl[0] = ll;
         split2(gv[4 * mbp + 2], gv[4 * mbp + 3], hh, ll); vh[1] = hh; vl[1] = ll;
         if (live) {
-            if (has_ts) { wgq_st16nt<256 * NBI>(bt[mbp], vo_t, vt); wgq_st16nt<256 * NBI>(bs[mbp], vo_t, vs); }
+            if (has_ts && bt[mbp]) wgq_st16nt<256 * NBI>(bt[mbp], vo_t, vt);
+            if (has_ts) wgq_st16nt<256 * NBI>(bs[mbp], vo_t, vs);
             wglq_st8_sc1<256 * NBI>(sh[mbp], vo_s, vh);
             wglq_st8_sc1<256 * NBI>(sl[mbp], vo_s, vl);
         }
@@ -81,13 +82,13 @@ __device__ __forceinline__ void wglq_gate_epilogue(const ConvGemmArgs &a, const 
     const int col = lane & 15, rq = lane >> 4;
     const int chb = (m0 >> 1) + wr * 32;
     if (2 * chb >= a.M) return;
-    const bool has_ts = a.out1.p != nullptr;
+    const bool has_ts = a.out2.p != nullptr;                  // (tanh only where out1 is given: conv_epilogue_q)
     const int tl0 = wc * (16 * NB);
     const float *bt[2], *bs[2];
     const unsigned short *sh[2], *sl[2];
 #pragma unroll
     for (int mbp = 0; mbp < 2; ++mbp) {
-        bt[mbp] = has_ts ? paddr4(a.out1, g, b, chb + mbp * 16, t0 + tl0) : nullptr;
+        bt[mbp] = (has_ts && a.out1.p) ? paddr4(a.out1, g, b, chb + mbp * 16, t0 + tl0) : nullptr;
         bs[mbp] = has_ts ? paddr4(a.out2, g, b, chb + mbp * 16, t0 + tl0) : nullptr;
         sh[mbp] = s0.hi + s_index(s0, g, b, chb + mbp * 16, t0 + tl0);
         sl[mbp] = sh[mbp] + s0.lo_off;

@@ -48,6 +48,7 @@ struct EnvSw {
     bool inv_seam = false;       // WG_INV_SEAM=1: end conv + affine + inverse 1x1 + next start conv as one launch, opt-in
     bool lowrank = true;         // WG_LOWRANK=0: the skip sum and its gradient are formed as planes again (lowrank_on below)
     bool lowrank_all = false;    // WG_LOWRANK=2: also where it was measured slower (2 ic > 8: WSRGlow) -- tests of those instantiations
+    bool tw_from_gate = true;    // WG_TW_FROM_GATE=0: a pass that keeps its planes keeps tanh as well (tw_from_gate below)
 };
 static std::atomic<const EnvSw *> g_env{nullptr};
 static const EnvSw *env_load()
@@ -63,6 +64,7 @@ static const EnvSw *env_load()
     n->inv_seam = is("WG_INV_SEAM", '1');
     n->lowrank = !is("WG_LOWRANK", '0');
     n->lowrank_all = is("WG_LOWRANK", '2');
+    n->tw_from_gate = !is("WG_TW_FROM_GATE", '0');
     return n;
 }
 static const EnvSw &env_sw()
@@ -240,6 +242,17 @@ inline bool fused_dy(const WnD &d)
 }
 
 
+// S-plane mode: a pass that keeps its planes for the gate backward (waveglow.py:13-15) keeps sigmoid only.  The gate itself is kept anyway (its
+// S-plane, hi + lo: W_o's operand), so tanh = gate / sigmoid costs the gate backward no byte more (8 bytes per element either way) and every
+// gate conv of a recompute pass 4 bytes per element less to write: 49 of the ~200 MB a layer launch stores at the training shape.
+inline bool tw_from_gate(const Ctx &cx)
+{
+#if WG_TS_INTERLEAVED && !defined(WG_OPT_KEEP_TANH)
+    return cx.prec == 2 && env_sw().tw_from_gate;
+#else
+    (void)cx; return false;
+#endif
+}
 // The skip sum S = sum_l Wskip_l gate_l and its gradient dS = W_end^T G never formed (Weff_l = W_end Wskip_l, wg_small.h weff_kernel):
 // S-plane mode, 1-D WN without biases (a skip bias would enter `out` through W_end as well), every layer's gate kept (fused_skip).
 inline bool lowrank_shape(const WnD &d)
@@ -2047,7 +2060,7 @@ static void wn_gate_conv(Ctx &cx, const WnRun &r, int i, int hin, bool keepg)
     sg[ns++] = {r.Y, d.auxp(), 0, d.auxp(), 0, r.YS, d.auxp(), 0, 0, d.mode2d};
     if (nb) sg[ns++] = ones_seg(cx, r, false);               // (wn_forward filled the plane of ones at the start of the pass)
     run_convgemm(cx, g, r.pk + r.L.Acat[i], r.L.ld_Acat, 2 * d.Cd, sg, ns, EPI_GATE, sp ? pnull() : pref(gate, d.Cd),
-                 r.save ? pref(ws + r.w.tw[i], d.Cd) : pnull(), r.save ? pref(ws + r.w.sf[i], d.Cd) : pnull(),
+                 (r.save && !tw_from_gate(cx)) ? pref(ws + r.w.tw[i], d.Cd) : pnull(), r.save ? pref(ws + r.w.sf[i], d.Cd) : pnull(),
                  pnull(), pnull(), 0, 0, sp ? sref(g, gateS, d.Cd) : snull());             // waveglow.py:42-44
 }
 static bool gate_parts_on(Ctx &cx, const WnRun &r)
@@ -2431,8 +2444,10 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
             if (!last) s[ns++] = {dH, d.C, 0, d.C, 0, dHSp(i + 1), d.C, 0};
             if (lr) s[ns++] = {G, Gc, 0, Gc, 0, ws + r.w.GS, Gc, 0};          // Wskip_i^T dS = Weff_i^T G: 2 ic channels (of kp_end) instead of Cs
             else s[ns++] = {dS, d.Cs, 0, d.Cs, 0, ws + r.w.dSS, d.Cs, 0};
+            const bool twg = tw_from_gate(cx);              // (tanh from the gate's S-plane: the recompute pass did not keep it)
             run_convgemm(cx, g, r.pk + (lr ? r.L.WoG[i] : r.L.WoN[i]), r.L.ld_WoN, d.Cd, s, ns, EPI_DGATE, sp ? pnull() : pref(dxy, 2 * d.Cd), pnull(), pnull(),
-                         pref(ws + r.w.tw[i], d.Cd), pref(ws + r.w.sf[i], d.Cd), d.Cd, 0, sp ? sref(g, dxyS, 2 * d.Cd) : snull());
+                         twg ? pnull() : pref(ws + r.w.tw[i], d.Cd), pref(ws + r.w.sf[i], d.Cd), d.Cd, 0, sp ? sref(g, dxyS, 2 * d.Cd) : snull(),
+                         twg ? sref(g, ws + r.w.gateS[i], d.Cd) : snull());
         }
         // dW (taps) and dV (conditioning) in one wgrad
         if (gw) {
