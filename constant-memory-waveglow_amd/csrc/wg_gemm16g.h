@@ -110,6 +110,9 @@ __device__ __forceinline__ void wgg_gate_nb(const ConvGemmArgs &a, const SRef &s
         o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eah, bl, o, 0, 0, 0);
         o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eah, bh, o, 0, 0, 0);
         const float *pb = part + (((size_t)slot * g.B + bb) * g.Tt + t0) * 8;
+        // (o comes straight out of the matrix pipe: up to 19 wait states before a vector-memory instruction may read it, and the hazard
+        // recogniser does not look into asm statements)
+        asm volatile("s_nop 15\n\ts_nop 3" : "+v"(o));
         if (live && rq < 2) wgg_st16(pb, (unsigned)(col * 32 + rq * 16), o);      // rows 4 rq .. 4 rq + 3 of column col
     }
 #if defined(WGG_OPT_UNIT16)

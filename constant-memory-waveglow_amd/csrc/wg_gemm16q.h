@@ -170,11 +170,22 @@ __device__ __forceinline__ void wgq_st16nt(const float *base, unsigned voff, con
     // hazard recogniser does not look into asm statements)
     asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(base), "n"(OFF) : "memory");
 }
-// EPI_GATE_SO, column block NBI of a wave tile: tanh, sigmoid, gate of the lane's 8 channels; stores at immediate offset 256 * NBI
+// (the data registers come straight out of an MFMA: a vector-memory instruction that reads the result of a matrix instruction needs up to
+// 19 wait states behind it, and the compiler's hazard recogniser does not look into asm statements -- without the s_nop pair the store
+// read registers the pipe had not written yet, and two runs of one step differed)
+template <int OFF>
+__device__ __forceinline__ void wgq_st16p(const float *base, unsigned voff, const f32x4 &v)
+{
+    asm volatile("s_nop 15\n\ts_nop 3\n\tglobal_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(base), "n"(OFF) : "memory");
+}
+// EPI_GATE_SO, column block NBI of a wave tile: tanh, sigmoid, gate of the lane's 8 channels; stores at immediate offset 256 * NBI.
+// pbase (nullptr: none): the wave's share of WN's `out` for this block -- Weff (rows 0-7, the wave's 32 gate channels: A fragments eah / eal)
+// times the split gate the lane holds, one more 16x16x32 product (wg_gemm16g.h, wgg_gate_nb) -- goes to pbase + 16 NBI columns of 8 floats
 template <int NB, int NBI>
 __device__ __forceinline__ void wgq_gate_nb(f32x4 (&acc)[4][NB], bool live, const float *const (&bt)[2], const float *const (&bs)[2],
                                             const unsigned short *const (&sh)[2], const unsigned short *const (&sl)[2], bool has_ts,
-                                            unsigned vo_t, unsigned vo_s)
+                                            unsigned vo_t, unsigned vo_s, const float *pbase = nullptr, unsigned vo_p = 0, bool plive = false,
+                                            bf16x8 eah = bf16x8{}, bf16x8 eal = bf16x8{})
 {
     float tw[8], sf[8], gv[8];
 #pragma unroll
@@ -183,15 +194,28 @@ __device__ __forceinline__ void wgq_gate_nb(f32x4 (&acc)[4][NB], bool live, cons
         sf[i] = wg_sigmoid(acc[2 + (i >> 2)][NBI][i & 3]);
         gv[i] = tw[i] * sf[i];
     }
+    u32x2 gh[2], gl[2];
+#pragma unroll
+    for (int mbp = 0; mbp < 2; ++mbp) {
+        unsigned hh, ll;
+        split2(gv[4 * mbp], gv[4 * mbp + 1], hh, ll); gh[mbp][0] = hh; gl[mbp][0] = ll;
+        split2(gv[4 * mbp + 2], gv[4 * mbp + 3], hh, ll); gh[mbp][1] = hh; gl[mbp][1] = ll;
+    }
+    if (pbase) {
+        const u32x4 bh4 = {gh[0][0], gh[0][1], gh[1][0], gh[1][1]}, bl4 = {gl[0][0], gl[0][1], gl[1][0], gl[1][1]};
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, bh4), bl = __builtin_bit_cast(bf16x8, bl4);
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eal, bh, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eah, bl, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eah, bh, o, 0, 0, 0);
+        if (live && plive) wgq_st16p<512 * NBI>(pbase, vo_p, o);      // lanes 0-31: rows 4 rq .. 4 rq + 3 of the lane's column
+    }
 #pragma unroll
     for (int mbp = 0; mbp < 2; ++mbp) {
         f32x4 vt, vs;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { vt[e] = tw[4 * mbp + e]; vs[e] = sf[4 * mbp + e]; }
-        u32x2 vh, vl;
-        unsigned hh, ll;
-        split2(gv[4 * mbp], gv[4 * mbp + 1], hh, ll); vh[0] = hh; vl[0] = ll;
-        split2(gv[4 * mbp + 2], gv[4 * mbp + 3], hh, ll); vh[1] = hh; vl[1] = ll;
+        const u32x2 vh = gh[mbp], vl = gl[mbp];
         if (live) {
             if (has_ts && bt[mbp]) wgq_st16nt<256 * NBI>(bt[mbp], vo_t, vt);      // (tanh: only where something still reads it, see conv_epilogue_q)
             if (has_ts) wgq_st16nt<256 * NBI>(bs[mbp], vo_t, vs);
@@ -256,7 +280,8 @@ __device__ __forceinline__ void wgq_store_row(const unsigned short *hb, const un
 }
 template <int EPI, int NB>
 __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRef &s0, f32x4 (&acc)[4][NB], int t0, int m0, int b,
-                                                int wr, int wc, int lane, const SRef &saux = SRef{nullptr, 0, 8, 0})
+                                                int wr, int wc, int lane, const SRef &saux = SRef{nullptr, 0, 8, 0}, const float *eff = nullptr,
+                                                float *part = nullptr)
 {
     const Geo g = a.g;
     const int col = lane & 15, rq = lane >> 4;
@@ -280,10 +305,24 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
         }
         const unsigned vo_t = (unsigned)((rq * g.P + col) * 16), vo_s = (unsigned)(((rq >> 1) * g.P + col) * 16 + 8 * (rq & 1));
         const int tw0 = t0 + tl0 + col;
-        wgq_gate_nb<NB, 0>(acc, tw0 < g.T, bt, bs, sh, sl, has_ts, vo_t, vo_s);
-        if constexpr (NB > 1) wgq_gate_nb<NB, 1>(acc, tw0 + 16 < g.T, bt, bs, sh, sl, has_ts, vo_t, vo_s);
-        if constexpr (NB > 2) wgq_gate_nb<NB, 2>(acc, tw0 + 32 < g.T, bt, bs, sh, sl, has_ts, vo_t, vo_s);
-        if constexpr (NB > 3) wgq_gate_nb<NB, 3>(acc, tw0 + 48 < g.T, bt, bs, sh, sl, has_ts, vo_t, vo_s);
+        // the wave's share of WN's `out` (ConvGemm16sArgs::part): its 32 gate channels are slice chb / 32 of the layer's Weff fragments
+        // ([slice][hi | lo][k-group][8 rows][16 B], weff_kernel); rows 8-15 of the A operand are zero
+        const int slot = chb >> 5;
+        bf16x8 eah = bf16x8{}, eal = bf16x8{};
+        const float *pbase = nullptr;
+        if (part) {
+            if (col < 8) {
+                const char *ef = reinterpret_cast<const char *>(eff) + slot * 1024 + (rq * 8 + col) * 16;
+                eah = *reinterpret_cast<const bf16x8 *>(ef); eal = *reinterpret_cast<const bf16x8 *>(ef + 512);
+            }
+            pbase = part + (((size_t)slot * g.B + b) * g.Tt + t0 + tl0) * 8;
+        }
+        const unsigned vo_p = (unsigned)(col * 32 + (rq & 1) * 16);
+        const bool plive = rq < 2;
+        wgq_gate_nb<NB, 0>(acc, tw0 < g.T, bt, bs, sh, sl, has_ts, vo_t, vo_s, pbase, vo_p, plive, eah, eal);
+        if constexpr (NB > 1) wgq_gate_nb<NB, 1>(acc, tw0 + 16 < g.T, bt, bs, sh, sl, has_ts, vo_t, vo_s, pbase, vo_p, plive, eah, eal);
+        if constexpr (NB > 2) wgq_gate_nb<NB, 2>(acc, tw0 + 32 < g.T, bt, bs, sh, sl, has_ts, vo_t, vo_s, pbase, vo_p, plive, eah, eal);
+        if constexpr (NB > 3) wgq_gate_nb<NB, 3>(acc, tw0 + 48 < g.T, bt, bs, sh, sl, has_ts, vo_t, vo_s, pbase, vo_p, plive, eah, eal);
         return;
     }
     if (EPI == EPI_GATE) {
@@ -895,7 +934,7 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
 #if defined(WG_OPT_EPI_PRIO)
         __builtin_amdgcn_s_setprio(WG_OPT_EPI_PRIO);         // experiment: the epilogue's VALU / store issue ahead of the co-resident workgroup's waves
 #endif
-        conv_epilogue_q<EPI, NB>(a, aa.s0, acc, t0, m0, b, wr, wc, le, aa.saux);
+        conv_epilogue_q<EPI, NB>(a, aa.s0, acc, t0, m0, b, wr, wc, le, aa.saux, aa.eff, aa.part);
 #if defined(WG_OPT_EPI_PRIO)
         __builtin_amdgcn_s_setprio(0);
 #endif

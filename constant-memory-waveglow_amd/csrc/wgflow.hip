@@ -1264,7 +1264,7 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                 if (nt >= cus && (double)(rounds * cus - nt) <= 0.1 * rounds * cus) {
                     as.ntx = nct; as.nty = nrb; as.ntz = 1; as.xcd_items = 0;
                     if (env_sw().g192_own) as.xcd_items = 1;                                   // experiment: column ownership
-                    if (cx.probe) { *cx.probe = so_gate ? 1 : 0; return; }
+                    if (cx.probe) { *cx.probe = (so_gate && as.part) ? 1 : 0; return; }
                     if (so_gate && as.part) { ++cx.part_written; g_gate_part_launches.fetch_add(1, std::memory_order_relaxed); }
                     if (so_gate) WG_LAUNCH(cx, convgemm16g_kernel<EPI_GATE_SO>, dim3(cus), dim3(512), 0, as);
                     else if (fo_g) WG_LAUNCH(cx, convgemm16g_kernel<EPI_STORE_FO>, dim3(cus), dim3(512), 0, as);
@@ -1287,7 +1287,7 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
             if (small) {
                 if (fo_epi) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE_FO, 1>), gp, dim3(512), 0, as); return; }
                 if (so_dgate) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_DGATE_SO, 1>), gp, dim3(512), 0, as); return; }
-                if (so_gate) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE_SO, 1>), gp, dim3(512), 0, as); return; }
+                if (so_gate) { if (cx.probe) { *cx.probe = as.part ? 1 : 0; return; } if (as.part) { ++cx.part_written; g_gate_part_launches.fetch_add(1, std::memory_order_relaxed); } WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE_SO, 1>), gp, dim3(512), 0, as); return; }
                 if (so_epi) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE_SO, 1>), gp, dim3(512), 0, as); return; }
                 switch (epi) {
                 case EPI_STORE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE, 1>), gp, dim3(512), 0, as); break;
@@ -1307,7 +1307,7 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                 if (nt2 >= cus) {
                     as.xcd_items = 0;
                     const dim3 gc(std::min(nt2, cus));
-                    if (so_gate) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE_SO, 2, 2, false, true>), gc, dim3(1024), 0, as); return; }
+                    if (so_gate) { if (cx.probe) { *cx.probe = as.part ? 1 : 0; return; } if (as.part) { ++cx.part_written; g_gate_part_launches.fetch_add(1, std::memory_order_relaxed); } WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE_SO, 2, 2, false, true>), gc, dim3(1024), 0, as); return; }
                     WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE, 2, 2, false, true>), gc, dim3(1024), 0, as);
                     return;
                 }
@@ -1327,7 +1327,7 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                 const dim3 g2(std::min(ntiles / 2, cus));
                 if (cus % 8) as.xcd_items = 0;                // (mg2_ok: at least one tile per CU)
                 if (so_epi) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE_SO, 2, 2>), g2, dim3(1024), 0, as); return; }
-                if (so_gate) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE_SO, 2, 2>), g2, dim3(1024), 0, as); return; }
+                if (so_gate) { if (cx.probe) { *cx.probe = as.part ? 1 : 0; return; } if (as.part) { ++cx.part_written; g_gate_part_launches.fetch_add(1, std::memory_order_relaxed); } WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE_SO, 2, 2>), g2, dim3(1024), 0, as); return; }
                 if (fo_epi) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE_FO, 2, 2>), g2, dim3(1024), 0, as); return; }
                 switch (epi) {
                 case EPI_STORE: WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE, 2, 2>), g2, dim3(1024), 0, as); break;
@@ -1338,7 +1338,7 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
             }
 #endif
             if (so_epi) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE_SO, 2>), gp, dim3(512), 0, as); return; }
-            if (so_gate) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE_SO, 2>), gp, dim3(512), 0, as); return; }
+            if (so_gate) { if (cx.probe) { *cx.probe = as.part ? 1 : 0; return; } if (as.part) { ++cx.part_written; g_gate_part_launches.fetch_add(1, std::memory_order_relaxed); } WG_LAUNCH(cx, (convgemm16q_kernel<EPI_GATE_SO, 2>), gp, dim3(512), 0, as); return; }
             if (so_dgate) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_DGATE_SO, 2>), gp, dim3(512), 0, as); return; }
             if (fo_epi) { WG_LAUNCH(cx, (convgemm16q_kernel<EPI_STORE_FO, 2>), gp, dim3(512), 0, as); return; }
             switch (epi) {
