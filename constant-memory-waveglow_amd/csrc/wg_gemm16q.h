@@ -181,11 +181,16 @@ __device__ __forceinline__ void wgq_st16p(const float *base, unsigned voff, cons
 // EPI_GATE_SO, column block NBI of a wave tile: tanh, sigmoid, gate of the lane's 8 channels; stores at immediate offset 256 * NBI.
 // pbase (nullptr: none): the wave's share of WN's `out` for this block -- Weff (rows 0-7, the wave's 32 gate channels: A fragments eah / eal)
 // times the split gate the lane holds, one more 16x16x32 product (wg_gemm16g.h, wgg_gate_nb) -- goes to pbase + 16 NBI columns of 8 floats
+template <int OFF>
+__device__ __forceinline__ void wgq_st8p(const float *base, unsigned voff, const f32x2_t &v)      // (as wgq_st16p: the data come out of an MFMA)
+{
+    asm volatile("s_nop 15\n\ts_nop 3\n\tglobal_store_dwordx2 %0, %1, %2 offset:%3" ::"v"(voff), "v"(v), "s"(base), "n"(OFF) : "memory");
+}
 template <int NB, int NBI>
 __device__ __forceinline__ void wgq_gate_nb(f32x4 (&acc)[4][NB], bool live, const float *const (&bt)[2], const float *const (&bs)[2],
                                             const unsigned short *const (&sh)[2], const unsigned short *const (&sl)[2], bool has_ts,
                                             unsigned vo_t, unsigned vo_s, const float *pbase = nullptr, unsigned vo_p = 0, bool plive = false,
-                                            bf16x8 eah = bf16x8{}, bf16x8 eal = bf16x8{})
+                                            bf16x8 eah = bf16x8{}, bf16x8 eal = bf16x8{}, bool prow2 = false)
 {
     float tw[8], sf[8], gv[8];
 #pragma unroll
@@ -208,7 +213,10 @@ __device__ __forceinline__ void wgq_gate_nb(f32x4 (&acc)[4][NB], bool live, cons
         o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eal, bh, o, 0, 0, 0);
         o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eah, bl, o, 0, 0, 0);
         o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(eah, bh, o, 0, 0, 0);
-        if (live && plive) wgq_st16p<512 * NBI>(pbase, vo_p, o);      // lanes 0-31: rows 4 rq .. 4 rq + 3 of the lane's column
+        if (prow2) {                                        // two rows per column (2 ic <= 2): lanes 0-15, 8 bytes each
+            const f32x2_t o2 = {o[0], o[1]};
+            if (live && plive) wgq_st8p<128 * NBI>(pbase, vo_p, o2);
+        } else if (live && plive) wgq_st16p<512 * NBI>(pbase, vo_p, o);      // lanes 0-31: rows 4 rq .. 4 rq + 3 of the lane's column
     }
 #pragma unroll
     for (int mbp = 0; mbp < 2; ++mbp) {
@@ -281,7 +289,7 @@ __device__ __forceinline__ void wgq_store_row(const unsigned short *hb, const un
 template <int EPI, int NB>
 __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRef &s0, f32x4 (&acc)[4][NB], int t0, int m0, int b,
                                                 int wr, int wc, int lane, const SRef &saux = SRef{nullptr, 0, 8, 0}, const float *eff = nullptr,
-                                                float *part = nullptr)
+                                                float *part = nullptr, int prow = 8)
 {
     const Geo g = a.g;
     const int col = lane & 15, rq = lane >> 4;
@@ -315,14 +323,15 @@ __device__ __forceinline__ void conv_epilogue_q(const ConvGemmArgs &a, const SRe
                 const char *ef = reinterpret_cast<const char *>(eff) + slot * 1024 + (rq * 8 + col) * 16;
                 eah = *reinterpret_cast<const bf16x8 *>(ef); eal = *reinterpret_cast<const bf16x8 *>(ef + 512);
             }
-            pbase = part + (((size_t)slot * g.B + b) * g.Tt + t0 + tl0) * 8;
+            pbase = part + (((size_t)slot * g.B + b) * g.Tt + t0 + tl0) * prow;
         }
-        const unsigned vo_p = (unsigned)(col * 32 + (rq & 1) * 16);
-        const bool plive = rq < 2;
-        wgq_gate_nb<NB, 0>(acc, tw0 < g.T, bt, bs, sh, sl, has_ts, vo_t, vo_s, pbase, vo_p, plive, eah, eal);
-        if constexpr (NB > 1) wgq_gate_nb<NB, 1>(acc, tw0 + 16 < g.T, bt, bs, sh, sl, has_ts, vo_t, vo_s, pbase, vo_p, plive, eah, eal);
-        if constexpr (NB > 2) wgq_gate_nb<NB, 2>(acc, tw0 + 32 < g.T, bt, bs, sh, sl, has_ts, vo_t, vo_s, pbase, vo_p, plive, eah, eal);
-        if constexpr (NB > 3) wgq_gate_nb<NB, 3>(acc, tw0 + 48 < g.T, bt, bs, sh, sl, has_ts, vo_t, vo_s, pbase, vo_p, plive, eah, eal);
+        const bool prow2 = prow == 2;
+        const unsigned vo_p = prow2 ? (unsigned)(col * 8) : (unsigned)(col * 32 + (rq & 1) * 16);
+        const bool plive = prow2 ? rq == 0 : rq < 2;
+        wgq_gate_nb<NB, 0>(acc, tw0 < g.T, bt, bs, sh, sl, has_ts, vo_t, vo_s, pbase, vo_p, plive, eah, eal, prow2);
+        if constexpr (NB > 1) wgq_gate_nb<NB, 1>(acc, tw0 + 16 < g.T, bt, bs, sh, sl, has_ts, vo_t, vo_s, pbase, vo_p, plive, eah, eal, prow2);
+        if constexpr (NB > 2) wgq_gate_nb<NB, 2>(acc, tw0 + 32 < g.T, bt, bs, sh, sl, has_ts, vo_t, vo_s, pbase, vo_p, plive, eah, eal, prow2);
+        if constexpr (NB > 3) wgq_gate_nb<NB, 3>(acc, tw0 + 48 < g.T, bt, bs, sh, sl, has_ts, vo_t, vo_s, pbase, vo_p, plive, eah, eal, prow2);
         return;
     }
     if (EPI == EPI_GATE) {
@@ -934,7 +943,7 @@ __global__ __launch_bounds__(512 * MG) void convgemm16q_kernel(const ConvGemm16s
 #if defined(WG_OPT_EPI_PRIO)
         __builtin_amdgcn_s_setprio(WG_OPT_EPI_PRIO);         // experiment: the epilogue's VALU / store issue ahead of the co-resident workgroup's waves
 #endif
-        conv_epilogue_q<EPI, NB>(a, aa.s0, acc, t0, m0, b, wr, wc, le, aa.saux, aa.eff, aa.part);
+        conv_epilogue_q<EPI, NB>(a, aa.s0, acc, t0, m0, b, wr, wc, le, aa.saux, aa.eff, aa.part, aa.prow);
 #if defined(WG_OPT_EPI_PRIO)
         __builtin_amdgcn_s_setprio(0);
 #endif

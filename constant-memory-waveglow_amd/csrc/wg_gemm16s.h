@@ -117,6 +117,7 @@ struct ConvGemm16sArgs {
     // plane again.  eff: Weff_l as MFMA fragments, [M / 64 slices of 32 gate channels][hi | lo][k-group][8 rows][8 bf16] (weff_kernel)
     const float *eff;
     float *part;
+    int prow;                     // floats per partial row: 8, or 2 where 2 ic <= 2 (WaveFlow's WN2D: the 16x16x32 kernels only)
     int xcd_items;                // convgemm16q, persistent launches: > 0 = plane rows per XCD (ntz / 8): XCD x (workgroup id & 7) owns the plane
                                   // rows x, x + 8, ... and walks their tiles row by row -- all time tiles of a row are then in flight on ONE
                                   // XCD, so a dilation tap's window (another tile's centre window) and the other row tiles' copy of the same

@@ -167,7 +167,46 @@ struct WfCoupleArgs {
     int noflip;             // use_conv1x1: x_next = cat(x[0], xout) (the 1x1 over the height axis follows) instead of cat(flip(xout), x[0])
     float *raw_ls, *raw_t;  // mode 3 (WN2D.forward on its own, waveflow.py:128-135): plain [items][raw_rows][T] outputs of WN2D.end, no coupling
     int raw_rows;
+    // the rank-2 form of the skip path (csrc/wgflow.hip lowrank_on): S does not exist; (log_s, t) of an element = the sum of `nsrc` partial rows
+    // of two floats the gate convs left (wg_gemm16q.h wgq_gate_nb), [src][plane row][Tt][2], added in source order
+    const float *part;
+    int nsrc;
 };
+// (log_s, t) of (plane row, t) without their biases: W_end . S, or the partial rows
+__device__ __forceinline__ void wf_end_out(const WfCoupleArgs &a, const Geo &g, int row, int t, float &ls, float &tt)
+{
+    if (a.part) {
+        const size_t stride = (size_t)g.B * g.Tt * 2;
+        const float *q = a.part + ((size_t)row * g.Tt + t) * 2;
+        int s = 0;
+        for (; s + 8 <= a.nsrc; s += 8) {
+            f32x2_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x2_t *>(q + (size_t)(s + u) * stride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { ls += v[u][0]; tt += v[u][1]; }
+        }
+        for (; s < a.nsrc; ++s) { const f32x2_t v = *reinterpret_cast<const f32x2_t *>(q + (size_t)s * stride); ls += v[0]; tt += v[1]; }
+        return;
+    }
+    const float *sp = paddr(a.S, g, row, 0, t);
+    int c = 0;
+    for (; c + 16 <= a.Cs; c += 16) {                          // sixteen channel loads in flight (the same order of fmas as one at a time)
+        float sv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) sv[u] = sp[(size_t)(c + u) * g.P];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            ls = fmaf(a.endw[c + u], sv[u], ls);
+            tt = fmaf(a.endw[a.Cs + c + u], sv[u], tt);
+        }
+    }
+    for (; c < a.Cs; ++c) {
+        const float s = sp[(size_t)c * g.P];
+        ls = fmaf(a.endw[c], s, ls);
+        tt = fmaf(a.endw[a.Cs + c], s, tt);
+    }
+}
 // (a device function: the stage interpreter, wg_stage.h, runs it as one stage; NT threads, `blk` = the block index, row_sel overrides a.row_sel)
 template <int NT>
 __device__ __forceinline__ void wf_couple_body(const WfCoupleArgs &a, int blk, int row_sel, float *red)
@@ -183,6 +222,8 @@ __device__ __forceinline__ void wf_couple_body(const WfCoupleArgs &a, int blk, i
         if (r >= a.raw_rows) return;
         for (int t = tid; t < g.T; t += NT) {
             float ls = a.endb ? a.endb[0] : 0.f, tt = a.endb ? a.endb[1] : 0.f;
+            if (a.part) wf_end_out(a, g, row, t, ls, tt);
+            else
             for (int c = 0; c < a.Cs; ++c) {
                 const float s = *paddr(a.S, g, row, c, t);
                 ls = fmaf(a.endw[c], s, ls);
@@ -208,23 +249,7 @@ __device__ __forceinline__ void wf_couple_body(const WfCoupleArgs &a, int blk, i
     }
     for (int t = tid; t < g.T; t += NT) {
         float ls = a.endb ? a.endb[0] : 0.f, tt = a.endb ? a.endb[1] : 0.f;
-        const float *sp = paddr(a.S, g, row, 0, t);
-        int c = 0;
-        for (; c + 16 <= a.Cs; c += 16) {                      // sixteen channel loads in flight (the same order of fmas as one at a time)
-            float sv[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) sv[u] = sp[(size_t)(c + u) * g.P];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                ls = fmaf(a.endw[c + u], sv[u], ls);
-                tt = fmaf(a.endw[a.Cs + c + u], sv[u], tt);
-            }
-        }
-        for (; c < a.Cs; ++c) {
-            const float s = sp[(size_t)c * g.P];
-            ls = fmaf(a.endw[c], s, ls);
-            tt = fmaf(a.endw[a.Cs + c], s, tt);
-        }
+        wf_end_out(a, g, row, t, ls, tt);
         const float es = expf(ls);
         if (a.mode == 0) {
             *paddr(a.Xn, g, orow, 0, t) = fmaf(*paddr(a.X, g, row + 1, 0, t), es, tt);

@@ -95,6 +95,7 @@ struct Ctx {
     // the gate conv's share of WN's `out` from its own epilogue (ConvGemm16sArgs::part; wn_forward sets these around a layer's gate conv):
     const float *gate_eff = nullptr; // Weff of the layer as A fragments (WnPack::effA)
     float *gate_part = nullptr;      // that layer's partial rows
+    int gate_prow = 8;               // floats per row (gate_part_prow)
     int part_written = 0;            // gate convs of this call that were launched with them
     int *probe = nullptr;            // set while run_convgemm only REPORTS whether a gate conv would take the kernel that writes them (1) or not (0)
 };
@@ -260,7 +261,7 @@ inline bool lowrank_shape(const WnD &d)
 #if defined(WG_OPT_NO_LOWRANK)
     (void)d; return false;
 #else
-    return d.prec == 2 && !d.mode2d && !d.bias && fused_skip(d) && d.Cd % 64 == 0 && 2 * d.ic * d.Cs <= 8192;                           // (W_end in weff_kernel's LDS)
+    return d.prec == 2 && !d.bias && fused_skip(d) && d.Cd % 64 == 0 && 2 * d.ic * d.Cs <= 8192 && (!d.mode2d || d.ic == 1);                           // (W_end in weff_kernel's LDS)
 #endif
 }
 
@@ -270,10 +271,11 @@ inline bool gate_parts_shape(const WnD &d)
 #if defined(WG_OPT_NO_GATE_PARTS)
     (void)d; return false;
 #else
-    return lowrank_shape(d) && 2 * d.ic <= 8 && (2 * d.Cd) % 256 == 0 && 8 * d.Cd * sizeof(float) <= 8192;
+    return lowrank_shape(d) && 2 * d.ic <= 8 && (2 * d.Cd) % 64 == 0 && (size_t)(d.Cd / 32) * 1024 <= 8192;
 #endif
 }
-inline int gate_part_slots(const WnD &d) { return (2 * d.Cd / 256) * 4; }
+inline int gate_part_slots(const WnD &d) { return 2 * d.Cd / 64; }      // one per 32 gate channels = per wave row of a gate conv
+inline int gate_part_prow(const WnD &d) { return 2 * d.ic <= 2 ? 2 : 8; }   // floats per partial row (2: WaveFlow's WN2D, the 16x16x32 kernels' epilogue only)
 
 Geo make_geo(int B, int T, int halo_need)
 {
@@ -862,8 +864,8 @@ void wn_ws_layout(Bump &bp, const WnD &d, int ic_max, const Geo &g, int mode, in
         for (int i = 0; i < d.depth; ++i) w.gateS[i] = (mode || i == 0 || fused_skip(d)) ? bp.take(pD) : w.gateS[0];
         w.XaS = bp.take((size_t)g.B * rup(ic_max, WG_BK) * g.P);
         w.lsync = bp.take(WGL_SYNC_WORDS);
-        if (gate_parts_shape(d) && g.rows == 0) {
-            w.gpart_step = rupz((size_t)gate_part_slots(d) * g.B * g.Tt * 8, 64);
+        if (gate_parts_shape(d) && (g.rows == 0 || d.mode2d)) {
+            w.gpart_step = rupz((size_t)gate_part_slots(d) * g.B * g.Tt * gate_part_prow(d), 64);
             w.gpart = bp.take(w.gpart_step * d.depth);
         }
         if (mode) {
@@ -943,7 +945,7 @@ void wn_ws_layout_kept(Bump &bp, const WnD &d, int ic_max, const Geo &g, int pre
         for (int i = 0; i < d.depth; ++i) { w.HS[i] = bp.take(pC); w.gateS[i] = bp.take(pD); }
         w.XaS = bp.take((size_t)g.B * rup(ic_max, WG_BK) * g.P);
         if (gate_parts_shape(d) && g.rows == 0) {                // (every flow keeps its own: the backward's end conv reads them again)
-            w.gpart_step = rupz((size_t)gate_part_slots(d) * g.B * g.Tt * 8, 64);
+            w.gpart_step = rupz((size_t)gate_part_slots(d) * g.B * g.Tt * gate_part_prow(d), 64);
             w.gpart = bp.take(w.gpart_step * d.depth);
         }
     } else {
@@ -1122,7 +1124,7 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
             }
 #endif
             as.img = a16.img; as.img_stride = a16.img_stride; as.c = a; as.s0 = s0; as.saux = saux;
-            as.eff = nullptr; as.part = nullptr;
+            as.eff = nullptr; as.part = nullptr; as.prow = cx.gate_prow;
             if (epi == EPI_GATE && cx.gate_part && (size_t)(M / 64) * 1024 <= WGG_EFF_BYTES) { as.eff = cx.gate_eff; as.part = cx.gate_part; }
             for (int s = 0; s < nseg; ++s) {
                 as.sseg[s].hi = (const unsigned short *)segs[s].s;
@@ -1264,6 +1266,7 @@ void run_convgemm(Ctx &cx, const Geo &g, const float *A, int lda, int M, const S
                 if (nt >= cus && (double)(rounds * cus - nt) <= 0.1 * rounds * cus) {
                     as.ntx = nct; as.nty = nrb; as.ntz = 1; as.xcd_items = 0;
                     if (env_sw().g192_own) as.xcd_items = 1;                                   // experiment: column ownership
+                    if (as.prow != 8) as.part = nullptr;      // (this kernel's epilogue writes 8-float rows)
                     if (cx.probe) { *cx.probe = (so_gate && as.part) ? 1 : 0; return; }
                     if (so_gate && as.part) { ++cx.part_written; g_gate_part_launches.fetch_add(1, std::memory_order_relaxed); }
                     if (so_gate) WG_LAUNCH(cx, convgemm16g_kernel<EPI_GATE_SO>, dim3(cus), dim3(512), 0, as);
@@ -1985,17 +1988,19 @@ static void wn_gate_conv(Ctx &cx, const WnRun &r, int i, int hin, bool keepg);
 // The WN runs in the rank-2ic form of its skip path (lowrank_shape; wg_small.h weff_kernel): no skip sum, no dS.  One predicate for the
 // forward, the recompute pass and the backward of a shape, so that a kept flow and a recomputed one produce the same bits: the shapes
 // whose forward keeps every layer's gate anyway (the one-product skip sum's, fs below).
-static bool lowrank_on(const Ctx &cx, const WnRun &r)
+static bool lowrank_base(const Ctx &cx, const WnRun &r)
 {
     const Geo &g = r.g;
     // (2 ic <= 8: where the gate convs can leave their share of `out` themselves.  WSRGlow -- 2 ic = 16, 6 144 columns per launch -- runs
     // the form that reads the gate planes, on 96 workgroups: measured 41.9 against 40.7 ms per step, gpurun_out/r06j_wsr_ab.txt)
     return env_sw().lowrank && cx.prec == 2 && lowrank_shape(r.d) && (2 * r.d.ic <= 8 || env_sw().lowrank_all) && r.L.effT && !cx.rec &&
-           !cx.row_sel1 && g.rows == 0 && g.B * g.Tt >= WG_FUSED_SKIP_MIN_COLS;
+           !cx.row_sel1 && (g.rows == 0 || r.d.mode2d) && g.B * g.Tt >= WG_FUSED_SKIP_MIN_COLS;
 }
 // Do this WN's gate convs leave their share of `out` (ConvGemm16sArgs::part)?  Asked of run_convgemm itself (Ctx::probe: the launch is
 // described, routed, and not run), so that the answer cannot drift from the routing: 1 = the kernel that writes the partial rows.
 static bool gate_parts_on(Ctx &cx, const WnRun &r);
+// (WaveFlow's WN2D, mode2d: only together with the partial rows -- its coupling kernel has no form that reads the gate planes)
+static bool lowrank_on(Ctx &cx, const WnRun &r) { return lowrank_base(cx, r) && (!r.d.mode2d || gate_parts_on(cx, r)); }
 // where end_affine_kernel takes `out` from: 0 = W_end . S (the skip plane), 1 = sum_l Weff_l gate_l straight from the gate planes,
 // 2 = the partial rows the gate convs left
 static int affine_source(Ctx &cx, const WnRun &r, AffineArgs &a)
@@ -2012,7 +2017,7 @@ static int affine_source(Ctx &cx, const WnRun &r, AffineArgs &a)
     if (gate_parts_on(cx, r)) {
         a.part = r.ws + r.w.gpart;
         a.nsrc = r.d.depth * gate_part_slots(r.d);
-        if (r.w.gpart_step != (size_t)gate_part_slots(r.d) * r.g.B * r.g.Tt * 8 && !cx.err) cx.err = WG_EINVAL;      // (the sources are one array)
+        if (r.w.gpart_step != (size_t)gate_part_slots(r.d) * r.g.B * r.g.Tt * gate_part_prow(r.d) && !cx.err) cx.err = WG_EINVAL;      // (the sources are one array)
         return 2;
     }
     for (int i = 0; i < r.d.depth; ++i) a.gS[i] = (const unsigned short *)(r.ws + r.w.gateS[i]);
@@ -2065,13 +2070,13 @@ static void wn_gate_conv(Ctx &cx, const WnRun &r, int i, int hin, bool keepg)
 }
 static bool gate_parts_on(Ctx &cx, const WnRun &r)
 {
-    if (!lowrank_on(cx, r) || !gate_parts_shape(r.d) || !r.w.gpart_step || !r.L.effA || cx.probe) return false;
+    if (!lowrank_base(cx, r) || !gate_parts_shape(r.d) || !r.w.gpart_step || !r.L.effA || cx.probe) return false;
     if (env_sw().layer_fusion_big) return false;              // (the opt-in one-launch layer on 256 x 128 tiles has its own gate epilogue)
     int route = 0;
     cx.probe = &route;
-    cx.gate_eff = r.pk + r.L.effA; cx.gate_part = r.ws + r.w.gpart;
+    cx.gate_eff = r.pk + r.L.effA; cx.gate_part = r.ws + r.w.gpart; cx.gate_prow = gate_part_prow(r.d);
     wn_gate_conv(cx, r, 0, 0, true);
-    cx.probe = nullptr; cx.gate_eff = nullptr; cx.gate_part = nullptr;
+    cx.probe = nullptr; cx.gate_eff = nullptr; cx.gate_part = nullptr; cx.gate_prow = 8;
     return route == 1;
 }
 
@@ -2130,9 +2135,12 @@ void wn_forward(Ctx &cx, const WnRun &r)
         const float *gateS = ws + r.w.gateS[(r.save || fs) ? i : 0];
         // fp32 gate plane: only the on-the-fly weight-gradient kernel still reads it (backward); the S-plane feeds W_o
         auto gate_call = [&]() {
-            if (gparts) { cx.gate_eff = r.pk + r.L.effA + (size_t)i * (d.Cd / 32) * 256; cx.gate_part = ws + r.w.gpart + (size_t)i * r.w.gpart_step; }
+            if (gparts) {
+                cx.gate_eff = r.pk + r.L.effA + (size_t)i * (d.Cd / 32) * 256; cx.gate_part = ws + r.w.gpart + (size_t)i * r.w.gpart_step;
+                cx.gate_prow = gate_part_prow(d);
+            }
             wn_gate_conv(cx, r, i, hin, r.save || fs);
-            cx.gate_eff = nullptr; cx.gate_part = nullptr;
+            cx.gate_eff = nullptr; cx.gate_part = nullptr; cx.gate_prow = 8;
         };
         SegSpec sgt[2] = {{gate, d.Cd, 0, d.Cd, 0, gateS, d.Cd, 0}, sone};
         const int last = i == d.depth - 1;
@@ -2723,6 +2731,10 @@ void wf_couple(Ctx &cx, const WnRun &r, const float *endw, const float *endb, in
     memset(&a, 0, sizeof(a));
     a.endw = endw; a.endb = endb;
     a.S = pref(r.ws + r.w.skip, r.d.Cs); a.Cs = r.d.Cs;
+    if (lowrank_on(cx, r)) {                                  // (mode2d: with the partial rows, or not at all)
+        a.part = r.ws + r.w.gpart; a.nsrc = r.d.depth * gate_part_slots(r.d);
+        if (r.w.gpart_step != (size_t)gate_part_slots(r.d) * r.g.B * r.g.Tt * 2 && !cx.err) cx.err = WG_EINVAL;
+    }
     a.X = X; a.Xn = Xn; a.dXn = dXn; a.dX = dX;
     a.G = pref(r.ws + r.w.G, r.L.kp_end);
     a.dld = dld; a.rowsum = rowsum; a.row_sel = row_sel; a.g = r.g; a.mode = mode; a.noflip = noflip;
@@ -3336,6 +3348,9 @@ int wg_wf_pack_weights(const wg_wf_config *cf, const void *const *params, void *
     jb.norm(p[1], p[2], pk + L.up_scale, cf->n_mels, cf->n_mels * (2 * s + 1));      // ConvTranspose1d: dim 0 is the input channel
     for (int k = 0; k < cf->flows; ++k) wn_pack_norms(jb, d, WL, p + 3 + wf_pf(cf) * k, pk + L.wn[k]);
     jb.flush_norm();
+    EffBatch eb(&cx);
+    for (int k = 0; k < cf->flows; ++k) wn_pack_eff(eb, d, WL, p + 3 + wf_pf(cf) * k, pk + L.wn[k]);
+    eb.flush();
     for (int k = 0; k < cf->flows; ++k) wn_pack_mats(jb, d, WL, p + 3 + wf_pf(cf) * k, pk + L.wn[k], ones);
     jb.flush_pack();
     ImgBatch ib(&cx);
