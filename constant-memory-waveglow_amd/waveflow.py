@@ -20,11 +20,13 @@ from ._lib import WgError, WgWfConfig, default_precision
 from .base import FlowBase
 from .efficient_modules import InvertibleConv1x1
 from .utils import add_weight_norms, conv_gv
+from .waveglow import layer_bias_in, layer_bias_out
 
 
 class NonCausalLayer2D(nn.Module):
     """One WN2D layer (waveflow.py:14-51): W = 3x3 conv with dilation (h_dilation, dilation), causal along the height axis, W_o = 1x1.  Inside
-    WaveFlow its arithmetic runs in the WN kernels; called on its own, `forward` goes through wg_layer_apply."""
+    WaveFlow its arithmetic runs in the WN kernels; called on its own, `forward` goes through wg_layer_apply (bias=True: the two biases are
+    constants on y and on the outputs, added around that call)."""
 
     def __init__(self, h_dilation, dilation, dilation_channels, residual_channels, skip_channels, radix, bias, last_layer=False):
         super().__init__()
@@ -41,19 +43,18 @@ class NonCausalLayer2D(nn.Module):
     def forward(self, x, y):
         """x [B, residual, H, W], y [B, 2 * dilation, 1, W] -> (x + res or None, skip) as waveflow.py:41-51 (wg_layer_apply: exact fp32 MFMA,
         forward only)."""
-        if self.W.bias is not None or self.W_o.bias is not None:
-            raise WgError("NonCausalLayer2D(bias=True) is not built into the HIP kernels")
         from ._lib import WgLayerDims
         last = len(self.chs_split) == 1
         dims = WgLayerDims(self.W.in_channels, self.W.out_channels // 2, self.chs_split[-1], self.W.kernel_size[0], self.W.dilation[1], int(last),
                            self.W.dilation[0], x.shape[2])
         wg_, wv = conv_gv(self.W)
         og, ov = conv_gv(self.W_o)
+        y = layer_bias_in(self.W, y.float())                                      # bias=True: as NonCausalLayer (waveglow.py)
         if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad or any(p.requires_grad for p in self.parameters())):
-            out = engine.LayerFn.apply(x.float(), y.float(), dims, wg_, wv, og, ov)    # differentiable like the module upstream (wg_layer_backward)
-            return (None, out[0]) if last else out
+            out = engine.LayerFn.apply(x.float(), y, dims, wg_, wv, og, ov)           # differentiable like the module upstream (wg_layer_backward)
+            return layer_bias_out(self.W_o, self.chs_split, (None, out[0]) if last else out)
         with torch.no_grad():
-            return engine.layer_apply(dims, [wg_, wv, og, ov], x.float(), y.float())
+            return layer_bias_out(self.W_o, self.chs_split, engine.layer_apply(dims, [wg_, wv, og, ov], x.float(), y))
 
 
 class WN2D(nn.Module):

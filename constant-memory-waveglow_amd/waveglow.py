@@ -27,11 +27,32 @@ def fused_gate(x1: Tensor, x2: Tensor) -> Tensor:
     return torch.tanh(x1) * torch.sigmoid(x2)
 
 
+def layer_bias_in(conv, y):
+    """y + the bias of a stand-alone layer's W (one value per conditioning channel, broadcast over batch and positions)."""
+    if conv.bias is None:
+        return y
+    return y + conv.bias.to(y.dtype).view(1, -1, *([1] * (y.dim() - 2)))
+
+
+def layer_bias_out(conv, chs_split, out):
+    """(res, skip) + the bias of a stand-alone layer's W_o, split like its output channels (waveglow.py:45)."""
+    if conv.bias is None:
+        return out
+    res, skip = out
+    parts = conv.bias.split(chs_split)
+    shape = (1, -1) + (1,) * (skip.dim() - 2)
+    skip = skip + parts[-1].to(skip.dtype).view(shape)
+    if res is not None:
+        res = res + parts[0].to(res.dtype).view(shape)
+    return res, skip
+
+
 class NonCausalLayer(nn.Module):
     """One WN layer: W = dilated conv (residual -> 2*dilation channels), W_o = 1x1 (dilation -> residual+skip, or skip only on the
     last layer)  (waveglow.py:18-46).  Inside a WN its arithmetic runs in the WN kernels; called on its own, `forward` runs the two
     products through the C ABI (wg_layer_apply: exact fp32 MFMA, any dilation, forward only -- the class has no backward upstream
-    either: gradients flow through AffineCouplingBlock)."""
+    either: gradients flow through AffineCouplingBlock).  bias=True: W's bias is a constant on y, W_o's one on the outputs, added around
+    that call (layer_bias_in / layer_bias_out)."""
 
     def __init__(self, dilation, dilation_channels, residual_channels, skip_channels, radix, bias, last_layer=False):
         super().__init__()
@@ -44,18 +65,19 @@ class NonCausalLayer(nn.Module):
     def forward(self, x, y):
         """x [B, residual, T], y [B, 2 * dilation, T] (this layer's slice of the conditioning projection) -> (x + res or None, skip)
         as waveglow.py:41-46."""
-        if self.W.bias is not None or self.W_o.bias is not None:
-            raise WgError("NonCausalLayer(bias=True) is served inside WN only (the block-level path folds the biases into its K segments)")
         from ._lib import WgLayerDims
         last = len(self.chs_split) == 1
         dims = WgLayerDims(self.W.in_channels, self.W.out_channels // 2, self.chs_split[-1], self.W.kernel_size[0], self.W.dilation[0], int(last), 0, 0)
         wg_, wv = conv_gv(self.W)
         og, ov = conv_gv(self.W_o)
+        # bias=True: xy = W(x) + y, so W's bias is a constant added to y's channels, and W_o's a constant on (res, skip); their gradients are
+        # the sums autograd takes of d y and of the output gradients (inside WN the biases ride in the kernels' K segments instead)
+        y = layer_bias_in(self.W, y)
         if torch.is_grad_enabled() and (x.requires_grad or y.requires_grad or any(p.requires_grad for p in self.parameters())):
             out = engine.LayerFn.apply(x, y, dims, wg_, wv, og, ov)            # differentiable like the module upstream (wg_layer_backward)
-            return (None, out[0]) if last else out
+            return layer_bias_out(self.W_o, self.chs_split, (None, out[0]) if last else out)
         with torch.no_grad():
-            return engine.layer_apply(dims, [wg_, wv, og, ov], x, y)
+            return layer_bias_out(self.W_o, self.chs_split, engine.layer_apply(dims, [wg_, wv, og, ov], x, y))
 
 
 class WN(nn.Module):

@@ -435,6 +435,63 @@ def test_noncausal_layer2d_alone_is_differentiable_vs_reference_golden(dev, gold
     _layer_grads_vs_golden(m.to(dev), wn, last, x, y, "layer2d/" + cname, "2d_" + cname, gold, dev)
 
 
+@pytest.mark.parametrize("cname", ["d4", "last", "2d_hd2d4", "2d_last"])
+def test_noncausal_layer_alone_with_biases_vs_torch(dev, precision, cname):
+    """NonCausalLayer(bias=True) / NonCausalLayer2D(bias=True) called on their own (model/waveglow.py:18-46, model/waveflow.py:14-51 accept
+    the flag): xy = W(x) + b_W + y and W_o(z) + b_o, so the biases are constants on y and on the outputs around wg_layer_apply, and their
+    gradients are sums of d y / of the output gradients.  Outputs and every gradient (x, y, the weights, both biases) against a float64
+    torch evaluation of the reference's formulas on the CPU, with and without autograd."""
+    if precision != "f32":
+        pytest.skip("the stand-alone layer always runs the exact-fp32 kernels")
+    import torch.nn.functional as Fn
+    from make_golden import LAYER2D_CASES, LAYER_CASES, layer2d_inputs, layer_inputs
+    two_d = cname.startswith("2d_")
+    if two_d:
+        C, Cd, Cs, hd, dil, last, _, B, H, W = LAYER2D_CASES[cname[3:]]
+        P, x, y = layer2d_inputs(cname[3:])
+        m = cm.waveflow.NonCausalLayer2D(hd, dil, Cd, C, Cs, 3, True, last_layer=last)
+    else:
+        C, Cd, Cs, radix, dil, last, _, B, Tn = LAYER_CASES[cname]
+        P, x, y = layer_inputs(cname)
+        m = cm.NonCausalLayer(dil, Cd, C, Cs, radix, True, last_layer=last)
+    R = Cs if last else C + Cs
+    bW, bO = fill.normal("layerb/" + cname + "/bW", (2 * Cd,)) * 0.5, fill.normal("layerb/" + cname + "/bO", (R,)) * 0.5
+    m.load_state_dict({"W.weight": torch.from_numpy(P["W.weight_v"]), "W_o.weight": torch.from_numpy(P["W_o.weight_v"]),
+                       "W.bias": torch.from_numpy(bW), "W_o.bias": torch.from_numpy(bO)})
+    m = m.to(dev)
+
+    def ref(xr, yr, Wr, Or, bWr, bOr):
+        if two_d:                                               # waveflow.py:41-51
+            tmp = Fn.pad(xr, [dil, dil, 2 * hd, 0])
+            xy = Fn.conv2d(tmp, Wr, bWr, dilation=(hd, dil)) + yr
+            o = Fn.conv2d(torch.tanh(xy[:, :Cd]) * torch.sigmoid(xy[:, Cd:]), Or, bOr)
+        else:                                                   # waveglow.py:41-46
+            xy = Fn.conv1d(xr, Wr, bWr, padding=dil * (radix - 1) // 2, dilation=dil) + yr
+            o = Fn.conv1d(torch.tanh(xy[:, :Cd]) * torch.sigmoid(xy[:, Cd:]), Or, bOr)
+        return (None, o) if last else (o[:, :C] + xr, o[:, C:])
+    leaves = [torch.from_numpy(a).double().requires_grad_(True) for a in (x, y, P["W.weight_v"], P["W_o.weight_v"], bW, bO)]
+    want_res, want_skip = ref(*leaves)
+    with torch.no_grad():
+        res, skip = m(T(x, dev), T(y, dev))
+    assert np.abs(npy(skip) - want_skip.detach().numpy()).max() < 2e-5
+    assert (res is None) == bool(last) and (last or np.abs(npy(res) - want_res.detach().numpy()).max() < 2e-5)
+    gs = fill.normal("layerb/" + cname + "/gs", tuple(skip.shape))
+    gr = None if last else fill.normal("layerb/" + cname + "/gr", tuple(res.shape))
+    sc = (want_skip * want_skip * torch.from_numpy(gs).double()).sum()
+    if not last:
+        sc = sc + (want_res * torch.from_numpy(gr).double()).sum()
+    want = torch.autograd.grad(sc, leaves)
+    xt, yt = T(x, dev).requires_grad_(True), T(y, dev).requires_grad_(True)
+    res, skip = m(xt, yt)
+    sc = (skip * skip * T(gs, dev)).sum()
+    if not last:
+        sc = sc + (res * T(gr, dev)).sum()
+    sc.backward()
+    got = [xt.grad, yt.grad, m.W.weight.grad, m.W_o.weight.grad, m.W.bias.grad, m.W_o.bias.grad]
+    for nme, a, b in zip(("dx", "dy", "dW", "dW_o", "db_W", "db_o"), got, want):
+        assert relmax(npy(a), b.numpy()) < GRAD_RTOL, nme
+
+
 @pytest.mark.parametrize("name", ["micro", "c1", "c2"])
 def test_one_launch_layer_vs_two_launches(dev, precision, monkeypatch, name):
     """convlayer16h_kernel (wg_layer16h.h): one launch per WN layer -- gate conv -> gate -> W_o -> residual / skip, model/waveglow.py:41-46 --
