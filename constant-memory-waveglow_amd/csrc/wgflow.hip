@@ -2068,10 +2068,26 @@ static void wn_gate_conv(Ctx &cx, const WnRun &r, int i, int hin, bool keepg)
                  (r.save && !tw_from_gate(cx)) ? pref(ws + r.w.tw[i], d.Cd) : pnull(), r.save ? pref(ws + r.w.sf[i], d.Cd) : pnull(),
                  pnull(), pnull(), 0, 0, sp ? sref(g, gateS, d.Cd) : snull());             // waveglow.py:42-44
 }
+// the weight-gradient slab of a training workspace is idle while a WN runs forward (wn_backward's queue is flushed when it returns): scratch
+// for a split gate conv's parts.  `asked_outside`: the routing probe asks what a FORWARD pass of this WN does from wherever the answer is
+// needed -- behind wn_forward (the end conv's source), inside wn_backward (its queue owns the slab then) -- and must see what that pass saw:
+// without it a WN whose gate convs are cut along K (no partial rows) was told, after the pass, that they had been written.
+struct GslabScope {
+    Ctx &c;
+    float *p0;
+    size_t n0;
+    GslabScope(Ctx &cx_, const WnRun &r, bool asked_outside) : c(cx_), p0(cx_.gslab), n0(cx_.gslab_floats)
+    {
+        const size_t n = (r.w.slab_floats && (asked_outside || !c.fq)) ? r.w.slab_floats : 0;
+        c.gslab = n ? r.ws + r.w.slab : nullptr; c.gslab_floats = n;
+    }
+    ~GslabScope() { c.gslab = p0; c.gslab_floats = n0; }
+};
 static bool gate_parts_on(Ctx &cx, const WnRun &r)
 {
     if (!lowrank_base(cx, r) || !gate_parts_shape(r.d) || !r.w.gpart_step || !r.L.effA || cx.probe) return false;
     if (env_sw().layer_fusion_big) return false;              // (the opt-in one-launch layer on 256 x 128 tiles has its own gate epilogue)
+    GslabScope gslab_scope(cx, r, true);
     int route = 0;
     cx.probe = &route;
     cx.gate_eff = r.pk + r.L.effA; cx.gate_part = r.ws + r.w.gpart; cx.gate_prow = gate_part_prow(r.d);
@@ -2086,13 +2102,7 @@ void wn_forward(Ctx &cx, const WnRun &r)
     const Geo &g = r.g;
     float *ws = r.ws;
     const bool sp = cx.prec == 2;
-    // the weight-gradient slab of a training workspace is idle while a WN runs forward (wn_backward's queue is flushed when it returns): scratch
-    // for a split gate conv's parts
-    struct GslabScope {
-        Ctx &c;
-        GslabScope(Ctx &cx_, float *p, size_t n) : c(cx_) { c.gslab = n ? p : nullptr; c.gslab_floats = n; }
-        ~GslabScope() { c.gslab = nullptr; c.gslab_floats = 0; }
-    } gslab_scope(cx, ws + r.w.slab, (r.w.slab_floats && !cx.fq) ? r.w.slab_floats : 0);
+    GslabScope gslab_scope(cx, r, false);                     // (scratch for a split gate conv's parts)
     const int nb = d.bias ? 1 : 0;
     const SegSpec sone = d.bias ? ones_seg(cx, r, true) : SegSpec{};
     const int cols0 = (cx.row_sel1 && g.rows > 0 ? g.B / g.rows : g.B) * g.Tt;

@@ -2143,6 +2143,9 @@ def test_weight_gradient_kernel_plans_vs_oracle(dev, precision, B, Tn, depth, au
     ((z * T(gz, dev)).sum() + (ls * T(gls, dev)).sum()).backward()
     torch.cuda.synchronize()
     assert (_lib.lib().wg_stat_wgrad16t_launches() - before == 1) == planned
+    # (the forward too: six items of 1024 columns with 1 500 conditioning channels is the one shape here whose gate convs are cut along K while
+    # the skip path runs in its rank form -- the end conv must then read the gate planes, not partial rows nobody wrote)
+    assert np.abs(npy(z) - z_ref).max() < Z_ATOL
     named = dict(blk.named_parameters())
     for i, (n, _, _) in enumerate(specs):
         assert relmax(npy(named[n].grad), ref["grads"][i]) < GRAD_RTOL, n
