@@ -843,6 +843,40 @@ __global__ __launch_bounds__(256) void weff_kernel(const EffArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// WN.start folded into the first layer's dilated conv (start_fold_shape in wgflow.hip).  h_0 = W_start xa has rank ic (2-4 channels of
+// the flow) and layer 0 convolves it at once (model/waveglow.py:99, 41-43): W_0 * (W_start xa) = (W_0[kt] W_start) * xa, a conv over ic
+// channels instead of C = 256.  This kernel forms the composed weight in the layout of a conv weight, w0x[o][j][kt] =
+// sum_c sW[o] vW[o][c][kt] . sS[c] vS[c][j] (o < 2 Cd, j < ic; the weight-norm scales of both factors applied), so that the ordinary pack
+// jobs image it like W_0 itself.  One thread per (o, j, kt); runs between the row norms and the pack jobs of a weight pack.
+// ------------------------------------------------------------------------------------------------
+struct FoldJob {
+    const float *vW, *sW;   // W_0.weight_v [2 Cd][C][radix], g / |v| per row
+    const float *vS, *sS;   // start.weight_v [C][ic], g / |v| per row
+    float *out;             // [2 Cd][ic][radix]
+    int M, C, ic, radix;
+};
+#define WG_FOLD_JOBS 32
+struct FoldArgs {
+    int n;
+    FoldJob job[WG_FOLD_JOBS];
+};
+__global__ __launch_bounds__(256) void start_fold_kernel(const FoldArgs a)
+{
+    const FoldJob j = a.job[blockIdx.y];
+    const int e = blockIdx.x * 256 + threadIdx.x, per = j.ic * j.radix;
+    if (e >= j.M * per) return;
+    const int o = e / per, r = e - o * per, jj = r / j.radix, kt = r - jj * j.radix;
+    const float *w = j.vW + (size_t)o * j.C * j.radix + kt;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};                      // four interleaved partial sums: fixed order, four loads in flight
+    for (int c = 0; c < j.C; c += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (c + u < j.C) acc[u] = fmaf(w[(size_t)(c + u) * j.radix], j.sS[c + u] * j.vS[(size_t)(c + u) * j.ic + jj], acc[u]);
+    }
+    j.out[e] = j.sW[o] * ((acc[0] + acc[1]) + (acc[2] + acc[3]));
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight packing: effective weights (weight norm, utils.py:14-16) laid out k-major for the MFMA kernels
 // ------------------------------------------------------------------------------------------------
 struct NormJob {

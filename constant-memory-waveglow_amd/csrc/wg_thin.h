@@ -301,6 +301,8 @@ struct StartFwdArgs {
     int ldw, C, ic;
     PRef H;              // fp32 output plane (p == nullptr: none)
     SRef HS;             // S-plane output
+    SRef XS;             // hi != nullptr: xa itself as an S-plane of XS.Cp channels (zero beyond ic) -- the first layer's conv reads it when
+                         // WN.start is folded into its weight (wgflow.hip start_fold_on); written by the blocks of the first Cp / 8 channel groups
     Geo g;
     int row_sel1;        // Geo::rows > 0: r + 1 = blockIdx.z is the item and the launch covers its height row r
 };
@@ -317,10 +319,26 @@ __global__ __launch_bounds__(256) void start_fwd_kernel(const StartFwdArgs a)
     __syncthreads();
     if (t >= g.T) return;
     float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float xk[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // channels 8 cg .. 8 cg + 7 of xa (zero beyond ic)
     for (int j = 0; j < a.ic; ++j) {
         const float xv = *paddr(a.X, g, b, j, t);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = fmaf(w[e][j], xv, o[e]);
+        for (int e = 0; e < 8; ++e) {
+            o[e] = fmaf(w[e][j], xv, o[e]);
+            if (j == cg * 8 + e) xk[e] = xv;
+        }
+    }
+    if (a.XS.hi && cg * 8 < a.XS.Cp) {
+        u32x4 xh, xl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned hh, ll;
+            split2(xk[2 * e], xk[2 * e + 1], hh, ll);
+            xh[e] = hh; xl[e] = ll;
+        }
+        const size_t ix = s_index(a.XS, g, b, cg * 8, t);
+        *reinterpret_cast<u32x4 *>(a.XS.hi + ix) = xh;
+        *reinterpret_cast<u32x4 *>(a.XS.hi + a.XS.lo_off + ix) = xl;
     }
     if (a.H.p) {
 #pragma unroll

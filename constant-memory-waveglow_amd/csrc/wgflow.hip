@@ -49,6 +49,8 @@ struct EnvSw {
     bool lowrank = true;         // WG_LOWRANK=0: the skip sum and its gradient are formed as planes again (lowrank_on below)
     bool lowrank_all = false;    // WG_LOWRANK=2: also where it was measured slower (2 ic > 8: WSRGlow) -- tests of those instantiations
     bool tw_from_gate = true;    // WG_TW_FROM_GATE=0: a pass that keeps its planes keeps tanh as well (tw_from_gate below)
+    bool start_fold = true;      // WG_START_FOLD=0: the first layer's dilated conv reads h_0 again instead of xa through the composed weight (start_fold_on below)
+    int layer_min_chunks = 16;   // WG_LAYER_MIN_CHUNKS=n: the shortest gate product (in 32-deep chunks) that still takes the one-launch layer of wg_gemm16g.h
 };
 static std::atomic<const EnvSw *> g_env{nullptr};
 static const EnvSw *env_load()
@@ -65,6 +67,8 @@ static const EnvSw *env_load()
     n->lowrank = !is("WG_LOWRANK", '0');
     n->lowrank_all = is("WG_LOWRANK", '2');
     n->tw_from_gate = !is("WG_TW_FROM_GATE", '0');
+    n->start_fold = !is("WG_START_FOLD", '0');
+    { const char *e = getenv("WG_LAYER_MIN_CHUNKS"); if (e && atoi(e) >= 2) n->layer_min_chunks = atoi(e); }
     return n;
 }
 static const EnvSw &env_sw()
@@ -276,6 +280,19 @@ inline bool gate_parts_shape(const WnD &d)
 }
 inline int gate_part_slots(const WnD &d) { return 2 * d.Cd / 64; }      // one per 32 gate channels = per wave row of a gate conv
 inline int gate_part_prow(const WnD &d) { return 2 * d.ic <= 2 ? 2 : 8; }   // floats per partial row (2: WaveFlow's WN2D, the 16x16x32 kernels' epilogue only)
+// WN.start folded into the first layer's dilated conv: h_0 = W_start xa has rank ic, so W_0 * h_0 = (W_0[kt] W_start) * xa is a conv over the
+// flow's ic channels (one 32-deep chunk per tap) instead of C = 256 (eight): the first layer's gate conv is 6 chunks instead of 27 at the
+// shipped shape.  S-plane mode, 1-D WN without biases (a start bias would have to ride through W_0 as well); h_0 itself is still made
+// (the residual stream starts from it, the backward's weight gradient reads it).  wg_small.h start_fold_kernel forms the weight.
+inline bool wn_pack_fused_shape(const WnD &d);
+inline bool start_fold_shape(const WnD &d)
+{
+#if defined(WG_OPT_NO_START_FOLD)
+    (void)d; return false;
+#else
+    return d.prec == 2 && !d.bias && d.ic <= 16 && d.depth >= 2 && wn_pack_fused_shape(d);
+#endif
+}
 
 Geo make_geo(int B, int T, int halo_need)
 {
@@ -309,6 +326,8 @@ struct WnPack {
     size_t Acat[16], WoT[16], WoN[16], WT[16], VN[16], WskT, VNall;
     size_t effA = 0;                                          // gate_parts_shape: Weff as A fragments for the gate conv's epilogue, Cd / 32 KB per layer
     size_t effT = 0, effN = 0, WoG[16] = {0};                // lowrank_shape: Weff^T [depth Cd][32]; Weff per layer [depth][32][Cd]; [Wres_l^T | Weff_l^T] k-major
+    size_t w0x = 0, Acat0x = 0;                              // start_fold_shape: the composed weight [2 Cd][ic][radix]; layer 0's gate matrix over xa: [radix x kp_start | auxp] rows
+    int kcat0 = 0;
     int ld_startT, ld_startN, ld_endN, ld_Acat, ld_WoT[16], ld_WoN, ld_WT, ld_VN, ld_WskT;
     int kp_start, kp_end, kcat;
     size_t total;
@@ -365,11 +384,19 @@ WnPack wn_pack_layout(const WnD &d)
         // (kp_end rows, as the G plane has them: run_convgemm finds a matrix's image behind K = the segments' channels)
         for (int i = 0; i < d.depth; ++i) L.WoG[i] = take_mat((i == d.depth - 1 ? 0 : d.C) + L.kp_end, L.ld_WoN);
     }
+    if (start_fold_shape(d)) {
+        L.w0x = take((size_t)2 * d.Cd * d.ic * d.radix);
+        L.kcat0 = d.radix * L.kp_start + d.auxp();
+        // (chunks: one per tap -- kp_start <= 32 channels each -- and the conditioning's: mat_floats leaves room for K / 32 + WG_MAX_SEG + 1)
+        L.Acat0x = take_mat(L.kcat0, L.ld_Acat);
+    }
     L.total = off;
     return L;
 }
 
 // weight images written by the pack jobs themselves (packimg_kernel) instead of a second pass over fp32 matrices
+inline bool wn_pack_fused(const WnD &d);
+inline bool wn_pack_fused_shape(const WnD &d) { return wn_pack_fused(d); }
 inline bool wn_pack_fused(const WnD &d)
 {
 #if defined(WG_OPT_NO_PACK_FUSE)
@@ -400,15 +427,17 @@ struct JobBatch {
     }
     // rows [row, row + Kp) of the k-major matrix A32 ([Ktot][ld] fp32 + its split image, mat_floats): with `fuse` the job writes its
     // chunks of the image itself (packimg_kernel) and the fp32 rows only if `want32`; without, it is a plain pack job (img_kernel follows)
+    // (chunk0 / nchunks given: a matrix whose K segments are shorter than a chunk -- every segment starts a chunk of the image, so the
+    // image's chunk index is no longer row / 32)
     void pack_m(bool fuse, float *A32, int Ktot, int ld, int row, bool want32, int Kp, int mode, int no, int ni, int half,
-                const float *src, const float *scale, int so, int si, int off)
+                const float *src, const float *scale, int so, int si, int off, int chunk0 = -1, int nchunks = -1)
     {
         pack(A32 + (size_t)row * ld, ld, Kp, ld, mode, no, ni, half, src, scale, so, si, off);
         if (!fuse) return;
         PackJob &j = pa.job[pa.n - 1];
-        j.img = mat_img(A32, Ktot, ld); j.chunk0 = row / 32; j.nchunks = (Ktot + 31) / 32;
+        j.img = mat_img(A32, Ktot, ld); j.chunk0 = chunk0 >= 0 ? chunk0 : row / 32; j.nchunks = nchunks >= 0 ? nchunks : (Ktot + 31) / 32;
         if (!want32) j.dst = nullptr;
-        if (row % 32 && !ctx->err) ctx->err = WG_EINVAL;
+        if (chunk0 < 0 && row % 32 && !ctx->err) ctx->err = WG_EINVAL;
     }
     void flush_norm()
     {
@@ -463,6 +492,35 @@ void wn_pack_eff(EffBatch &eb, const WnD &d, const WnPack &L, const float *const
         eb.add(j);
     }
 }
+struct FoldBatch {
+    Ctx *ctx;
+    FoldArgs fa;
+    int maxe = 0;
+    FoldBatch(Ctx *c) : ctx(c) { fa.n = 0; }
+    void flush()
+    {
+        if (!fa.n) return;
+        WG_LAUNCH(*ctx, start_fold_kernel, dim3((maxe + 255) / 256, fa.n), dim3(256), 0, fa);
+        fa.n = 0; maxe = 0;
+    }
+    void add(const FoldJob &j)
+    {
+        if (fa.n == WG_FOLD_JOBS) flush();
+        fa.job[fa.n++] = j;
+        maxe = std::max(maxe, j.M * j.ic * j.radix);
+    }
+};
+// the composed weight of layer 0 (start_fold_shape): behind the row norms (it reads both factors' scales), in front of the pack jobs
+void wn_pack_fold(FoldBatch &fb, const WnD &d, const WnPack &L, const float *const *p, float *pk)
+{
+    if (!start_fold_shape(d) || !L.Acat0x) return;
+    FoldJob j;
+    j.vW = p[5]; j.sW = pk + L.scale_W[0];
+    j.vS = p[3]; j.sS = pk + L.scale_start;
+    j.out = pk + L.w0x;
+    j.M = 2 * d.Cd; j.C = d.C; j.ic = d.ic; j.radix = d.radix;
+    fb.add(j);
+}
 // params: WN table (nparams entries).  Two passes over the stream: all row norms, then all packs.
 void wn_pack_norms(JobBatch &jb, const WnD &d, const WnPack &L, const float *const *p, float *pk)
 {
@@ -497,6 +555,17 @@ void wn_pack_mats(JobBatch &jb, const WnD &d, const WnPack &L, const float *cons
         // conditioning rows: A[radix*C + j][perm m] = V[i*2Cd + o][j]
         jb.pack_m(fuse, acat, L.kcat + kb, L.ld_Acat, d.radix * d.C, f32, d.auxp(), 0, 2 * d.Cd, d.aux, d.Cd,
                   vV + (size_t)i * 2 * d.Cd * d.aux, pk + L.scale_V + (size_t)i * 2 * d.Cd, d.aux, 1, 0);
+        if (i == 0 && start_fold_shape(d) && L.Acat0x) {
+            // layer 0 over xa: rows kt * kp_start + j = the composed weight's [o][j][kt] (a conv weight with ic input channels: the tap jobs' own
+            // form), then the conditioning rows as above; one image chunk per tap, the conditioning's chunks behind them
+            float *a0 = pk + L.Acat0x;
+            const int nck = d.radix + (d.auxp() + 31) / 32;
+            for (int kt = 0; kt < d.radix; ++kt)
+                jb.pack_m(fuse, a0, L.kcat0, L.ld_Acat, kt * L.kp_start, false, L.kp_start, 0, 2 * d.Cd, d.ic, d.Cd, pk + L.w0x, ones,
+                          d.ic * d.radix, d.radix, kt, kt, nck);
+            jb.pack_m(fuse, a0, L.kcat0, L.ld_Acat, d.radix * L.kp_start, false, d.auxp(), 0, 2 * d.Cd, d.aux, d.Cd, vV,
+                      pk + L.scale_V, d.aux, 1, 0, d.radix, nck);
+        }
         jb.pack_m(fuse, pk + L.WoT[i], d.Cd + kb, L.ld_WoT[i], 0, f32, d.Cd, 0, rows, d.Cd, 0, vWo, pk + L.scale_Wo[i], d.Cd, 1, 0);
         {   // rows i*Cd .. of WskT: A[i*Cd + j][m] = Wo_i[skip row m][j]  (the skip rows follow the C residual rows, except on the last layer)
             const int r0 = rows - d.Cs;
@@ -1943,7 +2012,9 @@ bool run_convlayer_g(Ctx &cx, FA &&gate_call, FB &&res_call)
     int ncA = 0, ncR = 0;
     for (int q = 0; q < A.c.nseg; ++q) ncA += (A.c.seg[q].nch + WG16_BK - 1) / WG16_BK;
     for (int q = 0; q < R.c.nseg; ++q) ncR += (R.c.seg[q].nch + WG16_BK - 1) / WG16_BK;
-    if (ncA < 16 || ncA > WGG_MAXCHUNKS || ncR < 2 || ncR > WGG_MAXCHUNKS) return false;
+    // (a gate product of a few chunks -- layer 0 over xa, start_fold_on -- measured the same as two launches: 89.5 against 44.8 + 39.5 us,
+    // gpurun_out/r06w; env WG_LAYER_MIN_CHUNKS lowers the bar for A/B runs)
+    if (ncA < env_sw().layer_min_chunks || ncA > WGG_MAXCHUNKS || ncR < 2 || ncR > WGG_MAXCHUNKS) return false;
     if (!g192_fits(A, A.img_stride, A.c.nseg) || !g192_fits(R, R.img_stride, R.c.nseg)) return false;
     const int nct = (g.B * g.Tt + WGG_BN - 1) / WGG_BN;
     const int rounds = (nct + cus - 1) / cus;
@@ -2042,6 +2113,13 @@ static void launch_end_affine(Ctx &cx, const AffineArgs &a, int src)
     }
 }
 
+// Layer 0's dilated conv over xa through the composed weight (start_fold_shape): one predicate for every pass of a shape -- forward,
+// recompute, inverse -- so that a kept flow and a recomputed one produce the same bits.  (Not inside the recorded row walk; env
+// WG_START_FOLD=0 restores the conv over h_0.)
+static bool start_fold_on(const Ctx &cx, const WnRun &r)
+{
+    return env_sw().start_fold && cx.prec == 2 && start_fold_shape(r.d) && r.L.Acat0x && !cx.rec && !cx.row_sel1 && (r.g.rows == 0 || r.d.mode2d);
+}
 static void wn_gate_conv(Ctx &cx, const WnRun &r, int i, int hin, bool keepg)
 {
     const WnD &d = r.d;
@@ -2054,17 +2132,19 @@ static void wn_gate_conv(Ctx &cx, const WnRun &r, int i, int hin, bool keepg)
     const float *gateS = ws + r.w.gateS[keepg ? i : 0];
     SegSpec sg[WG_MAX_SEG];
     int ns = 0;
+    const bool fold = i == 0 && start_fold_on(cx, r);
     for (int kt = 0; kt < d.radix; ++kt) {
         int ts, ro;
         d.tap(i, kt, ts, ro);
-        sg[ns++] = {Hin, d.C, 0, d.C, ts, ws + r.w.HS[hin], d.C, 0, ro, 0};
+        if (fold) sg[ns++] = {r.X.p, r.X.Cp, r.X.ch0, r.L.kp_start, ts, ws + r.w.XaS, r.L.kp_start, 0, ro, 0};    // (xa's S-plane: wn_forward)
+        else sg[ns++] = {Hin, d.C, 0, d.C, ts, ws + r.w.HS[hin], d.C, 0, ro, 0};
     }
 #if defined(WG_DBG_NOCOND)      // timing experiment only (results are garbage): the gate conv without its conditioning segment
     if (false)
 #endif
     sg[ns++] = {r.Y, d.auxp(), 0, d.auxp(), 0, r.YS, d.auxp(), 0, 0, d.mode2d};
     if (nb) sg[ns++] = ones_seg(cx, r, false);               // (wn_forward filled the plane of ones at the start of the pass)
-    run_convgemm(cx, g, r.pk + r.L.Acat[i], r.L.ld_Acat, 2 * d.Cd, sg, ns, EPI_GATE, sp ? pnull() : pref(gate, d.Cd),
+    run_convgemm(cx, g, r.pk + (fold ? r.L.Acat0x : r.L.Acat[i]), r.L.ld_Acat, 2 * d.Cd, sg, ns, EPI_GATE, sp ? pnull() : pref(gate, d.Cd),
                  (r.save && !tw_from_gate(cx)) ? pref(ws + r.w.tw[i], d.Cd) : pnull(), r.save ? pref(ws + r.w.sf[i], d.Cd) : pnull(),
                  pnull(), pnull(), 0, 0, sp ? sref(g, gateS, d.Cd) : snull());             // waveglow.py:42-44
 }
@@ -2117,12 +2197,14 @@ void wn_forward(Ctx &cx, const WnRun &r)
         ;
     if (r.start_done) {
         // (the seam launch of the flow visited before wrote h_0: same arithmetic as start_fwd_kernel below)
+        if (start_fold_on(cx, r)) run_to_splane(cx, g, r.X, d.ic, ws + r.w.XaS, r.L.kp_start);      // (layer 0 reads xa itself: wn_gate_conv)
     } else if (vstart) {
         StartFwdArgs a;
         memset(&a, 0, sizeof(a));
         a.X = r.X; a.W = r.pk + r.L.startN; a.ldw = r.L.ld_startN; a.C = d.C; a.ic = d.ic;
         a.H = so ? pnull() : pref(ws + r.w.H[0], d.C);
         a.HS = sref(g, ws + r.w.HS[0], d.C);
+        if (start_fold_on(cx, r)) a.XS = sref(g, ws + r.w.XaS, r.L.kp_start);      // (layer 0 reads xa itself: wn_gate_conv)
         a.g = g; a.row_sel1 = cx.row_sel1;
         WG_LAUNCH(cx, start_fwd_kernel, dim3((g.T + 255) / 256, d.C / 8, cx.row_sel1 && g.rows > 0 ? g.B / g.rows : g.B), dim3(256), 0, a);
     } else {
@@ -2940,6 +3022,9 @@ int wg_wn_pack_weights(const wg_wn_dims *dd, const void *const *params, void *pa
     EffBatch eb(&cx);
     wn_pack_eff(eb, d, L, (const float *const *)params, wn);
     eb.flush();
+    FoldBatch fb(&cx);
+    wn_pack_fold(fb, d, L, (const float *const *)params, wn);
+    fb.flush();
     wn_pack_mats(jb, d, L, (const float *const *)params, wn, ones);
     jb.flush_pack();
     ImgBatch ib(&cx);
@@ -2981,6 +3066,12 @@ int wg_pack_weights(const wg_config *cf, const void *const *params, void *packed
         wn_pack_eff(eb, d, wn_pack_layout(d), p + wn_table_off(cf, k), pk + M.wn[k]);
     }
     eb.flush();
+    FoldBatch fb(&cx);
+    for (int k = 0; k < cf->n_flows; ++k) {
+        const WnD d = flow_wn(cf, k);
+        wn_pack_fold(fb, d, wn_pack_layout(d), p + wn_table_off(cf, k), pk + M.wn[k]);
+    }
+    fb.flush();
     jb.pack(pk + M.up_w, cf->up_kernel, cf->n_mels, cf->up_kernel, 1, cf->n_mels, cf->up_kernel, 0, p[2], pk + M.up_scale, cf->up_kernel, 1, 0);
     jb.pack(pk + M.up_bias, cf->n_mels, 1, cf->n_mels, 1, 1, cf->n_mels, 0, p[0], ones, cf->n_mels, 1, 0);
     for (int k = 0; k < cf->n_flows; ++k) {
@@ -3361,6 +3452,9 @@ int wg_wf_pack_weights(const wg_wf_config *cf, const void *const *params, void *
     EffBatch eb(&cx);
     for (int k = 0; k < cf->flows; ++k) wn_pack_eff(eb, d, WL, p + 3 + wf_pf(cf) * k, pk + L.wn[k]);
     eb.flush();
+    FoldBatch fb(&cx);
+    for (int k = 0; k < cf->flows; ++k) wn_pack_fold(fb, d, WL, p + 3 + wf_pf(cf) * k, pk + L.wn[k]);
+    fb.flush();
     for (int k = 0; k < cf->flows; ++k) wn_pack_mats(jb, d, WL, p + 3 + wf_pf(cf) * k, pk + L.wn[k], ones);
     jb.flush_pack();
     ImgBatch ib(&cx);

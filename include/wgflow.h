@@ -88,7 +88,8 @@ const char *wg_strerror(int code);
  * structs: the Python loader compares this with its own ABI_VERSION and refuses the library otherwise. */
 #define WG_ABI_VERSION 9
 int wg_abi_version(void);
-/* Developer switches (WG_G192, WG_G192_SPLITK, WG_LOWRANK, WG_LAYER_G, WG_LAYER_FUSION, WG_LAYER_FUSION_BIG, WG_INV_SEAM: A/B switches between
+/* Developer switches (WG_G192, WG_G192_SPLITK, WG_LOWRANK, WG_TW_FROM_GATE, WG_START_FOLD, WG_LAYER_G, WG_LAYER_MIN_CHUNKS, WG_LAYER_FUSION,
+ * WG_LAYER_FUSION_BIG, WG_INV_SEAM: A/B switches between
  * kernels that compute the same thing, csrc/wgflow.hip EnvSw) are read from the environment ONCE per process, at the first call that needs
  * one; a caller that changes one afterwards -- a test, an A/B run -- calls this to have them read again.  Not to be called while
  * another thread is inside the library.  No counterpart upstream. */

@@ -162,6 +162,44 @@ def test_rank_form_of_the_skip_path_with_sixteen_rows_vs_oracle(dev, monkeypatch
     assert np.abs(npy(xr) - audio).max() < Z_ATOL
 
 
+@pytest.mark.parametrize("name", ["c1", "wsr_like"])
+def test_start_conv_folded_into_the_first_layer_vs_conv_over_h0(dev, precision, monkeypatch, name):
+    """WN.start has rank ic, so the first layer's dilated conv runs over xa through the composed weight W_0[kt] W_start (csrc/wgflow.hip
+    start_fold_on, wg_small.h start_fold_kernel; model/waveglow.py:99, 41-43) -- by default, i.e. in every other parity test.  Here the
+    same step with the fold switched off (WG_START_FOLD=0: the conv over h_0): both against the float64 oracle, the two against each other
+    far inside the bars, and NOT bit for bit (the switch must reach the kernels)."""
+    if precision != "bf16x3p":
+        pytest.skip("the fold exists in the S-plane mode only")
+    m, cfg, specs, P = build(name, dev)
+    _, N, F = fill.SHAPES[name]
+    B = 5
+    audio, h = fill.inputs(name + "_fold_x5", B, N, F, cfg["n_mels"])
+    ref = orc.train_step(orc.make_config(**cfg), fill.table(specs, P), audio, h, fill.SIGMA, need_dh=True, double=True)
+    got = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("WG_START_FOLD", sw)
+        cm._lib.lib().wg_reload_env()
+        m.zero_grad()
+        x, ht = T(audio, dev), T(h, dev).requires_grad_(True)
+        z, logdet = m(x, ht)
+        loss = cm.WaveGlowLoss(fill.SIGMA)(z, logdet)
+        loss.backward()
+        assert np.abs(npy(z) - ref["z"]).max() < Z_ATOL and logdet_close(npy(logdet), ref["logdet"], N)
+        assert abs(float(loss) - ref["loss"]) < LOSS_ATOL and relmax(npy(ht.grad), ref["dh"]) < GRAD_RTOL
+        named = dict(m.named_parameters())
+        for i, (n, _, _) in enumerate(specs):
+            assert relmax(npy(named[n].grad), ref["grads"][i]) < GRAD_RTOL, n
+        with torch.no_grad():
+            xr, _ = m.reverse(z.detach(), ht.detach())
+        assert np.abs(npy(xr) - audio).max() < Z_ATOL
+        got[sw] = (z.detach().clone(), {n: q.grad.clone() for n, q in named.items()})
+    z1, g1 = got["1"]
+    z0, g0 = got["0"]
+    assert float((z1 - z0).abs().max()) < 2e-5 and not torch.equal(z1, z0)
+    for n in g1:
+        assert relmax(npy(g1[n]), npy(g0[n])) < 2e-5, n
+
+
 def test_bias_wide_batch_step_vs_oracle(dev):
     """WN(bias=True) (model/waveglow.py:58) at 4 608 columns per launch: the one-product skip sum (its bias rows: one per layer), the
     S-plane-only residual stream and the grouped weight-gradient launch with the ones segment.  Against the float64 oracle."""
@@ -964,10 +1002,11 @@ def test_coupling_block_on_flattened_column_tiles_vs_oracle(dev, precision, B, T
     L.wg_timer_destroy(timer)
     gate = {k[1]: v for k, v in sites.items() if k[0] == _lib.K_CONV_GATE}
     layer = sum(v for k, v in sites.items() if k[0] == _lib.K_LAYER and k[1] == "convlayer16g_kernel")
-    if want_store:          # 256 column tiles, one per CU: 7 of the 8 layers run gate conv + residual product as ONE launch (convlayer16g_kernel)
-        assert layer == 14 and gate.get("convgemm16g_kernel<EPI_GATE_SO>", 0) == 2, sites
-    else:                   # 8 layers, forward + the backward's recompute
-        assert layer == 0 and gate.get("convgemm16g_kernel<EPI_GATE_SO>", 0) == 16, sites
+    # (the first layer's gate conv reads xa through the composed weight -- start_fold_on: 6 chunks of K -- and takes a 16x16x32 kernel)
+    if want_store:          # 256 column tiles, one per CU: layers 1-6 of 8 run gate conv + residual product as ONE launch (convlayer16g_kernel)
+        assert layer == 12 and gate.get("convgemm16g_kernel<EPI_GATE_SO>", 0) == 2 and sum(gate.values()) == 4, sites
+    else:                   # layers 1-7 of 8, forward + the backward's recompute
+        assert layer == 0 and gate.get("convgemm16g_kernel<EPI_GATE_SO>", 0) == 14 and sum(gate.values()) == 16, sites
     store = sum(v for k, v in sites.items() if k[0] == _lib.K_CONV_STORE and k[1] == "convgemm16g_kernel<EPI_STORE_SO>")
     assert (store >= 8) == want_store, sites                                     # the 8 data-gradient convs (K = 1536) of the backward
     assert np.abs(npy(z) - z_ref).max() < 1e-5 and np.abs(npy(ls) - ls_ref).max() < 1e-5
@@ -983,7 +1022,7 @@ def test_layer_as_one_launch_on_flattened_tiles_vs_two_launches(dev, precision, 
     """convlayer16g_kernel (csrc/wg_gemm16g.h): a layer's gate conv and residual product in ONE launch -- a workgroup owns whole 192-column
     tiles, computes both 256-row gate tiles and then, from its own stores, the residual product.  A whole training step at the headline
     columns (24 x 2000) must agree with the two-launch path (WG_LAYER_G=0) to rounding and repeat bit for bit, and the counter must show
-    the kernel ran: 7 of 8 layers of every flow in the forward and in the recompute of every flow but the one the forward kept."""
+    the kernel ran: 6 of 8 layers of every flow in the forward and in the recompute of every flow but the one the forward kept."""
     if precision != "bf16x3p":
         pytest.skip("the LDS-DMA kernels exist in the S-plane mode only")
     from constant_memory_waveglow_amd import _lib
@@ -1004,7 +1043,9 @@ def test_layer_as_one_launch_on_flattened_tiles_vs_two_launches(dev, precision, 
             runs.append((loss.clone(), z.clone(), logdet.clone(), tr.fg.flat.clone()))
         torch.cuda.synchronize()
         n = _lib.lib().wg_stat_layerg_launches() - before
-        assert n == (2 * (cfg["flows"] * 7 + (cfg["flows"] - 1) * 7) if fused == "1" else 0), n
+        # (6 of 8 layers: the last has no residual product, the first -- WN.start folded into its weight, start_fold_on -- is a gate product of
+        # 6 chunks and takes the 16x16x32 kernel + its own residual launch)
+        assert n == (2 * (cfg["flows"] * 6 + (cfg["flows"] - 1) * 6) if fused == "1" else 0), n
         for a, b in zip(runs[0], runs[1]):
             assert torch.equal(a, b)
         res[fused] = runs[0]
