@@ -827,6 +827,10 @@ def main(argv=None):
         per_class = {c: float(ms_all[info[:, 0] == c].sum()) for c in (_lib.K_CONV_GATE, _lib.K_LAYER)}
         dom = max(per_class, key=per_class.get)
         sel = np.nonzero(info[:, 0] == dom)[0]
+        # (a class holds launches of more than one K since the first layer's conv reads xa through the composed weight -- DESIGN.md 4g: its
+        # gate conv is a few chunks long.  The roofline line is about the full-K launches: the others would be credited FLOPs they do not do)
+        if sel.size:
+            sel = sel[info[sel, 2] == info[sel, 2].max()]
         names = {}
         nb = C.create_string_buffer(256)
         for i in sel:
@@ -852,6 +856,8 @@ def main(argv=None):
             traffic_src += " (committed rocprofv3 --pmc summary of this command; not re-measured in this run)"
         gate_alone = None
         galone = np.nonzero(info[:, 0] == _lib.K_CONV_GATE)[0]
+        if galone.size:
+            galone = galone[info[galone, 2] == info[galone, 2].max()]
         if dom == _lib.K_LAYER and galone.size:                          # the gate conv launches that run on their own (a WN's last layer)
             g_ms = float(np.mean(ms_all[galone]))
             g_ach = wl["gate_flop_per_launch"] / (g_ms * 1e-3) / 1e12
