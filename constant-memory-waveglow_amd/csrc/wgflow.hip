@@ -2403,7 +2403,11 @@ static const float *run_lowrank_end(Ctx &cx, const WnRun &r, const float *const 
     const int ic2 = 2 * d.ic, mrows = rup(ic2, 8), nblk = g.B * (g.Tt / 64);
     // column ranges: 8 where the unit rows alone give 64 workgroups per range (the 256-channel WN: 512 workgroups), more where they do not
     // (WaveFlow's 64 channels: 16 workgroups per range -- with 8 ranges half the chip ran this pass: 199 us for the bytes the headline's takes 105 for)
+#if defined(WG_OPT_PGATE_NCR8)                           // A/B build: eight ranges whatever the channel count (before round 6's last commit)
+    const int want = 8;
+#else
     const int wgr = (d.depth * (d.Cd / 8) + 3) / 4, want = std::min(32, std::max(8, (512 + wgr - 1) / wgr));
+#endif
     const int ncr = std::max(1, std::min(want, nblk / 4)), per = (nblk + ncr - 1) / ncr;
     const size_t n = (size_t)d.depth * mrows * d.Cd;
     PGateArgs a;
