@@ -210,7 +210,14 @@ inline bool s_only_chain(const Ctx &cx, const WnD &d)
 #if !defined(WG_OPT_NO_S_ONLY) && !defined(WG_OPT_MFMA32) && !defined(WG_OPT_NO_WSPEC) && !defined(WG_OPT_DMA)
     // (only convgemm16q / convgemm16h read the accumulate-into value from an S-plane -- ConvGemm16sArgs::saux --: the superseded
     // kernels of the A/B builds ignore it and would lose the residual term)
-    return cx.prec == 2 && !d.mode2d;                       // measured: step 78.8 -> 75.8 ms; errors against the oracle unchanged
+#if defined(WG_OPT_S_ONLY_1D)                               // A/B build: WN2D keeps its fp32 residual planes (before round 6's last commits)
+    return cx.prec == 2 && !d.mode2d;
+#else
+    // (WN2D since the end of round 6 -- its 64-row products read the accumulate-into S-plane like every other form of convgemm16q: WaveFlow's
+    // step 39.4 -> 36.6 ms on one box, residual conv 43 -> 31 us, data-gradient conv 131 -> 119 us; not inside the row-by-row inverse, whose
+    // recorded stages keep the planes they were built and tested with)
+    return cx.prec == 2 && (!d.mode2d || (!cx.rec && !cx.row_sel1));      // measured (1-D): step 78.8 -> 75.8 ms; errors against the oracle unchanged
+#endif
 #else                                                       // (tools/experiments/err_report.py: z 3.8e-6, worst gradient 8.9e-6 of its max)
     (void)cx; (void)d; return false;
 #endif
