@@ -591,7 +591,7 @@ void wn_pack_mats(JobBatch &jb, const WnD &d, const WnPack &L, const float *cons
                       pk + L.scale_W[i], d.C * d.radix, d.radix, kt);
         jb.pack_m(fuse, pk + L.VN[i], 2 * d.Cd, L.ld_VN, 0, f32, 2 * d.Cd, 1, 2 * d.Cd, d.aux, 0, vV + (size_t)i * 2 * d.Cd * d.aux,
                   pk + L.scale_V + (size_t)i * 2 * d.Cd, d.aux, 1, 0);
-        if (fused_dy(d))
+        if (fused_dy(d) || (d.mode2d && d.depth <= WG_MAX_SEG))      // (WN2D: the one product over the layers' height-axis sums, wn_backward)
             jb.pack_m(fuse, pk + L.VNall, d.depth * 2 * d.Cd, L.ld_VN, i * 2 * d.Cd, f32, 2 * d.Cd, 1, 2 * d.Cd, d.aux, 0,
                       vV + (size_t)i * 2 * d.Cd * d.aux, pk + L.scale_V + (size_t)i * 2 * d.Cd, d.aux, 1, 0);
     }
@@ -674,7 +674,7 @@ void wn_pack_images(ImgBatch &ib, const WnD &d, const WnPack &L, float *pk)
         if (nb) sgs[d.depth] = 32;
         ib.add(pk + L.WskT, L.ld_WskT, sgs, d.depth + nb);
         for (int i = 0; i < d.depth; ++i) sgs[i] = 2 * d.Cd;
-        if (fused_dy(d)) ib.add(pk + L.VNall, L.ld_VN, sgs, d.depth);
+        if (fused_dy(d) || d.mode2d) ib.add(pk + L.VNall, L.ld_VN, sgs, d.depth);
     }
 }
 
@@ -2607,9 +2607,12 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
             else                                              // exact-fp32 mode: the same sum on the fp32 plane (r.rs holds 2 Cd fp32 channels then)
                 WG_LAUNCH(cx, wf_rowsum_kernel, dim3((g.T + 255) / 256, 2 * d.Cd, r.gi.B), dim3(256), 0, pref(dxy, 2 * d.Cd), g,
                           pref(r.rs, 2 * d.Cd), r.gi, 2 * d.Cd);
-            SegSpec s = {sp ? nullptr : r.rs, 2 * d.Cd, 0, 2 * d.Cd, 0, sp ? rsp(i) : nullptr, 2 * d.Cd, 0};
-            run_convgemm(cx, r.gi, r.pk + r.L.VN[i], r.L.ld_VN, d.aux, &s, 1, EPI_STORE, pref(dY, d.auxp()), pnull(), pnull(),
-                         pref(dY, d.auxp()), pnull(), 0, 0);
+            // (every layer's sums kept -- hv: the weight gradient of V reads them as well --: ONE product over all of them behind the loop)
+            if (!(hv && nd <= WG_MAX_SEG)) {
+                SegSpec s = {sp ? nullptr : r.rs, 2 * d.Cd, 0, 2 * d.Cd, 0, sp ? rsp(i) : nullptr, 2 * d.Cd, 0};
+                run_convgemm(cx, r.gi, r.pk + r.L.VN[i], r.L.ld_VN, d.aux, &s, 1, EPI_STORE, pref(dY, d.auxp()), pnull(), pnull(),
+                             pref(dY, d.auxp()), pnull(), 0, 0);
+            }
         } else if (dY && !fdy) {
             SegSpec s = {dxy, 2 * d.Cd, 0, 2 * d.Cd, 0, dxyS, 2 * d.Cd, 0};
             run_convgemm(cx, g, r.pk + r.L.VN[i], r.L.ld_VN, d.aux, &s, 1, EPI_STORE, pref(dY, d.auxp()), pnull(), pnull(),
@@ -2669,6 +2672,12 @@ void wn_backward(Ctx &cx, const WnRun &r, const float *const *p, float *const *g
             run_finalize(cx, slab, woO[i], last ? d.C : 0, d.wo_rows(i), d.Cd, 1, 0, 1, 0, p[6 + 4 * i], p[7 + 4 * i], grads[6 + 4 * i], grads[7 + 4 * i]);
             fin_bias(slab, woO[i], last ? d.C : 0, d.wo_rows(i), rup(d.Cd, 32), gb(3 + 2 * i));
         }
+    }
+    if (hv && nd <= WG_MAX_SEG) {                             // WN2D: dy[item] += [V_0^T .. V_{d-1}^T] [rowsum_0; ..; rowsum_{d-1}] (eight launches of K = 2 Cd before)
+        SegSpec sv[WG_MAX_SEG];
+        for (int i = 0; i < nd; ++i) sv[i] = {nullptr, 2 * d.Cd, 0, 2 * d.Cd, 0, rsp(i), 2 * d.Cd, 0};
+        run_convgemm(cx, r.gi, r.pk + r.L.VNall, r.L.ld_VN, d.aux, sv, nd, EPI_STORE, pref(dY, d.auxp()), pnull(), pnull(),
+                     pref(dY, d.auxp()), pnull(), 0, 0);
     }
     if (fdy) {                                                // dy += [V_0^T .. V_{d-1}^T] [dxy_0; ..; dxy_{d-1}]
         SegSpec sv[WG_MAX_SEG];
